@@ -1,0 +1,793 @@
+/*
+ * mgrit_oracle.c -- TEST INFRASTRUCTURE ONLY (parity oracle + bench.py's cpu_baseline "port").
+ *
+ * Plain-C restatement of PyMGRIT's MGRIT hot path (reference: /root/reference, v1.0.6):
+ *   src/pymgrit/core/mgrit.py:261-549,715-726,742-858   (cycle, relaxation, FAS residual, layout)
+ *   src/pymgrit/heat/heat_1d.py:177-217                 (Heat1D backward-Euler step)
+ *   src/pymgrit/advection/advection_1d.py:101-143       (Advection1D backward-Euler step)
+ *   src/pymgrit/dahlquist/dahlquist.py:88-111           (Dahlquist steps)
+ *   examples/example_spatial_coarsening.py:33-82        (full-weighting / linear transfer)
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this file. The product
+ * (pymgrit_amd/ + libmgrit_hip.so) never links, imports or calls it.
+ *
+ * Third-party arithmetic: the reference's Phi is scipy.sparse.linalg.spsolve -> SuperLU (scipy>=1.4.1,
+ * installed 1.15.3), which is not under /root/reference. Two restatements of the same linear solve live here:
+ *   variant 0 "natural": textbook Thomas / forward substitution (pinned against the reference's KATs and
+ *                        reference-generated fixtures in tests/golden to forward-error tolerance);
+ *   variant 1 "spec":    the chunked-scan arithmetic specification of DESIGN.md section 3 (E=16 elements per
+ *                        chunk, 64 chunks per group, Kogge-Stone inside a group, serial carry across groups),
+ *                        written independently of the HIP kernels, which must reproduce it bit for bit.
+ * Parity pinned: yes (tests/test_oracle_golden.py vs the json/npz fixtures in tests/golden).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: every fused multiply-add below is an explicit fma()).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_E 16      /* elements per chunk (one GPU lane)      */
+#define ORC_LANES 64  /* chunks per group   (one GPU wavefront) */
+#define ORC_GROUP (ORC_E * ORC_LANES)
+#define ORC_MAX_LEVELS 16
+#define ORC_MAX_K 4
+
+/* ================================================================================================
+ * Layout  (mgrit.py:742-838)
+ * ============================================================================================== */
+typedef struct {
+    int32_t n_local;      /* len(t[lvl]) including the ghost point (mgrit.py:783-792) */
+    int32_t ghost;        /* 1 when a ghost point precedes the owned block             */
+    int32_t first_owned;  /* global index of the first owned point, -1 if none         */
+    int32_t n_owned;
+    int32_t comm_front, comm_back;
+    int32_t first_is_c_point, first_is_f_point, last_is_c_point, last_is_f_point;
+    int32_t send_to, get_from;
+    int32_t n_c, n_f;
+    int32_t m;            /* np.diff(cpts)[0] of the global C-point set (mgrit.py:213), 1 on the coarsest */
+} orc_layout_info;
+
+/* mgrit.py:829-838 */
+void orc_split_into(int number_points, int number_processes, int32_t *out) {
+    int q = number_points / number_processes, r = number_points % number_processes;
+    for (int p = 0; p < number_processes; ++p) out[p] = (p < r) ? q + 1 : q;
+}
+
+static int member_sorted(const double *a, int n, double v) { /* exact float membership (np.in1d) */
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) / 2; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo < n && a[lo] == v;
+}
+
+static int searchsorted_left(const double *a, int n, double v) {
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) / 2; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+/* is_c for the global level-lvl grid: mgrit.py:767-770 */
+static void global_is_c(int n_levels, const int32_t *nt, const double *t_all, const int64_t *t_off, int lvl, uint8_t *is_c) {
+    const double *t = t_all + t_off[lvl];
+    if (lvl == n_levels - 1) { for (int i = 0; i < nt[lvl]; ++i) is_c[i] = 1; return; }
+    const double *tc = t_all + t_off[lvl + 1];
+    for (int i = 0; i < nt[lvl]; ++i) is_c[i] = (uint8_t)member_sorted(tc, nt[lvl + 1], t[i]);
+}
+
+/*
+ * Per-(rank, level) layout. t_all holds the level grids back to back (offsets t_off).
+ * Outputs (caller-allocated, capacity nt[lvl]+1): cpts (global indices of owned C-points), index_local,
+ * index_local_c, index_local_f. index_local_f is emitted in the canonical order "consecutive runs reversed,
+ * ascending inside a run" (the reference's exact order is a CPython set-iteration artefact: SURVEY App. A).
+ */
+int orc_layout(int n_levels, const int32_t *nt, const double *t_all, int lvl, int rank, int size,
+               orc_layout_info *info, int64_t *cpts, int64_t *index_local, int64_t *index_local_c,
+               int64_t *index_local_f) {
+    int64_t t_off[ORC_MAX_LEVELS + 1];
+    t_off[0] = 0;
+    for (int l = 0; l < n_levels; ++l) t_off[l + 1] = t_off[l] + nt[l];
+    const double *t0 = t_all, *t = t_all + t_off[lvl];
+    int N = nt[lvl];
+    memset(info, 0, sizeof(*info));
+    info->send_to = -99; info->get_from = -99; info->first_owned = -1;
+
+    int32_t *split = (int32_t *)malloc(sizeof(int32_t) * (size_t)size);
+    orc_split_into(nt[0], size, split);
+    /* level-0 block of this rank (mgrit.py:756-762) */
+    int64_t first0 = 0;
+    for (int p = 0; p < rank; ++p) first0 += split[p];
+    if (split[rank] <= 0) { free(split); return -1; } /* more processes than points: reference raises (mgrit.py:127) */
+    double int_start = t0[first0], int_stop = t0[first0 + split[rank] - 1];
+    /* owned points on this level (mgrit.py:760,764) */
+    int a = -1, z = -2;
+    if (lvl == 0) { a = (int)first0; z = (int)(first0 + split[rank] - 1); }
+    else {
+        for (int i = 0; i < N; ++i) if (t[i] >= int_start && t[i] <= int_stop) { if (a < 0) a = i; z = i; }
+        if (a < 0) { a = 0; z = -1; }
+    }
+    int n_owned = z - a + 1;
+    uint8_t *is_c = (uint8_t *)malloc((size_t)N + 1);
+    global_is_c(n_levels, nt, t_all, t_off, lvl, is_c);
+    /* m (mgrit.py:211-219) */
+    if (lvl < n_levels - 1) {
+        int c0 = -1, c1 = -1;
+        for (int i = 0; i < N && c1 < 0; ++i) if (is_c[i]) { if (c0 < 0) c0 = i; else c1 = i; }
+        info->m = (c1 >= 0) ? c1 - c0 : 0;
+    } else info->m = 1;
+
+    int ghost = (rank != 0 && n_owned > 0) ? 1 : 0; /* mgrit.py:783 */
+    info->ghost = ghost; info->n_owned = n_owned; info->n_local = n_owned + ghost;
+    info->first_owned = n_owned > 0 ? a : -1;
+    int nc = 0, nf = 0;
+    for (int i = a; i <= z; ++i) {
+        index_local[i - a] = ghost + (i - a);
+        if (is_c[i]) { cpts[nc] = i; index_local_c[nc] = ghost + (i - a); ++nc; }
+    }
+    /* F-points: runs of consecutive owned F indices, runs reversed (mgrit.py:773-776, canonical order) */
+    {
+        int i = z;
+        while (i >= a) {
+            if (is_c[i]) { --i; continue; }
+            int e = i; while (i - 1 >= a && !is_c[i - 1]) --i;
+            for (int j = i; j <= e; ++j) index_local_f[nf++] = ghost + (j - a);
+            --i;
+        }
+    }
+    info->n_c = nc; info->n_f = nf;
+#define IS_F(i) ((i) >= 0 && (i) < N && !is_c[i])
+#define IS_C(i) ((i) >= 0 && (i) < N && is_c[i])
+    if (n_owned > 0) {
+        int fmin = -1, fmax = -1;
+        for (int i = a; i <= z; ++i) if (!is_c[i]) { if (fmin < 0) fmin = i; fmax = i; }
+        info->comm_front = (fmin >= 0) && IS_F(fmin - 1);              /* mgrit.py:796 */
+        info->comm_back = (fmax >= 0) && IS_F(fmax + 1);               /* mgrit.py:797 */
+        info->first_is_c_point = is_c[a] && a != 0 && IS_F(a - 1);     /* mgrit.py:805-806 */
+        info->first_is_f_point = !is_c[a] && IS_C(a - 1);              /* mgrit.py:807 */
+        info->last_is_c_point = is_c[z] && z != N - 1 && IS_F(z + 1);  /* mgrit.py:808-810 */
+        info->last_is_f_point = !is_c[z] && z != N - 1 && IS_C(z + 1); /* mgrit.py:811-813 */
+    }
+    /* send_to / get_from (mgrit.py:816-827) */
+    if (info->n_local > 0) {
+        double *ends = (double *)malloc(sizeof(double) * (size_t)size);
+        int64_t acc = 0;
+        for (int p = 0; p < size; ++p) { acc += split[p]; ends[p] = t0[acc - 1]; }
+        if (z != N - 1) info->send_to = searchsorted_left(ends, size, t[z + 1]);
+        double tfirst = t[ghost ? a - 1 : a];
+        if (ghost || tfirst != t0[0]) info->get_from = searchsorted_left(ends, size, tfirst);
+        free(ends);
+    }
+    free(is_c); free(split);
+    return 0;
+}
+
+/* ================================================================================================
+ * Coefficient sets for the "spec" variant
+ * ============================================================================================== */
+typedef struct {
+    double dt;
+    double rho, ik, scal;   /* heat: rho, 1/kappa ; advection: r, 1/D */
+    double pw[ORC_E + 1];   /* pw[k] = rho^k, pw[0] = 1, sequential products */
+    double sc[6];           /* sc[s] = rho^(E*2^s), repeated squaring of pw[E] */
+    double gc;              /* rho^(64E) = sc[5]^2 */
+    double lp[ORC_LANES];   /* lp[l] = rho^(E*l), sequential products of pw[E] */
+    double *tab;            /* heat: wg[j] (n) ; advection: rp[j] = r^(j+1)/(1-r^n) folded (n) */
+} orc_cset;
+
+static void cset_powers(orc_cset *c, double rho) {
+    c->rho = rho;
+    c->pw[0] = 1.0; c->pw[1] = rho;
+    for (int k = 2; k <= ORC_E; ++k) c->pw[k] = c->pw[k - 1] * rho;
+    c->sc[0] = c->pw[ORC_E];
+    for (int s = 1; s < 6; ++s) c->sc[s] = c->sc[s - 1] * c->sc[s - 1];
+    c->gc = c->sc[5] * c->sc[5];
+    c->lp[0] = 1.0;
+    for (int l = 1; l < ORC_LANES; ++l) c->lp[l] = c->lp[l - 1] * c->pw[ORC_E];
+}
+
+/* Heat1D: T = tridiag(-beta, D, -beta) = kappa (I - rho S)(I - rho S^T) + kappa rho^2 e0 e0^T */
+static void cset_heat1d(orc_cset *c, int n, double fac, double dt) {
+    double beta = dt * fac;
+    double D = dt * (2.0 * fac) + 1.0;           /* heat_1d.py:213 diag entry: dt*(2*fac) + 1 */
+    double s = sqrt((D - 2.0 * beta) * (D + 2.0 * beta));
+    double kappa = 0.5 * (D + s);
+    double rho = beta / kappa;
+    c->dt = dt; c->ik = 1.0 / kappa; c->scal = 0.0;
+    cset_powers(c, rho);
+    c->tab = (double *)malloc(sizeof(double) * (size_t)n);
+    double *y = (double *)malloc(sizeof(double) * (size_t)n);
+    y[0] = 1.0;
+    for (int j = 1; j < n; ++j) y[j] = rho * y[j - 1];
+    double zn = y[n - 1];
+    c->tab[n - 1] = zn;
+    for (int j = n - 2; j >= 0; --j) { zn = fma(rho, zn, y[j]); c->tab[j] = zn; }
+    double kr2 = beta * rho;
+    double w0 = c->tab[0] * c->ik;
+    double gamma = kr2 / (1.0 + kr2 * w0);
+    for (int j = 0; j < n; ++j) c->tab[j] = gamma * (c->tab[j] * c->ik);
+    free(y);
+}
+
+/* Advection1D: (1+alpha) x_j - alpha x_{j-1 mod n} = u_j ; r = alpha/D, x_j = y_j + r^(j+1) x_{n-1} */
+static void cset_advection1d(orc_cset *c, int n, double fac, double dt) {
+    double alpha = dt * fac;
+    double D = alpha + 1.0;                      /* advection_1d.py:140 diag: dt*fac + 1 */
+    double r = alpha / D;
+    c->dt = dt; c->ik = 1.0 / D;
+    cset_powers(c, r);
+    c->tab = (double *)malloc(sizeof(double) * (size_t)n);
+    double p = r;
+    for (int j = 0; j < n; ++j) { c->tab[j] = p; p = p * r; }  /* tab[j] = r^(j+1) */
+    c->scal = 1.0 / (1.0 - c->tab[n - 1]);                     /* 1/(1 - r^n) */
+}
+
+/* ================================================================================================
+ * Chunked scans (spec) -- forward y_j = rho*y_{j-1} + d_j, backward z_j = rho*z_{j+1} + y_j
+ * Arrays have length G*ORC_GROUP (zero padded).
+ * ============================================================================================== */
+static void spec_scan_fwd(const orc_cset *c, int G, double *y) {
+    double S[ORC_LANES], T[ORC_LANES];
+    double *A = (double *)malloc(sizeof(double) * (size_t)(G + 1));
+    double *Ssave = (double *)malloc(sizeof(double) * (size_t)G * ORC_LANES);
+    for (int g = 0; g < G; ++g) {
+        for (int l = 0; l < ORC_LANES; ++l) {
+            double *b = y + ((size_t)g * ORC_LANES + l) * ORC_E;
+            for (int k = 1; k < ORC_E; ++k) b[k] = fma(c->rho, b[k - 1], b[k]);
+            S[l] = b[ORC_E - 1];
+        }
+        for (int s = 0; s < 6; ++s) {
+            int off = 1 << s;
+            for (int l = 0; l < ORC_LANES; ++l) T[l] = (l >= off) ? fma(c->sc[s], S[l - off], S[l]) : S[l];
+            memcpy(S, T, sizeof(S));
+        }
+        memcpy(Ssave + (size_t)g * ORC_LANES, S, sizeof(S));
+        A[g] = S[ORC_LANES - 1];
+    }
+    double carry = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const double *Sg = Ssave + (size_t)g * ORC_LANES;
+        for (int l = 0; l < ORC_LANES; ++l) {
+            double prev = l > 0 ? Sg[l - 1] : 0.0;
+            double cin = fma(c->lp[l], carry, prev);
+            double *b = y + ((size_t)g * ORC_LANES + l) * ORC_E;
+            for (int k = 0; k < ORC_E; ++k) b[k] = fma(c->pw[k + 1], cin, b[k]);
+        }
+        carry = fma(c->gc, carry, A[g]);
+    }
+    free(A); free(Ssave);
+}
+
+static void spec_scan_bwd(const orc_cset *c, int G, double *z) {
+    double S[ORC_LANES], T[ORC_LANES];
+    double *A = (double *)malloc(sizeof(double) * (size_t)(G + 1));
+    double *Ssave = (double *)malloc(sizeof(double) * (size_t)G * ORC_LANES);
+    for (int g = 0; g < G; ++g) {
+        for (int l = 0; l < ORC_LANES; ++l) {
+            double *b = z + ((size_t)g * ORC_LANES + l) * ORC_E;
+            for (int k = ORC_E - 2; k >= 0; --k) b[k] = fma(c->rho, b[k + 1], b[k]);
+            S[l] = b[0];
+        }
+        for (int s = 0; s < 6; ++s) {
+            int off = 1 << s;
+            for (int l = 0; l < ORC_LANES; ++l) T[l] = (l + off < ORC_LANES) ? fma(c->sc[s], S[l + off], S[l]) : S[l];
+            memcpy(S, T, sizeof(S));
+        }
+        memcpy(Ssave + (size_t)g * ORC_LANES, S, sizeof(S));
+        A[g] = S[0];
+    }
+    double carry = 0.0;
+    for (int g = G - 1; g >= 0; --g) {
+        const double *Sg = Ssave + (size_t)g * ORC_LANES;
+        for (int l = 0; l < ORC_LANES; ++l) {
+            double next = l < ORC_LANES - 1 ? Sg[l + 1] : 0.0;
+            double cin = fma(c->lp[ORC_LANES - 1 - l], carry, next);
+            double *b = z + ((size_t)g * ORC_LANES + l) * ORC_E;
+            for (int k = 0; k < ORC_E; ++k) b[k] = fma(c->pw[ORC_E - k], cin, b[k]);
+        }
+        carry = fma(c->gc, carry, A[g]);
+    }
+    free(A); free(Ssave);
+}
+
+/* sum of squares with the spec's reduction tree: lane-local fma chain, xor-butterfly over 64 lanes, serial
+ * sum over groups (mirrors the HIP kernels; replaces np.linalg.norm's BLAS ddot, vector.norm()). */
+double orc_sumsq_spec(const double *r, int n) {
+    int G = (n + ORC_GROUP - 1) / ORC_GROUP;
+    double tot = 0.0;
+    for (int g = 0; g < G; ++g) {
+        double a[ORC_LANES], b[ORC_LANES];
+        for (int l = 0; l < ORC_LANES; ++l) {
+            double acc = 0.0;
+            for (int k = 0; k < ORC_E; ++k) {
+                int j = (g * ORC_LANES + l) * ORC_E + k;
+                if (j < n) acc = fma(r[j], r[j], acc);
+            }
+            a[l] = acc;
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            for (int l = 0; l < ORC_LANES; ++l) b[l] = a[l] + a[l ^ off];
+            memcpy(a, b, sizeof(a));
+        }
+        tot = tot + a[0];
+    }
+    return tot;
+}
+
+/* ================================================================================================
+ * Steppers
+ * ============================================================================================== */
+enum { ORC_DAHLQUIST = 0, ORC_HEAT1D = 1, ORC_ADVECTION1D = 2 };
+enum { ORC_BE = 0, ORC_FE = 1, ORC_TR = 2, ORC_MR = 3 };
+
+typedef struct {
+    int kind, variant, n;
+    double fac;            /* heat: a/dx^2 ; advection: c/dx ; dahlquist: lambda */
+    int method;            /* dahlquist */
+    int K;                 /* separable forcing terms: b(x,t_i) = sum_k s_k(x)*tau_k(t_i) */
+    double *s;             /* [K][n] */
+    double *tau;           /* [K][nt] */
+    orc_cset *csets; int n_csets, cap_csets;
+    double *w1, *w2;       /* work (padded) */
+} orc_stepper;
+
+static orc_cset *get_cset(orc_stepper *st, double dt) {
+    for (int i = 0; i < st->n_csets; ++i)
+        if (memcmp(&st->csets[i].dt, &dt, sizeof(double)) == 0) return &st->csets[i];
+    if (st->n_csets == st->cap_csets) {
+        st->cap_csets = st->cap_csets ? 2 * st->cap_csets : 4;
+        st->csets = (orc_cset *)realloc(st->csets, sizeof(orc_cset) * (size_t)st->cap_csets);
+    }
+    orc_cset *c = &st->csets[st->n_csets++];
+    memset(c, 0, sizeof(*c));
+    if (st->kind == ORC_HEAT1D) cset_heat1d(c, st->n, st->fac, dt);
+    else cset_advection1d(c, st->n, st->fac, dt);
+    return c;
+}
+
+static int padded(int n) { return ((n + ORC_GROUP - 1) / ORC_GROUP) * ORC_GROUP; }
+
+/* heat_1d.py:198-217:  spsolve(dt*L + I, u + rhs(x, t_stop)*dt) */
+static void heat1d_rhs(const orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *d) {
+    int n = st->n;
+    if (st->K == 0) { memcpy(d, u, sizeof(double) * (size_t)n); return; }
+    for (int j = 0; j < n; ++j) {
+        double f = st->s[j] * st->tau[i_stop];
+        for (int k = 1; k < st->K; ++k) f = f + st->s[(size_t)k * n + j] * st->tau[(size_t)k * nt + i_stop];
+        d[j] = u[j] + f * dt;
+    }
+}
+
+static void heat1d_step_natural(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out) {
+    int n = st->n;
+    double beta = dt * st->fac, D = dt * (2.0 * st->fac) + 1.0;
+    double *d = st->w1, *cp = st->w2;
+    heat1d_rhs(st, nt, i_stop, dt, u, d);
+    /* Thomas algorithm on tridiag(-beta, D, -beta) */
+    double piv = D;
+    cp[0] = -beta / piv; d[0] = d[0] / piv;
+    for (int j = 1; j < n; ++j) {
+        piv = D + beta * cp[j - 1];
+        cp[j] = -beta / piv;
+        d[j] = (d[j] + beta * d[j - 1]) / piv;
+    }
+    out[n - 1] = d[n - 1];
+    for (int j = n - 2; j >= 0; --j) out[j] = d[j] - cp[j] * out[j + 1];
+}
+
+static void heat1d_step_spec(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out) {
+    int n = st->n, NP = padded(n), G = NP / ORC_GROUP;
+    orc_cset *c = get_cset(st, dt);
+    double *d = st->w1;
+    heat1d_rhs(st, nt, i_stop, dt, u, d);
+    for (int j = n; j < NP; ++j) d[j] = 0.0;
+    spec_scan_fwd(c, G, d);
+    for (int j = n; j < NP; ++j) d[j] = 0.0;
+    spec_scan_bwd(c, G, d);
+    double z0 = d[0] * c->ik;
+    for (int j = 0; j < n; ++j) out[j] = fma(-z0, c->tab[j], d[j] * c->ik);
+}
+
+/* advection_1d.py:129-143: spsolve(dt*L + I, u), L = (c/dx)(I - S_periodic) */
+static void advection1d_step_natural(orc_stepper *st, double dt, const double *u, double *out) {
+    int n = st->n;
+    double alpha = dt * st->fac, D = alpha + 1.0;
+    double *p = st->w1, *q = st->w2;
+    p[0] = u[0] / D; q[0] = alpha / D;
+    for (int j = 1; j < n; ++j) { p[j] = (u[j] + alpha * p[j - 1]) / D; q[j] = alpha * q[j - 1] / D; }
+    double xl = p[n - 1] / (1.0 - q[n - 1]);
+    for (int j = 0; j < n - 1; ++j) out[j] = p[j] + q[j] * xl;
+    out[n - 1] = xl;
+}
+
+static void advection1d_step_spec(orc_stepper *st, double dt, const double *u, double *out) {
+    int n = st->n, NP = padded(n), G = NP / ORC_GROUP;
+    orc_cset *c = get_cset(st, dt);
+    double *d = st->w1;
+    for (int j = 0; j < n; ++j) d[j] = u[j] * c->ik;
+    for (int j = n; j < NP; ++j) d[j] = 0.0;
+    spec_scan_fwd(c, G, d);
+    double xl = d[n - 1] * c->scal;
+    for (int j = 0; j < n; ++j) out[j] = fma(c->tab[j], xl, d[j]);
+}
+
+/* dahlquist.py:88-111 */
+static void dahlquist_step(const orc_stepper *st, double t_start, double t_stop, const double *u, double *out) {
+    double z = (t_stop - t_start) * st->fac;
+    switch (st->method) {
+    case ORC_BE: out[0] = 1.0 / (1.0 - z) * u[0]; break;
+    case ORC_FE: out[0] = (1.0 + z) * u[0]; break;
+    case ORC_TR: out[0] = (1.0 + z / 2.0) / (1.0 - z / 2.0) * u[0]; break;
+    default: { double k1 = -1.0 / (1.0 - z / 2.0) * u[0]; out[0] = u[0] + (t_stop - t_start) * k1; }
+    }
+}
+
+/* ================================================================================================
+ * Problem / solver state (single rank: the reference is bit-identical for every P)
+ * ============================================================================================== */
+typedef struct {
+    int nt, n;              /* time points, DOFs per vector */
+    double *t;
+    orc_stepper st;
+    double *u, *v, *g;      /* slabs [nt][n] ; v,g NULL on level 0 */
+    double *u0;             /* vector_t_start of this level */
+    uint8_t *is_c;
+    int transfer;           /* to next coarser level: 0 copy, 1 heat full-weighting/linear */
+} orc_level;
+
+typedef struct {
+    int n_levels;
+    orc_level L[ORC_MAX_LEVELS];
+    double weight_c;
+    int cf_iter[ORC_MAX_LEVELS];
+    int cycle_type;         /* 0 V, 1 F */
+    int nested, t_norm, conv_crit, max_iter, norm_spec;
+    double tol;
+    double *save_last;      /* conv_crit 1: clone of u[0] */
+    double *tmp1, *tmp2, *tmp3;
+    int64_t phi_count[ORC_MAX_LEVELS];
+} orc_problem;
+
+orc_problem *orc_problem_create(int n_levels) {
+    orc_problem *p = (orc_problem *)calloc(1, sizeof(orc_problem));
+    p->n_levels = n_levels; p->weight_c = 1.0; p->nested = 1; p->t_norm = 2; p->max_iter = 100; p->tol = 1e-7;
+    p->norm_spec = 1;
+    for (int l = 0; l < ORC_MAX_LEVELS; ++l) p->cf_iter[l] = 1;
+    return p;
+}
+
+static void free_stepper(orc_stepper *st) {
+    for (int i = 0; i < st->n_csets; ++i) free(st->csets[i].tab);
+    free(st->csets); free(st->s); free(st->tau); free(st->w1); free(st->w2);
+}
+
+void orc_problem_destroy(orc_problem *p) {
+    if (!p) return;
+    for (int l = 0; l < p->n_levels; ++l) {
+        orc_level *L = &p->L[l];
+        free(L->t); free(L->u); free(L->v); free(L->g); free(L->u0); free(L->is_c);
+        free_stepper(&L->st);
+    }
+    free(p->save_last); free(p->tmp1); free(p->tmp2); free(p->tmp3);
+    free(p);
+}
+
+static void level_common(orc_problem *p, int lvl, int nt, const double *t, int n, const double *u0) {
+    orc_level *L = &p->L[lvl];
+    L->nt = nt; L->n = n;
+    L->t = (double *)malloc(sizeof(double) * (size_t)nt);
+    memcpy(L->t, t, sizeof(double) * (size_t)nt);
+    L->u0 = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(L->u0, u0, sizeof(double) * (size_t)n);
+    L->st.n = n;
+    L->st.w1 = (double *)calloc((size_t)padded(n), sizeof(double));
+    L->st.w2 = (double *)calloc((size_t)padded(n), sizeof(double));
+}
+
+/* kind-specific level setup. variant: 0 natural, 1 spec. s: [K][n], tau: [K][nt] (may be NULL when K=0) */
+void orc_problem_set_level_heat1d(orc_problem *p, int lvl, int nt, const double *t, int n, double fac, int K,
+                                  const double *s, const double *tau, const double *u0, int variant) {
+    level_common(p, lvl, nt, t, n, u0);
+    orc_stepper *st = &p->L[lvl].st;
+    st->kind = ORC_HEAT1D; st->variant = variant; st->fac = fac; st->K = K;
+    if (K > 0) {
+        st->s = (double *)malloc(sizeof(double) * (size_t)K * n);
+        st->tau = (double *)malloc(sizeof(double) * (size_t)K * nt);
+        memcpy(st->s, s, sizeof(double) * (size_t)K * n);
+        memcpy(st->tau, tau, sizeof(double) * (size_t)K * nt);
+    }
+}
+
+void orc_problem_set_level_advection1d(orc_problem *p, int lvl, int nt, const double *t, int n, double fac,
+                                       const double *u0, int variant) {
+    level_common(p, lvl, nt, t, n, u0);
+    orc_stepper *st = &p->L[lvl].st;
+    st->kind = ORC_ADVECTION1D; st->variant = variant; st->fac = fac;
+}
+
+void orc_problem_set_level_dahlquist(orc_problem *p, int lvl, int nt, const double *t, double lambda, int method,
+                                     double u0) {
+    level_common(p, lvl, nt, t, 1, &u0);
+    orc_stepper *st = &p->L[lvl].st;
+    st->kind = ORC_DAHLQUIST; st->fac = lambda; st->method = method;
+}
+
+void orc_problem_set_transfer(orc_problem *p, int lvl, int kind) { p->L[lvl].transfer = kind; }
+
+void orc_problem_set_options(orc_problem *p, double weight_c, const int32_t *cf_iter, int cycle_type, int nested,
+                             int t_norm, int conv_crit, int max_iter, double tol, int norm_spec) {
+    p->weight_c = weight_c; p->cycle_type = cycle_type; p->nested = nested; p->t_norm = t_norm;
+    p->conv_crit = conv_crit; p->max_iter = max_iter; p->tol = tol; p->norm_spec = norm_spec;
+    for (int l = 0; l < p->n_levels; ++l) p->cf_iter[l] = cf_iter[l];
+}
+
+/* Phi on level lvl from point i-1 to point i (Application.step, application.py:98-107) */
+static void phi(orc_problem *p, int lvl, int i, const double *u_in, double *out) {
+    orc_level *L = &p->L[lvl];
+    double t_start = L->t[i - 1], t_stop = L->t[i], dt = t_stop - t_start;
+    p->phi_count[lvl]++;
+    switch (L->st.kind) {
+    case ORC_HEAT1D:
+        if (L->st.variant) heat1d_step_spec(&L->st, L->nt, i, dt, u_in, out);
+        else heat1d_step_natural(&L->st, L->nt, i, dt, u_in, out);
+        break;
+    case ORC_ADVECTION1D:
+        if (L->st.variant) advection1d_step_spec(&L->st, dt, u_in, out);
+        else advection1d_step_natural(&L->st, dt, u_in, out);
+        break;
+    default: dahlquist_step(&L->st, t_start, t_stop, u_in, out);
+    }
+}
+
+/* single Phi application for tests: out = step(u, t[i-1] -> t[i]) on level lvl */
+void orc_phi(orc_problem *p, int lvl, int i, const double *u_in, double *out) { phi(p, lvl, i, u_in, out); }
+
+/* examples/example_spatial_coarsening.py:33-55 / :58-82 ; kind 0: GridTransferCopy (grid_transfer_copy.py:23-47) */
+static void restrict_vec(int kind, const double *f, int nf, double *c, int nc) {
+    if (kind == 0) { memcpy(c, f, sizeof(double) * (size_t)nc); return; }
+    (void)nf;
+    for (int i = 0; i < nc; ++i) c[i] = f[2 * i] * 1.0 / 4.0 + f[2 * i + 1] * 1.0 / 2.0 + f[2 * i + 2] * 1.0 / 4.0;
+}
+
+static void interp_vec(int kind, const double *c, int nc, double *f, int nf) {
+    if (kind == 0) { memcpy(f, c, sizeof(double) * (size_t)nf); return; }
+    for (int j = 0; j < nf; ++j) f[j] = 0.0;
+    for (int i = 0; i < nc; ++i) {
+        f[2 * i] += 1.0 / 2.0 * c[i];
+        f[2 * i + 1] += c[i];
+        f[2 * i + 2] += 1.0 / 2.0 * c[i];
+    }
+}
+
+#define ROW(a, L, i) ((a) + (size_t)(i) * (size_t)(L)->n)
+
+/* mgrit.py:840-858 (+ level C/F sets, mgrit.py:767-770) */
+void orc_problem_init_state(orc_problem *p) {
+    int32_t nt[ORC_MAX_LEVELS];
+    int64_t off[ORC_MAX_LEVELS + 1];
+    int maxn = 1;
+    off[0] = 0;
+    for (int l = 0; l < p->n_levels; ++l) { nt[l] = p->L[l].nt; off[l + 1] = off[l] + nt[l]; if (p->L[l].n > maxn) maxn = p->L[l].n; }
+    double *t_all = (double *)malloc(sizeof(double) * (size_t)off[p->n_levels]);
+    for (int l = 0; l < p->n_levels; ++l) memcpy(t_all + off[l], p->L[l].t, sizeof(double) * (size_t)nt[l]);
+    for (int l = 0; l < p->n_levels; ++l) {
+        orc_level *L = &p->L[l];
+        size_t sz = (size_t)L->nt * (size_t)L->n;
+        free(L->u); free(L->v); free(L->g); free(L->is_c);
+        L->u = (double *)calloc(sz, sizeof(double));
+        L->v = l ? (double *)calloc(sz, sizeof(double)) : NULL;
+        L->g = l ? (double *)calloc(sz, sizeof(double)) : NULL;
+        memcpy(L->u, L->u0, sizeof(double) * (size_t)L->n);      /* u[lvl][0] = vector_t_start.clone() */
+        L->is_c = (uint8_t *)malloc((size_t)L->nt);
+        global_is_c(p->n_levels, nt, t_all, off, l, L->is_c);
+    }
+    free(t_all);
+    free(p->tmp1); free(p->tmp2); free(p->tmp3);
+    p->tmp1 = (double *)calloc((size_t)maxn, sizeof(double));
+    p->tmp2 = (double *)calloc((size_t)maxn, sizeof(double));
+    p->tmp3 = (double *)calloc((size_t)maxn, sizeof(double));
+    memset(p->phi_count, 0, sizeof(p->phi_count));
+}
+
+double *orc_state_ptr(orc_problem *p, int which, int lvl) {
+    orc_level *L = &p->L[lvl];
+    return which == 0 ? L->u : which == 1 ? L->v : L->g;
+}
+
+int64_t orc_phi_count(orc_problem *p, int lvl) { return p->phi_count[lvl]; }
+
+/* mgrit.py:292-333 (single rank: intervals are independent, ascending inside an interval) */
+void orc_f_relax(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl];
+    for (int i = 1; i < L->nt; ++i) {
+        if (L->is_c[i]) continue;
+        if (lvl == 0) phi(p, lvl, i, ROW(L->u, L, i - 1), ROW(L->u, L, i));
+        else {
+            phi(p, lvl, i, ROW(L->u, L, i - 1), p->tmp1);
+            double *ui = ROW(L->u, L, i); const double *gi = ROW(L->g, L, i);
+            for (int j = 0; j < L->n; ++j) ui[j] = gi[j] + p->tmp1[j];
+        }
+    }
+}
+
+/* mgrit.py:335-370 */
+void orc_c_relax(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl];
+    double w = p->weight_c, w1 = 1.0 - p->weight_c;
+    for (int i = 1; i < L->nt; ++i) {
+        if (!L->is_c[i]) continue;
+        phi(p, lvl, i, ROW(L->u, L, i - 1), p->tmp1);
+        double *ui = ROW(L->u, L, i);
+        if (lvl == 0) for (int j = 0; j < L->n; ++j) ui[j] = p->tmp1[j] * w + ui[j] * w1;
+        else { const double *gi = ROW(L->g, L, i); for (int j = 0; j < L->n; ++j) ui[j] = (gi[j] + p->tmp1[j]) * w + ui[j] * w1; }
+    }
+}
+
+/* mgrit.py:459-486 */
+void orc_forward_solve(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl];
+    for (int i = 1; i < L->nt; ++i) {
+        if (lvl == 0) phi(p, lvl, i, ROW(L->u, L, i - 1), ROW(L->u, L, i));
+        else {
+            phi(p, lvl, i, ROW(L->u, L, i - 1), p->tmp1);
+            double *ui = ROW(L->u, L, i); const double *gi = ROW(L->g, L, i);
+            for (int j = 0; j < L->n; ++j) ui[j] = gi[j] + p->tmp1[j];
+        }
+    }
+}
+
+/* mgrit.py:488-549 */
+void orc_fas_residual(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl], *C = &p->L[lvl + 1];
+    int j = 0;
+    for (int i = 0; i < L->nt; ++i) if (L->is_c[i]) { restrict_vec(L->transfer, ROW(L->u, L, i), L->n, ROW(C->u, C, j), C->n); ++j; }
+    memcpy(C->v, C->u, sizeof(double) * (size_t)C->nt * (size_t)C->n);
+    j = 0;
+    for (int i = 0; i < L->nt; ++i) {
+        if (!L->is_c[i]) continue;
+        if (j != 0) {
+            double *a = p->tmp1, *r = p->tmp2, *b = p->tmp3;
+            phi(p, lvl, i, ROW(L->u, L, i - 1), a);
+            const double *ui = ROW(L->u, L, i);
+            if (lvl == 0) for (int k = 0; k < L->n; ++k) a[k] = a[k] - ui[k];
+            else { const double *gi = ROW(L->g, L, i); for (int k = 0; k < L->n; ++k) a[k] = gi[k] - ui[k] + a[k]; }
+            restrict_vec(L->transfer, a, L->n, r, C->n);
+            phi(p, lvl + 1, j, ROW(C->v, C, j - 1), b);
+            double *gj = ROW(C->g, C, j); const double *vj = ROW(C->v, C, j);
+            for (int k = 0; k < C->n; ++k) gj[k] = r[k] + vj[k] - b[k];
+        }
+        ++j;
+    }
+}
+
+/* mgrit.py:715-726 */
+void orc_error_correction(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl], *C = &p->L[lvl + 1];
+    int j = 0;
+    for (int i = 0; i < L->nt; ++i) {
+        if (!L->is_c[i]) continue;
+        if (j != 0) {
+            const double *uj = ROW(C->u, C, j), *vj = ROW(C->v, C, j);
+            for (int k = 0; k < C->n; ++k) p->tmp1[k] = uj[k] - vj[k];
+            interp_vec(L->transfer, p->tmp1, C->n, p->tmp2, L->n);
+            double *ui = ROW(L->u, L, i);
+            for (int k = 0; k < L->n; ++k) ui[k] = ui[k] + p->tmp2[k];
+        }
+        ++j;
+    }
+}
+
+/* mgrit.py:261-290 */
+void orc_iteration(orc_problem *p, int lvl, int cycle_type, int iteration, int first_f) {
+    if (lvl == p->n_levels - 1) { orc_forward_solve(p, lvl); return; }
+    if ((lvl > 0 || (iteration == 0 && lvl == 0)) && first_f) orc_f_relax(p, lvl);
+    for (int k = 0; k < p->cf_iter[lvl]; ++k) { orc_c_relax(p, lvl); orc_f_relax(p, lvl); }
+    orc_fas_residual(p, lvl);
+    orc_iteration(p, lvl + 1, cycle_type, iteration, 1);
+    orc_error_correction(p, lvl);
+    orc_f_relax(p, lvl);
+    if (lvl != 0 && cycle_type == 1) orc_iteration(p, lvl, 0, iteration, 0);
+}
+
+/* mgrit.py:551-566 */
+void orc_nested_iteration(orc_problem *p) {
+    orc_forward_solve(p, p->n_levels - 1);
+    for (int lvl = p->n_levels - 2; lvl >= 0; --lvl) {
+        orc_level *L = &p->L[lvl], *C = &p->L[lvl + 1];
+        int j = 0;
+        for (int i = 0; i < L->nt; ++i) {
+            if (!L->is_c[i]) continue;
+            if (j != 0) interp_vec(L->transfer, ROW(C->u, C, j), C->n, ROW(L->u, L, i), L->n);
+            ++j;
+        }
+        if (lvl > 0) orc_iteration(p, lvl, 0, 0, 1);
+    }
+}
+
+static double vec_norm(const orc_problem *p, const double *r, int n) {
+    if (p->norm_spec) return sqrt(orc_sumsq_spec(r, n));
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += r[j] * r[j];
+    return sqrt(s);
+}
+
+/* mgrit.py:387-413 -> per-C-point residual norms (count returned) */
+int orc_compute_residual(orc_problem *p, double *r_norm) {
+    orc_level *L = &p->L[0];
+    int cnt = 0;
+    for (int i = 1; i < L->nt; ++i) {
+        if (!L->is_c[i]) continue;
+        phi(p, 0, i, ROW(L->u, L, i - 1), p->tmp1);
+        const double *ui = ROW(L->u, L, i);
+        for (int j = 0; j < L->n; ++j) p->tmp1[j] = p->tmp1[j] - ui[j];
+        r_norm[cnt++] = vec_norm(p, p->tmp1, L->n);
+    }
+    return cnt;
+}
+
+/* mgrit.py:372-385 */
+static int compute_jump(orc_problem *p, double *r_norm) {
+    orc_level *L = &p->L[0];
+    int cnt = 0;
+    for (int i = 1; i < L->nt; ++i) {
+        if (!L->is_c[i]) continue;
+        const double *ui = ROW(L->u, L, i), *si = ROW(p->save_last, L, i);
+        for (int j = 0; j < L->n; ++j) p->tmp1[j] = ui[j] - si[j];
+        r_norm[cnt++] = vec_norm(p, p->tmp1, L->n);
+    }
+    memcpy(p->save_last, L->u, sizeof(double) * (size_t)L->nt * (size_t)L->n);
+    return cnt;
+}
+
+/* np.linalg.norm(list, ord) with ord in {1, None(2), inf}  (mgrit.py:182,430) */
+double orc_time_norm(const double *v, int n, int t_norm) {
+    double s = 0.0;
+    if (t_norm == 1) { for (int i = 0; i < n; ++i) s += fabs(v[i]); return s; }
+    if (t_norm == 3) { for (int i = 0; i < n; ++i) if (fabs(v[i]) > s) s = fabs(v[i]); return s; }
+    for (int i = 0; i < n; ++i) s += v[i] * v[i];
+    return sqrt(s);
+}
+
+/* Mgrit.__init__ state part + nested iteration (mgrit.py:206-235). keep_u0: keep caller-provided level-0 guess */
+void orc_setup(orc_problem *p) {
+    if (p->nested) orc_nested_iteration(p);
+    if (p->conv_crit == 1) {
+        orc_level *L = &p->L[0];
+        size_t sz = (size_t)L->nt * (size_t)L->n;
+        free(p->save_last);
+        p->save_last = (double *)malloc(sizeof(double) * sz);
+        memcpy(p->save_last, L->u, sizeof(double) * sz);
+    }
+}
+
+/* Mgrit.solve (mgrit.py:590-646). conv_out capacity max_iter. Returns number of iterations performed. */
+int orc_solve(orc_problem *p, double *conv_out) {
+    orc_level *L = &p->L[0];
+    double *r_norm = (double *)malloc(sizeof(double) * (size_t)L->nt);
+    int it;
+    for (it = 0; it < p->max_iter; ++it) {
+        orc_iteration(p, 0, p->cycle_type, it, 1);
+        int cnt = (p->conv_crit == 0) ? orc_compute_residual(p, r_norm) : compute_jump(p, r_norm);
+        conv_out[it] = orc_time_norm(r_norm, cnt, p->t_norm);
+        if (conv_out[it] < p->tol || it == p->max_iter - 1) { ++it; break; }
+    }
+    free(r_norm);
+    return it;
+}
+
+/* stand-alone helpers for unit tests ---------------------------------------------------------- */
+void orc_restrict(int kind, const double *f, int nf, double *c, int nc) { restrict_vec(kind, f, nf, c, nc); }
+void orc_interp(int kind, const double *c, int nc, double *f, int nf) { interp_vec(kind, c, nc, f, nf); }
+
+/* coefficient-set introspection (tests compare the product's host-built tables with these) */
+int orc_cset_dump(orc_problem *p, int lvl, double dt, double *scalars /*[4+17+6+1+64]*/, double *tab) {
+    orc_stepper *st = &p->L[lvl].st;
+    if (st->kind == ORC_DAHLQUIST) return -1;
+    orc_cset *c = get_cset(st, dt);
+    int o = 0;
+    scalars[o++] = c->rho; scalars[o++] = c->ik; scalars[o++] = c->scal; scalars[o++] = c->gc;
+    for (int k = 0; k <= ORC_E; ++k) scalars[o++] = c->pw[k];
+    for (int s = 0; s < 6; ++s) scalars[o++] = c->sc[s];
+    for (int l = 0; l < ORC_LANES; ++l) scalars[o++] = c->lp[l];
+    memcpy(tab, c->tab, sizeof(double) * (size_t)st->n);
+    return o;
+}

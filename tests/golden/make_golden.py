@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the *reference* (PyMGRIT, /root/reference) in the build container.
+
+The reference is pure Python and cannot travel to the GPU box, so this script imports it here (with the
+size-1 ``mpi4py`` stand-in in ``tests/golden/_mpi_stub``) and writes small data-only fixtures:
+
+  tests/golden/layout.json      index sets / comm flags per (case, P, rank, level) via the rank-overwrite
+                                trick of reference tests/core/test_mgrit.py:86-218
+  tests/golden/phi.npz/.json    known-answer Application.step outputs (Heat1D, Advection1D, Dahlquist)
+  tests/golden/solve.json       residual histories (full precision) + selected solution vectors
+  tests/golden/ref_results.json the reference's own tests/mpi/results/* files (data) + literal KATs cited
+
+Usage:  python tests/golden/make_golden.py            (needs /root/reference; ~2 min)
+Nothing here is imported by the product; fixtures are data (inputs + expected outputs) only.
+"""
+import hashlib
+import json
+import os
+import sys
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("PYMGRIT_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "_mpi_stub"))
+sys.path.insert(0, os.path.join(REF, "src"))
+warnings.filterwarnings("ignore")
+
+import numpy as np  # noqa: E402
+from pymgrit.core.mgrit import Mgrit  # noqa: E402
+from pymgrit.core.grid_transfer_copy import GridTransferCopy  # noqa: E402
+from pymgrit.core.simple_setup_problem import simple_setup_problem  # noqa: E402
+from pymgrit.dahlquist.dahlquist import Dahlquist  # noqa: E402
+from pymgrit.heat.heat_1d import Heat1D, VectorHeat1D  # noqa: E402
+from pymgrit.advection.advection_1d import Advection1D, VectorAdvection1D  # noqa: E402
+
+QUIET = 30
+
+
+def rhs(x, t):
+    return - np.sin(np.pi * x) * (np.sin(t) - 1 * np.pi ** 2 * np.cos(t))
+
+
+def init_cond(x):
+    return np.sin(np.pi * x)
+
+
+# --------------------------------------------------------------------------------------------------
+# layout fixtures
+# --------------------------------------------------------------------------------------------------
+def digest(arr):
+    a = np.ascontiguousarray(np.asarray(arr, dtype=np.int64))
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def layout_for(problem, size, full):
+    """rank-overwrite trick (reference tests/core/test_mgrit.py:109-129)."""
+    mgrit = Mgrit(problem=problem, nested_iteration=False, logging_lvl=QUIET)
+    out = []
+    for rank in range(size):
+        mgrit.comm_time_size = size
+        mgrit.comm_time_rank = rank
+        mgrit.int_start = 0
+        mgrit.int_stop = 0
+        for name in ("cpts", "comm_front", "comm_back", "index_local_c", "index_local_f", "index_local",
+                     "first_is_f_point", "first_is_c_point", "last_is_f_point", "last_is_c_point",
+                     "send_to", "get_from"):
+            setattr(mgrit, name, [])
+        for lvl in range(mgrit.lvl_max):
+            mgrit.t.append(np.copy(mgrit.problem[lvl].t))
+            mgrit.setup_points_and_comm_info(lvl=lvl)
+        levels = []
+        for lvl in range(mgrit.lvl_max):
+            f_sorted = np.sort(np.asarray(mgrit.index_local_f[lvl], dtype=np.int64))
+            rec = {
+                "n_local": int(len(mgrit.t[lvl])),
+                "t_first": float(mgrit.t[lvl][0]) if len(mgrit.t[lvl]) else None,
+                "t_last": float(mgrit.t[lvl][-1]) if len(mgrit.t[lvl]) else None,
+                "comm_front": bool(mgrit.comm_front[lvl]), "comm_back": bool(mgrit.comm_back[lvl]),
+                "first_is_c_point": bool(mgrit.first_is_c_point[lvl]),
+                "first_is_f_point": bool(mgrit.first_is_f_point[lvl]),
+                "last_is_c_point": bool(mgrit.last_is_c_point[lvl]),
+                "last_is_f_point": bool(mgrit.last_is_f_point[lvl]),
+                "send_to": int(mgrit.send_to[lvl]), "get_from": int(mgrit.get_from[lvl]),
+                "m": int(mgrit.m[lvl]),
+            }
+            arrays = {"cpts": mgrit.cpts[lvl], "index_local": mgrit.index_local[lvl],
+                      "index_local_c": mgrit.index_local_c[lvl], "index_local_f_sorted": f_sorted}
+            for k, v in arrays.items():
+                v = np.asarray(v, dtype=np.int64)
+                if full:
+                    rec[k] = v.tolist()
+                else:
+                    rec[k + "_len"] = int(v.size)
+                    rec[k + "_sha256"] = digest(v)
+                    rec[k + "_first"] = int(v[0]) if v.size else None
+                    rec[k + "_last"] = int(v[-1]) if v.size else None
+            if full:
+                # the exact (CPython set-iteration dependent) order of the reference, informational
+                rec["index_local_f_ref_order"] = np.asarray(mgrit.index_local_f[lvl], dtype=np.int64).tolist()
+            levels.append(rec)
+        out.append(levels)
+    return out
+
+
+def dahl_levels(ts):
+    return [Dahlquist(t_interval=t) for t in ts]
+
+
+def make_layout():
+    cases = {}
+
+    def add(name, spec, ts, sizes, full=True):
+        problem = dahl_levels(ts)
+        cases[name] = {"spec": spec, "sizes": {}}
+        for p in sizes:
+            cases[name]["sizes"][str(p)] = layout_for(problem, p, full)
+
+    t65 = np.linspace(0, 2, 65)
+    add("nt65_m4_m4", {"t_stop": 2, "nt": [65, 17, 5], "kind": "linspace"},
+        [t65, np.linspace(0, 2, 17), np.linspace(0, 2, 5)], [1, 2, 3, 4, 5, 7, 8])
+    t101 = np.linspace(0, 5, 101)
+    add("nt101_m2", {"t_stop": 5, "nt": [101, 51], "kind": "stride", "strides": [2]},
+        [t101, t101[::2]], [1, 2, 3, 4, 5])
+    add("nt101_m2_m2", {"t_stop": 5, "nt": [101, 51, 26], "kind": "stride", "strides": [2, 2]},
+        [t101, t101[::2], t101[::4]], [1, 2, 3, 5])
+    t129 = np.linspace(0, 5, 129)
+    l1 = t129[::16]
+    add("nt129_m16_2_2_2", {"t_stop": 5, "nt": [129], "kind": "stride", "strides": [16, 2, 2, 2]},
+        [t129, l1, l1[::2], l1[::4], l1[::8]], [1, 2, 3, 4, 5, 6, 7])
+    t65b = np.linspace(0, 5, 65)
+    idx = [0, 3, 10, 12, 14, 17, 23, 27, 33, 34, 55, 57, 59, 61, 63, 64]
+    v1 = t65b[idx]
+    add("nt65_varying", {"t_stop": 5, "nt": [65], "kind": "index", "index": idx, "strides": [2, 2, 2]},
+        [t65b, v1, v1[::2], v1[::4], v1[::8]], [1, 2, 3, 4, 5, 6, 7])
+    t4097 = np.linspace(0, 2, 4097)
+    add("nt4097_m4_m4", {"t_stop": 2, "nt": [4097], "kind": "stride", "strides": [4, 4]},
+        [t4097, t4097[::4], t4097[::16]], [1, 3, 4, 8], full=False)
+    t65537 = np.linspace(0, 2, 65537)
+    add("nt65537_m4_m4", {"t_stop": 2, "nt": [65537], "kind": "stride", "strides": [4, 4]},
+        [t65537, t65537[::4], t65537[::16]], [8], full=False)
+    t16385 = np.linspace(0, 1, 16385)
+    add("nt16385_m8", {"t_stop": 1, "nt": [16385], "kind": "stride", "strides": [8]},
+        [t16385, t16385[::8]], [8], full=False)
+    return cases
+
+
+# --------------------------------------------------------------------------------------------------
+# Phi known-answer fixtures
+# --------------------------------------------------------------------------------------------------
+def heat_input(x, k):
+    return np.sin(np.pi * x) + 0.25 * np.sin(3 * np.pi * x + 0.1 * k) + 0.05 * np.cos(17.0 * x * x)
+
+
+def make_phi():
+    meta = {"heat1d": [], "advection1d": [], "dahlquist": []}
+    arrays = {}
+    # Heat1D: (nx, x_end, a, t_start, t_stop, forcing?)
+    heat_cases = [(6, 1.0, 1.0, 0.0, 0.1, False), (6, 1.0, 1.0, 0.0, 0.1, True), (5, 2.0, 1.0, 0.5, 0.53125, True),
+                  (17, 2.0, 1.0, 1.0, 1.015625, True), (33, 1.0, 0.7, 0.25, 0.375, True),
+                  (1001, 1.0, 1.0, 0.0, 0.03125, True), (1024, 1.0, 1.0, 1.0, 1.0 + 2.0 / 4096, True),
+                  (1024, 1.0, 1.0, 0.5, 0.5 + 2.0 / 256, True),
+                  (4096, 1.0, 1.0, 0.5, 0.5 + 2.0 / 1024, True),
+                  (16384, 1.0, 1.0, 1.0, 1.0 + 2.0 / 65536, True), (16384, 1.0, 1.0, 1.0, 1.0 + 2.0 / 4096, True)]
+    for k, (nx, x_end, a, t0, t1, forcing) in enumerate(heat_cases):
+        app = Heat1D(x_start=0, x_end=x_end, nx=nx, a=a, init_cond=init_cond,
+                     rhs=rhs if forcing else (lambda x, t: x * 0), t_start=0, t_stop=2, nt=3)
+        u = VectorHeat1D(app.nx)
+        u.set_values(heat_input(app.x, k))
+        out = app.step(u, t0, t1).get_values()
+        key = f"heat1d_{k}"
+        arrays[key] = out
+        meta["heat1d"].append({"key": key, "nx": nx, "x_end": x_end, "a": a, "t_start": t0, "t_stop": t1,
+                               "forcing": forcing, "input": "heat_input(x,k)", "k": k})
+    # Advection1D
+    adv_cases = [(6, 1.0, 0.0, 0.1), (129, 1.0, 0.0, 2.0 / 128), (129, 1.0, 1.0, 1.0 + 2.0 / 64), (8193, 1.0, 0.0, 2.0 / 32768),
+                 (4097, 0.5, 0.0, 2.0 / 16384)]
+    for k, (nx, c, t0, t1) in enumerate(adv_cases):
+        app = Advection1D(c=c, x_start=-1, x_end=1, nx=nx, t_start=0, t_stop=2, nt=3)
+        u = VectorAdvection1D(app.nx)
+        u.set_values(np.exp(-app.x ** 2) + 0.1 * np.sin(5 * np.pi * app.x + k))
+        out = app.step(u, t0, t1).get_values()
+        key = f"advection1d_{k}"
+        arrays[key] = out
+        meta["advection1d"].append({"key": key, "nx": nx, "c": c, "t_start": t0, "t_stop": t1, "k": k})
+    for method in ("BE", "FE", "TR", "MR"):
+        app = Dahlquist(method=method, t_start=0, t_stop=5, nt=11)
+        from pymgrit.dahlquist.dahlquist import VectorDahlquist
+        vals = [float(app.step(VectorDahlquist(0.75), 0.3, 0.3 + h).get_values()) for h in (0.05, 0.5, 0.1)]
+        meta["dahlquist"].append({"method": method, "u": 0.75, "t_start": 0.3, "h": [0.05, 0.5, 0.1], "out": vals})
+    return meta, arrays
+
+
+# --------------------------------------------------------------------------------------------------
+# solve fixtures
+# --------------------------------------------------------------------------------------------------
+sys.path.insert(0, os.path.join(REF, "examples"))
+from example_spatial_coarsening import GridTransferHeat  # noqa: E402  (reference class, imported not copied)
+
+
+def run(problem, sample_pts=(), sample_lvl0=True, **kw):
+    kw.setdefault("logging_lvl", QUIET)
+    m = Mgrit(problem=problem, **kw)
+    info = m.solve()
+    rec = {"conv": [float(c) for c in info["conv"]]}
+    if sample_lvl0:
+        rec["samples"] = {}
+        for i in sample_pts:
+            vals = m.u[0][i].get_values()
+            rec["samples"][str(i)] = np.asarray(vals, dtype=float).ravel().tolist()
+    return rec
+
+
+def heat_levels(nx, nts, x_end=1.0, a=1.0, t_stop=2.0, forcing=True):
+    return [Heat1D(x_start=0, x_end=x_end, nx=nx, a=a, init_cond=init_cond,
+                   rhs=rhs if forcing else (lambda x, t: x * 0), t_start=0, t_stop=t_stop, nt=nt) for nt in nts]
+
+
+def make_solve(big=True):
+    out = {}
+    # --- Dahlquist family (config 1 = example_dahlquist.py)
+    d = simple_setup_problem(Dahlquist(t_start=0, t_stop=5, nt=101), level=2, coarsening=2)
+    out["dahlquist_config1"] = run(d, tol=1e-10, sample_pts=(0, 1, 50, 100))
+    out["dahlquist_3lvl"] = run(simple_setup_problem(Dahlquist(t_start=0, t_stop=5, nt=101), 3, 2), tol=1e-10,
+                                sample_pts=(100,))
+    out["dahlquist_F"] = run(simple_setup_problem(Dahlquist(t_start=0, t_stop=5, nt=129), 4, 2), tol=1e-10,
+                             cycle_type='F', sample_pts=(128,))
+    out["dahlquist_time_integrators"] = run([Dahlquist(t_start=0, t_stop=5, nt=101, method='MR'),
+                                             Dahlquist(t_start=0, t_stop=5, nt=51, method='BE')],
+                                            sample_pts=(100,))
+    for meth in ("FE", "TR"):
+        out[f"dahlquist_{meth}"] = run(simple_setup_problem(Dahlquist(t_start=0, t_stop=5, nt=101, method=meth), 2, 2),
+                                       tol=1e-10, sample_pts=(100,))
+    t129 = np.linspace(0, 5, 129)
+    l1 = t129[::16]
+    out["dahlquist_procs_without_points"] = run(dahl_levels([t129, l1, l1[::2], l1[::4], l1[::8]]), tol=1e-10,
+                                                sample_pts=(128,))
+    t65b = np.linspace(0, 5, 65)
+    v1 = t65b[[0, 3, 10, 12, 14, 17, 23, 27, 33, 34, 55, 57, 59, 61, 63, 64]]
+    out["dahlquist_varying_coarsening"] = run(dahl_levels([t65b, v1, v1[::2], v1[::4], v1[::8]]), tol=1e-10,
+                                              nested_iteration=False, sample_pts=(64,))
+    # --- Heat1D small (tests/core/test_mgrit.py:59-70)
+    h = heat_levels(5, [65, 17, 5], x_end=2.0)
+    out["heat_nx5_test_mgrit"] = run(h, cf_iter=1, nested_iteration=True, max_iter=2, sample_pts=(1, 32, 64))
+    out["heat_nx5_to_tol"] = run(h, cf_iter=1, nested_iteration=True, max_iter=12, tol=1e-12, sample_pts=(64,))
+    # --- Heat1D nx=33, nt=65, 3 levels m=4: option sweep
+    def h33():
+        return heat_levels(33, [65, 17, 5])
+    opts = {
+        "V_nested": dict(), "V_nonested": dict(nested_iteration=False),
+        "F_nested": dict(cycle_type='F'), "F_nonested": dict(cycle_type='F', nested_iteration=False),
+        "V_weight13": dict(weight_c=1.3, nested_iteration=False), "V_cf2": dict(cf_iter=2),
+        "V_cflist": dict(cf_iter=[2, 1, 1]), "V_cf0": dict(cf_iter=0), "V_tnorm1": dict(t_norm=1), "V_tnorm3": dict(t_norm=3),
+        "V_jump": dict(conv_crit=1), "F_weight13_cf2": dict(cycle_type='F', weight_c=1.3, cf_iter=2),
+    }
+    for name, kw in opts.items():
+        out["heat_nx33_" + name] = run(h33(), tol=1e-9, max_iter=8, sample_pts=(1, 33, 64), **kw)
+    np.random.seed(0)
+    out["heat_nx33_V_random"] = run(h33(), tol=1e-9, max_iter=8, random_init_guess=True, nested_iteration=False,
+                                    sample_pts=(64,))
+    out["heat_nx33_2lvl_m8"] = run(heat_levels(33, [65, 9]), tol=1e-9, max_iter=8, sample_pts=(64,))
+    out["heat_nx33_1lvl"] = run(heat_levels(33, [65]), max_iter=2, sample_pts=(1, 64))
+    out["heat_nx33_noforcing"] = run(heat_levels(33, [65, 17, 5], forcing=False), tol=1e-9, max_iter=8, sample_pts=(64,))
+    # --- shrunken config 3: nx=257 nt=257 3-level m=4 (stiffer)
+    out["heat_nx257_nt257"] = run(heat_levels(257, [257, 65, 17]), tol=1e-9, max_iter=10, sample_pts=(128, 256))
+    # --- example_heat_1d.py / example_weighted_jacobi.py (tests/mpi/results/heat_1d, weighted_jacobi)
+    if big:
+        h5 = heat_levels(1001, [65, 33, 17, 9, 5])
+        out["heat_example_F5"] = run(h5, cf_iter=1, cycle_type='F', nested_iteration=False, max_iter=10,
+                                     random_init_guess=False, sample_pts=(64,))
+        out["heat_example_F5_w13"] = run(h5, weight_c=1.3, tol=1e-8, cf_iter=1, cycle_type='F', nested_iteration=False,
+                                         max_iter=10, sample_pts=(64,))
+    # --- spatial coarsening (examples/example_spatial_coarsening.py:112-123)
+    h0 = Heat1D(x_start=0, x_end=2, nx=2 ** 4 + 1, a=1, rhs=rhs, init_cond=init_cond, t_start=0, t_stop=2, nt=2 ** 7 + 1)
+    h1 = Heat1D(x_start=0, x_end=2, nx=2 ** 3 + 1, a=1, rhs=rhs, init_cond=init_cond, t_interval=h0.t[::2])
+    h2 = Heat1D(x_start=0, x_end=2, nx=2 ** 2 + 1, a=1, rhs=rhs, init_cond=init_cond, t_interval=h1.t[::2])
+    h3 = Heat1D(x_start=0, x_end=2, nx=2 ** 2 + 1, a=1, rhs=rhs, init_cond=init_cond, t_interval=h2.t[::2])
+    out["heat_spatial_coarsening"] = run([h0, h1, h2, h3],
+                                         transfer=[GridTransferHeat(), GridTransferHeat(), GridTransferCopy()],
+                                         sample_pts=(1, 64, 128))
+    g0 = Heat1D(x_start=0, x_end=1, nx=129, a=1, rhs=rhs, init_cond=init_cond, t_start=0, t_stop=2, nt=129)
+    g1 = Heat1D(x_start=0, x_end=1, nx=65, a=1, rhs=rhs, init_cond=init_cond, t_interval=g0.t[::4])
+    g2 = Heat1D(x_start=0, x_end=1, nx=33, a=1, rhs=rhs, init_cond=init_cond, t_interval=g1.t[::4])
+    out["heat_spatial_coarsening_F"] = run([g0, g1, g2], transfer=[GridTransferHeat(), GridTransferHeat()],
+                                           cycle_type='F', tol=1e-9, max_iter=10, sample_pts=(128,))
+    # --- advection (examples/example_advection.py)
+    a0 = Advection1D(c=1, x_start=-1, x_end=1, nx=129, t_start=0, t_stop=2, nt=129)
+    a1 = Advection1D(c=1, x_start=-1, x_end=1, nx=129, t_start=0, t_stop=2, nt=65)
+    out["advection_example"] = run([a0, a1], cf_iter=1, nested_iteration=False, max_iter=12, sample_pts=(1, 128))
+    b = [Advection1D(c=1, x_start=-1, x_end=1, nx=257, t_start=0, t_stop=2, nt=nt) for nt in (257, 65, 17)]
+    out["advection_3lvl_F"] = run(b, cycle_type='F', max_iter=8, sample_pts=(256,))
+    # --- config 2 (BASELINE.json configs[1]): heat_1d nx=1024 nt=4097 3-level m=4, V/FCF, nested
+    if big:
+        c2 = heat_levels(1024, [4097, 1025, 257])
+        rec = run(c2, cf_iter=1, nested_iteration=True, max_iter=4, tol=1e-30, sample_pts=(2048, 4096))
+        out["heat_config2"] = rec
+    return out
+
+
+def ref_results():
+    res = {}
+    d = os.path.join(REF, "tests", "mpi", "results")
+    for name in sorted(os.listdir(d)):
+        with open(os.path.join(d, name)) as f:
+            res[name] = [float(x) for x in f.read().split()]
+    kats = {}
+    return res, kats
+
+
+def main():
+    os.makedirs(HERE, exist_ok=True)
+    big = "--small" not in sys.argv
+    lay = make_layout()
+    with open(os.path.join(HERE, "layout.json"), "w") as f:
+        json.dump(lay, f, separators=(",", ":"))
+    meta, arrays = make_phi()
+    with open(os.path.join(HERE, "phi.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    np.savez_compressed(os.path.join(HERE, "phi.npz"), **arrays)
+    sol = make_solve(big)
+    with open(os.path.join(HERE, "solve.json"), "w") as f:
+        json.dump(sol, f, separators=(",", ":"))
+    res, kats = ref_results()
+    with open(os.path.join(HERE, "ref_results.json"), "w") as f:
+        json.dump({"tests_mpi_results": res}, f, indent=1)
+    print("wrote fixtures:", {k: os.path.getsize(os.path.join(HERE, k)) for k in
+                              ("layout.json", "phi.json", "phi.npz", "solve.json", "ref_results.json")})
+
+
+if __name__ == "__main__":
+    main()

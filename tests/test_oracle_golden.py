@@ -1,0 +1,220 @@
+"""Pin the parity oracle (oracle/mgrit_oracle.c) against fixtures generated from the reference
+(tests/golden/make_golden.py) and against the reference's own golden data (tests/mpi/results, unit-test KATs).
+
+CPU only. Tolerances:
+  * index sets / flags: bit-exact (index_local_f compared as a set: SURVEY App. A);
+  * Phi: forward-error tolerance 8*eps*cond(I+dt*L) relative (SuperLU vs Thomas/scan are different orderings);
+  * conv history: |d| <= 1e-9*conv + 2e-11  (the absolute floor ~ eps*cond*||u||, SURVEY section 7 hard part 1).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import cases
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(np.asarray(a, dtype=np.int64)).tobytes()).hexdigest()
+
+
+LAYOUT = cases.load_json("layout.json")
+
+
+@pytest.mark.parametrize("name", sorted(LAYOUT.keys()))
+def test_layout_matches_reference(oracle, name):
+    case = LAYOUT[name]
+    ts = cases.layout_case_grids(name, case["spec"])
+    checked = 0
+    for size_s, ranks in case["sizes"].items():
+        size = int(size_s)
+        for rank, levels in enumerate(ranks):
+            for lvl, rec in enumerate(levels):
+                got = oracle.layout(ts, lvl, rank, size)
+                for flag in ("comm_front", "comm_back", "first_is_c_point", "first_is_f_point", "last_is_c_point",
+                             "last_is_f_point"):
+                    assert bool(got[flag]) == rec[flag], (name, size, rank, lvl, flag)
+                for k in ("send_to", "get_from", "n_local", "m"):
+                    assert got[k] == rec[k], (name, size, rank, lvl, k, got[k], rec[k])
+                arrs = {"cpts": got["cpts"], "index_local": got["index_local"], "index_local_c": got["index_local_c"],
+                        "index_local_f_sorted": np.sort(got["index_local_f"])}
+                for k, v in arrs.items():
+                    if k in rec:
+                        assert v.tolist() == rec[k], (name, size, rank, lvl, k)
+                    else:
+                        assert v.size == rec[k + "_len"] and _sha(v) == rec[k + "_sha256"], (name, size, rank, lvl, k)
+                checked += 1
+    assert checked > 0
+
+
+def test_index_local_f_canonical_order_p7(oracle):
+    """reference tests/core/test_mgrit.py:172-189: runs reversed, ascending inside (rank 3's [1,2,3,9,5,6,7] is the
+    documented CPython set-order artefact and is compared as a set)."""
+    ts = [np.linspace(0, 2, n) for n in (65, 17, 5)]
+    got = oracle.layout(ts, 0, 0, 7)
+    assert got["index_local_f"].tolist() == [9, 5, 6, 7, 1, 2, 3]
+    got = oracle.layout(ts, 0, 3, 7)
+    assert sorted(got["index_local_f"].tolist()) == sorted([1, 2, 3, 9, 5, 6, 7])
+
+
+def test_split_into(oracle):
+    # reference tests/core/test_mgrit.py:39
+    assert oracle.split_into(10, 3).tolist() == [4, 3, 3]
+
+
+PHI = cases.load_json("phi.json")
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_phi_heat1d_matches_reference(oracle, variant):
+    arrs = cases.load_phi_arrays()
+    for rec in PHI["heat1d"]:
+        x, dx = cases.heat_grid(rec["nx"], 0.0, rec["x_end"])
+        t = np.array([rec["t_start"], rec["t_stop"]])
+        spec = {"kind": "heat1d", "t": t, "n": x.size, "fac": rec["a"] / dx ** 2, "u0": np.zeros(x.size)}
+        if rec["forcing"]:
+            spec["s"] = cases.rhs_space(x)[None, :]
+            spec["tau"] = np.array([cases.rhs_time(tt) for tt in t])[None, :]
+        p = oracle.OracleProblem([spec], variant=variant)
+        out = p.phi(0, 1, cases.heat_input(x, rec["k"]))
+        ref = arrs[rec["key"]]
+        beta = (t[1] - t[0]) * spec["fac"]
+        cond = (1 + 4 * beta) / (1 + 4 * beta * np.sin(np.pi / (2 * (x.size + 1))) ** 2)
+        err = np.linalg.norm(out - ref) / np.linalg.norm(ref)
+        assert err <= 8 * np.finfo(float).eps * cond + 1e-15, (rec, err, cond)
+
+
+def test_phi_heat1d_reference_unit_test_kat(oracle):
+    """reference tests/heat/test_heat_1d.py:31-42: nx=6, x in [0,1], a=1, init 2x, zero forcing, one BE step
+    0 -> 0.1; the four values are that test's literal expectation (asserted there to 7 decimals)."""
+    x, dx = cases.heat_grid(6, 0.0, 1.0)
+    t = np.array([0.0, 0.1])
+    for variant in (0, 1):
+        p = oracle.OracleProblem([{"kind": "heat1d", "t": t, "n": 4, "fac": 1.0 / dx ** 2, "u0": np.zeros(4)}],
+                                 variant=variant)
+        out = p.phi(0, 1, 2 * x)
+        np.testing.assert_almost_equal(out, np.array([0.28164, 0.51593599, 0.63660638, 0.53191933]))
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_phi_advection1d_matches_reference(oracle, variant):
+    arrs = cases.load_phi_arrays()
+    for rec in PHI["advection1d"]:
+        x, dx = cases.advection_grid(rec["nx"])
+        t = np.array([rec["t_start"], rec["t_stop"]])
+        p = oracle.OracleProblem([{"kind": "advection1d", "t": t, "n": x.size, "fac": rec["c"] / dx,
+                                   "u0": np.zeros(x.size)}], variant=variant)
+        u = np.exp(-x ** 2) + 0.1 * np.sin(5 * np.pi * x + rec["k"])
+        out = p.phi(0, 1, u)
+        ref = arrs[rec["key"]]
+        err = np.linalg.norm(out - ref) / np.linalg.norm(ref)
+        assert err <= 1e-13, (rec, err)
+
+
+def test_phi_advection1d_reference_unit_test_kat(oracle):
+    """reference tests/advection/test_advection_1d.py:32-44 (nx=6 on [0,1] -> 5 periodic points, c=1, 0 -> 0.1)."""
+    x, dx = cases.advection_grid(6, 0.0, 1.0)
+    t = np.array([0.0, 0.1])
+    for variant in (0, 1):
+        p = oracle.OracleProblem([{"kind": "advection1d", "t": t, "n": 5, "fac": 1.0 / dx, "u0": np.zeros(5)}],
+                                 variant=variant)
+        out = p.phi(0, 1, np.exp(-x ** 2))
+        np.testing.assert_almost_equal(out, np.array([0.868043, 0.92987396, 0.87805385, 0.75780217, 0.604129]))
+
+
+def test_phi_dahlquist_reference_unit_test_kat(oracle):
+    """reference tests/dahlquist/test_dahlquist.py:55-88."""
+    t = np.array([0.0, 0.1])
+    for method, exp in (("BE", 0.9090909090909091), ("FE", 0.9), ("TR", 0.9047619047619047), ("MR", 0.9047619047619047)):
+        p = oracle.OracleProblem([{"kind": "dahlquist", "t": t, "lambda": -1.0, "method": method}])
+        np.testing.assert_almost_equal(p.phi(0, 1, np.array([1.0]))[0], exp)
+
+
+def test_phi_dahlquist_matches_reference(oracle):
+    for rec in PHI["dahlquist"]:
+        for h, ref in zip(rec["h"], rec["out"]):
+            t = np.array([rec["t_start"], rec["t_start"] + h])
+            p = oracle.OracleProblem([{"kind": "dahlquist", "t": t, "lambda": -1.0, "method": rec["method"]}])
+            out = p.phi(0, 1, np.array([rec["u"]]))
+            assert out[0] == ref, (rec["method"], h, out[0], ref)
+
+
+def test_transfer_matches_example_arithmetic(oracle):
+    f = np.arange(1.0, 16.0) ** 1.5
+    c = oracle.restrict(1, f, 7)
+    exp = np.array([f[2 * i] * 1 / 4 + f[2 * i + 1] * 1 / 2 + f[2 * i + 2] * 1 / 4 for i in range(7)])
+    assert np.array_equal(c, exp)
+    g = oracle.interp(1, c, 15)
+    exp = np.zeros(15)
+    for i in range(7):
+        exp[2 * i] += 1 / 2 * c[i]
+        exp[2 * i + 1] += c[i]
+        exp[2 * i + 2] += 1 / 2 * c[i]
+    assert np.array_equal(g, exp)
+
+
+SOLVE = cases.load_json("solve.json")
+CASES = cases.solve_cases()
+
+
+def run_oracle_case(oracle, name, variant, **override):
+    c = CASES[name]
+    o = dict(c["opts"], **override)
+    rnd = o.pop("random_init_guess", False)
+    p = oracle.OracleProblem(c["levels"], transfer=c.get("transfer"), variant=variant, **o)
+    if rnd:
+        np.random.seed(c["seed"])
+        u = p.state("u", 0)
+        for i in range(u.shape[0]):
+            u[i] = np.random.rand(u.shape[1])
+        u[0] = c["levels"][0]["u0"]
+    return p, p.solve()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("name", sorted(CASES.keys()))
+def test_solve_matches_reference(oracle, name, variant):
+    p, conv = run_oracle_case(oracle, name, variant)
+    ref = np.array(SOLVE[name]["conv"])
+    n = min(len(conv), len(ref))
+    # the reference drops exactly-zero entries (mgrit.py:645); a trailing ~1e-33 of ours is the same event
+    assert len(conv) >= len(ref) and np.all(conv[len(ref):] < 1e-25), (conv, ref)
+    assert np.all(np.abs(conv[:n] - ref[:n]) <= 1e-9 * ref[:n] + 2e-11), (name, conv, ref)
+    for k, v in SOLVE[name].get("samples", {}).items():
+        v = np.array(v)
+        mine = p.state("u", 0)[int(k)]
+        assert np.abs(mine - v).max() <= 1e-11 * max(1.0, np.abs(v).max()), (name, k)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_reference_mpi_results_files(oracle, variant):
+    """The reference's own golden data tests/mpi/results/{dahlquist,heat_1d,weighted_jacobi,...}; upstream compares
+    with decimal=4 (tests/mpi/mpi.py:49), here 1e-9 rel + 2e-11 abs."""
+    res = cases.load_json("ref_results.json")["tests_mpi_results"]
+    pairs = {"dahlquist": ["dahlquist_config1"], "heat_1d": ["heat_example_F5"], "parameters": ["dahlquist_config1"],
+             "weighted_jacobi": [("heat_example_F5", dict(tol=1e-8)), "heat_example_F5_w13"],
+             "spatial_coarsening": ["heat_spatial_coarsening"], "time_integrators": ["dahlquist_time_integrators"],
+             "procs_without_points": ["dahlquist_procs_without_points"],
+             "varying_coarsening": ["dahlquist_varying_coarsening"]}
+    for fname, names in pairs.items():
+        names = [(n, {}) if isinstance(n, str) else n for n in names]
+        got = np.concatenate([run_oracle_case(oracle, n, variant, **kw)[1] for n, kw in names])
+        ref = np.array(res[fname])
+        assert len(got) == len(ref), (fname, got, ref)
+        assert np.all(np.abs(got - ref) <= 1e-9 * ref + 2e-11), (fname, got, ref)
+
+
+def test_reference_unit_test_conv_golden(oracle):
+    # reference tests/core/test_mgrit.py:59-70
+    for variant in (0, 1):
+        _, conv = run_oracle_case(oracle, "heat_nx5_test_mgrit", variant)
+        np.testing.assert_almost_equal(conv, [0.00267692, 0.00018053])
+
+
+def test_phi_work_model(oracle):
+    """Phi counts per level for nt=4097, m=4, L=3, V-cycle, no nesting: iteration 1 = [12288, 3840, 512],
+    later iterations [9216, 3840, 512] (residual check included)."""
+    levels = [cases.heat_level_spec(9, cases.lin(2, nt)) for nt in (4097, 1025, 257)]
+    p = oracle.OracleProblem(levels, variant=0, nested_iteration=False, max_iter=2, tol=0.0)
+    p.solve()
+    assert [p.phi_count(l) for l in range(3)] == [12288 + 9216, 2 * 3840, 2 * 512]
