@@ -1,0 +1,97 @@
+/*
+ * mgrit_hip.h -- C ABI of libmgrit_hip.so, the MI355X (gfx950) MGRIT relaxation engine.
+ *
+ * The reference (PyMGRIT, pure Python) has no FFI; this ABI is the boundary a maintainer would bind with ctypes
+ * to replace the per-time-point Python loops of src/pymgrit/core/mgrit.py. Every entry point
+ * names the reference code it replaces (file:line under /root/reference).
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a negative code on error
+ * (message via mgrit_hip_last_error()); no exceptions cross the ABI; one host thread per engine; all device work
+ * is enqueued on the hipStream_t given at creation; state slabs are DEVICE pointers owned by the caller
+ * (row-major [n_local_points][ld] float64, ld a multiple of 16, padding columns kept zero); host arrays are
+ * borrowed for the duration of the call only.
+ */
+#ifndef MGRIT_HIP_H
+#define MGRIT_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGRIT_HIP_ABI_VERSION 1
+#define MGRIT_HIP_E 16            /* elements per lane (arithmetic spec) */
+#define MGRIT_HIP_MAX_N 16384     /* max DOFs per time point for the register-resident steppers */
+
+typedef struct mgrit_hip_engine mgrit_hip_engine;
+
+enum { MGRIT_HIP_OK = 0, MGRIT_HIP_EINVAL = -1, MGRIT_HIP_EHIP = -2, MGRIT_HIP_ENODEV = -3, MGRIT_HIP_EUNSUPPORTED = -4 };
+enum { MGRIT_HIP_STEPPER_HEAT1D = 1, MGRIT_HIP_STEPPER_ADVECTION1D = 2 };
+enum { MGRIT_HIP_TRANSFER_COPY = 0, MGRIT_HIP_TRANSFER_HEAT1D = 1 };
+enum { MGRIT_HIP_RELAX_F = 0, MGRIT_HIP_RELAX_C = 1 };
+
+int mgrit_hip_abi_version(void);
+const char *mgrit_hip_last_error(void);
+/* number of visible HIP devices (0 when none); does not create a context */
+int mgrit_hip_device_count(void);
+
+/* Engine = per-rank solver state of Mgrit.__init__ (mgrit.py:145-222) minus the slabs. stream: hipStream_t. */
+int mgrit_hip_create(mgrit_hip_engine **out, int n_levels, void *stream);
+int mgrit_hip_destroy(mgrit_hip_engine *e);
+int mgrit_hip_sync(mgrit_hip_engine *e);
+
+/*
+ * Level description. t_local: the rank-local time grid Mgrit.t[lvl] (mgrit.py:792, ghost point first when present).
+ * Replaces Heat1D.__init__/compute_matrix/step (heat/heat_1d.py:138-217): Phi = (I + dt*L)^-1 (u + dt*b(x,t_stop)),
+ * L = fac*tridiag(-1,2,-1), fac = a/dx^2; forcing b(x,t_i) = sum_k s[k][x]*tau[k][i] (K = 0: zero forcing).
+ */
+int mgrit_hip_level_heat1d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int n, int ld,
+                           double fac, int K, const double *s, const double *tau);
+/* Replaces Advection1D.compute_matrix/step (advection/advection_1d.py:101-143): (I + dt*fac*(I - S_periodic)) x = u */
+int mgrit_hip_level_advection1d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int n, int ld,
+                                double fac);
+/* Device slabs u, v, g of Mgrit.create_u_v_g (mgrit.py:840-858); v and g may be NULL on level 0. */
+int mgrit_hip_level_bind(mgrit_hip_engine *e, int lvl, double *u, double *v, double *g);
+/* Spatial transfer between lvl and lvl+1: GridTransferCopy (core/grid_transfer_copy.py:23-47) or the full-weighting
+ * / linear-interpolation pair of examples/example_spatial_coarsening.py:33-82 (fine n = 2*coarse n + 1). */
+int mgrit_hip_level_transfer(mgrit_hip_engine *e, int lvl, int kind);
+
+/*
+ * Run list: run r covers the consecutive local points start[r] .. start[r]+len[r]-1, each computed from its
+ * predecessor (start[r]-1 must be a valid local index). F-intervals (mgrit.py:313-331), C-points (mgrit.py:355-368,
+ * len 1 unless C-points are adjacent) and the coarsest-level chain (mgrit.py:472-481) are all run lists.
+ */
+int mgrit_hip_runs_create(mgrit_hip_engine *e, int lvl, int n_runs, const int32_t *start, const int32_t *len, int *id_out);
+/* Pair list (fine local index on lvl, coarse local index on lvl+1) for the grid-transfer sweeps. */
+int mgrit_hip_pairs_create(mgrit_hip_engine *e, int lvl, int n_pairs, const int32_t *fine_idx, const int32_t *coarse_idx,
+                           int *id_out);
+
+/* Mgrit.f_relax (mgrit.py:292-333), Mgrit.c_relax (mgrit.py:335-370), Mgrit.forward_solve (mgrit.py:459-486):
+ * mode F:  u_i = [g_i +] Phi(u_{i-1});  mode C: u_i = ([g_i +] Phi(u_{i-1}))*w + u_i*(1-w). g is used on lvl > 0. */
+int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double weight_c);
+/* Mgrit.compute_residual (mgrit.py:387-413): per run r (len 1) sumsq_out[r] = ||Phi(u_{i-1}) - u_i||_2^2 (device ptr). */
+int mgrit_hip_residual(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_out);
+/* Mgrit.compute_jump (mgrit.py:372-385): sumsq_out[r] = ||u_i - prev_i||_2^2, prev a device slab shaped like u. */
+int mgrit_hip_jump(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev, double *sumsq_out);
+
+/* Mgrit.fas_residual (mgrit.py:488-549), split at its communication points:
+ *   restrict_u: u^{l+1}_j = R(u^l_i) for every pair                      (mgrit.py:498-500)
+ *   copy_u_to_v: v^{l+1} = clone(u^{l+1}) for the whole local slab         (mgrit.py:520)
+ *   fas_rhs:    g^{l+1}_j = R(Phi_l(u_{i-1}) - u_i) + v_j - Phi_{l+1}(v_{j-1})            (lvl 0, mgrit.py:528-536)
+ *               g^{l+1}_j = R(g_i - u_i + Phi_l(u_{i-1})) + v_j - Phi_{l+1}(v_{j-1})      (lvl>0, mgrit.py:538-547) */
+int mgrit_hip_restrict_u(mgrit_hip_engine *e, int lvl, int pairs_id);
+int mgrit_hip_copy_u_to_v(mgrit_hip_engine *e, int lvl_coarse);
+int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id);
+/* Mgrit.error_correction (mgrit.py:715-726): u^l_i = u^l_i + P(u^{l+1}_j - v^{l+1}_j) */
+int mgrit_hip_error_correction(mgrit_hip_engine *e, int lvl, int pairs_id);
+/* Mgrit.nested_iteration interpolation (mgrit.py:559-563): u^l_i = P(u^{l+1}_j) */
+int mgrit_hip_interpolate(mgrit_hip_engine *e, int lvl, int pairs_id);
+
+/* Timing of the most recent mgrit_hip_relax launch on this engine, measured with HIP events on the engine's stream
+ * (enable with mgrit_hip_set_timing(e, 1)); returns milliseconds in *ms. */
+int mgrit_hip_set_timing(mgrit_hip_engine *e, int enabled);
+int mgrit_hip_last_kernel_ms(mgrit_hip_engine *e, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,233 @@
+"""HIP sweep backend: the MGRIT sweeps as hand-written gfx950 kernels behind the C ABI of include/mgrit_hip.h.
+
+State layout: per level one row-major float64 slab ``[n_local_points][ld]`` per array (u, v, g) in HBM, allocated
+as torch CUDA tensors (PyTorch is plumbing here: device memory, the stream, torch.distributed); the library only
+sees raw device pointers. ``mgrit.u[lvl]`` stays an indexable sequence of Vector objects (lazy host views), which
+is what output_fcn callbacks and subclasses of the reference read.
+
+No CPU fallback: constructing this backend without libmgrit_hip.so or without a GPU raises MgritHipError.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from pymgrit_amd.core import hip_lib
+from pymgrit_amd.core.hip_lib import MgritHipError, check
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a.size else C.c_void_p(0)
+
+
+class SlabVectorList:
+    """``mgrit.u[lvl]``-compatible view of a device slab: indexing copies ONE row to the host and wraps it in the
+    application's Vector type; assignment uploads a Vector."""
+
+    def __init__(self, slab, n, template):
+        self.slab, self.n, self.template = slab, n, template
+
+    def __len__(self):
+        return self.slab.shape[0]
+
+    def _row(self, i):
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return i
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        vec = self.template.clone_zero()
+        host = self.slab[self._row(int(i)), :self.n].cpu().numpy()
+        vec.set_values(host.reshape(np.shape(vec.get_values())).copy())
+        return vec
+
+    def __setitem__(self, i, vec):
+        vals = np.ascontiguousarray(np.asarray(vec.get_values(), dtype=np.float64)).ravel()
+        self.slab[self._row(int(i)), :self.n] = torch.from_numpy(vals).to(self.slab.device)
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self, mg):
+        self.mg = mg
+        self.lib = hip_lib.load()
+        if not torch.cuda.is_available() or self.lib.mgrit_hip_device_count() < 1:
+            raise MgritHipError("no MI355X/HIP device visible: device applications have no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.stream = torch.cuda.current_stream(self.device)
+        self.h = C.c_void_p()
+        check(self.lib.mgrit_hip_create(C.byref(self.h), mg.lvl_max, C.c_void_p(self.stream.cuda_stream)))
+        self.desc = [p.device_stepper() for p in mg.problem]
+        self.n = [int(d["n"]) for d in self.desc]
+        self.ld = [((n + 15) // 16) * 16 for n in self.n]
+        self.U, self.V, self.G = [], [], []
+        self._runs, self._pairs = {}, {}
+        self._described = [False] * mg.lvl_max
+        self.prev = None
+        self._sumsq = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.mgrit_hip_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+    # -- state (mgrit.py:840-858) -------------------------------------------------------------------
+    def create_u_v_g(self, lvl):
+        mg = self.mg
+        d, n, ld = self.desc[lvl], self.n[lvl], self.ld[lvl]
+        t_local = np.ascontiguousarray(np.asarray(mg.t[lvl], dtype=np.float64))
+        n_pts = t_local.size
+        if d["kind"] == "heat1d":
+            s = np.ascontiguousarray(np.asarray(d.get("forcing_space", np.zeros((0, n))), dtype=np.float64).reshape(-1, n))
+            K = s.shape[0]
+            tau = np.zeros((K, n_pts))
+            for k in range(K):
+                tau[k] = [d["forcing_time"][k](tt) for tt in t_local]
+            tau = np.ascontiguousarray(tau)
+            check(self.lib.mgrit_hip_level_heat1d(self.h, lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"]), K,
+                                                  _ptr(s), _ptr(tau)))
+        elif d["kind"] == "advection1d":
+            check(self.lib.mgrit_hip_level_advection1d(self.h, lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"])))
+        else:
+            raise MgritHipError(f"unknown device stepper kind {d['kind']!r}")
+        u = torch.zeros((n_pts, ld), dtype=torch.float64, device=self.device)
+        tmpl = mg.problem[lvl].vector_template
+        if lvl == 0 and mg.random_init_guess and n_pts:
+            host = np.zeros((n_pts, ld))
+            for i in range(n_pts):  # clone_rand per time point, in time order (heat_1d.py:88-96)
+                host[i, :n] = np.asarray(tmpl.clone_rand().get_values(), dtype=np.float64).ravel()
+            u.copy_(torch.from_numpy(host))
+        v = g = None
+        if lvl > 0:
+            v = torch.zeros_like(u)
+            g = torch.zeros_like(u)
+        self.U.append(u), self.V.append(v), self.G.append(g)
+        check(self.lib.mgrit_hip_level_bind(self.h, lvl, C.c_void_p(u.data_ptr()),
+                                            C.c_void_p(v.data_ptr() if v is not None else 0),
+                                            C.c_void_p(g.data_ptr() if g is not None else 0)))
+        mg.u.append(SlabVectorList(u, n, tmpl))
+        mg.v.append(SlabVectorList(v, n, tmpl) if v is not None else None)
+        mg.g.append(SlabVectorList(g, n, tmpl) if g is not None else None)
+        if mg.comm_time_rank == 0 and n_pts:
+            mg.u[lvl][0] = mg.problem[lvl].vector_t_start
+        self._described[lvl] = True
+
+    def finalize(self):
+        """after every level is described: register the spatial transfers"""
+        mg = self.mg
+        for lvl in range(mg.lvl_max - 1):
+            tr = mg.transfer_objects[lvl]
+            if not hasattr(tr, "device_transfer"):
+                raise MgritHipError(f"transfer {type(tr).__name__} has no device_transfer(): device applications need a "
+                                    f"device-capable GridTransfer (GridTransferCopy, GridTransferHeat)")
+            check(self.lib.mgrit_hip_level_transfer(self.h, lvl, int(tr.device_transfer())))
+
+    # -- exchange payloads: slab rows travel in place over RCCL ---------------------------------------
+    def payload(self, lvl, idx):
+        return self.U[lvl][idx]
+
+    def recv_buffer(self, lvl, idx):
+        return self.U[lvl][idx]
+
+    def commit(self, lvl, idx, got):
+        pass
+
+    # -- helpers ---------------------------------------------------------------------------------------
+    def _run_id(self, lvl, runs):
+        key = (lvl, tuple(runs))
+        if key not in self._runs:
+            rid = C.c_int(-1)
+            st, ln = _i32([r[0] for r in runs]), _i32([r[1] for r in runs])
+            check(self.lib.mgrit_hip_runs_create(self.h, lvl, len(runs), _ptr(st), _ptr(ln), C.byref(rid)))
+            self._runs[key] = rid.value
+        return self._runs[key]
+
+    def _pair_id(self, lvl, pairs):
+        key = (lvl, tuple(pairs))
+        if key not in self._pairs:
+            pid = C.c_int(-1)
+            fi, co = _i32([p[0] for p in pairs]), _i32([p[1] for p in pairs])
+            check(self.lib.mgrit_hip_pairs_create(self.h, lvl, len(pairs), _ptr(fi), _ptr(co), C.byref(pid)))
+            self._pairs[key] = pid.value
+        return self._pairs[key]
+
+    def _sumsq_buf(self, n):
+        if self._sumsq is None or self._sumsq.numel() < n:
+            self._sumsq = torch.zeros(max(n, 1), dtype=torch.float64, device=self.device)
+        return self._sumsq
+
+    # -- sweeps ----------------------------------------------------------------------------------------
+    def relax(self, lvl, runs, mode):
+        if not runs:
+            return
+        check(self.lib.mgrit_hip_relax(self.h, lvl, self._run_id(lvl, runs), hip_lib.RELAX_C if mode == 'C' else
+                                       hip_lib.RELAX_F, float(self.mg.weight_c)))
+
+    def residual_norms(self, points):
+        if not len(points):
+            return []
+        runs = [(int(i), 1) for i in points]
+        buf = self._sumsq_buf(len(runs))
+        check(self.lib.mgrit_hip_residual(self.h, 0, self._run_id(0, runs), C.c_void_p(buf.data_ptr())))
+        return np.sqrt(buf[:len(runs)].cpu().numpy()).tolist()
+
+    def save_last(self):
+        self.prev = self.U[0].clone()
+        self.mg.save_values_last_iter = SlabVectorList(self.prev, self.n[0], self.mg.problem[0].vector_template)
+
+    def jump_norms(self, points):
+        out = []
+        if len(points):
+            runs = [(int(i), 1) for i in points]
+            buf = self._sumsq_buf(len(runs))
+            check(self.lib.mgrit_hip_jump(self.h, 0, self._run_id(0, runs), C.c_void_p(self.prev.data_ptr()),
+                                          C.c_void_p(buf.data_ptr())))
+            out = np.sqrt(buf[:len(runs)].cpu().numpy()).tolist()
+        self.prev.copy_(self.U[0])
+        return out
+
+    def restrict_u(self, lvl, pairs):
+        if pairs:
+            check(self.lib.mgrit_hip_restrict_u(self.h, lvl, self._pair_id(lvl, pairs)))
+
+    def copy_u_to_v(self, lvl):
+        check(self.lib.mgrit_hip_copy_u_to_v(self.h, lvl))
+
+    def fas_rhs(self, lvl, pairs):
+        if pairs:
+            check(self.lib.mgrit_hip_fas_rhs(self.h, lvl, self._pair_id(lvl, pairs)))
+
+    def error_correction(self, lvl, pairs):
+        if pairs:
+            check(self.lib.mgrit_hip_error_correction(self.h, lvl, self._pair_id(lvl, pairs)))
+
+    def interpolate(self, lvl, pairs):
+        if pairs:
+            check(self.lib.mgrit_hip_interpolate(self.h, lvl, self._pair_id(lvl, pairs)))
+
+    def sync(self):
+        check(self.lib.mgrit_hip_sync(self.h))
+
+    # -- measurement hooks (bench.py) ------------------------------------------------------------------
+    def set_timing(self, on):
+        check(self.lib.mgrit_hip_set_timing(self.h, int(bool(on))))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0.0)
+        check(self.lib.mgrit_hip_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,67 @@
+"""ctypes binding of libmgrit_hip.so (C ABI: include/mgrit_hip.h). The library is mandatory for device
+applications: there is no CPU fallback -- a missing library or a missing GPU raises."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libmgrit_hip.so")
+
+RELAX_F, RELAX_C = 0, 1
+STEPPER_HEAT1D, STEPPER_ADVECTION1D = 1, 2
+TRANSFER_COPY, TRANSFER_HEAT1D = 0, 1
+MAX_N = 16384
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "mgrit_hip_abi_version": (C.c_int, []),
+    "mgrit_hip_last_error": (C.c_char_p, []),
+    "mgrit_hip_device_count": (C.c_int, []),
+    "mgrit_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    "mgrit_hip_destroy": (C.c_int, [C.c_void_p]),
+    "mgrit_hip_sync": (C.c_int, [C.c_void_p]),
+    "mgrit_hip_level_heat1d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                                         C.c_int, C.c_void_p, C.c_void_p]),
+    "mgrit_hip_level_advection1d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]),
+    "mgrit_hip_level_bind": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgrit_hip_level_transfer": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_runs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "mgrit_hip_pairs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "mgrit_hip_relax": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "mgrit_hip_residual": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mgrit_hip_jump": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mgrit_hip_restrict_u": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_copy_u_to_v": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgrit_hip_fas_rhs": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_error_correction": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_interpolate": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgrit_hip_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+class MgritHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libmgrit_hip.so and type every export; raises MgritHipError when the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MgritHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                                f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.mgrit_hip_abi_version() != 1:
+            raise MgritHipError("libmgrit_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MgritHipError(f"libmgrit_hip error {rc}: {load().mgrit_hip_last_error().decode()}")

@@ -1,0 +1,394 @@
+"""MGRIT solver driver for MI355X: same constructor, attributes and ``solve()`` surface as the reference's
+``pymgrit.core.mgrit.Mgrit`` (reference src/pymgrit/core/mgrit.py:33-37,590-646), with the relaxation / residual /
+grid-transfer sweeps delegated to a sweep backend:
+
+  * ``HipBackend``    -- every level's states in one HBM slab, sweeps as gfx950 kernels (libmgrit_hip.so);
+                         chosen when ALL level Applications provide ``device_stepper()``. No CPU fallback.
+  * ``PluginBackend`` -- the user's own Python ``Application.step`` per time point; chosen when NO level provides
+                         a device description (user plugins, Dahlquist).
+
+What stays on the host is control flow only: the cycle recursion (mgrit.py:261-290), the exchange schedule at rank
+boundaries (mgrit.py:304-331,346-352,397-403,467-484,502-517 -- mpi4py pickled isend/recv replaced by
+torch.distributed point-to-point, RCCL over xGMI for device rows) and the stopping test.
+
+Out of scope this round: local convergence criteria conv_crit 2/3 and their drain protocol.
+"""
+import logging
+import sys
+import time
+from typing import List, Tuple
+
+import numpy as np
+
+from pymgrit_amd.core.application import Application
+from pymgrit_amd.core.comm import resolve_comm
+from pymgrit_amd.core.grid_transfer import GridTransfer
+from pymgrit_amd.core.grid_transfer_copy import GridTransferCopy
+from pymgrit_amd.core.layout import compute_layout, consecutive_runs, split_into as _split_into, \
+    split_points as _split_points
+
+
+class Mgrit:
+    """Multigrid-reduction-in-time (FAS) solver. The solved space-time stencil is [-Phi I] on every level."""
+
+    def __init__(self, problem: List[Application], transfer: List[GridTransfer] = None, weight_c: float = 1.0,
+                 max_iter: int = 100, tol: float = 1e-7, nested_iteration: bool = True, cf_iter: int = 1,
+                 cycle_type: str = 'V', comm_time=None, comm_space=None, logging_lvl: int = logging.INFO,
+                 output_fcn=None, output_lvl=1, t_norm=2, random_init_guess: bool = False, conv_crit: int = 0) -> None:
+        logging.basicConfig(format='%(levelname)s - %(asctime)s - %(message)s', datefmt='%d-%m-%y %H:%M:%S',
+                            level=logging_lvl, stream=sys.stdout)
+        if transfer is None:
+            transfer = [GridTransferCopy() for _ in range(len(problem) - 1)]
+        cf_iter = self._validate(problem, transfer, cycle_type, output_lvl, t_norm, conv_crit, cf_iter)
+
+        self.comm_time = resolve_comm(comm_time)
+        self.comm_space = comm_space
+        self.comm_time_rank = self.comm_time.Get_rank()
+        self.comm_time_size = self.comm_time.Get_size()
+        if self.comm_time_size > len(problem[0].t):
+            raise Exception('More processors than time points. Not useful and not implemented yet')
+        self.spatial_parallel = comm_space is not None
+        self.comm_space_rank = comm_space.Get_rank() if self.spatial_parallel else -99
+        self.comm_space_size = comm_space.Get_size() if self.spatial_parallel else 1
+
+        self.comm_time.barrier()
+        setup_start = time.time()
+        self.log_info("Start setup")
+
+        self.problem = problem
+        self.transfer_objects = transfer
+        self.weight_c = weight_c
+        self.lvl_max = len(problem)
+        self.step, self.u, self.v, self.g, self.t, self.m = [], [], [], [], [], []
+        self.restriction, self.interpolation = [], []
+        self.tol = tol
+        self.conv = np.zeros(max_iter + 1)
+        self.cf_iter = cf_iter
+        self.cycle_type = cycle_type
+        self.random_init_guess = random_init_guess
+        self.iter_max = max_iter
+        self.solve_iter = 0
+        self.nes_it = nested_iteration
+        self.runtime_solve = self.runtime_setup = 0
+        self.int_start = self.int_stop = 0
+        self.cpts, self.index_local, self.index_local_c, self.index_local_f = [], [], [], []
+        self.comm_front, self.comm_back = [], []
+        self.first_is_f_point, self.first_is_c_point, self.last_is_f_point, self.last_is_c_point = [], [], [], []
+        self.send_to, self.get_from, self.global_t = [], [], []
+        self.t_norm = 1 if t_norm == 1 else None if t_norm == 2 else np.inf
+        self.conv_crit = conv_crit
+        self.global_conv_crit = True
+        self.save_values_last_iter = None
+        self.output_lvl = output_lvl
+        self.output_fcn = output_fcn if (output_fcn is not None and callable(output_fcn)) else None
+        self._ghost, self._is_c_local = [], []
+
+        self.backend = self._select_backend(problem)
+
+        for lvl in range(self.lvl_max):
+            self.t.append(np.copy(problem[lvl].t))
+            if lvl != self.lvl_max - 1:
+                self.restriction.append(transfer[lvl].restriction)
+                self.interpolation.append(transfer[lvl].interpolation)
+                cp = np.where(np.isin(problem[lvl].t, problem[lvl + 1].t))[0]
+                gaps = np.diff(cp)
+                self.m.append(int(gaps[0]))
+                if not np.all(np.isclose(gaps, gaps[0])) and self.comm_time_rank == 0:
+                    logging.warning('Non-uniform coarsening between level ' + str(lvl) + ' and ' + str(lvl + 1) +
+                                    '. Poorly tested.')
+            else:
+                self.m.append(1)
+            self.setup_points_and_comm_info(lvl=lvl)
+            self.step.append(problem[lvl].step)
+            self.create_u_v_g(lvl=lvl)
+        self.backend.finalize()
+
+        if nested_iteration:
+            self.nested_iteration()
+        if self.conv_crit == 1:
+            self.backend.save_last()
+
+        if self.iter_max == 0:
+            self.comm_time.barrier()
+        self.runtime_setup = time.time() - setup_start
+        if self.output_fcn is not None and self.output_lvl == 2:
+            self.output_fcn(self)
+        self.log_info(f"Setup took {self.runtime_setup} s")
+
+    # ------------------------------------------------------------------------------------------------
+    # construction helpers
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _validate(problem, transfer, cycle_type, output_lvl, t_norm, conv_crit, cf_iter):
+        """Constructor checks and messages of the reference (mgrit.py:78-120)."""
+        if len(problem) != (len(transfer) + 1):
+            raise Exception('There should be exactly one transfer operator for each level except the coarsest grid')
+        for i in range(len(problem) - 1):
+            if len(problem[i].t) < len(problem[i + 1].t):
+                raise Exception('The time grid on level ' + str(i + 1) + ' contains more time points than level ' + str(i))
+        if cycle_type not in ('V', 'F'):
+            raise Exception("Cycle-type " + str(cycle_type) + " is not implemented. Choose 'V' or 'F'")
+        if output_lvl not in [0, 1, 2]:
+            raise Exception("Unknown output level. Choose 0, 1 or 2.")
+        for lvl in range(1, len(problem)):
+            if np.count_nonzero(np.isin(np.unique(problem[lvl].t), problem[lvl - 1].t)) != len(problem[lvl].t):
+                raise Exception('Some points from level ' + str(lvl - 1) + ' are not points of level ' + str(lvl))
+        if t_norm not in [1, 2, 3]:
+            raise Exception('Unknown norm. Please choose 1 (one norm), 2 (two-norm) or 3 (inf-norm)')
+        if conv_crit not in [0, 1, 2, 3]:
+            raise Exception('Unknown convergence criterion. Please choose: 0 (global space-time residual), '
+                            '1 (global jump)2 (local space-time residual)3 (local jump)')
+        if conv_crit in (2, 3):
+            raise Exception('Local convergence criteria (conv_crit 2/3) are not implemented in the MI355X engine yet; '
+                            'choose 0 (global space-time residual) or 1 (global jump)')
+        if isinstance(cf_iter, int):
+            return [cf_iter for _ in range(len(problem))]
+        if isinstance(cf_iter, list):
+            if len(cf_iter) < len(problem) - 1:
+                raise Exception('Too few cf_iter. Specify a list of values for all but the coarsest level or an integer '
+                                '(used for all levels).')
+            return cf_iter
+        raise Exception('Incorrect datatype cf_iter. Specify a list of values for all but the coarsest level or an '
+                        'integer ( used for all levels).')
+
+    def _select_backend(self, problem):
+        """Backend by application TYPE (never by hardware availability)."""
+        has_desc = [hasattr(p, "device_stepper") and p.device_stepper() is not None for p in problem]
+        if all(has_desc):
+            from pymgrit_amd.core.backend_hip import HipBackend
+            return HipBackend(self)
+        if any(has_desc):
+            raise Exception('Mixed hierarchy: every level must be a device application (device_stepper()) or none')
+        from pymgrit_amd.core.backend_plugin import PluginBackend
+        return PluginBackend(self)
+
+    def log_info(self, message: str) -> None:
+        """Only the last time rank (and space rank 0) logs (mgrit.py:247-259)."""
+        if self.comm_time_rank == self.comm_time_size - 1 and (not self.spatial_parallel or self.comm_space_rank == 0):
+            logging.info(message)
+
+    def split_into(self, number_points: int, number_processes: int) -> np.ndarray:
+        return _split_into(number_points, number_processes)
+
+    def split_points(self, length: int, size: int, rank: int) -> Tuple[int, int]:
+        return _split_points(length, size, rank)
+
+    def setup_points_and_comm_info(self, lvl: int) -> None:
+        """Local index sets and exchange flags of level ``lvl`` for (comm_time_rank, comm_time_size); appends to the
+        per-level attribute lists exactly like the reference (mgrit.py:742-827) so the rank-overwrite trick of its
+        tests (tests/core/test_mgrit.py:109-129) works on this class too."""
+        self.global_t.append(np.copy(self.problem[lvl].t))
+        lay = compute_layout([p.t for p in self.problem], lvl, self.comm_time_rank, self.comm_time_size)
+        if lvl == 0:
+            self.int_start, self.int_stop = lay.int_start, lay.int_stop
+        self.t[lvl] = lay.t_local
+        self.cpts.append(lay.cpts)
+        self.comm_front.append(lay.comm_front)
+        self.comm_back.append(lay.comm_back)
+        self.index_local.append(lay.index_local)
+        self.index_local_c.append(lay.index_local_c)
+        self.index_local_f.append(lay.index_local_f)
+        self.first_is_c_point.append(lay.first_is_c_point)
+        self.first_is_f_point.append(lay.first_is_f_point)
+        self.last_is_c_point.append(lay.last_is_c_point)
+        self.last_is_f_point.append(lay.last_is_f_point)
+        self.send_to.append(lay.send_to)
+        self.get_from.append(lay.get_from)
+        self._ghost.append(lay.ghost)
+        self._is_c_local.append(lay.is_c_local)
+
+    def create_u_v_g(self, lvl: int) -> None:
+        self.backend.create_u_v_g(lvl)
+
+    # ------------------------------------------------------------------------------------------------
+    # run / pair lists derived from the index sets
+    # ------------------------------------------------------------------------------------------------
+    def _f_runs(self, lvl):
+        return consecutive_runs(np.sort(np.asarray(self.index_local_f[lvl], dtype=np.int64)))
+
+    def _c_points(self, lvl):
+        """local C-point slots that are relaxed: all except global index 0 (mgrit.py:357,408,525)."""
+        pts = [int(i) for i in self.index_local_c[lvl]]
+        if self.comm_time_rank == 0 and pts and pts[0] == 0:
+            pts = pts[1:]
+        return pts
+
+    def _pairs(self, lvl, skip_first):
+        """(fine slot of the i-th local C-point, coarse slot index_local[lvl+1][i]) (mgrit.py:498-500,528,722-726)."""
+        fine, coarse = self.index_local_c[lvl], self.index_local[lvl + 1]
+        out = [(int(fine[i]), int(coarse[i])) for i in range(len(fine))]
+        if skip_first and self.comm_time_rank == 0:
+            out = out[1:]
+        return out
+
+    def _exchange(self, lvl, send_idx=None, recv_idx=None, dest=None, src=None):
+        send = (self.backend.payload(lvl, send_idx), dest) if send_idx is not None else None
+        recv = (self.backend.recv_buffer(lvl, recv_idx), src) if recv_idx is not None else None
+        if send is None and recv is None:
+            return
+        got = self.comm_time.exchange(send=send, recv=recv)
+        if recv is not None:
+            self.backend.commit(lvl, recv_idx, got)
+
+    def _last_slot(self, lvl):
+        return len(self.t[lvl]) - 1
+
+    # ------------------------------------------------------------------------------------------------
+    # the MGRIT cycle (mgrit.py:261-290)
+    # ------------------------------------------------------------------------------------------------
+    def iteration(self, lvl: int, cycle_type: str, iteration: int, first_f: bool) -> None:
+        if lvl == self.lvl_max - 1:
+            self.forward_solve(lvl=lvl)
+            return
+        if first_f and (lvl > 0 or iteration == 0):
+            self.f_relax(lvl=lvl)
+        for _ in range(self.cf_iter[lvl]):
+            self.c_relax(lvl=lvl)
+            self.f_relax(lvl=lvl)
+        self.fas_residual(lvl=lvl)
+        self.iteration(lvl=lvl + 1, cycle_type=cycle_type, iteration=iteration, first_f=True)
+        self.error_correction(lvl=lvl)
+        self.f_relax(lvl=lvl)
+        if lvl != 0 and cycle_type == 'F':
+            self.iteration(lvl=lvl, cycle_type='V', iteration=iteration, first_f=False)
+
+    def f_relax(self, lvl: int) -> None:
+        """F-relaxation (mgrit.py:292-333): every F-interval is propagated from its preceding point. Exchange:
+        op 0 = last local C-point to the next owner's ghost; op 1 = hand-off inside an F-interval that straddles a
+        rank boundary (comm_front / comm_back)."""
+        t0 = time.time()
+        self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_c_point[lvl] else None,
+                       recv_idx=0 if self.first_is_f_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl])
+        runs = self._f_runs(lvl)
+        if runs:
+            front, back = self.comm_front[lvl], self.comm_back[lvl]
+            if front and back and len(runs) == 1:
+                self._exchange(lvl, recv_idx=0, src=self.get_from[lvl])
+                self.backend.relax(lvl, runs, 'F')
+                self._exchange(lvl, send_idx=self._last_slot(lvl), dest=self.send_to[lvl])
+            else:
+                if back:  # the interval feeding the next rank goes first
+                    self.backend.relax(lvl, runs[-1:], 'F')
+                    self._exchange(lvl, send_idx=self._last_slot(lvl), dest=self.send_to[lvl])
+                    runs = runs[:-1]
+                if front:
+                    self.backend.relax(lvl, runs[1:], 'F')
+                    self._exchange(lvl, recv_idx=0, src=self.get_from[lvl])
+                    self.backend.relax(lvl, runs[:1], 'F')
+                else:
+                    self.backend.relax(lvl, runs, 'F')
+        logging.debug(f"F-relax on {self.comm_time_rank} took {time.time() - t0} s")
+
+    def c_relax(self, lvl: int) -> None:
+        """C-relaxation (mgrit.py:335-370); op 2 = last local F-point to the next owner's ghost."""
+        t0 = time.time()
+        self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
+                       recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl])
+        self.backend.relax(lvl, consecutive_runs(self._c_points(lvl)), 'C')
+        logging.debug(f"C-relax on {self.comm_time_rank} took {time.time() - t0} s")
+
+    def compute_jump(self) -> list:
+        """||u_i - u_i(previous iteration)|| at the local C-points (mgrit.py:372-385)."""
+        return self.backend.jump_norms(self._c_points(0))
+
+    def compute_residual(self) -> list:
+        """Per-C-point norms of r_i = Phi(u_{i-1}) - u_i on level 0 (mgrit.py:387-413); op 7 ghost refresh."""
+        self._exchange(0, send_idx=self._last_slot(0) if self.last_is_f_point[0] else None,
+                       recv_idx=0 if self.first_is_c_point[0] else None, dest=self.send_to[0], src=self.get_from[0])
+        return self.backend.residual_norms(self._c_points(0))
+
+    def convergence_criterion(self, iteration: int) -> None:
+        """Global stopping value (mgrit.py:415-432): the per-point norms of all ranks, in time order, reduced with
+        np.linalg.norm(ord=t_norm). gather+bcast of the reference becomes one all-gather of a few floats."""
+        t0 = time.time()
+        val = self.compute_residual() if self.conv_crit == 0 else self.compute_jump()
+        parts = self.comm_time.allgather_object([float(x) for x in val])
+        self.conv[iteration] = np.linalg.norm(np.array([x for part in parts for x in part]), ord=self.t_norm)
+        logging.debug(f"Convergence criterion on {self.comm_time_rank} took {time.time() - t0} s")
+
+    def forward_solve(self, lvl: int) -> None:
+        """Sequential time stepping on level ``lvl`` (mgrit.py:459-486); op 5 = pipeline hand-off between owners."""
+        t0 = time.time()
+        if self.get_from[lvl] != -99:
+            self._exchange(lvl, recv_idx=0, src=self.get_from[lvl])
+        n = len(self.t[lvl])
+        if n > 1:
+            self.backend.relax(lvl, [(1, n - 1)], 'F')
+        if self.send_to[lvl] != -99:
+            self._exchange(lvl, send_idx=int(self.index_local[lvl][-1]), dest=self.send_to[lvl])
+        logging.debug(f"Forward solve on {self.comm_time_rank} took {time.time() - t0} s")
+
+    def fas_residual(self, lvl: int) -> None:
+        """Inject the C-points and the FAS right-hand side into level lvl+1 (mgrit.py:488-549). op 3 = ghost refresh on
+        lvl, op 4 = last local point of lvl+1 to the next owner's ghost."""
+        t0 = time.time()
+        self.backend.restrict_u(lvl, self._pairs(lvl, skip_first=False))
+        self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
+                       recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl])
+        self._exchange(lvl + 1,
+                       send_idx=int(self.index_local[lvl + 1][-1]) if self.send_to[lvl + 1] >= 0 else None,
+                       recv_idx=0 if self.get_from[lvl + 1] >= 0 else None,
+                       dest=self.send_to[lvl + 1], src=self.get_from[lvl + 1])
+        self.backend.copy_u_to_v(lvl + 1)
+        self.backend.fas_rhs(lvl, self._pairs(lvl, skip_first=True))
+        logging.debug(f"Fas residual on {self.comm_time_rank} took {time.time() - t0} s")
+
+    def error_correction(self, lvl: int) -> None:
+        """u^l at C-points += P(u^{l+1} - v^{l+1}) (mgrit.py:715-726)."""
+        self.backend.error_correction(lvl, self._pairs(lvl, skip_first=True))
+
+    def nested_iteration(self) -> None:
+        """Initial guess from the coarsest level upwards (mgrit.py:551-566)."""
+        self.forward_solve(self.lvl_max - 1)
+        for lvl in range(self.lvl_max - 2, -1, -1):
+            self.backend.interpolate(lvl, self._pairs(lvl, skip_first=True))
+            if lvl > 0:
+                self.iteration(lvl=lvl, cycle_type='V', iteration=0, first_f=True)
+
+    # ------------------------------------------------------------------------------------------------
+    # solve (mgrit.py:590-646) -- log lines keep the reference's wire format (tests/mpi/mpi.py parses "conv:")
+    # ------------------------------------------------------------------------------------------------
+    def ouput_run_information(self) -> None:
+        rows = [('time interval', '[' + str(self.problem[0].t[0]) + ', ' + str(self.problem[0].t[-1]) + ']'),
+                ('number of time points ', str(len(self.problem[0].t))),
+                ('max dt ', str(np.max(self.problem[0].t[1:] - self.problem[0].t[:-1]))),
+                ('number of levels', str(self.lvl_max)),
+                ('coarsening factors', str(self.m[:-1])),
+                ('relaxation weight', str(self.weight_c)),
+                ('cf_iter', str(self.cf_iter[:self.lvl_max - 1])),
+                ('nested iteration', str(self.nes_it)),
+                ('cycle type', str(self.cycle_type)),
+                ('stopping tolerance', str(self.tol)),
+                ('time communicator size', str(self.comm_time_size)),
+                ('space communicator size', str(self.comm_space_size)),
+                ('convergence criterion', str(self.conv_crit))]
+        self.log_info('\n'.join(['Run parameter overview'] + ['  ' + '{0: <25}'.format(k) + ' : ' + v for k, v in rows]))
+
+    def solve(self) -> dict:
+        self.log_info("Start solve")
+        solve_start = time.time()
+        for iteration in range(self.iter_max):
+            self.solve_iter = iteration + 1
+            it_start = time.time()
+            self.iteration(lvl=0, cycle_type=self.cycle_type, iteration=iteration, first_f=True)
+            self.backend.sync()
+            it_stop = time.time()
+            self.convergence_criterion(iteration=iteration + 1)
+            now, before = self.conv[iteration + 1], self.conv[iteration]
+            factor = '-' if iteration == 0 else str(now / before)
+            self.log_info('{0: <7}'.format(f"iter {iteration + 1}") + '{0: <32}'.format(f" | conv: {now}") +
+                          '{0: <37}'.format(f" | conv factor: {factor}") +
+                          '{0: <35}'.format(f" | runtime: {it_stop - it_start} s"))
+            if self.output_fcn is not None and self.output_lvl == 2:
+                self.output_fcn(self)
+            if now < self.tol or iteration == self.iter_max - 1:
+                break
+        self.backend.sync()
+        self.comm_time.barrier()
+        self.runtime_solve = time.time() - solve_start
+        self.log_info(f"Solve took {self.runtime_solve} s")
+        if self.output_fcn is not None and self.output_lvl == 1:
+            self.output_fcn(self)
+        self.ouput_run_information()
+        return {'conv': self.conv[np.where(self.conv != 0)], 'time_setup': self.runtime_setup,
+                'time_solve': self.runtime_solve}
