@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- MGRIT V-cycle throughput of the MI355X engine on BASELINE.json's headline workload.
+
+Workload (config.workload): BASELINE configs[2] = heat_1d nx=16384 (16382 DOF), nt=65537, 3-level m=4, FCF-relaxation,
+V-cycle. It fits one MI355X (16.6 GB of slabs), so it is also the N=1 workload; with N>1 the SAME problem is sharded
+over the ranks by time blocks (strong scaling) and ghost time points travel over RCCL point-to-point.
+
+One "step" = one steady-state MGRIT V-cycle on level 0 (C-relax, F-relax, FAS residual, recursion, error correction,
+F-relax) + the residual-norm convergence check -- exactly what Mgrit.solve() does per iteration after the first.
+value = time-point-DOF updates per second = (Phi applications of the cycle, SURVEY 3.5 work model) x DOFs / wall time,
+inputs resident in HBM. "roofline" is measured live with HIP events on the engine's stream around the level-0 F-relax
+launch (the dominant kernel): algorithmic bytes = F_0 x 16 B x nx.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def rhs_space(x):
+    return - np.sin(np.pi * x)
+
+
+def rhs_time(t):
+    return np.sin(t) - 1 * np.pi ** 2 * np.cos(t)
+
+
+def init_cond(x):
+    return np.sin(np.pi * x)
+
+
+def phi_counts(nts, m_list, first_iteration=False):
+    """SURVEY 3.5 work model: Phi applications per level for one V-cycle with cf_iter=1 incl. the residual check."""
+    L = len(nts)
+    counts = []
+    for l in range(L):
+        N = nts[l] - 1
+        if l == L - 1:
+            counts.append(N + (nts[l] - 1 if L > 1 else 0))  # forward solve + coarse half of fas_residual(L-2)
+            continue
+        m = m_list[l]
+        F, C = N * (m - 1) // m, N // m
+        if l == 0:
+            counts.append((3 if first_iteration else 2) * F + 3 * C)
+        else:
+            counts.append(3 * F + 2 * C + (nts[l] - 1))
+    return counts
+
+
+def cpu_baseline(nx, seconds_target=12.0):
+    """The parity oracle ("port", variant 0 = plain Thomas) timed single-threaded on this host on a bounded sample of
+    the same workload: nx as given, nt=1025, 3-level m=4, V-cycles until ~seconds_target."""
+    import cases
+    from oracle import oracle as orc
+    nts = (1025, 257, 65)
+    levels = [cases.heat_level_spec(nx, cases.lin(2.0 * (nts[0] - 1) / 65536, nt)) for nt in nts]
+    p = orc.OracleProblem(levels, variant=0, nested_iteration=False, max_iter=1, tol=0.0)
+    upd_per_cycle = sum(c * (nx - 2) for c in phi_counts(nts, [4, 4]))
+    p.iteration(0, 'V', 0, True)  # warm-up cycle (first iteration does one more F-relax)
+    t0, cycles = time.perf_counter(), 0
+    while True:
+        p.iteration(0, 'V', 1, True)
+        p.residual_norms()
+        cycles += 1
+        el = time.perf_counter() - t0
+        if el > seconds_target or cycles >= 64:
+            break
+    return {"value": upd_per_cycle * cycles / el, "unit": "time-point-DOF updates/s", "cores": 1, "kind": "port",
+            "sample": f"oracle variant 0 (Thomas), heat_1d nx={nx} nt={nts[0]} 3-level m=4, {cycles} V-cycles "
+                      f"incl. residual check, {el:.1f} s, host has {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nx", type=int, default=16384)
+    ap.add_argument("--nt", type=int, default=65537)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pymgrit_amd import Heat1D, Mgrit
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    nx, nt0 = args.nx, args.nt
+    nts = [nt0, (nt0 - 1) // 4 + 1, (nt0 - 1) // 16 + 1]
+    t0 = np.linspace(0, 2.0 * (nt0 - 1) / 65536, nt0)
+    grids = [t0, t0[::4], t0[::16]]
+    problem = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=init_cond, rhs_separable=[(rhs_space, rhs_time)],
+                      t_interval=g) for g in grids]
+    mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=False, max_iter=1, tol=0.0, logging_lvl=30)
+    be = mg.backend
+    dof = nx - 2
+    counts = phi_counts(nts, [4, 4])
+    updates_per_cycle = float(sum(c * dof for c in counts))
+
+    def cycle(it):
+        mg.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True)
+        mg.convergence_criterion(iteration=1)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    cycle(0)  # iteration 0 (does the extra leading F-relax), then steady-state warm-up
+    for _ in range(args.warmup):
+        cycle(1)
+    fence()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        cycle(1)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # --- roofline of the dominant kernel: level-0 F-relax launch, HIP events on the engine's stream -----------
+    f_runs = mg._f_runs(0)
+    n_f_local = sum(r[1] for r in f_runs)
+    be.set_timing(True)
+    ms = []
+    for _ in range(5):
+        be.relax(0, f_runs, 'F')
+        ms.append(be.last_kernel_ms())
+    c_runs = mg._c_runs(0)
+    ms_c = []
+    for _ in range(5):
+        be.relax(0, c_runs, 'C')
+        ms_c.append(be.last_kernel_ms())
+    be.set_timing(False)
+    f_ms, c_ms = float(np.mean(ms[1:])), float(np.mean(ms_c[1:]))
+    alg_bytes_f = n_f_local * 16.0 * dof
+    achieved = alg_bytes_f / (f_ms * 1e-3) / 1e9
+    fcf_bytes = (2 * n_f_local + len(c_runs)) * 16.0 * dof
+    fcf_gbs = fcf_bytes / ((2 * f_ms + c_ms) * 1e-3) / 1e9
+
+    out = {
+        "metric": "time-point-DOF updates/sec per MGRIT V-cycle", "value": updates_per_cycle * args.steps / elapsed,
+        "unit": "time-point-DOF updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle + residual check "
+                               f"(BASELINE configs[2]; time points sharded over {world} GPU(s))",
+                   "phi_per_cycle_by_level": counts, "dof": dof},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "relax_kernel<HEAT1D,false,ROLE_F> (level-0 F-relax)", "launch_ms": f_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes_f},
+        "fcf_relax_level0": {"ms": 2 * f_ms + c_ms, "algorithmic_GBps": fcf_gbs, "frac_of_hbm_peak": fcf_gbs / HBM_PEAK_GBS,
+                             "updates_per_s": (2 * n_f_local + len(c_runs)) * dof / ((2 * f_ms + c_ms) * 1e-3),
+                             "c_relax_ms": c_ms, "f_relax_ms": f_ms},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nx)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

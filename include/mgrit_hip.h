@@ -7,9 +7,10 @@
  *
  * Conventions: plain pointers and sizes only; every function returns 0 on success and a negative code on error
  * (message via mgrit_hip_last_error()); no exceptions cross the ABI; one host thread per engine; all device work
- * is enqueued on the hipStream_t given at creation; state slabs are DEVICE pointers owned by the caller
- * (row-major [n_local_points][ld] float64, ld a multiple of 16, padding columns kept zero); host arrays are
- * borrowed for the duration of the call only.
+ * is enqueued on the hipStream_t given at creation; state slabs are DEVICE pointers owned by the caller:
+ * float64 [n_local_points][ld] with ld = mgrit_hip_row_stride(n); inside a row the n spatial values are stored in the
+ * engine's lane-blocked order (natural index j lives at mgrit_hip_row_position(n, j); the other positions are padding
+ * and must stay zero). Host arrays are borrowed for the duration of the call only.
  */
 #ifndef MGRIT_HIP_H
 #define MGRIT_HIP_H
@@ -27,10 +28,14 @@ typedef struct mgrit_hip_engine mgrit_hip_engine;
 enum { MGRIT_HIP_OK = 0, MGRIT_HIP_EINVAL = -1, MGRIT_HIP_EHIP = -2, MGRIT_HIP_ENODEV = -3, MGRIT_HIP_EUNSUPPORTED = -4 };
 enum { MGRIT_HIP_STEPPER_HEAT1D = 1, MGRIT_HIP_STEPPER_ADVECTION1D = 2 };
 enum { MGRIT_HIP_TRANSFER_COPY = 0, MGRIT_HIP_TRANSFER_HEAT1D = 1 };
-enum { MGRIT_HIP_RELAX_F = 0, MGRIT_HIP_RELAX_C = 1 };
+enum { MGRIT_HIP_RELAX_F = 0, MGRIT_HIP_RELAX_C = 1, MGRIT_HIP_RELAX_CHAIN = 2 };
 
 int mgrit_hip_abi_version(void);
 const char *mgrit_hip_last_error(void);
+/* Row geometry of a slab (pure functions, no device needed): stride in doubles for n DOFs per time point, and the
+ * position of natural spatial index j inside a row (-1 when out of range). */
+int mgrit_hip_row_stride(int n);
+int mgrit_hip_row_position(int n, int j);
 /* number of visible HIP devices (0 when none); does not create a context */
 int mgrit_hip_device_count(void);
 
@@ -66,7 +71,8 @@ int mgrit_hip_pairs_create(mgrit_hip_engine *e, int lvl, int n_pairs, const int3
                            int *id_out);
 
 /* Mgrit.f_relax (mgrit.py:292-333), Mgrit.c_relax (mgrit.py:335-370), Mgrit.forward_solve (mgrit.py:459-486):
- * mode F:  u_i = [g_i +] Phi(u_{i-1});  mode C: u_i = ([g_i +] Phi(u_{i-1}))*w + u_i*(1-w). g is used on lvl > 0. */
+ * mode F / CHAIN:  u_i = [g_i +] Phi(u_{i-1})  (CHAIN = the sequential coarsest-level solve, same arithmetic);
+ * mode C: u_i = ([g_i +] Phi(u_{i-1}))*w + u_i*(1-w). g is used on lvl > 0. */
 int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double weight_c);
 /* Mgrit.compute_residual (mgrit.py:387-413): per run r (len 1) sumsq_out[r] = ||Phi(u_{i-1}) - u_i||_2^2 (device ptr). */
 int mgrit_hip_residual(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_out);

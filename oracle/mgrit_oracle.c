@@ -16,7 +16,7 @@
  *   variant 0 "natural": textbook Thomas / forward substitution (pinned against the reference's KATs and
  *                        reference-generated fixtures in tests/golden to forward-error tolerance);
  *   variant 1 "spec":    the chunked-scan arithmetic specification of DESIGN.md section 3 (E=16 elements per
- *                        chunk, 64 chunks per group, Kogge-Stone inside a group, serial carry across groups),
+ *                        chunk, 64 chunks per group, row-wise Kogge-Stone + two row broadcasts inside a group, serial carry across groups),
  *                        written independently of the HIP kernels, which must reproduce it bit for bit.
  * Parity pinned: yes (tests/test_oracle_golden.py vs the json/npz fixtures in tests/golden).
  *
@@ -235,11 +235,18 @@ static void spec_scan_fwd(const orc_cset *c, int G, double *y) {
             for (int k = 1; k < ORC_E; ++k) b[k] = fma(c->rho, b[k - 1], b[k]);
             S[l] = b[ORC_E - 1];
         }
-        for (int s = 0; s < 6; ++s) {
+        /* wave scan: Kogge-Stone inside each row of 16 lanes (offsets 1,2,4,8), then two row broadcasts */
+        for (int s = 0; s < 4; ++s) {
             int off = 1 << s;
-            for (int l = 0; l < ORC_LANES; ++l) T[l] = (l >= off) ? fma(c->sc[s], S[l - off], S[l]) : S[l];
+            for (int l = 0; l < ORC_LANES; ++l) T[l] = ((l & 15) >= off) ? fma(c->sc[s], S[l - off], S[l]) : S[l];
             memcpy(S, T, sizeof(S));
         }
+        for (int l = 0; l < ORC_LANES; ++l) /* rows 1 and 3 take the last lane of the row below */
+            T[l] = ((l >> 4) & 1) ? fma(c->lp[(l & 15) + 1], S[(l & ~15) - 1], S[l]) : S[l];
+        memcpy(S, T, sizeof(S));
+        for (int l = 0; l < ORC_LANES; ++l) /* lanes 32..63 take lane 31 */
+            T[l] = (l >= 32) ? fma(c->lp[l - 31], S[31], S[l]) : S[l];
+        memcpy(S, T, sizeof(S));
         memcpy(Ssave + (size_t)g * ORC_LANES, S, sizeof(S));
         A[g] = S[ORC_LANES - 1];
     }
@@ -267,11 +274,17 @@ static void spec_scan_bwd(const orc_cset *c, int G, double *z) {
             for (int k = ORC_E - 2; k >= 0; --k) b[k] = fma(c->rho, b[k + 1], b[k]);
             S[l] = b[0];
         }
-        for (int s = 0; s < 6; ++s) {
+        for (int s = 0; s < 4; ++s) {
             int off = 1 << s;
-            for (int l = 0; l < ORC_LANES; ++l) T[l] = (l + off < ORC_LANES) ? fma(c->sc[s], S[l + off], S[l]) : S[l];
+            for (int l = 0; l < ORC_LANES; ++l) T[l] = ((l & 15) + off < 16) ? fma(c->sc[s], S[l + off], S[l]) : S[l];
             memcpy(S, T, sizeof(S));
         }
+        for (int l = 0; l < ORC_LANES; ++l) /* rows 0 and 2 take the first lane of the row above */
+            T[l] = (((l >> 4) & 1) == 0) ? fma(c->lp[16 - (l & 15)], S[(l & ~15) + 16], S[l]) : S[l];
+        memcpy(S, T, sizeof(S));
+        for (int l = 0; l < ORC_LANES; ++l) /* lanes 0..31 take lane 32 */
+            T[l] = (l < 32) ? fma(c->lp[32 - l], S[32], S[l]) : S[l];
+        memcpy(S, T, sizeof(S));
         memcpy(Ssave + (size_t)g * ORC_LANES, S, sizeof(S));
         A[g] = S[0];
     }

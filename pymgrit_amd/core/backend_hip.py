@@ -1,7 +1,7 @@
 """HIP sweep backend: the MGRIT sweeps as hand-written gfx950 kernels behind the C ABI of include/mgrit_hip.h.
 
-State layout: per level one row-major float64 slab ``[n_local_points][ld]`` per array (u, v, g) in HBM, allocated
-as torch CUDA tensors (PyTorch is plumbing here: device memory, the stream, torch.distributed); the library only
+State layout: per level one float64 slab ``[n_local_points][ld]`` per array (u, v, g) in HBM (rows in the engine's
+lane-blocked order, ``hip_lib.row_permutation``), allocated as torch CUDA tensors (PyTorch is plumbing here: device memory, the stream, torch.distributed); the library only
 sees raw device pointers. ``mgrit.u[lvl]`` stays an indexable sequence of Vector objects (lazy host views), which
 is what output_fcn callbacks and subclasses of the reference read.
 
@@ -25,11 +25,12 @@ def _ptr(a):
 
 
 class SlabVectorList:
-    """``mgrit.u[lvl]``-compatible view of a device slab: indexing copies ONE row to the host and wraps it in the
-    application's Vector type; assignment uploads a Vector."""
+    """``mgrit.u[lvl]``-compatible view of a device slab: indexing copies ONE row to the host (undoing the engine's
+    lane-blocked storage order, include/mgrit_hip.h) and wraps it in the application's Vector type; assignment
+    uploads a Vector."""
 
-    def __init__(self, slab, n, template):
-        self.slab, self.n, self.template = slab, n, template
+    def __init__(self, slab, n, template, perm):
+        self.slab, self.n, self.template, self.perm = slab, n, template, perm
 
     def __len__(self):
         return self.slab.shape[0]
@@ -45,13 +46,13 @@ class SlabVectorList:
         if isinstance(i, slice):
             return [self[k] for k in range(*i.indices(len(self)))]
         vec = self.template.clone_zero()
-        host = self.slab[self._row(int(i)), :self.n].cpu().numpy()
+        host = self.slab[self._row(int(i))][self.perm].cpu().numpy()
         vec.set_values(host.reshape(np.shape(vec.get_values())).copy())
         return vec
 
     def __setitem__(self, i, vec):
         vals = np.ascontiguousarray(np.asarray(vec.get_values(), dtype=np.float64)).ravel()
-        self.slab[self._row(int(i)), :self.n] = torch.from_numpy(vals).to(self.slab.device)
+        self.slab[self._row(int(i))][self.perm] = torch.from_numpy(vals).to(self.slab.device)
 
     def __iter__(self):
         return (self[k] for k in range(len(self)))
@@ -71,7 +72,8 @@ class HipBackend:
         check(self.lib.mgrit_hip_create(C.byref(self.h), mg.lvl_max, C.c_void_p(self.stream.cuda_stream)))
         self.desc = [p.device_stepper() for p in mg.problem]
         self.n = [int(d["n"]) for d in self.desc]
-        self.ld = [((n + 15) // 16) * 16 for n in self.n]
+        self.ld = [hip_lib.row_stride(n) for n in self.n]
+        self.perm = [torch.from_numpy(hip_lib.row_permutation(n)).to(self.device) for n in self.n]
         self.U, self.V, self.G = [], [], []
         self._runs, self._pairs = {}, {}
         self._described = [False] * mg.lvl_max
@@ -109,8 +111,9 @@ class HipBackend:
         tmpl = mg.problem[lvl].vector_template
         if lvl == 0 and mg.random_init_guess and n_pts:
             host = np.zeros((n_pts, ld))
+            perm = self.perm[lvl].cpu().numpy()
             for i in range(n_pts):  # clone_rand per time point, in time order (heat_1d.py:88-96)
-                host[i, :n] = np.asarray(tmpl.clone_rand().get_values(), dtype=np.float64).ravel()
+                host[i, perm] = np.asarray(tmpl.clone_rand().get_values(), dtype=np.float64).ravel()
             u.copy_(torch.from_numpy(host))
         v = g = None
         if lvl > 0:
@@ -120,9 +123,9 @@ class HipBackend:
         check(self.lib.mgrit_hip_level_bind(self.h, lvl, C.c_void_p(u.data_ptr()),
                                             C.c_void_p(v.data_ptr() if v is not None else 0),
                                             C.c_void_p(g.data_ptr() if g is not None else 0)))
-        mg.u.append(SlabVectorList(u, n, tmpl))
-        mg.v.append(SlabVectorList(v, n, tmpl) if v is not None else None)
-        mg.g.append(SlabVectorList(g, n, tmpl) if g is not None else None)
+        mg.u.append(SlabVectorList(u, n, tmpl, self.perm[lvl]))
+        mg.v.append(SlabVectorList(v, n, tmpl, self.perm[lvl]) if v is not None else None)
+        mg.g.append(SlabVectorList(g, n, tmpl, self.perm[lvl]) if g is not None else None)
         if mg.comm_time_rank == 0 and n_pts:
             mg.u[lvl][0] = mg.problem[lvl].vector_t_start
         self._described[lvl] = True
@@ -137,6 +140,17 @@ class HipBackend:
                                     f"device-capable GridTransfer (GridTransferCopy, GridTransferHeat)")
             check(self.lib.mgrit_hip_level_transfer(self.h, lvl, int(tr.device_transfer())))
 
+    def natural(self, which, lvl):
+        """host copy of a whole slab in natural x order, shape [n_local_points][n] (tests / post-processing)"""
+        slab = {"u": self.U, "v": self.V, "g": self.G}[which][lvl]
+        return slab[:, self.perm[lvl]].cpu().numpy()
+
+    def set_natural(self, which, lvl, values):
+        """upload a [n_local_points][n] host array given in natural x order"""
+        slab = {"u": self.U, "v": self.V, "g": self.G}[which][lvl]
+        slab.zero_()
+        slab[:, self.perm[lvl]] = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64)).to(slab.device)
+
     # -- exchange payloads: slab rows travel in place over RCCL ---------------------------------------
     def payload(self, lvl, idx):
         return self.U[lvl][idx]
@@ -148,23 +162,47 @@ class HipBackend:
         pass
 
     # -- helpers ---------------------------------------------------------------------------------------
+    def _handle(self, store, lvl, items, tag, create):
+        """device-side list handle: cached on the list object itself when it can carry attributes (Mgrit's IndexList),
+        else in a dict keyed by content"""
+        attr = f"_hip_{tag}_{lvl}_{id(self)}"
+        hid = getattr(items, attr, None)
+        if hid is None:
+            key = None
+            if not hasattr(items, "__dict__"):
+                key = (lvl, tuple(items))
+                hid = store.get(key)
+            if hid is None:
+                hid = create()
+                if key is None:
+                    setattr(items, attr, hid)
+                else:
+                    store[key] = hid
+        return hid
+
     def _run_id(self, lvl, runs):
-        key = (lvl, tuple(runs))
-        if key not in self._runs:
+        def create():
             rid = C.c_int(-1)
             st, ln = _i32([r[0] for r in runs]), _i32([r[1] for r in runs])
             check(self.lib.mgrit_hip_runs_create(self.h, lvl, len(runs), _ptr(st), _ptr(ln), C.byref(rid)))
-            self._runs[key] = rid.value
-        return self._runs[key]
+            return rid.value
+        return self._handle(self._runs, lvl, runs, "runs", create)
+
+    def _point_run_id(self, lvl, points):
+        def create():
+            rid = C.c_int(-1)
+            st, ln = _i32(list(points)), _i32([1] * len(points))
+            check(self.lib.mgrit_hip_runs_create(self.h, lvl, len(points), _ptr(st), _ptr(ln), C.byref(rid)))
+            return rid.value
+        return self._handle(self._runs, lvl, points, "pts", create)
 
     def _pair_id(self, lvl, pairs):
-        key = (lvl, tuple(pairs))
-        if key not in self._pairs:
+        def create():
             pid = C.c_int(-1)
             fi, co = _i32([p[0] for p in pairs]), _i32([p[1] for p in pairs])
             check(self.lib.mgrit_hip_pairs_create(self.h, lvl, len(pairs), _ptr(fi), _ptr(co), C.byref(pid)))
-            self._pairs[key] = pid.value
-        return self._pairs[key]
+            return pid.value
+        return self._handle(self._pairs, lvl, pairs, "pairs", create)
 
     def _sumsq_buf(self, n):
         if self._sumsq is None or self._sumsq.numel() < n:
@@ -175,29 +213,28 @@ class HipBackend:
     def relax(self, lvl, runs, mode):
         if not runs:
             return
-        check(self.lib.mgrit_hip_relax(self.h, lvl, self._run_id(lvl, runs), hip_lib.RELAX_C if mode == 'C' else
-                                       hip_lib.RELAX_F, float(self.mg.weight_c)))
+        code = {'F': hip_lib.RELAX_F, 'C': hip_lib.RELAX_C, 'CHAIN': hip_lib.RELAX_CHAIN}[mode]
+        check(self.lib.mgrit_hip_relax(self.h, lvl, self._run_id(lvl, runs), code, float(self.mg.weight_c)))
 
     def residual_norms(self, points):
         if not len(points):
             return []
-        runs = [(int(i), 1) for i in points]
-        buf = self._sumsq_buf(len(runs))
-        check(self.lib.mgrit_hip_residual(self.h, 0, self._run_id(0, runs), C.c_void_p(buf.data_ptr())))
-        return np.sqrt(buf[:len(runs)].cpu().numpy()).tolist()
+        buf = self._sumsq_buf(len(points))
+        check(self.lib.mgrit_hip_residual(self.h, 0, self._point_run_id(0, points), C.c_void_p(buf.data_ptr())))
+        return np.sqrt(buf[:len(points)].cpu().numpy()).tolist()
 
     def save_last(self):
         self.prev = self.U[0].clone()
-        self.mg.save_values_last_iter = SlabVectorList(self.prev, self.n[0], self.mg.problem[0].vector_template)
+        self.mg.save_values_last_iter = SlabVectorList(self.prev, self.n[0], self.mg.problem[0].vector_template,
+                                                       self.perm[0])
 
     def jump_norms(self, points):
         out = []
         if len(points):
-            runs = [(int(i), 1) for i in points]
-            buf = self._sumsq_buf(len(runs))
-            check(self.lib.mgrit_hip_jump(self.h, 0, self._run_id(0, runs), C.c_void_p(self.prev.data_ptr()),
+            buf = self._sumsq_buf(len(points))
+            check(self.lib.mgrit_hip_jump(self.h, 0, self._point_run_id(0, points), C.c_void_p(self.prev.data_ptr()),
                                           C.c_void_p(buf.data_ptr())))
-            out = np.sqrt(buf[:len(runs)].cpu().numpy()).tolist()
+            out = np.sqrt(buf[:len(points)].cpu().numpy()).tolist()
         self.prev.copy_(self.U[0])
         return out
 

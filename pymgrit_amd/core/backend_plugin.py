@@ -51,6 +51,7 @@ class PluginBackend:
         return mg.step[lvl](u_start=src[i - 1], t_start=mg.t[lvl][i - 1], t_stop=mg.t[lvl][i])
 
     def relax(self, lvl, runs, mode):
+        """mode 'F' (F-intervals), 'C' (weighted C-points) or 'CHAIN' (sequential coarsest-level solve = 'F' arithmetic)"""
         mg = self.mg
         u = mg.u[lvl]
         for start, length in runs:

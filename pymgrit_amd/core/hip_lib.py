@@ -6,7 +6,7 @@ import os
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libmgrit_hip.so")
 
-RELAX_F, RELAX_C = 0, 1
+RELAX_F, RELAX_C, RELAX_CHAIN = 0, 1, 2
 STEPPER_HEAT1D, STEPPER_ADVECTION1D = 1, 2
 TRANSFER_COPY, TRANSFER_HEAT1D = 0, 1
 MAX_N = 16384
@@ -16,6 +16,8 @@ EXPORTS = {
     "mgrit_hip_abi_version": (C.c_int, []),
     "mgrit_hip_last_error": (C.c_char_p, []),
     "mgrit_hip_device_count": (C.c_int, []),
+    "mgrit_hip_row_stride": (C.c_int, [C.c_int]),
+    "mgrit_hip_row_position": (C.c_int, [C.c_int, C.c_int]),
     "mgrit_hip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "mgrit_hip_destroy": (C.c_int, [C.c_void_p]),
     "mgrit_hip_sync": (C.c_int, [C.c_void_p]),
@@ -65,3 +67,19 @@ def load():
 def check(rc):
     if rc != 0:
         raise MgritHipError(f"libmgrit_hip error {rc}: {load().mgrit_hip_last_error().decode()}")
+
+
+def row_stride(n):
+    """slab row stride (doubles) for n DOFs per time point: 1024*ceil(n/1024)"""
+    return load().mgrit_hip_row_stride(int(n))
+
+
+def row_permutation(n):
+    """perm[j] = row position of natural spatial index j (the engine's lane-blocked storage order)"""
+    import numpy as np
+    j = np.arange(int(n), dtype=np.int64)
+    perm = ((((j >> 10) * 8 + ((j & 15) >> 1)) * 64 + ((j >> 4) & 63)) << 1) + (j & 1)
+    lib = load()
+    for probe in (0, n // 2, n - 1):  # the formula must agree with the library
+        assert perm[probe] == lib.mgrit_hip_row_position(int(n), int(probe))
+    return perm

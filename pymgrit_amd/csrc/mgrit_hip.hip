@@ -3,14 +3,15 @@
 // Replaces the per-time-point Python loops of the reference's hot path (src/pymgrit/core/mgrit.py:292-549,715-726)
 // and the per-step SuperLU solves of heat/heat_1d.py:198-217 and advection/advection_1d.py:129-143.
 //
-// Data layout: every level keeps its time-point states in one row-major float64 slab [n_local_points][ld] in HBM
-// (x contiguous -> every global access below is a 16-byte-per-lane coalesced stream).
+// Data layout: every level keeps its time-point states in one float64 slab [n_local_points][ld] in HBM; inside a row
+// the x-values are stored in "lane-blocked" order (row_pos below) so that the lane owning 16 consecutive x-values
+// fetches them with 8 fully coalesced 16-byte loads -- no LDS transpose, no strided access.
 // Execution model: ONE workgroup per run of consecutive time points (an F-interval, a C-point, or the coarsest-level
 // chain). The workgroup keeps the whole state vector in registers (16 consecutive x per lane, 64 lanes per wave,
-// up to 16 waves = 16384 x), converts between the coalesced global layout and the per-lane blocked layout through a
-// per-wave padded LDS tile (no workgroup barrier), and applies Phi as two constant-coefficient first-order
-// recurrences (forward, backward) + a rank-one correction -- each recurrence is a chunked scan: lane-local FMA chain,
-// Kogge-Stone over the 64 lanes of a wave via cross-lane shuffles, serial carry across waves through LDS.
+// up to 16 waves = 16384 x), the rank-one correction table of the current time-step size in LDS, and applies Phi as
+// two constant-coefficient first-order recurrences (forward, backward) + a rank-one correction -- each recurrence is
+// a chunked scan: lane-local FMA chain, row-wise Kogge-Stone over DPP row shifts + two readlane row broadcasts inside
+// a wave (no LDS), serial carry across waves through LDS (one barrier).
 // The arithmetic (operation order, FMA placement, reduction trees) is specified in DESIGN.md section 3 and must
 // match oracle/mgrit_oracle.c variant 1 bit for bit: compile with -ffp-contract=off; every FMA is explicit.
 //
@@ -32,8 +33,7 @@ namespace {
 constexpr int E = MGRIT_HIP_E;          // elements per lane
 constexpr int LANES = 64;               // lanes per wave
 constexpr int GROUP = E * LANES;        // elements per wave
-constexpr int WAVE_TILE_BYTES = LANES * (E * 8 + 16);  // 144-byte padded lane rows: conflict-free b128 access
-constexpr int MAX_G = MGRIT_HIP_MAX_N / GROUP;         // 16 waves
+constexpr int MAX_G = MGRIT_HIP_MAX_N / GROUP;  // 16 waves
 
 thread_local std::string g_err;
 
@@ -63,161 +63,243 @@ struct CSet {
     double lp[LANES];   // rho^(E*l)
 };
 
+// Row storage order ("lane-blocked"): wave w of the workgroup owns the natural indices
+// [1024w, 1024w+1024); inside that block lane l owns 16 consecutive values j = 1024w + 16l + 2q + r (q = 0..7, r = 0..1)
+// and the pair (q) of lane l lives at 16-byte slot (8w + q)*64 + l of the row. One wave instruction therefore moves one
+// contiguous 1 KiB segment (64 lanes x 16 B), the 8 segments of a wave are 1 KiB apart (immediate offsets), and no LDS
+// transpose or strided access is needed to give every lane its 16 consecutive x-values. Row stride ld = 1024*ceil(n/1024).
 struct LevelDev {
     double *u, *v, *g;
     const int32_t *cidx;  // [n_pts] coefficient set of the step (i-1 -> i)
     const double *dt;     // [n_pts]
     const double *tau;    // [K][n_pts]
-    const double *sT;     // [K][E][T]   forcing space factors, lane-transposed
+    const double2 *sP;    // [K][ld/2] forcing space factors, row storage order
     const CSet *cs;       // [n_csets]
-    const double *tabT;   // [n_csets][E][T] rank-one correction table, lane-transposed
+    const double2 *tabP;  // [n_csets][ld/2] rank-one correction table, row storage order
     int n, ld, T, n_pts, K, kind;
 };
+
+__host__ __device__ __forceinline__ int row_pos(int j) {
+    return ((((j >> 10) * 8 + ((j & 15) >> 1)) * 64 + ((j >> 4) & 63)) << 1) + (j & 1);
+}
+__host__ __device__ __forceinline__ int row_nat(int p) {
+    const int slot = p >> 1, lane = slot & 63, q = (slot >> 6) & 7, w = slot >> 9;
+    return 1024 * w + 16 * lane + 2 * q + (p & 1);
+}
+// 16-byte slot of pair q for thread t = 64*wave + lane
+__device__ __forceinline__ unsigned slot0(int t) { return (unsigned)(((t >> 6) << 9) + (t & 63)); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// coalesced global row -> blocked registers (lane owns x[16t .. 16t+15]) through this wave's padded LDS tile
-__device__ __forceinline__ void load_row(const double *__restrict__ row, int n, int ld, char *tile, int lane, int wave,
-                                         double (&x)[E]) {
-    const int base = wave * GROUP;
+__device__ __forceinline__ void load_row(const double *__restrict__ row, unsigned s0, double (&x)[E]) {
+    const double2 *r2 = reinterpret_cast<const double2 *>(row) + s0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int e = base + 128 * q + 2 * lane;
-        double2 v = make_double2(0.0, 0.0);
-        if (e < ld) v = *reinterpret_cast<const double2 *>(row + e);
-        if (e >= n) v.x = 0.0;
-        if (e + 1 >= n) v.y = 0.0;
-        const int o = 8 * q + (lane >> 3), k = 2 * (lane & 7);
-        *reinterpret_cast<double2 *>(tile + o * 144 + k * 8) = v;
-    }
-    wave_sync();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const double2 v = *reinterpret_cast<const double2 *>(tile + lane * 144 + 16 * q);
+        const double2 v = r2[q * 64];
         x[2 * q] = v.x;
         x[2 * q + 1] = v.y;
     }
-    wave_sync();
 }
 
-// blocked registers -> coalesced global row (padding columns [n, ld) are written as zero)
-__device__ __forceinline__ void store_row(double *__restrict__ row, int n, int ld, char *tile, int lane, int wave,
-                                          const double (&x)[E]) {
-    const int base = wave * GROUP;
+__device__ __forceinline__ void store_row(double *__restrict__ row, unsigned s0, const double (&x)[E]) {
+    double2 *r2 = reinterpret_cast<double2 *>(row) + s0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-        *reinterpret_cast<double2 *>(tile + lane * 144 + 16 * q) = make_double2(x[2 * q], x[2 * q + 1]);
-    wave_sync();
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int e = base + 128 * q + 2 * lane;
-        const int o = 8 * q + (lane >> 3), k = 2 * (lane & 7);
-        double2 v = *reinterpret_cast<const double2 *>(tile + o * 144 + k * 8);
-        if (e >= n) v.x = 0.0;
-        if (e + 1 >= n) v.y = 0.0;
-        if (e < ld) *reinterpret_cast<double2 *>(row + e) = v;
-    }
-    wave_sync();
+    for (int q = 0; q < 8; ++q) r2[q * 64] = make_double2(x[2 * q], x[2 * q + 1]);
 }
 
-// forward chunked scan  y_j = rho*y_{j-1} + d_j   -- two workgroup barriers are the caller's:
-// this routine ends with x holding y; tot[] is an LDS array of MAX_G doubles.
-__device__ __forceinline__ void scan_fwd(double (&x)[E], const CSet &c, double *tot, int lane, int wave) {
+// cross-lane moves of a double inside one wave, DPP / readlane (no LDS)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
+
+__device__ __forceinline__ double read_lane(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+struct Smem {
+    double2 *tab;   // [8][T] rank-one correction table of the current coefficient set
+    double *totF;   // [MAX_G]
+    double *totB;   // [MAX_G]
+    double *bc;     // [2] broadcast scalars
+    double *lp;     // [LANES] rho^(E*l) of the current coefficient set
+};
+
+// wave-uniform scalar coefficients of the current coefficient set, forced into SGPRs (readfirstlane)
+struct Coef {
+    double rho, ik, scal, gc;
+    double pw[E + 1];
+    double sc[4];
+};
+
+__device__ __forceinline__ double to_sgpr(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ Smem carve_smem(char *base, int T) {
+    Smem s;
+    s.tab = reinterpret_cast<double2 *>(base);
+    double *tail = reinterpret_cast<double *>(base + (size_t)8 * T * sizeof(double2));
+    s.totF = tail;
+    s.totB = tail + MAX_G;
+    s.bc = tail + 2 * MAX_G;
+    s.lp = tail + 2 * MAX_G + 2;
+    return s;
+}
+
+// forward chunked scan  y_j = rho*y_{j-1} + d_j  (DESIGN.md 3.2): lane-local chain, row-wise Kogge-Stone over DPP
+// row shifts, two row broadcasts, serial carry across waves through LDS (one workgroup barrier).
+__device__ __forceinline__ void scan_fwd(double (&x)[E], const Coef &c, const double *lp, double *tot, int lane, int wave) {
 #pragma unroll
     for (int k = 1; k < E; ++k) x[k] = fma(c.rho, x[k - 1], x[k]);
     double a = x[E - 1];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const double v = __shfl_up(a, 1u << s);
-        if (lane >= (1 << s)) a = fma(c.sc[s], v, a);
+    const int li = lane & 15;
+    {
+        double v;
+        v = dpp_mov<DPP_ROW_SHR + 1>(a); if (li >= 1) a = fma(c.sc[0], v, a);
+        v = dpp_mov<DPP_ROW_SHR + 2>(a); if (li >= 2) a = fma(c.sc[1], v, a);
+        v = dpp_mov<DPP_ROW_SHR + 4>(a); if (li >= 4) a = fma(c.sc[2], v, a);
+        v = dpp_mov<DPP_ROW_SHR + 8>(a); if (li >= 8) a = fma(c.sc[3], v, a);
+    }
+    {
+        const double s15 = read_lane(a, 15), s47 = read_lane(a, 47);
+        if ((lane >> 4) & 1) a = fma(lp[li + 1], lane < 32 ? s15 : s47, a);
+        const double s31 = read_lane(a, 31);
+        if (lane >= 32) a = fma(lp[lane - 31], s31, a);
     }
     if (lane == LANES - 1) tot[wave] = a;
     __syncthreads();
     double carry = 0.0;
     for (int g = 0; g < wave; ++g) carry = fma(c.gc, carry, tot[g]);
-    double prev = __shfl_up(a, 1u);
+    double prev = dpp_mov<DPP_WAVE_SHR1>(a);
     if (lane == 0) prev = 0.0;
-    const double cin = fma(c.lp[lane], carry, prev);
+    const double cin = fma(lp[lane], carry, prev);
 #pragma unroll
     for (int k = 0; k < E; ++k) x[k] = fma(c.pw[k + 1], cin, x[k]);
 }
 
 // backward chunked scan  z_j = rho*z_{j+1} + y_j
-__device__ __forceinline__ void scan_bwd(double (&x)[E], const CSet &c, double *tot, int lane, int wave, int G) {
+__device__ __forceinline__ void scan_bwd(double (&x)[E], const Coef &c, const double *lp, double *tot, int lane, int wave, int G) {
 #pragma unroll
     for (int k = E - 2; k >= 0; --k) x[k] = fma(c.rho, x[k + 1], x[k]);
     double a = x[0];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const double v = __shfl_down(a, 1u << s);
-        if (lane + (1 << s) < LANES) a = fma(c.sc[s], v, a);
+    const int li = lane & 15;
+    {
+        double v;
+        v = dpp_mov<DPP_ROW_SHL + 1>(a); if (li + 1 < 16) a = fma(c.sc[0], v, a);
+        v = dpp_mov<DPP_ROW_SHL + 2>(a); if (li + 2 < 16) a = fma(c.sc[1], v, a);
+        v = dpp_mov<DPP_ROW_SHL + 4>(a); if (li + 4 < 16) a = fma(c.sc[2], v, a);
+        v = dpp_mov<DPP_ROW_SHL + 8>(a); if (li + 8 < 16) a = fma(c.sc[3], v, a);
+    }
+    {
+        const double s16 = read_lane(a, 16), s48 = read_lane(a, 48);
+        if (((lane >> 4) & 1) == 0) a = fma(lp[16 - li], lane < 32 ? s16 : s48, a);
+        const double s32 = read_lane(a, 32);
+        if (lane < 32) a = fma(lp[32 - lane], s32, a);
     }
     if (lane == 0) tot[wave] = a;
     __syncthreads();
     double carry = 0.0;
     for (int g = G - 1; g > wave; --g) carry = fma(c.gc, carry, tot[g]);
-    double next = __shfl_down(a, 1u);
+    double next = dpp_mov<DPP_WAVE_SHL1>(a);
     if (lane == LANES - 1) next = 0.0;
-    const double cin = fma(c.lp[LANES - 1 - lane], carry, next);
+    const double cin = fma(lp[LANES - 1 - lane], carry, next);
 #pragma unroll
     for (int k = 0; k < E; ++k) x[k] = fma(c.pw[E - k], cin, x[k]);
 }
 
-struct Smem {
-    char *tile;     // this wave's transposition tile
-    double *totF;   // [MAX_G]
-    double *totB;   // [MAX_G]
-    double *bc;     // [2] broadcast scalars
+// Per-workgroup stepper state that survives across the steps of a run: the forcing space factor of this lane (first
+// term) in registers and the correction table of the current coefficient set in LDS.
+struct StepCtx {
+    double s0[E];
+    Coef c;    // scalar coefficients of the resident coefficient set
+    int cur;   // coefficient set whose tables are resident in LDS / SGPRs (-1: none)
 };
 
-__device__ __forceinline__ Smem carve_smem(char *base, int G, int wave) {
-    Smem s;
-    s.tile = base + wave * WAVE_TILE_BYTES;
-    double *tail = reinterpret_cast<double *>(base + G * WAVE_TILE_BYTES);
-    s.totF = tail;
-    s.totB = tail + MAX_G;
-    s.bc = tail + 2 * MAX_G;
-    return s;
+// FORCE: 0 = no forcing term, 1 = one separable term (space factor held in registers), 2 = K >= 2 terms (streamed)
+template <int KIND, int FORCE>
+__device__ __forceinline__ void ctx_init(StepCtx &ctx, const LevelDev &L, int t) {
+    ctx.cur = -1;
+    if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double2 v = L.sP[slot0(t) + q * 64];
+            ctx.s0[2 * q] = v.x;
+            ctx.s0[2 * q + 1] = v.y;
+        }
+    }
 }
 
 // x <- Phi(x) for the step (i-1 -> i) of level L.  heat_1d.py:198-217 / advection_1d.py:129-143.
-template <int KIND>
-__device__ __forceinline__ void phi_apply(double (&x)[E], const LevelDev &L, int i, const Smem &sm, int t, int lane,
-                                          int wave, int G) {
-    const CSet &c = L.cs[L.cidx[i]];
-    const double *tab = L.tabT + (size_t)L.cidx[i] * E * L.T;
+template <int KIND, int FORCE>
+__device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const LevelDev &L, int i, const Smem &sm, int t,
+                                          int lane, int wave, int G) {
+    const int ci = __builtin_amdgcn_readfirstlane(L.cidx[i]);
+    if (ci != ctx.cur) {  // (re)load this coefficient set: table + lane powers -> LDS, scalars -> SGPRs; uniform branch
+        __syncthreads();
+        const double2 *src = L.tabP + (size_t)ci * 8 * L.T + slot0(t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sm.tab[slot0(t) + q * 64] = src[q * 64];
+        const CSet *g = L.cs + ci;
+        if (t < LANES) sm.lp[t] = g->lp[t];
+        ctx.c.rho = to_sgpr(g->rho); ctx.c.ik = to_sgpr(g->ik); ctx.c.scal = to_sgpr(g->scal); ctx.c.gc = to_sgpr(g->gc);
+#pragma unroll
+        for (int k = 0; k <= E; ++k) ctx.c.pw[k] = to_sgpr(g->pw[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ctx.c.sc[k] = to_sgpr(g->sc[k]);
+        ctx.cur = ci;
+        __syncthreads();
+    }
+    const Coef &c = ctx.c;
     const int j0 = t * E;
     if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
-        if (L.K > 0) {
+        if (FORCE == 1) {
+            const double dt = L.dt[i], tau0 = L.tau[i];
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = x[k] + (ctx.s0[k] * tau0) * dt;
+        } else if (FORCE == 2) {
             const double dt = L.dt[i];
 #pragma unroll
-            for (int k = 0; k < E; ++k) {
-                double f = L.sT[k * L.T + t] * L.tau[i];
-                for (int kk = 1; kk < L.K; ++kk) f = f + L.sT[(size_t)(kk * E + k) * L.T + t] * L.tau[(size_t)kk * L.n_pts + i];
-                x[k] = x[k] + f * dt;
+            for (int q = 0; q < 8; ++q) {
+                const double2 s0v = L.sP[slot0(t) + q * 64];
+                double f0 = s0v.x * L.tau[i], f1 = s0v.y * L.tau[i];
+                for (int kk = 1; kk < L.K; ++kk) {
+                    const double2 sv = L.sP[(size_t)kk * 8 * L.T + slot0(t) + q * 64];
+                    const double tk = L.tau[(size_t)kk * L.n_pts + i];
+                    f0 = f0 + sv.x * tk;
+                    f1 = f1 + sv.y * tk;
+                }
+                x[2 * q] = x[2 * q] + f0 * dt;
+                x[2 * q + 1] = x[2 * q + 1] + f1 * dt;
             }
         }
-        scan_fwd(x, c, sm.totF, lane, wave);
+        scan_fwd(x, c, sm.lp, sm.totF, lane, wave);
 #pragma unroll
         for (int k = 0; k < E; ++k)
             if (j0 + k >= L.n) x[k] = 0.0;
-        scan_bwd(x, c, sm.totB, lane, wave, G);
+        scan_bwd(x, c, sm.lp, sm.totB, lane, wave, G);
         if (t == 0) sm.bc[0] = x[0] * c.ik;
         __syncthreads();
         const double z0 = sm.bc[0];
 #pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = fma(-z0, tab[k * L.T + t], x[k] * c.ik);
+        for (int q = 0; q < 8; ++q) {
+            const double2 w = sm.tab[slot0(t) + q * 64];
+            x[2 * q] = fma(-z0, w.x, x[2 * q] * c.ik);
+            x[2 * q + 1] = fma(-z0, w.y, x[2 * q + 1] * c.ik);
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] * c.ik;
-        scan_fwd(x, c, sm.totF, lane, wave);
+        scan_fwd(x, c, sm.lp, sm.totF, lane, wave);
         const int jl = L.n - 1;
         if (t == jl / E) {
             double y = 0.0;
@@ -229,7 +311,11 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], const LevelDev &L, int
         __syncthreads();
         const double xl = sm.bc[0];
 #pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = (j0 + k < L.n) ? fma(tab[k * L.T + t], xl, x[k]) : 0.0;
+        for (int q = 0; q < 8; ++q) {
+            const double2 w = sm.tab[slot0(t) + q * 64];
+            x[2 * q] = (j0 + 2 * q < L.n) ? fma(w.x, xl, x[2 * q]) : 0.0;
+            x[2 * q + 1] = (j0 + 2 * q + 1 < L.n) ? fma(w.y, xl, x[2 * q + 1]) : 0.0;
+        }
         __syncthreads();  // protects totF / bc reuse by the next step (heat has 3 barriers per step, advection 2 + this)
     }
 }
@@ -255,45 +341,51 @@ __device__ __forceinline__ double block_sumsq(const double (&r)[E], const Smem &
 // ---------------------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
-// f_relax / c_relax / forward_solve (mgrit.py:292-370,459-486)
-template <int KIND>
+#define WG_PROLOGUE                                                                        \
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = blockDim.x >> 6;          \
+    const Smem sm = carve_smem(smem_raw, L.T);                                             \
+    const unsigned sl = slot0(t);                                                          \
+    StepCtx ctx;                                                                           \
+    ctx_init<KIND, FORCE>(ctx, L, t)
+
+// f_relax / c_relax / forward_solve (mgrit.py:292-370,459-486). ROLE only separates the launches by purpose (distinct
+// kernel symbols in rocprof traces; the weighted C-relaxation is the only one that re-reads the old u_i).
+enum { ROLE_F = 0, ROLE_C = 1, ROLE_C_WEIGHTED = 2, ROLE_CHAIN = 3 };
+
+template <int KIND, int FORCE, bool USE_G, int ROLE>
 __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *__restrict__ run_start,
-                                                     const int32_t *__restrict__ run_len, int use_g, int mode,
-                                                     double w, double w1) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = blockDim.x >> 6;
-    const Smem sm = carve_smem(smem_raw, G, wave);
+                                                     const int32_t *__restrict__ run_len, double w, double w1) {
+    WG_PROLOGUE;
     const int start = run_start[blockIdx.x], len = run_len[blockIdx.x];
-    double x[E];
-    load_row(L.u + (size_t)(start - 1) * L.ld, L.n, L.ld, sm.tile, lane, wave, x);
+    double x[E], gi[E];
+    load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
     for (int i = start; i < start + len; ++i) {
-        phi_apply<KIND>(x, L, i, sm, t, lane, wave, G);
-        if (use_g) {
-            double gi[E];
-            load_row(L.g + (size_t)i * L.ld, L.n, L.ld, sm.tile, lane, wave, gi);
+        if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);  // in flight while Phi runs
+        phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+        if (USE_G) {
 #pragma unroll
             for (int k = 0; k < E; ++k) x[k] = gi[k] + x[k];
         }
-        if (mode == MGRIT_HIP_RELAX_C && w != 1.0) {
+        if (ROLE == ROLE_C_WEIGHTED) {
             double uo[E];
-            load_row(L.u + (size_t)i * L.ld, L.n, L.ld, sm.tile, lane, wave, uo);
+            load_row(L.u + (size_t)i * L.ld, sl, uo);
 #pragma unroll
             for (int k = 0; k < E; ++k) x[k] = x[k] * w + uo[k] * w1;
         }
-        store_row(L.u + (size_t)i * L.ld, L.n, L.ld, sm.tile, lane, wave, x);
+        store_row(L.u + (size_t)i * L.ld, sl, x);
     }
 }
 
 // compute_residual (mgrit.py:387-413): out[run] = || Phi(u_{i-1}) - u_i ||^2
-template <int KIND>
+template <int KIND, int FORCE>
 __global__ void __launch_bounds__(1024) residual_kernel(LevelDev L, const int32_t *__restrict__ run_start,
                                                         double *__restrict__ out) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = blockDim.x >> 6;
-    const Smem sm = carve_smem(smem_raw, G, wave);
+    WG_PROLOGUE;
     const int i = run_start[blockIdx.x];
     double x[E], ui[E];
-    load_row(L.u + (size_t)(i - 1) * L.ld, L.n, L.ld, sm.tile, lane, wave, x);
-    phi_apply<KIND>(x, L, i, sm, t, lane, wave, G);
-    load_row(L.u + (size_t)i * L.ld, L.n, L.ld, sm.tile, lane, wave, ui);
+    load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
+    load_row(L.u + (size_t)i * L.ld, sl, ui);
+    phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
 #pragma unroll
     for (int k = 0; k < E; ++k) x[k] = x[k] - ui[k];
     const double tot = block_sumsq(x, sm, t, lane, wave, G);
@@ -304,11 +396,12 @@ __global__ void __launch_bounds__(1024) residual_kernel(LevelDev L, const int32_
 __global__ void __launch_bounds__(1024) jump_kernel(LevelDev L, const int32_t *__restrict__ run_start,
                                                     const double *__restrict__ prev, double *__restrict__ out) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = blockDim.x >> 6;
-    const Smem sm = carve_smem(smem_raw, G, wave);
+    const Smem sm = carve_smem(smem_raw, L.T);
+    const unsigned sl = slot0(t);
     const int i = run_start[blockIdx.x];
     double x[E], p[E];
-    load_row(L.u + (size_t)i * L.ld, L.n, L.ld, sm.tile, lane, wave, x);
-    load_row(prev + (size_t)i * L.ld, L.n, L.ld, sm.tile, lane, wave, p);
+    load_row(L.u + (size_t)i * L.ld, sl, x);
+    load_row(prev + (size_t)i * L.ld, sl, p);
 #pragma unroll
     for (int k = 0; k < E; ++k) x[k] = x[k] - p[k];
     const double tot = block_sumsq(x, sm, t, lane, wave, G);
@@ -316,82 +409,96 @@ __global__ void __launch_bounds__(1024) jump_kernel(LevelDev L, const int32_t *_
 }
 
 // fas_residual, fine half (mgrit.py:528-532 / 538-543): out_p = Phi_l(u_{i-1}) - u_i   or   (g_i - u_i) + Phi_l(u_{i-1})
-template <int KIND>
+template <int KIND, int FORCE>
 __global__ void __launch_bounds__(1024) fas_fine_kernel(LevelDev L, const int32_t *__restrict__ fine_idx,
                                                         const int32_t *__restrict__ out_idx, double *__restrict__ out,
                                                         int out_ld, int use_g) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = blockDim.x >> 6;
-    const Smem sm = carve_smem(smem_raw, G, wave);
+    WG_PROLOGUE;
     const int i = fine_idx[blockIdx.x];
     double x[E], ui[E];
-    load_row(L.u + (size_t)(i - 1) * L.ld, L.n, L.ld, sm.tile, lane, wave, x);
-    phi_apply<KIND>(x, L, i, sm, t, lane, wave, G);
-    load_row(L.u + (size_t)i * L.ld, L.n, L.ld, sm.tile, lane, wave, ui);
-    if (use_g) {
+    load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
+    load_row(L.u + (size_t)i * L.ld, sl, ui);
+    if (use_g) {  // fold (g_i - u_i) first: one live vector less while Phi runs
         double gi[E];
-        load_row(L.g + (size_t)i * L.ld, L.n, L.ld, sm.tile, lane, wave, gi);
+        load_row(L.g + (size_t)i * L.ld, sl, gi);
 #pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = (gi[k] - ui[k]) + x[k];
+        for (int k = 0; k < E; ++k) ui[k] = gi[k] - ui[k];
+    }
+    phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+    if (use_g) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = ui[k] + x[k];
     } else {
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] - ui[k];
     }
-    store_row(out + (size_t)out_idx[blockIdx.x] * out_ld, L.n, out_ld, sm.tile, lane, wave, x);
+    store_row(out + (size_t)out_idx[blockIdx.x] * out_ld, sl, x);
 }
 
 // fas_residual, coarse half (mgrit.py:533-536 / 544-547): g_j = (g_j + v_j) - Phi_{l+1}(v_{j-1})
-template <int KIND>
+template <int KIND, int FORCE>
 __global__ void __launch_bounds__(1024) fas_coarse_kernel(LevelDev L, const int32_t *__restrict__ coarse_idx) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = blockDim.x >> 6;
-    const Smem sm = carve_smem(smem_raw, G, wave);
+    WG_PROLOGUE;
     const int j = coarse_idx[blockIdx.x];
-    double x[E], a[E], b[E];
-    load_row(L.v + (size_t)(j - 1) * L.ld, L.n, L.ld, sm.tile, lane, wave, x);
-    phi_apply<KIND>(x, L, j, sm, t, lane, wave, G);
-    load_row(L.g + (size_t)j * L.ld, L.n, L.ld, sm.tile, lane, wave, a);
-    load_row(L.v + (size_t)j * L.ld, L.n, L.ld, sm.tile, lane, wave, b);
+    double x[E], a[E];
+    load_row(L.v + (size_t)(j - 1) * L.ld, sl, x);
+    {
+        double b[E];
+        load_row(L.g + (size_t)j * L.ld, sl, a);
+        load_row(L.v + (size_t)j * L.ld, sl, b);
 #pragma unroll
-    for (int k = 0; k < E; ++k) x[k] = (a[k] + b[k]) - x[k];
-    store_row(L.g + (size_t)j * L.ld, L.n, L.ld, sm.tile, lane, wave, x);
+        for (int k = 0; k < E; ++k) a[k] = a[k] + b[k];
+    }
+    phi_apply<KIND, FORCE>(x, ctx, L, j, sm, t, lane, wave, G);
+#pragma unroll
+    for (int k = 0; k < E; ++k) x[k] = a[k] - x[k];
+    store_row(L.g + (size_t)j * L.ld, sl, x);
 }
 
-// --- spatial transfer kernels (bandwidth-bound, elementwise). grid = (pairs, ceil(n_out/256)) -------------------
-// restriction: dst row d_idx[p] (n_c) <- R(src row s_idx[p] (n_f)). kind 0 copy; kind 1 full weighting
-// (examples/example_spatial_coarsening.py:33-55: sol[2i]*1/4 + sol[2i+1]*1/2 + sol[2i+2]*1/4).
-__global__ void restrict_rows_kernel(const double *__restrict__ src, int src_ld, const int32_t *__restrict__ s_idx,
-                                     double *__restrict__ dst, int dst_ld, const int32_t *__restrict__ d_idx, int n_c,
-                                     int kind) {
-    const int p = blockIdx.x, i = blockIdx.y * blockDim.x + threadIdx.x;
-    if (i >= n_c) return;
+// --- spatial transfer kernels (bandwidth-bound, elementwise over ROW POSITIONS of the destination) ---------------
+// restriction: dst row d_idx[p] <- R(src row s_idx[p]). kind 0 copy (same T: position-wise copy); kind 1 full
+// weighting (examples/example_spatial_coarsening.py:33-55: sol[2i]*1/4 + sol[2i+1]*1/2 + sol[2i+2]*1/4).
+__global__ void restrict_rows_kernel(const double *__restrict__ src, int src_ld, int T_f, const int32_t *__restrict__ s_idx,
+                                     double *__restrict__ dst, int dst_ld, int T_c, const int32_t *__restrict__ d_idx,
+                                     int n_c, int kind) {
+    const int p = blockIdx.x, pos = blockIdx.y * blockDim.x + threadIdx.x;
+    if (pos >= dst_ld) return;
     const double *f = src + (size_t)s_idx[p] * src_ld;
     double *c = dst + (size_t)d_idx[p] * dst_ld;
-    if (kind == MGRIT_HIP_TRANSFER_COPY) c[i] = f[i];
-    else c[i] = f[2 * i] * 1.0 / 4.0 + f[2 * i + 1] * 1.0 / 2.0 + f[2 * i + 2] * 1.0 / 4.0;
-}
-
-// interpolation value at fine index j of coarse vector e (examples/example_spatial_coarsening.py:58-82)
-__device__ __forceinline__ double interp_at(const double *e, const double *e2, int n_c, int j, int kind) {
-    // value of P(e - e2) (e2 may be null -> P(e))
-    auto at = [&](int i) { return e2 ? e[i] - e2[i] : e[i]; };
-    if (kind == MGRIT_HIP_TRANSFER_COPY) return at(j);
-    if (j & 1) return 0.0 + at(j >> 1);
-    const int i = j >> 1;
+    if (kind == MGRIT_HIP_TRANSFER_COPY) { c[pos] = f[pos]; return; }
+    const int i = row_nat(pos);
     double r = 0.0;
-    if (i - 1 >= 0) r = r + 1.0 / 2.0 * at(i - 1);
-    if (i < n_c) r = r + 1.0 / 2.0 * at(i);
-    return r;
+    if (i < n_c)
+        r = f[row_pos(2 * i)] * 1.0 / 4.0 + f[row_pos(2 * i + 1)] * 1.0 / 2.0 + f[row_pos(2 * i + 2)] * 1.0 / 4.0;
+    c[pos] = r;
 }
 
 // mode 0: u^l_i = P(u^{l+1}_j)  (mgrit.py:562-563);  mode 1: u^l_i = u^l_i + P(u^{l+1}_j - v^{l+1}_j)  (mgrit.py:724-726)
-__global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, const int32_t *__restrict__ f_idx,
-                                   const double *__restrict__ uc, const double *__restrict__ vc, int c_ld,
+// linear interpolation of examples/example_spatial_coarsening.py:58-82
+__global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, const int32_t *__restrict__ f_idx,
+                                   const double *__restrict__ uc, const double *__restrict__ vc, int c_ld, int T_c,
                                    const int32_t *__restrict__ c_idx, int n_f, int n_c, int kind, int mode) {
-    const int p = blockIdx.x, j = blockIdx.y * blockDim.x + threadIdx.x;
-    if (j >= n_f) return;
+    const int p = blockIdx.x, pos = blockIdx.y * blockDim.x + threadIdx.x;
+    if (pos >= f_ld) return;
     double *f = uf + (size_t)f_idx[p] * f_ld;
     const double *e = uc + (size_t)c_idx[p] * c_ld;
-    if (mode == 0) f[j] = interp_at(e, nullptr, n_c, j, kind);
-    else f[j] = f[j] + interp_at(e, vc + (size_t)c_idx[p] * c_ld, n_c, j, kind);
+    const double *e2 = mode == 1 ? vc + (size_t)c_idx[p] * c_ld : nullptr;
+    auto at = [&](int cpos) { return e2 ? e[cpos] - e2[cpos] : e[cpos]; };
+    double val;
+    if (kind == MGRIT_HIP_TRANSFER_COPY) {
+        val = at(pos);
+    } else {
+        const int j = row_nat(pos);
+        if (j >= n_f) return;  // padding stays zero
+        if (j & 1) val = 0.0 + at(row_pos(j >> 1));
+        else {
+            const int i = j >> 1;
+            val = 0.0;
+            if (i - 1 >= 0) val = val + 1.0 / 2.0 * at(row_pos(i - 1));
+            if (i < n_c) val = val + 1.0 / 2.0 * at(row_pos(i));
+        }
+    }
+    f[pos] = mode == 0 ? val : f[pos] + val;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -492,7 +599,7 @@ int dev_upload(Level &lv, hipStream_t st, const std::vector<T> &h, T **out) {
     return 0;
 }
 
-size_t smem_bytes(int G) { return (size_t)G * WAVE_TILE_BYTES + (2 * MAX_G + 2) * sizeof(double); }
+size_t smem_bytes(int G) { return (size_t)8 * G * LANES * sizeof(double2) + (2 * MAX_G + 2 + LANES) * sizeof(double); }
 
 template <typename K>
 int allow_big_lds(K kernel) {
@@ -501,18 +608,23 @@ int allow_big_lds(K kernel) {
     return 0;
 }
 
+// Dispatch tables over the template space: kind (heat1d, advection1d) x forcing mode (0, 1, 2; advection has none).
+#define FOR_EACH_STEPPER(X) X(MGRIT_HIP_STEPPER_HEAT1D, 0) X(MGRIT_HIP_STEPPER_HEAT1D, 1) X(MGRIT_HIP_STEPPER_HEAT1D, 2) \
+    X(MGRIT_HIP_STEPPER_ADVECTION1D, 0)
+
 bool g_attr_done = false;
 int setup_kernel_attrs() {
     if (g_attr_done) return 0;
     int rc;
-    if ((rc = allow_big_lds(relax_kernel<MGRIT_HIP_STEPPER_HEAT1D>))) return rc;
-    if ((rc = allow_big_lds(relax_kernel<MGRIT_HIP_STEPPER_ADVECTION1D>))) return rc;
-    if ((rc = allow_big_lds(residual_kernel<MGRIT_HIP_STEPPER_HEAT1D>))) return rc;
-    if ((rc = allow_big_lds(residual_kernel<MGRIT_HIP_STEPPER_ADVECTION1D>))) return rc;
-    if ((rc = allow_big_lds(fas_fine_kernel<MGRIT_HIP_STEPPER_HEAT1D>))) return rc;
-    if ((rc = allow_big_lds(fas_fine_kernel<MGRIT_HIP_STEPPER_ADVECTION1D>))) return rc;
-    if ((rc = allow_big_lds(fas_coarse_kernel<MGRIT_HIP_STEPPER_HEAT1D>))) return rc;
-    if ((rc = allow_big_lds(fas_coarse_kernel<MGRIT_HIP_STEPPER_ADVECTION1D>))) return rc;
+#define ATTR_RELAX(K, F, G_, R) if ((rc = allow_big_lds(relax_kernel<K, F, G_, R>))) return rc;
+#define ATTR_ALL(K, F)                                                                                              \
+    ATTR_RELAX(K, F, false, ROLE_F) ATTR_RELAX(K, F, true, ROLE_F) ATTR_RELAX(K, F, false, ROLE_C)                   \
+    ATTR_RELAX(K, F, true, ROLE_C) ATTR_RELAX(K, F, false, ROLE_C_WEIGHTED) ATTR_RELAX(K, F, true, ROLE_C_WEIGHTED)  \
+    ATTR_RELAX(K, F, false, ROLE_CHAIN) ATTR_RELAX(K, F, true, ROLE_CHAIN)                                           \
+    if ((rc = allow_big_lds(residual_kernel<K, F>))) return rc;                                                      \
+    if ((rc = allow_big_lds(fas_fine_kernel<K, F>))) return rc;                                                      \
+    if ((rc = allow_big_lds(fas_coarse_kernel<K, F>))) return rc;
+    FOR_EACH_STEPPER(ATTR_ALL)
     if ((rc = allow_big_lds(jump_kernel))) return rc;
     g_attr_done = true;
     return 0;
@@ -532,7 +644,7 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     if (n < 1 || n > MGRIT_HIP_MAX_N)
         return fail(MGRIT_HIP_EUNSUPPORTED, "n=%d DOFs per time point outside [1,%d] (register-resident stepper)", n,
                     MGRIT_HIP_MAX_N);
-    if (ld < n || (ld % 16) != 0) return fail(MGRIT_HIP_EINVAL, "ld=%d must be a multiple of 16 and >= n=%d", ld, n);
+    if (ld != mgrit_hip_row_stride(n)) return fail(MGRIT_HIP_EINVAL, "ld=%d must equal mgrit_hip_row_stride(n=%d)=%d", ld, n, mgrit_hip_row_stride(n));
     if (n_pts < 0 || (n_pts > 0 && !t_local)) return fail(MGRIT_HIP_EINVAL, "bad local time grid");
     if (K < 0 || K > 8 || (K > 0 && (!s || !tau))) return fail(MGRIT_HIP_EINVAL, "bad forcing description (K=%d)", K);
     if ((rc = setup_kernel_attrs())) return rc;
@@ -561,16 +673,16 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     if (n_pts > 0) cidx[0] = 0;
     lv.n_csets = (int)uniq.size();
     std::vector<CSet> cs(uniq.size());
-    std::vector<double> tabT(uniq.size() * (size_t)E * T, 0.0), tab;
+    std::vector<double> tabT(uniq.size() * (size_t)E * T, 0.0), tab;  // row storage order per coefficient set
     for (size_t q = 0; q < uniq.size(); ++q) {
         std::memset(&cs[q], 0, sizeof(CSet));
         if (kind == MGRIT_HIP_STEPPER_HEAT1D) build_cset_heat1d(cs[q], tab, n, fac, uniq[q]);
         else build_cset_advection1d(cs[q], tab, n, fac, uniq[q]);
-        for (int j = 0; j < n; ++j) tabT[q * (size_t)E * T + (size_t)(j % E) * T + (j / E)] = tab[j];
+        for (int j = 0; j < n; ++j) tabT[q * (size_t)E * T + row_pos(j)] = tab[j];
     }
     std::vector<double> sT((size_t)(K > 0 ? K : 0) * E * T, 0.0), tauv;
     for (int kk = 0; kk < K; ++kk)
-        for (int j = 0; j < n; ++j) sT[((size_t)kk * E + (j % E)) * T + (j / E)] = s[(size_t)kk * n + j];
+        for (int j = 0; j < n; ++j) sT[(size_t)kk * E * T + row_pos(j)] = s[(size_t)kk * n + j];
     if (K > 0) tauv.assign(tau, tau + (size_t)K * n_pts);
     int32_t *d_cidx; double *d_dt, *d_tau, *d_sT, *d_tabT; CSet *d_cs;
     if ((rc = dev_upload(lv, e->stream, cidx, &d_cidx))) return rc;
@@ -579,7 +691,9 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     if ((rc = dev_upload(lv, e->stream, sT, &d_sT))) return rc;
     if ((rc = dev_upload(lv, e->stream, cs, &d_cs))) return rc;
     if ((rc = dev_upload(lv, e->stream, tabT, &d_tabT))) return rc;
-    d.cidx = d_cidx; d.dt = d_dt; d.tau = d_tau; d.sT = d_sT; d.cs = d_cs; d.tabT = d_tabT;
+    d.cidx = d_cidx; d.dt = d_dt; d.tau = d_tau; d.cs = d_cs;
+    d.sP = reinterpret_cast<const double2 *>(d_sT);
+    d.tabP = reinterpret_cast<const double2 *>(d_tabT);
     lv.set = true;
     return 0;
 }
@@ -607,15 +721,18 @@ int check_bound(const Level &lv, bool need_vg) {
     return 0;
 }
 
-#define LAUNCH_BY_KIND(kernel, lv, grid, ...)                                                                     \
-    do {                                                                                                          \
-        if ((lv).dev.kind == MGRIT_HIP_STEPPER_HEAT1D)                                                             \
-            hipLaunchKernelGGL(kernel<MGRIT_HIP_STEPPER_HEAT1D>, dim3(grid), dim3((lv).dev.T), smem_bytes((lv).G), \
-                               e->stream, __VA_ARGS__);                                                           \
-        else                                                                                                      \
-            hipLaunchKernelGGL(kernel<MGRIT_HIP_STEPPER_ADVECTION1D>, dim3(grid), dim3((lv).dev.T),                \
-                               smem_bytes((lv).G), e->stream, __VA_ARGS__);                                       \
-        HIP_TRY(hipGetLastError());                                                                               \
+int force_mode(const Level &lv) { return lv.dev.kind != MGRIT_HIP_STEPPER_HEAT1D ? 0 : lv.dev.K == 0 ? 0 : lv.dev.K == 1 ? 1 : 2; }
+
+#define LAUNCH_CASE(kernel, K_, F_, lv, grid, ...)                                                               \
+    if ((lv).dev.kind == K_ && force_mode(lv) == F_)                                                              \
+        hipLaunchKernelGGL((kernel<K_, F_>), dim3(grid), dim3((lv).dev.T), smem_bytes((lv).G), e->stream, __VA_ARGS__);
+#define LAUNCH_BY_KIND(kernel, lv, grid, ...)                                                                    \
+    do {                                                                                                         \
+        LAUNCH_CASE(kernel, MGRIT_HIP_STEPPER_HEAT1D, 0, lv, grid, __VA_ARGS__)                                   \
+        LAUNCH_CASE(kernel, MGRIT_HIP_STEPPER_HEAT1D, 1, lv, grid, __VA_ARGS__)                                   \
+        LAUNCH_CASE(kernel, MGRIT_HIP_STEPPER_HEAT1D, 2, lv, grid, __VA_ARGS__)                                   \
+        LAUNCH_CASE(kernel, MGRIT_HIP_STEPPER_ADVECTION1D, 0, lv, grid, __VA_ARGS__)                              \
+        HIP_TRY(hipGetLastError());                                                                              \
     } while (0)
 
 }  // namespace
@@ -627,6 +744,13 @@ extern "C" {
 
 int mgrit_hip_abi_version(void) { return MGRIT_HIP_ABI_VERSION; }
 const char *mgrit_hip_last_error(void) { return g_err.c_str(); }
+
+int mgrit_hip_row_stride(int n) { return n < 1 ? 0 : ((n + GROUP - 1) / GROUP) * GROUP; }
+
+int mgrit_hip_row_position(int n, int j) {
+    if (n < 1 || j < 0 || j >= n) return -1;
+    return row_pos(j);
+}
 
 int mgrit_hip_device_count(void) {
     int n = 0;
@@ -744,14 +868,33 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     int rc = get_runs(e, lvl, runs_id, &rl);
     if (rc) return rc;
     Level &lv = e->L[lvl];
-    if (mode != MGRIT_HIP_RELAX_F && mode != MGRIT_HIP_RELAX_C) return fail(MGRIT_HIP_EINVAL, "bad relax mode %d", mode);
+    if (mode != MGRIT_HIP_RELAX_F && mode != MGRIT_HIP_RELAX_C && mode != MGRIT_HIP_RELAX_CHAIN) return fail(MGRIT_HIP_EINVAL, "bad relax mode %d", mode);
     if ((rc = check_bound(lv, lvl > 0))) return rc;
     if (rl->n == 0) return 0;
     if (e->timing) {
         if (!e->ev0) { HIP_TRY(hipEventCreate(&e->ev0)); HIP_TRY(hipEventCreate(&e->ev1)); }
         HIP_TRY(hipEventRecord(e->ev0, e->stream));
     }
-    LAUNCH_BY_KIND(relax_kernel, lv, rl->n, lv.dev, rl->d_start, rl->d_len, lvl > 0 ? 1 : 0, mode, weight_c, 1.0 - weight_c);
+    {
+        const bool use_g = lvl > 0;
+        const int role = mode == MGRIT_HIP_RELAX_CHAIN ? ROLE_CHAIN
+                         : mode == MGRIT_HIP_RELAX_F   ? ROLE_F
+                         : (weight_c != 1.0)           ? ROLE_C_WEIGHTED
+                                                       : ROLE_C;
+        const double w = weight_c, w1 = 1.0 - weight_c;
+        const dim3 grid(rl->n), block(lv.dev.T);
+        const size_t lds = smem_bytes(lv.G);
+        const int fm = force_mode(lv);
+#define RELAX_CASE(K, F, G_, R)                                                                                    \
+    if (lv.dev.kind == K && fm == F && use_g == G_ && role == R)                                                    \
+        hipLaunchKernelGGL((relax_kernel<K, F, G_, R>), grid, block, lds, e->stream, lv.dev, rl->d_start, rl->d_len, w, w1);
+#define RELAX_CASES(K, F)                                                                                          \
+    RELAX_CASE(K, F, false, ROLE_F) RELAX_CASE(K, F, true, ROLE_F) RELAX_CASE(K, F, false, ROLE_C)                  \
+    RELAX_CASE(K, F, true, ROLE_C) RELAX_CASE(K, F, false, ROLE_C_WEIGHTED) RELAX_CASE(K, F, true, ROLE_C_WEIGHTED) \
+    RELAX_CASE(K, F, false, ROLE_CHAIN) RELAX_CASE(K, F, true, ROLE_CHAIN)
+        FOR_EACH_STEPPER(RELAX_CASES)
+        HIP_TRY(hipGetLastError());
+    }
     if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
     return 0;
 }
@@ -788,9 +931,9 @@ int mgrit_hip_restrict_u(mgrit_hip_engine *e, int lvl, int pairs_id) {
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     if ((rc = check_bound(lf, false)) || (rc = check_bound(lc, false))) return rc;
     if (pl->n == 0) return 0;
-    dim3 grid(pl->n, (lc.dev.n + 255) / 256);
-    hipLaunchKernelGGL(restrict_rows_kernel, grid, dim3(256), 0, e->stream, lf.dev.u, lf.dev.ld, pl->d_fine, lc.dev.u, lc.dev.ld,
-                       pl->d_coarse, lc.dev.n, lf.transfer);
+    dim3 grid(pl->n, (lc.dev.ld + 255) / 256);
+    hipLaunchKernelGGL(restrict_rows_kernel, grid, dim3(256), 0, e->stream, lf.dev.u, lf.dev.ld, lf.dev.T, pl->d_fine, lc.dev.u,
+                       lc.dev.ld, lc.dev.T, pl->d_coarse, lc.dev.n, lf.transfer);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -822,9 +965,9 @@ int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id) {
             lf.scratch_rows = pl->n;
         }
         LAUNCH_BY_KIND(fas_fine_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_iota, lf.scratch, lf.dev.ld, lvl > 0 ? 1 : 0);
-        dim3 grid(pl->n, (lc.dev.n + 255) / 256);
-        hipLaunchKernelGGL(restrict_rows_kernel, grid, dim3(256), 0, e->stream, lf.scratch, lf.dev.ld, pl->d_iota, lc.dev.g,
-                           lc.dev.ld, pl->d_coarse, lc.dev.n, lf.transfer);
+        dim3 grid(pl->n, (lc.dev.ld + 255) / 256);
+        hipLaunchKernelGGL(restrict_rows_kernel, grid, dim3(256), 0, e->stream, lf.scratch, lf.dev.ld, lf.dev.T, pl->d_iota,
+                           lc.dev.g, lc.dev.ld, lc.dev.T, pl->d_coarse, lc.dev.n, lf.transfer);
         HIP_TRY(hipGetLastError());
     }
     LAUNCH_BY_KIND(fas_coarse_kernel, lc, pl->n, lc.dev, pl->d_coarse);
@@ -838,9 +981,9 @@ static int interp_common(mgrit_hip_engine *e, int lvl, int pairs_id, int mode) {
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     if ((rc = check_bound(lf, false)) || (rc = check_bound(lc, mode == 1))) return rc;
     if (pl->n == 0) return 0;
-    dim3 grid(pl->n, (lf.dev.n + 255) / 256);
-    hipLaunchKernelGGL(interp_rows_kernel, grid, dim3(256), 0, e->stream, lf.dev.u, lf.dev.ld, pl->d_fine, lc.dev.u, lc.dev.v,
-                       lc.dev.ld, pl->d_coarse, lf.dev.n, lc.dev.n, lf.transfer, mode);
+    dim3 grid(pl->n, (lf.dev.ld + 255) / 256);
+    hipLaunchKernelGGL(interp_rows_kernel, grid, dim3(256), 0, e->stream, lf.dev.u, lf.dev.ld, lf.dev.T, pl->d_fine, lc.dev.u,
+                       lc.dev.v, lc.dev.ld, lc.dev.T, pl->d_coarse, lf.dev.n, lc.dev.n, lf.transfer, mode);
     HIP_TRY(hipGetLastError());
     return 0;
 }

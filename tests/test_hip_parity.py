@@ -61,9 +61,7 @@ def randomize(mg, op, seed=0):
                 continue
             ref = op.state(name, lvl)
             ref[:] = rng.standard_normal(ref.shape)
-            slab = slabs[lvl]
-            slab.zero_()
-            slab[:, :ref.shape[1]] = torch.from_numpy(ref).to(slab.device)
+            mg.backend.set_natural(name, lvl, ref)
 
 
 def assert_state_equal(mg, op, what=("u", "v", "g")):
@@ -72,9 +70,11 @@ def assert_state_equal(mg, op, what=("u", "v", "g")):
             if name not in what or slabs[lvl] is None:
                 continue
             ref = op.state(name, lvl)
-            got = slabs[lvl].cpu().numpy()
-            assert np.array_equal(got[:, :ref.shape[1]], ref), (name, lvl, np.abs(got[:, :ref.shape[1]] - ref).max())
-            assert not got[:, ref.shape[1]:].any(), ("padding columns must stay zero", name, lvl)
+            got = mg.backend.natural(name, lvl)
+            assert np.array_equal(got, ref), (name, lvl, np.abs(got - ref).max())
+            pad = torch.ones(slabs[lvl].shape[1], dtype=torch.bool, device=slabs[lvl].device)
+            pad[mg.backend.perm[lvl]] = False
+            assert not slabs[lvl][:, pad].any().item(), ("padding positions must stay zero", name, lvl)
 
 
 GRIDS3 = [cases.lin(2, 65), cases.lin(2, 17), cases.lin(2, 5)]
@@ -210,8 +210,7 @@ def test_solve_matches_oracle_and_reference(oracle, name):
     ref = np.array(SOLVE[name]["conv"])
     n = min(len(ref), len(conv))
     assert np.all(np.abs(conv[:n] - ref[:n]) <= 1e-9 * ref[:n] + 2e-11), (name, conv, ref)
-    got = mg.backend.U[0].cpu().numpy()
-    assert np.array_equal(got[:, :op.n[0]], op.state("u", 0))
+    assert np.array_equal(mg.backend.natural("u", 0), op.state("u", 0))
     for k, v in SOLVE[name].get("samples", {}).items():
         v = np.array(v)
         assert np.abs(mg.u[0][int(k)].get_values() - v).max() <= 1e-11 * max(1.0, np.abs(v).max())
@@ -265,9 +264,16 @@ def test_full_size_properties_config3(oracle):
     mg = Mgrit(prob, nested_iteration=False, logging_lvl=30)
     U = mg.backend.U[0]
     n = 16382
+    perm = mg.backend.perm[0]
     gen = torch.Generator(device="cpu").manual_seed(5)
     cvals = torch.randn((len(grids[1]), n), generator=gen, dtype=torch.float64)
-    U[::4, :n] = cvals.to(U.device)
+
+    def set_c(vals):
+        rows = torch.zeros((vals.shape[0], U.shape[1]), dtype=torch.float64, device=U.device)
+        rows[:, perm] = vals.to(U.device)
+        U[::4] = rows
+
+    set_c(cvals)
     mg.f_relax(0)
     first = U.clone()
     mg.f_relax(0)
@@ -276,7 +282,7 @@ def test_full_size_properties_config3(oracle):
     fpts = [int(i) for i in np.sort(mg.index_local_f[0])][:4096]
     assert max(mg.backend.residual_norms(fpts)) == 0.0
     # linearity under exact scaling
-    U[::4, :n] = (cvals * 8.0).to(U.device)
+    set_c(cvals * 8.0)
     mg.f_relax(0)
     assert torch.equal(first * 8.0, U)
     # sampled intervals vs oracle
@@ -287,4 +293,4 @@ def test_full_size_properties_config3(oracle):
         x = (cvals[c_idx] * 8.0).numpy()
         for k in range(1, 4):
             x = op.phi(0, 4 * c_idx + k, x)
-            assert np.array_equal(U[4 * c_idx + k, :n].cpu().numpy(), x), (c_idx, k)
+            assert np.array_equal(U[4 * c_idx + k][perm].cpu().numpy(), x), (c_idx, k)
