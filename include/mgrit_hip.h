@@ -92,6 +92,11 @@ int mgrit_hip_error_correction(mgrit_hip_engine *e, int lvl, int pairs_id);
 /* Mgrit.nested_iteration interpolation (mgrit.py:559-563): u^l_i = P(u^{l+1}_j) */
 int mgrit_hip_interpolate(mgrit_hip_engine *e, int lvl, int pairs_id);
 
+/* Same two reductions with the result delivered to HOST memory (sumsq_host[r], r < n_runs) when the call returns: the
+ * device->host leg of Mgrit.convergence_criterion (mgrit.py:425-432). */
+int mgrit_hip_residual_host(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_host);
+int mgrit_hip_jump_host(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev, double *sumsq_host);
+
 /* Timing of the most recent mgrit_hip_relax launch on this engine, measured with HIP events on the engine's stream
  * (enable with mgrit_hip_set_timing(e, 1)); returns milliseconds in *ms. */
 int mgrit_hip_set_timing(mgrit_hip_engine *e, int enabled);

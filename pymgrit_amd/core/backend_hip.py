@@ -219,9 +219,9 @@ class HipBackend:
     def residual_norms(self, points):
         if not len(points):
             return []
-        buf = self._sumsq_buf(len(points))
-        check(self.lib.mgrit_hip_residual(self.h, 0, self._point_run_id(0, points), C.c_void_p(buf.data_ptr())))
-        return np.sqrt(buf[:len(points)].cpu().numpy()).tolist()
+        host = np.empty(len(points), dtype=np.float64)
+        check(self.lib.mgrit_hip_residual_host(self.h, 0, self._point_run_id(0, points), _ptr(host)))
+        return np.sqrt(host).tolist()
 
     def save_last(self):
         self.prev = self.U[0].clone()
@@ -231,10 +231,10 @@ class HipBackend:
     def jump_norms(self, points):
         out = []
         if len(points):
-            buf = self._sumsq_buf(len(points))
-            check(self.lib.mgrit_hip_jump(self.h, 0, self._point_run_id(0, points), C.c_void_p(self.prev.data_ptr()),
-                                          C.c_void_p(buf.data_ptr())))
-            out = np.sqrt(buf[:len(points)].cpu().numpy()).tolist()
+            host = np.empty(len(points), dtype=np.float64)
+            check(self.lib.mgrit_hip_jump_host(self.h, 0, self._point_run_id(0, points),
+                                               C.c_void_p(self.prev.data_ptr()), _ptr(host)))
+            out = np.sqrt(host).tolist()
         self.prev.copy_(self.U[0])
         return out
 

@@ -36,6 +36,8 @@ EXPORTS = {
     "mgrit_hip_fas_rhs": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_error_correction": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_interpolate": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_residual_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "mgrit_hip_jump_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mgrit_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "mgrit_hip_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
 }

@@ -527,6 +527,9 @@ struct mgrit_hip_engine {
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    double *pinned = nullptr;     // host staging buffer for small read-backs
+    size_t pinned_len = 0;
+    hipEvent_t ev_read = nullptr;
 };
 
 namespace {
@@ -776,6 +779,8 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
         for (void *p : lv.allocs) (void)hipFree(p);
         if (lv.scratch) (void)hipFree(lv.scratch);
     }
+    if (e->pinned) (void)hipHostFree(e->pinned);
+    if (e->ev_read) (void)hipEventDestroy(e->ev_read);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     delete e;
@@ -990,6 +995,53 @@ static int interp_common(mgrit_hip_engine *e, int lvl, int pairs_id, int mode) {
 
 int mgrit_hip_error_correction(mgrit_hip_engine *e, int lvl, int pairs_id) { return interp_common(e, lvl, pairs_id, 1); }
 int mgrit_hip_interpolate(mgrit_hip_engine *e, int lvl, int pairs_id) { return interp_common(e, lvl, pairs_id, 0); }
+
+// Host read-back of per-run scalars without any copy command: the kernels store straight into pinned, device-mapped
+// host memory and the host spins on an event recorded behind the kernel. (A D2H copy command issued after a long mostly
+// idle stretch -- the single-workgroup coarsest-level chain -- was observed to start ~46 ms late on MI355X/ROCm 7.2.)
+static int ensure_pinned(mgrit_hip_engine *e, int n) {
+    if (e->pinned_len < (size_t)n) {
+        if (e->pinned) HIP_TRY(hipHostFree(e->pinned));
+        e->pinned = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->pinned), sizeof(double) * (size_t)n, hipHostMallocMapped));
+        e->pinned_len = n;
+    }
+    if (!e->ev_read) HIP_TRY(hipEventCreateWithFlags(&e->ev_read, hipEventDisableTiming));
+    return 0;
+}
+
+static int wait_pinned(mgrit_hip_engine *e, int n, double *host) {
+    HIP_TRY(hipEventRecord(e->ev_read, e->stream));
+    for (;;) {  // spin: the convergence check sits on the critical path of every MGRIT iteration
+        const hipError_t q = hipEventQuery(e->ev_read);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return fail(MGRIT_HIP_EHIP, "hipEventQuery: %s", hipGetErrorString(q));
+    }
+    std::memcpy(host, e->pinned, sizeof(double) * (size_t)n);
+    return 0;
+}
+
+int mgrit_hip_residual_host(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_host) {
+    RunList *rl;
+    int rc = get_runs(e, lvl, runs_id, &rl);
+    if (rc) return rc;
+    if (rl->n == 0) return 0;
+    if (!sumsq_host) return fail(MGRIT_HIP_EINVAL, "null output");
+    if ((rc = ensure_pinned(e, rl->n))) return rc;
+    if ((rc = mgrit_hip_residual(e, lvl, runs_id, e->pinned))) return rc;
+    return wait_pinned(e, rl->n, sumsq_host);
+}
+
+int mgrit_hip_jump_host(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev, double *sumsq_host) {
+    RunList *rl;
+    int rc = get_runs(e, lvl, runs_id, &rl);
+    if (rc) return rc;
+    if (rl->n == 0) return 0;
+    if (!sumsq_host) return fail(MGRIT_HIP_EINVAL, "null output");
+    if ((rc = ensure_pinned(e, rl->n))) return rc;
+    if ((rc = mgrit_hip_jump(e, lvl, runs_id, prev, e->pinned))) return rc;
+    return wait_pinned(e, rl->n, sumsq_host);
+}
 
 int mgrit_hip_set_timing(mgrit_hip_engine *e, int enabled) {
     if (!e) return fail(MGRIT_HIP_EINVAL, "null engine");
