@@ -65,10 +65,12 @@ class TorchTimeComm:
         Tensors travel as they are (the receive buffer must be a tensor of the same shape); other payloads are
         pickled. Send and receive of one point are posted together (ncclGroup on RCCL), so a ring of ranks executing
         the same point cannot deadlock. Returns the received object (the filled tensor, or the unpickled payload)."""
-        ops, result = [], None
+        ops, result, staged = [], None, None
         if send is not None:
             payload, dest = send
             if torch.is_tensor(payload):
+                if payload.is_cuda and self.backend != "nccl":  # e.g. gloo: device rows are staged through the host
+                    payload = payload.cpu()
                 ops.append(dist.P2POp(dist.isend, payload, self._global(dest), self.group))
             else:
                 raw = torch.frombuffer(bytearray(pickle.dumps(payload)), dtype=torch.uint8).to(self._device())
@@ -79,7 +81,9 @@ class TorchTimeComm:
         if recv is not None:
             buf, src = recv
             if torch.is_tensor(buf):
-                ops.append(dist.P2POp(dist.irecv, buf, self._global(src), self.group))
+                if buf.is_cuda and self.backend != "nccl":
+                    staged = torch.empty(buf.shape, dtype=buf.dtype, device="cpu")
+                ops.append(dist.P2POp(dist.irecv, staged if staged is not None else buf, self._global(src), self.group))
                 result = buf
             else:
                 size = torch.zeros(1, dtype=torch.int64, device=self._device())
@@ -93,6 +97,8 @@ class TorchTimeComm:
             works += dist.batch_isend_irecv(p2p)
         for w in works:
             w.wait()
+        if staged is not None:
+            result.copy_(staged)
         return result
 
 

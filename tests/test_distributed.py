@@ -1,0 +1,69 @@
+"""The N>1 path on CPU: world_size 2/3/5 torch.distributed jobs (gloo, 127.0.0.1) running the SAME Mgrit host logic and
+exchange schedule as the multi-GPU runs, on the plugin path. The reference is bit-identical for every P with uniform
+coarsening; so must we be: residual history and every solution vector equal the single-rank run
+bit for bit. The HIP twin of this test (two ranks sharing one GPU, gloo transport) lives in test_hip_distributed.py."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(world, case, mode="plugin", backend="gloo", timeout=600):
+    out = tempfile.mkdtemp(prefix=f"mgrit_{case}_{world}_")
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port), case,
+                               mode, out, backend], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=timeout)
+            logs.append(o.decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    res = [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(world)]
+    conv = res[0]["conv"]
+    for r in res[1:]:
+        assert np.array_equal(r["conv"], conv), "every rank must hold the same residual history"
+    t = np.concatenate([r["t"] for r in res])
+    u = np.concatenate([r["u"] for r in res if r["u"].size], axis=0)
+    assert np.all(np.diff(t) > 0), "owned blocks must tile the time grid in rank order"
+    return conv, u
+
+
+CASES = [
+    ("dahlquist_config1", [2, 3]),              # nt=101, m=2: aligned and unaligned splits
+    ("dahlquist_F", [2, 3]),                    # 4 levels, F-cycle
+    ("dahlquist_procs_without_points", [5]),    # first factor 16: ranks that own no coarse point
+    ("heat_nx33_V_nested", [2, 3]),             # nt=65/17/5 m=4: P=3 exercises comm_front/comm_back (op 1) and ops 2/3/7
+    ("heat_nx33_F_nonested", [3]),
+    ("heat_nx33_V_jump", [2]),                  # conv_crit=1
+    ("heat_spatial_coarsening", [2]),
+]
+
+
+@pytest.mark.parametrize("case,sizes", CASES, ids=[c for c, _ in CASES])
+def test_multi_rank_equals_single_rank(case, sizes):
+    conv1, u1 = launch(1, case)
+    for world in sizes:
+        conv, u = launch(world, case)
+        assert np.array_equal(conv, conv1), (case, world, conv, conv1)
+        assert np.array_equal(u, u1), (case, world, np.abs(u - u1).max())

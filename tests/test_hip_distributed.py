@@ -1,0 +1,24 @@
+"""GPU twin of test_distributed.py: the time-sharded HIP path with TWO (or three) ranks sharing the one GPU of the test
+box, ghost rows exchanged over torch.distributed (gloo transport here, staged through the host; on a multi-GPU node the
+same schedule runs over RCCL). Sharded runs must equal the single-rank GPU run bit for bit."""
+import numpy as np
+import pytest
+
+from test_distributed import launch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("heat_nx33_V_nested", [2, 3]), ("heat_nx257_nt257", [2]), ("heat_nx33_F_nonested", [3]),
+         ("heat_nx33_V_jump", [2]), ("heat_spatial_coarsening", [2]), ("advection_3lvl_F", [2])]
+
+
+@pytest.mark.parametrize("case,sizes", CASES, ids=[c for c, _ in CASES])
+def test_sharded_hip_equals_single_rank(case, sizes):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    conv1, u1 = launch(1, case, mode="hip")
+    for world in sizes:
+        conv, u = launch(world, case, mode="hip", backend="gloo")
+        assert np.array_equal(conv, conv1), (case, world, conv, conv1)
+        assert np.array_equal(u, u1), (case, world, np.abs(u - u1).max())
