@@ -159,6 +159,12 @@ def main():
     fcf_bytes = (2 * n_f_local + len(c_runs)) * 16.0 * dof
     fcf_gbs = fcf_bytes / ((2 * f_ms + c_ms) * 1e-3) / 1e9
 
+    traffic = None  # HBM bytes per level-0 F-relax launch from the committed PMC passes (same workload, N=1 only)
+    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if world == 1 and nx == 16384 and nt0 == 65537 and os.path.exists(tfile):
+        k = json.load(open(tfile))["kernels"].get("relax_kernel<1, 1, false, 0>")
+        traffic = k["hbm_bytes_per_launch"] if k else None
+
     out = {
         "metric": "time-point-DOF updates/sec per MGRIT V-cycle", "value": updates_per_cycle * args.steps / elapsed,
         "unit": "time-point-DOF updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,7 +174,7 @@ def main():
                                f"(BASELINE configs[2]; time points sharded over {world} GPU(s))",
                    "phi_per_cycle_by_level": counts, "dof": dof},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "relax_kernel<HEAT1D,false,ROLE_F> (level-0 F-relax)", "launch_ms": f_ms,
                      "algorithmic_bytes_per_launch": alg_bytes_f},
         "fcf_relax_level0": {"ms": 2 * f_ms + c_ms, "algorithmic_GBps": fcf_gbs, "frac_of_hbm_peak": fcf_gbs / HBM_PEAK_GBS,
