@@ -170,9 +170,22 @@ typedef struct {
     double pw[ORC_E + 1];   /* pw[k] = rho^k, pw[0] = 1, sequential products */
     double sc[6];           /* sc[s] = rho^(E*2^s), repeated squaring of pw[E] */
     double gc;              /* rho^(64E) = sc[5]^2 */
+    double gcp[4];          /* gc^(2^s): coefficients of the cross-group Kogge-Stone scans */
     double lp[ORC_LANES];   /* lp[l] = rho^(E*l), sequential products of pw[E] */
-    double *tab;            /* heat: wg[j] (n) ; advection: rp[j] = r^(j+1)/(1-r^n) folded (n) */
+    double *tab;            /* heat: wg[j] (n) ; advection: rp[j] = r^(j+1) (n) */
+    double pt_full[ORC_GROUP]; /* heat: local backward scan of rho^(j'+1) over a full group of 1024           */
+    double pt_last[ORC_GROUP]; /* same for the last (possibly partial) group, zero beyond its length          */
 } orc_cset;
+
+/* Pt_j' = sum_{i>=j'} rho^(i-j') * rho^(i+1) over a group of len elements: serial recurrences in double */
+static void cset_pt(const orc_cset *c, int len, double *pt) {
+    double q[ORC_GROUP];
+    double p = c->rho;
+    for (int j = 0; j < ORC_GROUP; ++j) { q[j] = (j < len) ? p : 0.0; p = p * c->rho; }
+    double z = q[ORC_GROUP - 1];
+    pt[ORC_GROUP - 1] = z;
+    for (int j = ORC_GROUP - 2; j >= 0; --j) { z = fma(c->rho, z, q[j]); pt[j] = z; }
+}
 
 static void cset_powers(orc_cset *c, double rho) {
     c->rho = rho;
@@ -181,6 +194,8 @@ static void cset_powers(orc_cset *c, double rho) {
     c->sc[0] = c->pw[ORC_E];
     for (int s = 1; s < 6; ++s) c->sc[s] = c->sc[s - 1] * c->sc[s - 1];
     c->gc = c->sc[5] * c->sc[5];
+    c->gcp[0] = c->gc;
+    for (int s = 1; s < 4; ++s) c->gcp[s] = c->gcp[s - 1] * c->gcp[s - 1];
     c->lp[0] = 1.0;
     for (int l = 1; l < ORC_LANES; ++l) c->lp[l] = c->lp[l - 1] * c->pw[ORC_E];
 }
@@ -206,6 +221,8 @@ static void cset_heat1d(orc_cset *c, int n, double fac, double dt) {
     double gamma = kr2 / (1.0 + kr2 * w0);
     for (int j = 0; j < n; ++j) c->tab[j] = gamma * (c->tab[j] * c->ik);
     free(y);
+    cset_pt(c, ORC_GROUP, c->pt_full);
+    cset_pt(c, n - ((n - 1) / ORC_GROUP) * ORC_GROUP, c->pt_last);
 }
 
 /* Advection1D: (1+alpha) x_j - alpha x_{j-1 mod n} = u_j ; r = alpha/D, x_j = y_j + r^(j+1) x_{n-1} */
@@ -222,84 +239,61 @@ static void cset_advection1d(orc_cset *c, int n, double fac, double dt) {
 }
 
 /* ================================================================================================
- * Chunked scans (spec) -- forward y_j = rho*y_{j-1} + d_j, backward z_j = rho*z_{j+1} + y_j
- * Arrays have length G*ORC_GROUP (zero padded).
+ * Group-local chunked scans (spec). A group = 64 lanes x 16 elements = 1024 consecutive values (one GPU
+ * wavefront). Forward: y_j = rho*y_{j-1} + d_j with ZERO carry into the group; backward mirrored. Returns the group
+ * total (last element of the forward scan / first element of the backward scan).
  * ============================================================================================== */
-static void spec_scan_fwd(const orc_cset *c, int G, double *y) {
+static double group_scan_fwd(const orc_cset *c, double *y) {
     double S[ORC_LANES], T[ORC_LANES];
-    double *A = (double *)malloc(sizeof(double) * (size_t)(G + 1));
-    double *Ssave = (double *)malloc(sizeof(double) * (size_t)G * ORC_LANES);
-    for (int g = 0; g < G; ++g) {
-        for (int l = 0; l < ORC_LANES; ++l) {
-            double *b = y + ((size_t)g * ORC_LANES + l) * ORC_E;
-            for (int k = 1; k < ORC_E; ++k) b[k] = fma(c->rho, b[k - 1], b[k]);
-            S[l] = b[ORC_E - 1];
-        }
-        /* wave scan: Kogge-Stone inside each row of 16 lanes (offsets 1,2,4,8), then two row broadcasts */
-        for (int s = 0; s < 4; ++s) {
-            int off = 1 << s;
-            for (int l = 0; l < ORC_LANES; ++l) T[l] = ((l & 15) >= off) ? fma(c->sc[s], S[l - off], S[l]) : S[l];
-            memcpy(S, T, sizeof(S));
-        }
-        for (int l = 0; l < ORC_LANES; ++l) /* rows 1 and 3 take the last lane of the row below */
-            T[l] = ((l >> 4) & 1) ? fma(c->lp[(l & 15) + 1], S[(l & ~15) - 1], S[l]) : S[l];
-        memcpy(S, T, sizeof(S));
-        for (int l = 0; l < ORC_LANES; ++l) /* lanes 32..63 take lane 31 */
-            T[l] = (l >= 32) ? fma(c->lp[l - 31], S[31], S[l]) : S[l];
-        memcpy(S, T, sizeof(S));
-        memcpy(Ssave + (size_t)g * ORC_LANES, S, sizeof(S));
-        A[g] = S[ORC_LANES - 1];
+    for (int l = 0; l < ORC_LANES; ++l) {
+        double *b = y + (size_t)l * ORC_E;
+        for (int k = 1; k < ORC_E; ++k) b[k] = fma(c->rho, b[k - 1], b[k]);
+        S[l] = b[ORC_E - 1];
     }
-    double carry = 0.0;
-    for (int g = 0; g < G; ++g) {
-        const double *Sg = Ssave + (size_t)g * ORC_LANES;
-        for (int l = 0; l < ORC_LANES; ++l) {
-            double prev = l > 0 ? Sg[l - 1] : 0.0;
-            double cin = fma(c->lp[l], carry, prev);
-            double *b = y + ((size_t)g * ORC_LANES + l) * ORC_E;
-            for (int k = 0; k < ORC_E; ++k) b[k] = fma(c->pw[k + 1], cin, b[k]);
-        }
-        carry = fma(c->gc, carry, A[g]);
+    /* Kogge-Stone inside each row of 16 lanes (offsets 1,2,4,8), then two row broadcasts */
+    for (int s = 0; s < 4; ++s) {
+        int off = 1 << s;
+        for (int l = 0; l < ORC_LANES; ++l) T[l] = ((l & 15) >= off) ? fma(c->sc[s], S[l - off], S[l]) : S[l];
+        memcpy(S, T, sizeof(S));
     }
-    free(A); free(Ssave);
+    for (int l = 0; l < ORC_LANES; ++l) /* rows 1 and 3 take the last lane of the row below */
+        T[l] = ((l >> 4) & 1) ? fma(c->lp[(l & 15) + 1], S[(l & ~15) - 1], S[l]) : S[l];
+    memcpy(S, T, sizeof(S));
+    for (int l = 0; l < ORC_LANES; ++l) /* lanes 32..63 take lane 31 */
+        T[l] = (l >= 32) ? fma(c->lp[l - 31], S[31], S[l]) : S[l];
+    memcpy(S, T, sizeof(S));
+    for (int l = 0; l < ORC_LANES; ++l) {
+        double prev = l > 0 ? S[l - 1] : 0.0;
+        double *b = y + (size_t)l * ORC_E;
+        for (int k = 0; k < ORC_E; ++k) b[k] = fma(c->pw[k + 1], prev, b[k]);
+    }
+    return S[ORC_LANES - 1];
 }
 
-static void spec_scan_bwd(const orc_cset *c, int G, double *z) {
+static double group_scan_bwd(const orc_cset *c, double *z) {
     double S[ORC_LANES], T[ORC_LANES];
-    double *A = (double *)malloc(sizeof(double) * (size_t)(G + 1));
-    double *Ssave = (double *)malloc(sizeof(double) * (size_t)G * ORC_LANES);
-    for (int g = 0; g < G; ++g) {
-        for (int l = 0; l < ORC_LANES; ++l) {
-            double *b = z + ((size_t)g * ORC_LANES + l) * ORC_E;
-            for (int k = ORC_E - 2; k >= 0; --k) b[k] = fma(c->rho, b[k + 1], b[k]);
-            S[l] = b[0];
-        }
-        for (int s = 0; s < 4; ++s) {
-            int off = 1 << s;
-            for (int l = 0; l < ORC_LANES; ++l) T[l] = ((l & 15) + off < 16) ? fma(c->sc[s], S[l + off], S[l]) : S[l];
-            memcpy(S, T, sizeof(S));
-        }
-        for (int l = 0; l < ORC_LANES; ++l) /* rows 0 and 2 take the first lane of the row above */
-            T[l] = (((l >> 4) & 1) == 0) ? fma(c->lp[16 - (l & 15)], S[(l & ~15) + 16], S[l]) : S[l];
-        memcpy(S, T, sizeof(S));
-        for (int l = 0; l < ORC_LANES; ++l) /* lanes 0..31 take lane 32 */
-            T[l] = (l < 32) ? fma(c->lp[32 - l], S[32], S[l]) : S[l];
-        memcpy(S, T, sizeof(S));
-        memcpy(Ssave + (size_t)g * ORC_LANES, S, sizeof(S));
-        A[g] = S[0];
+    for (int l = 0; l < ORC_LANES; ++l) {
+        double *b = z + (size_t)l * ORC_E;
+        for (int k = ORC_E - 2; k >= 0; --k) b[k] = fma(c->rho, b[k + 1], b[k]);
+        S[l] = b[0];
     }
-    double carry = 0.0;
-    for (int g = G - 1; g >= 0; --g) {
-        const double *Sg = Ssave + (size_t)g * ORC_LANES;
-        for (int l = 0; l < ORC_LANES; ++l) {
-            double next = l < ORC_LANES - 1 ? Sg[l + 1] : 0.0;
-            double cin = fma(c->lp[ORC_LANES - 1 - l], carry, next);
-            double *b = z + ((size_t)g * ORC_LANES + l) * ORC_E;
-            for (int k = 0; k < ORC_E; ++k) b[k] = fma(c->pw[ORC_E - k], cin, b[k]);
-        }
-        carry = fma(c->gc, carry, A[g]);
+    for (int s = 0; s < 4; ++s) {
+        int off = 1 << s;
+        for (int l = 0; l < ORC_LANES; ++l) T[l] = ((l & 15) + off < 16) ? fma(c->sc[s], S[l + off], S[l]) : S[l];
+        memcpy(S, T, sizeof(S));
     }
-    free(A); free(Ssave);
+    for (int l = 0; l < ORC_LANES; ++l) /* rows 0 and 2 take the first lane of the row above */
+        T[l] = (((l >> 4) & 1) == 0) ? fma(c->lp[16 - (l & 15)], S[(l & ~15) + 16], S[l]) : S[l];
+    memcpy(S, T, sizeof(S));
+    for (int l = 0; l < ORC_LANES; ++l) /* lanes 0..31 take lane 32 */
+        T[l] = (l < 32) ? fma(c->lp[32 - l], S[32], S[l]) : S[l];
+    memcpy(S, T, sizeof(S));
+    for (int l = 0; l < ORC_LANES; ++l) {
+        double next = l < ORC_LANES - 1 ? S[l + 1] : 0.0;
+        double *b = z + (size_t)l * ORC_E;
+        for (int k = 0; k < ORC_E; ++k) b[k] = fma(c->pw[ORC_E - k], next, b[k]);
+    }
+    return S[0];
 }
 
 /* sum of squares with the spec's reduction tree: lane-local fma chain, xor-butterfly over 64 lanes, serial
@@ -387,17 +381,61 @@ static void heat1d_step_natural(orc_stepper *st, int nt, int i_stop, double dt, 
     for (int j = n - 2; j >= 0; --j) out[j] = d[j] - cp[j] * out[j + 1];
 }
 
+/* Cross-group carries: the <= 16 group totals sit in one row of 16 lanes; inclusive Kogge-Stone
+ * scans with coefficients gc^(2^s). fwd: I_g = sum_{h<=g} gc^(g-h) A_h ; bwd: J_g = sum_{h>=g} gc^(h-g) A_h. */
+static void cross_scan(const orc_cset *c, double *a, int backward) {
+    double t[16];
+    for (int s = 0; s < 4; ++s) {
+        int off = 1 << s;
+        for (int g = 0; g < 16; ++g) {
+            if (!backward) t[g] = (g >= off) ? fma(c->gcp[s], a[g - off], a[g]) : a[g];
+            else t[g] = (g + off < 16) ? fma(c->gcp[s], a[g + off], a[g]) : a[g];
+        }
+        memcpy(a, t, sizeof(t));
+    }
+}
+
+/* Spec variant of the Heat1D step: every group scans locally forward and backward, ONE exchange of the
+ * group totals (A_g, B_g), two short carry chains, then one pass that adds the carries and the rank-one correction. */
 static void heat1d_step_spec(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out) {
     int n = st->n, NP = padded(n), G = NP / ORC_GROUP;
     orc_cset *c = get_cset(st, dt);
     double *d = st->w1;
-    heat1d_rhs(st, nt, i_stop, dt, u, d);
+    double A[16] = {0}, B[16] = {0}, C[17] = {0}, Zf[17] = {0};
+    /* d = u + dt*b(x, t_i) with the forcing folded as fma(s_k, tau_k*dt, .) */
+    for (int j = 0; j < n; ++j) {
+        double v = u[j];
+        for (int k = 0; k < st->K; ++k) v = fma(st->s[(size_t)k * n + j], st->tau[(size_t)k * nt + i_stop] * dt, v);
+        d[j] = v;
+    }
     for (int j = n; j < NP; ++j) d[j] = 0.0;
-    spec_scan_fwd(c, G, d);
-    for (int j = n; j < NP; ++j) d[j] = 0.0;
-    spec_scan_bwd(c, G, d);
-    double z0 = d[0] * c->ik;
-    for (int j = 0; j < n; ++j) out[j] = fma(-z0, c->tab[j], d[j] * c->ik);
+    for (int g = 0; g < G; ++g) {
+        double *dg = d + (size_t)g * ORC_GROUP;
+        A[g] = group_scan_fwd(c, dg);
+        for (int j = 0; j < ORC_GROUP; ++j) if (g * ORC_GROUP + j >= n) dg[j] = 0.0;
+        B[g] = group_scan_bwd(c, dg);
+    }
+    cross_scan(c, A, 0);                       /* A[g] := inclusive forward scan */
+    C[0] = 0.0;
+    for (int g = 1; g < 16; ++g) C[g] = A[g - 1];
+    for (int g = 0; g < 16; ++g)
+        Zf[g] = (g < G) ? fma(C[g], (g == G - 1) ? c->pt_last[0] : c->pt_full[0], B[g]) : 0.0;
+    cross_scan(c, Zf, 1);                      /* Zf[g] := true z at the first element of group g */
+    Zf[16] = 0.0;
+    double z0 = Zf[0] * c->ik;
+    for (int g = 0; g < G; ++g) {
+        const double *pt = (g == G - 1) ? c->pt_last : c->pt_full;
+        for (int l = 0; l < ORC_LANES; ++l) {
+            double cb = c->lp[ORC_LANES - 1 - l] * Zf[g + 1];
+            for (int k = 0; k < ORC_E; ++k) {
+                int jj = l * ORC_E + k, j = g * ORC_GROUP + jj;
+                if (j >= n) continue;
+                double t = fma(C[g], pt[jj], d[j]);
+                double z = fma(c->pw[ORC_E - k], cb, t);
+                out[j] = fma(-z0, c->tab[j], z * c->ik);
+            }
+        }
+    }
 }
 
 /* advection_1d.py:129-143: spsolve(dt*L + I, u), L = (c/dx)(I - S_periodic) */
@@ -416,11 +454,27 @@ static void advection1d_step_spec(orc_stepper *st, double dt, const double *u, d
     int n = st->n, NP = padded(n), G = NP / ORC_GROUP;
     orc_cset *c = get_cset(st, dt);
     double *d = st->w1;
+    double A[16] = {0}, C[17] = {0};
     for (int j = 0; j < n; ++j) d[j] = u[j] * c->ik;
     for (int j = n; j < NP; ++j) d[j] = 0.0;
-    spec_scan_fwd(c, G, d);
-    double xl = d[n - 1] * c->scal;
-    for (int j = 0; j < n; ++j) out[j] = fma(c->tab[j], xl, d[j]);
+    for (int g = 0; g < G; ++g) A[g] = group_scan_fwd(c, d + (size_t)g * ORC_GROUP);
+    cross_scan(c, A, 0);
+    C[0] = 0.0;
+    for (int g = 1; g < 16; ++g) C[g] = A[g - 1];
+    /* periodic closure from the last real element n-1 (lane l*, element k* of group G-1) */
+    int jl = n - 1, gl = jl / ORC_GROUP, ll = (jl % ORC_GROUP) / ORC_E, kl = jl % ORC_E;
+    double ylast = fma(c->pw[kl + 1], c->lp[ll] * C[gl], d[jl]);
+    double xl = ylast * c->scal;
+    for (int g = 0; g < G; ++g)
+        for (int l = 0; l < ORC_LANES; ++l) {
+            double cf = c->lp[l] * C[g];
+            for (int k = 0; k < ORC_E; ++k) {
+                int j = g * ORC_GROUP + l * ORC_E + k;
+                if (j >= n) continue;
+                double y = fma(c->pw[k + 1], cf, d[j]);
+                out[j] = fma(c->tab[j], xl, y);
+            }
+        }
 }
 
 /* dahlquist.py:88-111 */

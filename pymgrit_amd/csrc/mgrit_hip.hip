@@ -58,6 +58,7 @@ int fail(int code, const char *fmt, ...) {
 // ---------------------------------------------------------------------------------------------------------------
 struct CSet {
     double rho, ik, scal, gc;
+    double pi_full, pi_last;  // heat: Pt[0] of a full / of the last group
     double pw[E + 1];   // rho^k
     double sc[6];       // rho^(E*2^s)
     double lp[LANES];   // rho^(E*l)
@@ -72,10 +73,11 @@ struct LevelDev {
     double *u, *v, *g;
     const int32_t *cidx;  // [n_pts] coefficient set of the step (i-1 -> i)
     const double *dt;     // [n_pts]
-    const double *tau;    // [K][n_pts]
+    const double *tc;     // [K][n_pts] tau_k(t_i) * dt_i
     const double2 *sP;    // [K][ld/2] forcing space factors, row storage order
     const CSet *cs;       // [n_csets]
     const double2 *tabP;  // [n_csets][ld/2] rank-one correction table, row storage order
+    const double2 *ptP;   // [n_csets][2][512] heat: group-local backward scan of rho^(j'+1) (full group, last group)
     int n, ld, T, n_pts, K, kind;
 };
 
@@ -125,19 +127,39 @@ __device__ __forceinline__ double read_lane(double v, int src) {
 }
 
 struct Smem {
-    double2 *tab;   // [8][T] rank-one correction table of the current coefficient set
-    double *totF;   // [MAX_G]
-    double *totB;   // [MAX_G]
-    double *bc;     // [2] broadcast scalars
+    double2 *tab;   // [8*T] correction table of the current coefficient set (heat: w-gamma, advection: r^(j+1)), row order
+    double2 *pt;    // [2][512] heat: group-local backward scan of rho^(j'+1): [0] full group, [1] last group
+    double *ga;     // [2][MAX_G] forward group totals A_g, double-buffered by step parity
+    double *gb;     // [2][MAX_G] backward group totals B_g (advection: slot [p][0] carries y-hat of the last real element)
     double *lp;     // [LANES] rho^(E*l) of the current coefficient set
 };
 
 // wave-uniform scalar coefficients of the current coefficient set, forced into SGPRs (readfirstlane)
 struct Coef {
-    double rho, ik, scal, gc;
+    double rho, ik, scal, pi_full, pi_last;
     double pw[E + 1];
     double sc[4];
+    double gcp[4];  // gc^(2^s), gc = rho^1024: cross-group scan coefficients
 };
+
+// per-lane powers of the current coefficient set used by the wave scans
+struct LaneCoef {
+    double f_row, f_hi;   // forward:  lp[(l&15)+1], lp[l-31]
+    double b_row, b_lo;   // backward: lp[16-(l&15)], lp[32-l]
+    double f_in, b_in;    // carry-in: lp[l], lp[63-l]
+};
+
+__device__ __forceinline__ LaneCoef lane_coef(const double *lp, int lane) {
+    LaneCoef k;
+    const int li = lane & 15;
+    k.f_row = lp[li + 1];
+    k.f_hi = lp[lane >= 32 ? lane - 31 : 0];
+    k.b_row = lp[16 - li];
+    k.b_lo = lp[lane < 32 ? 32 - lane : 0];
+    k.f_in = lp[lane];
+    k.b_in = lp[LANES - 1 - lane];
+    return k;
+}
 
 __device__ __forceinline__ double to_sgpr(double v) {
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
@@ -148,17 +170,18 @@ __device__ __forceinline__ double to_sgpr(double v) {
 __device__ __forceinline__ Smem carve_smem(char *base, int T) {
     Smem s;
     s.tab = reinterpret_cast<double2 *>(base);
-    double *tail = reinterpret_cast<double *>(base + (size_t)8 * T * sizeof(double2));
-    s.totF = tail;
-    s.totB = tail + MAX_G;
-    s.bc = tail + 2 * MAX_G;
-    s.lp = tail + 2 * MAX_G + 2;
+    s.pt = s.tab + (size_t)8 * T;
+    double *tail = reinterpret_cast<double *>(s.pt + 2 * 512);
+    s.ga = tail;
+    s.gb = tail + 2 * MAX_G;
+    s.lp = tail + 4 * MAX_G;
     return s;
 }
 
-// forward chunked scan  y_j = rho*y_{j-1} + d_j  (DESIGN.md 3.2): lane-local chain, row-wise Kogge-Stone over DPP
-// row shifts, two row broadcasts, serial carry across waves through LDS (one workgroup barrier).
-__device__ __forceinline__ void scan_fwd(double (&x)[E], const Coef &c, const double *lp, double *tot, int lane, int wave) {
+// Group-local forward scan  y_j = rho*y_{j-1} + d_j  with zero carry into the group: lane-local chain,
+// row-wise Kogge-Stone over DPP row shifts, two readlane row broadcasts, lane carry-in. No LDS, no barrier.
+// Returns the group total (value at the last element), wave-uniform.
+__device__ __forceinline__ double scan_fwd(double (&x)[E], const Coef &c, const LaneCoef &lc, int lane) {
 #pragma unroll
     for (int k = 1; k < E; ++k) x[k] = fma(c.rho, x[k - 1], x[k]);
     double a = x[E - 1];
@@ -172,23 +195,19 @@ __device__ __forceinline__ void scan_fwd(double (&x)[E], const Coef &c, const do
     }
     {
         const double s15 = read_lane(a, 15), s47 = read_lane(a, 47);
-        if ((lane >> 4) & 1) a = fma(lp[li + 1], lane < 32 ? s15 : s47, a);
+        if ((lane >> 4) & 1) a = fma(lc.f_row, lane < 32 ? s15 : s47, a);
         const double s31 = read_lane(a, 31);
-        if (lane >= 32) a = fma(lp[lane - 31], s31, a);
+        if (lane >= 32) a = fma(lc.f_hi, s31, a);
     }
-    if (lane == LANES - 1) tot[wave] = a;
-    __syncthreads();
-    double carry = 0.0;
-    for (int g = 0; g < wave; ++g) carry = fma(c.gc, carry, tot[g]);
     double prev = dpp_mov<DPP_WAVE_SHR1>(a);
     if (lane == 0) prev = 0.0;
-    const double cin = fma(lp[lane], carry, prev);
 #pragma unroll
-    for (int k = 0; k < E; ++k) x[k] = fma(c.pw[k + 1], cin, x[k]);
+    for (int k = 0; k < E; ++k) x[k] = fma(c.pw[k + 1], prev, x[k]);
+    return read_lane(a, LANES - 1);
 }
 
-// backward chunked scan  z_j = rho*z_{j+1} + y_j
-__device__ __forceinline__ void scan_bwd(double (&x)[E], const Coef &c, const double *lp, double *tot, int lane, int wave, int G) {
+// Group-local backward scan  z_j = rho*z_{j+1} + y_j  with zero carry from the right; returns the value at the first element
+__device__ __forceinline__ double scan_bwd(double (&x)[E], const Coef &c, const LaneCoef &lc, int lane) {
 #pragma unroll
     for (int k = E - 2; k >= 0; --k) x[k] = fma(c.rho, x[k + 1], x[k]);
     double a = x[0];
@@ -202,33 +221,30 @@ __device__ __forceinline__ void scan_bwd(double (&x)[E], const Coef &c, const do
     }
     {
         const double s16 = read_lane(a, 16), s48 = read_lane(a, 48);
-        if (((lane >> 4) & 1) == 0) a = fma(lp[16 - li], lane < 32 ? s16 : s48, a);
+        if (((lane >> 4) & 1) == 0) a = fma(lc.b_row, lane < 32 ? s16 : s48, a);
         const double s32 = read_lane(a, 32);
-        if (lane < 32) a = fma(lp[32 - lane], s32, a);
+        if (lane < 32) a = fma(lc.b_lo, s32, a);
     }
-    if (lane == 0) tot[wave] = a;
-    __syncthreads();
-    double carry = 0.0;
-    for (int g = G - 1; g > wave; --g) carry = fma(c.gc, carry, tot[g]);
     double next = dpp_mov<DPP_WAVE_SHL1>(a);
     if (lane == LANES - 1) next = 0.0;
-    const double cin = fma(lp[LANES - 1 - lane], carry, next);
 #pragma unroll
-    for (int k = 0; k < E; ++k) x[k] = fma(c.pw[E - k], cin, x[k]);
+    for (int k = 0; k < E; ++k) x[k] = fma(c.pw[E - k], next, x[k]);
+    return read_lane(a, 0);
 }
 
-// Per-workgroup stepper state that survives across the steps of a run: the forcing space factor of this lane (first
-// term) in registers and the correction table of the current coefficient set in LDS.
+// Per-workgroup stepper state that survives across the steps of a run.
 struct StepCtx {
-    double s0[E];
-    Coef c;    // scalar coefficients of the resident coefficient set
-    int cur;   // coefficient set whose tables are resident in LDS / SGPRs (-1: none)
+    double s0[E];   // forcing space factor of this lane (first term), FORCE == 1
+    Coef c;         // scalar coefficients of the resident coefficient set
+    int cur;        // coefficient set whose tables are resident in LDS / SGPRs (-1: none)
+    int parity;     // double-buffer index of the LDS gather slots
 };
 
 // FORCE: 0 = no forcing term, 1 = one separable term (space factor held in registers), 2 = K >= 2 terms (streamed)
 template <int KIND, int FORCE>
 __device__ __forceinline__ void ctx_init(StepCtx &ctx, const LevelDev &L, int t) {
     ctx.cur = -1;
+    ctx.parity = 0;
     if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -239,84 +255,161 @@ __device__ __forceinline__ void ctx_init(StepCtx &ctx, const LevelDev &L, int t)
     }
 }
 
-// x <- Phi(x) for the step (i-1 -> i) of level L.  heat_1d.py:198-217 / advection_1d.py:129-143.
+__device__ __forceinline__ void load_coef(Coef &c, const CSet *g) {
+    c.rho = to_sgpr(g->rho); c.ik = to_sgpr(g->ik); c.scal = to_sgpr(g->scal);
+    c.pi_full = to_sgpr(g->pi_full); c.pi_last = to_sgpr(g->pi_last);
+    c.gcp[0] = to_sgpr(g->gc);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) c.gcp[k] = c.gcp[k - 1] * c.gcp[k - 1];
+#pragma unroll
+    for (int k = 0; k <= E; ++k) c.pw[k] = to_sgpr(g->pw[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c.sc[k] = to_sgpr(g->sc[k]);
+}
+
+// d <- u + dt*b(x, t_i), forcing folded as fma(s_k, tau_k*dt, .)  (L.tc[k][i] = tau_k(t_i)*dt_i)
+template <int FORCE>
+__device__ __forceinline__ void add_forcing(double (&x)[E], const StepCtx &ctx, const LevelDev &L, int i, int t) {
+    if (FORCE == 1) {
+        const double c0 = L.tc[i];
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = fma(ctx.s0[k], c0, x[k]);
+    } else if (FORCE == 2) {
+        for (int kk = 0; kk < L.K; ++kk) {
+            const double ck = L.tc[(size_t)kk * L.n_pts + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double2 sv = L.sP[(size_t)kk * 8 * L.T + slot0(t) + q * 64];
+                x[2 * q] = fma(sv.x, ck, x[2 * q]);
+                x[2 * q + 1] = fma(sv.y, ck, x[2 * q + 1]);
+            }
+        }
+    }
+}
+
+// Cross-group carries. Lane g (g < 16) of each row holds the value of group g; inclusive
+// Kogge-Stone scans over the row with coefficients gc^(2^s).
+__device__ __forceinline__ double cross_fwd(double a, const Coef &c, int li) {
+    double v;
+    v = dpp_mov<DPP_ROW_SHR + 1>(a); if (li >= 1) a = fma(c.gcp[0], v, a);
+    v = dpp_mov<DPP_ROW_SHR + 2>(a); if (li >= 2) a = fma(c.gcp[1], v, a);
+    v = dpp_mov<DPP_ROW_SHR + 4>(a); if (li >= 4) a = fma(c.gcp[2], v, a);
+    v = dpp_mov<DPP_ROW_SHR + 8>(a); if (li >= 8) a = fma(c.gcp[3], v, a);
+    return a;
+}
+__device__ __forceinline__ double cross_bwd(double a, const Coef &c, int li) {
+    double v;
+    v = dpp_mov<DPP_ROW_SHL + 1>(a); if (li + 1 < 16) a = fma(c.gcp[0], v, a);
+    v = dpp_mov<DPP_ROW_SHL + 2>(a); if (li + 2 < 16) a = fma(c.gcp[1], v, a);
+    v = dpp_mov<DPP_ROW_SHL + 4>(a); if (li + 4 < 16) a = fma(c.gcp[2], v, a);
+    v = dpp_mov<DPP_ROW_SHL + 8>(a); if (li + 8 < 16) a = fma(c.gcp[3], v, a);
+    return a;
+}
+
+// heat: A, B = totals of group (lane & 15) (0 beyond G). Outputs: cm = C_wave, zin = Zf_{wave+1}, zf0 = Zf_0.
+__device__ __forceinline__ void heat_chains(const Coef &c, double A, double B, int G, int wave, int lane, double &cm,
+                                            double &zin, double &zf0) {
+    const int li = lane & 15;
+    const double I = cross_fwd(A, c, li);
+    double C = dpp_mov<DPP_ROW_SHR + 1>(I);
+    if (li == 0) C = 0.0;
+    const double Bt = li < G ? fma(C, li == G - 1 ? c.pi_last : c.pi_full, B) : 0.0;
+    const double J = cross_bwd(Bt, c, li);
+    double Jn = dpp_mov<DPP_ROW_SHL + 1>(J);
+    if (li == 15) Jn = 0.0;
+    const int w = __builtin_amdgcn_readfirstlane(wave);
+    cm = read_lane(C, w);
+    zin = read_lane(Jn, w);
+    zf0 = read_lane(J, 0);
+}
+
+// advection: forward carries only. Returns C_wave; c_last = C_{G-1}.
+__device__ __forceinline__ double fwd_chain(const Coef &c, double A, int G, int wave, int lane, double &c_last) {
+    const int li = lane & 15;
+    const double I = cross_fwd(A, c, li);
+    double C = dpp_mov<DPP_ROW_SHR + 1>(I);
+    if (li == 0) C = 0.0;
+    c_last = read_lane(C, __builtin_amdgcn_readfirstlane(G - 1));
+    return read_lane(C, __builtin_amdgcn_readfirstlane(wave));
+}
+
+// final pass of the heat step for one lane: carries + rank-one correction
+__device__ __forceinline__ void heat_finish(double (&x)[E], const Coef &c, double cm, double cb, double z0, int q, double2 w,
+                                            double2 p) {
+    const double t0 = fma(cm, p.x, x[2 * q]), t1 = fma(cm, p.y, x[2 * q + 1]);
+    const double z_0 = fma(c.pw[E - 2 * q], cb, t0), z_1 = fma(c.pw[E - 2 * q - 1], cb, t1);
+    x[2 * q] = fma(-z0, w.x, z_0 * c.ik);
+    x[2 * q + 1] = fma(-z0, w.y, z_1 * c.ik);
+}
+
+// x <- Phi(x) for the step (i-1 -> i) of level L, one workgroup holding the whole vector (heat_1d.py:198-217 /
+// advection_1d.py:129-143; arithmetic: DESIGN.md section 3). One workgroup barrier per application.
 template <int KIND, int FORCE>
 __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const LevelDev &L, int i, const Smem &sm, int t,
                                           int lane, int wave, int G) {
     const int ci = __builtin_amdgcn_readfirstlane(L.cidx[i]);
-    if (ci != ctx.cur) {  // (re)load this coefficient set: table + lane powers -> LDS, scalars -> SGPRs; uniform branch
+    if (ci != ctx.cur) {  // (re)load this coefficient set: tables + lane powers -> LDS, scalars -> SGPRs; uniform branch
         __syncthreads();
         const double2 *src = L.tabP + (size_t)ci * 8 * L.T + slot0(t);
 #pragma unroll
         for (int q = 0; q < 8; ++q) sm.tab[slot0(t) + q * 64] = src[q * 64];
         const CSet *g = L.cs + ci;
         if (t < LANES) sm.lp[t] = g->lp[t];
-        ctx.c.rho = to_sgpr(g->rho); ctx.c.ik = to_sgpr(g->ik); ctx.c.scal = to_sgpr(g->scal); ctx.c.gc = to_sgpr(g->gc);
-#pragma unroll
-        for (int k = 0; k <= E; ++k) ctx.c.pw[k] = to_sgpr(g->pw[k]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ctx.c.sc[k] = to_sgpr(g->sc[k]);
+        if (KIND == MGRIT_HIP_STEPPER_HEAT1D && t < 2 * 512) sm.pt[t] = L.ptP[(size_t)ci * 1024 + t];
+        if (KIND == MGRIT_HIP_STEPPER_HEAT1D && L.T < 1024)
+            for (int r = t + L.T; r < 1024; r += L.T) sm.pt[r] = L.ptP[(size_t)ci * 1024 + r];
+        load_coef(ctx.c, g);
         ctx.cur = ci;
         __syncthreads();
     }
     const Coef &c = ctx.c;
-    const int j0 = t * E;
+    const LaneCoef lc = lane_coef(sm.lp, lane);
+    const int j0 = t * E, par = ctx.parity, li = lane & 15;
+    ctx.parity ^= 1;
+    double *ga = sm.ga + par * MAX_G, *gb = sm.gb + par * MAX_G;
     if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
-        if (FORCE == 1) {
-            const double dt = L.dt[i], tau0 = L.tau[i];
-#pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = x[k] + (ctx.s0[k] * tau0) * dt;
-        } else if (FORCE == 2) {
-            const double dt = L.dt[i];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double2 s0v = L.sP[slot0(t) + q * 64];
-                double f0 = s0v.x * L.tau[i], f1 = s0v.y * L.tau[i];
-                for (int kk = 1; kk < L.K; ++kk) {
-                    const double2 sv = L.sP[(size_t)kk * 8 * L.T + slot0(t) + q * 64];
-                    const double tk = L.tau[(size_t)kk * L.n_pts + i];
-                    f0 = f0 + sv.x * tk;
-                    f1 = f1 + sv.y * tk;
-                }
-                x[2 * q] = x[2 * q] + f0 * dt;
-                x[2 * q + 1] = x[2 * q + 1] + f1 * dt;
-            }
-        }
-        scan_fwd(x, c, sm.lp, sm.totF, lane, wave);
+        add_forcing<FORCE>(x, ctx, L, i, t);
+        const double a = scan_fwd(x, c, lc, lane);
 #pragma unroll
         for (int k = 0; k < E; ++k)
             if (j0 + k >= L.n) x[k] = 0.0;
-        scan_bwd(x, c, sm.lp, sm.totB, lane, wave, G);
-        if (t == 0) sm.bc[0] = x[0] * c.ik;
+        const double b = scan_bwd(x, c, lc, lane);
+        if (lane == 0) { ga[wave] = a; gb[wave] = b; }
         __syncthreads();
-        const double z0 = sm.bc[0];
+        double cm, zin, zf0;
+        heat_chains(c, li < G ? ga[li] : 0.0, li < G ? gb[li] : 0.0, G, wave, lane, cm, zin, zf0);
+        const double z0 = zf0 * c.ik;
+        const double cb = lc.b_in * zin;
+        const double2 *pt = sm.pt + (wave == G - 1 ? 512 : 0) + lane;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const double2 w = sm.tab[slot0(t) + q * 64];
-            x[2 * q] = fma(-z0, w.x, x[2 * q] * c.ik);
-            x[2 * q + 1] = fma(-z0, w.y, x[2 * q + 1] * c.ik);
-        }
+        for (int q = 0; q < 8; ++q) heat_finish(x, c, cm, cb, z0, q, sm.tab[slot0(t) + q * 64], pt[q * 64]);
     } else {
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] * c.ik;
-        scan_fwd(x, c, sm.lp, sm.totF, lane, wave);
+        const double a = scan_fwd(x, c, lc, lane);
         const int jl = L.n - 1;
+        if (lane == 0) ga[wave] = a;
         if (t == jl / E) {
             double y = 0.0;
 #pragma unroll
             for (int k = 0; k < E; ++k)
                 if (k == jl % E) y = x[k];
-            sm.bc[0] = y * c.scal;
+            gb[0] = y;
         }
         __syncthreads();
-        const double xl = sm.bc[0];
+        double c_last = 0.0;
+        const double cm = fwd_chain(c, li < G ? ga[li] : 0.0, G, wave, lane, c_last);
+        const int ll = (jl % GROUP) / E, kl = jl % E;
+        const double ylast = fma(c.pw[kl + 1], sm.lp[ll] * c_last, gb[0]);
+        const double xl = ylast * c.scal;
+        const double cf = lc.f_in * cm;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const double2 w = sm.tab[slot0(t) + q * 64];
-            x[2 * q] = (j0 + 2 * q < L.n) ? fma(w.x, xl, x[2 * q]) : 0.0;
-            x[2 * q + 1] = (j0 + 2 * q + 1 < L.n) ? fma(w.y, xl, x[2 * q + 1]) : 0.0;
+            const double y0 = fma(c.pw[2 * q + 1], cf, x[2 * q]), y1 = fma(c.pw[2 * q + 2], cf, x[2 * q + 1]);
+            x[2 * q] = (j0 + 2 * q < L.n) ? fma(w.x, xl, y0) : 0.0;
+            x[2 * q + 1] = (j0 + 2 * q + 1 < L.n) ? fma(w.y, xl, y1) : 0.0;
         }
-        __syncthreads();  // protects totF / bc reuse by the next step (heat has 3 barriers per step, advection 2 + this)
     }
 }
 
@@ -328,11 +421,11 @@ __device__ __forceinline__ double block_sumsq(const double (&r)[E], const Smem &
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
     __syncthreads();
-    if (lane == 0) sm.totF[wave] = acc;
+    if (lane == 0) sm.ga[wave] = acc;
     __syncthreads();
     double tot = 0.0;
     if (t == 0)
-        for (int g = 0; g < G; ++g) tot = tot + sm.totF[g];
+        for (int g = 0; g < G; ++g) tot = tot + sm.ga[g];
     return tot;
 }
 
@@ -371,6 +464,138 @@ __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *
             load_row(L.u + (size_t)i * L.ld, sl, uo);
 #pragma unroll
             for (int k = 0; k < E; ++k) x[k] = x[k] * w + uo[k] * w1;
+        }
+        store_row(L.u + (size_t)i * L.ld, sl, x);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sequential chain across workgroups (forward_solve, mgrit.py:459-486, for n > 1024). A single workgroup streaming
+// 24*n bytes per step through one CU is bound by that CU's memory pipe (~31 GB/s measured: 8 us per step at n = 16382).
+// Here group g of the vector (1024 values) lives in its own single-wave workgroup on its own CU; per step every worker
+// scans its group locally, publishes its two group totals as 8-byte {epoch, half} granules (one relaxed agent-scope store
+// each, cdna_hip_programming.md Guideline 16, form R2), sweeps the granules of all workers until every tag carries the
+// step's epoch, then finishes locally. One exchange per step, the arithmetic is exactly that of phi_apply.
+// Workers are the blocks with blockIdx % 8 == 0 (observed to share an XCD: speed only, never correctness); all other
+// blocks exit at once. Granules are double-buffered by epoch parity; every spin is bounded and reports through *err.
+// ---------------------------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 26;
+
+template <int KIND, int FORCE, bool USE_G>
+__global__ void __launch_bounds__(64) chain_kernel(LevelDev L, int start, int len, u64 *gran, unsigned *err) {
+    if (blockIdx.x & 7) return;
+    const int wave = blockIdx.x >> 3, lane = threadIdx.x, G = L.T >> 6, t = wave * LANES + lane, li = lane & 15;
+    const unsigned sl = slot0(t);
+    const int j0 = t * E;
+    double x[E], s0[E], wg[E], pt[E], gi[E];
+    Coef c;
+    LaneCoef lc;
+    int cur = -1;
+    if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) load_row(reinterpret_cast<const double *>(L.sP), sl, s0);
+    load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
+    for (int i = start; i < start + len; ++i) {
+        const unsigned epoch = (unsigned)(i - start + 1);
+        u64 *slots = gran + (size_t)(epoch & 1) * MAX_G * 4;
+        if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);  // in flight during the local scans and the exchange
+        const int ci = __builtin_amdgcn_readfirstlane(L.cidx[i]);
+        if (ci != cur) {
+            const CSet *g = L.cs + ci;
+            load_coef(c, g);
+            lc = lane_coef(g->lp, lane);
+            load_row(reinterpret_cast<const double *>(L.tabP + (size_t)ci * 8 * L.T), sl, wg);
+            if (KIND == MGRIT_HIP_STEPPER_HEAT1D)
+                load_row(reinterpret_cast<const double *>(L.ptP + (size_t)ci * 1024 + (wave == G - 1 ? 512 : 0)), (unsigned)lane, pt);
+            cur = ci;
+        }
+        double v0, v1 = 0.0;  // the two published values of this worker
+        if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
+            if (FORCE == 1) {
+                const double c0 = L.tc[i];
+#pragma unroll
+                for (int k = 0; k < E; ++k) x[k] = fma(s0[k], c0, x[k]);
+            } else if (FORCE == 2) {
+                for (int kk = 0; kk < L.K; ++kk) {
+                    const double ck = L.tc[(size_t)kk * L.n_pts + i];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const double2 sv = L.sP[(size_t)kk * 8 * L.T + sl + q * 64];
+                        x[2 * q] = fma(sv.x, ck, x[2 * q]);
+                        x[2 * q + 1] = fma(sv.y, ck, x[2 * q + 1]);
+                    }
+                }
+            }
+            v0 = scan_fwd(x, c, lc, lane);
+#pragma unroll
+            for (int k = 0; k < E; ++k)
+                if (j0 + k >= L.n) x[k] = 0.0;
+            v1 = scan_bwd(x, c, lc, lane);
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = x[k] * c.ik;
+            v0 = scan_fwd(x, c, lc, lane);
+            const int jl = L.n - 1;
+            double y = 0.0;
+#pragma unroll
+            for (int k = 0; k < E; ++k)
+                if (j0 + k == jl) y = x[k];
+            v1 = read_lane(y, __builtin_amdgcn_readfirstlane((jl % GROUP) / E));  // only meaningful on the last worker
+        }
+        // ---- publish: 4 granules {epoch, 32-bit half}
+        if (lane < 4) {
+            const double v = lane < 2 ? v0 : v1;
+            const unsigned half = (lane & 1) ? (unsigned)__double2loint(v) : (unsigned)__double2hiint(v);
+            __hip_atomic_store(slots + wave * 4 + lane, ((u64)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- sweep: lane k watches granule (worker k>>2, item k&3)
+        unsigned mine = 0;
+        {
+            const bool watch = (lane >> 2) < G;
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                if (watch) {
+                    const u64 g64 = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mine = (unsigned)g64;
+                    ok = (unsigned)(g64 >> 32) == epoch;
+                }
+                if (__all(ok)) break;
+                if (++spins > CHAIN_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return;  // bounded spin: give up, the host reports the failure
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        // group (lane & 15) totals: hi/lo halves sit in lanes 4g .. 4g+3
+        const int src = (li < G ? li : 0) * 4;
+        const double A = __hiloint2double((int)__shfl(mine, src), (int)__shfl(mine, src + 1));
+        const double B = __hiloint2double((int)__shfl(mine, src + 2), (int)__shfl(mine, src + 3));
+        if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
+            double cm, zin, zf0;
+            heat_chains(c, li < G ? A : 0.0, li < G ? B : 0.0, G, wave, lane, cm, zin, zf0);
+            const double z0 = zf0 * c.ik, cb = lc.b_in * zin;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                heat_finish(x, c, cm, cb, z0, q, make_double2(wg[2 * q], wg[2 * q + 1]), make_double2(pt[2 * q], pt[2 * q + 1]));
+        } else {
+            double c_last = 0.0;
+            const double cm = fwd_chain(c, li < G ? A : 0.0, G, wave, lane, c_last);
+            const int jl = L.n - 1, ll = (jl % GROUP) / E, kl = jl % E;
+            const double e_last = read_lane(B, __builtin_amdgcn_readfirstlane(G - 1));  // y-hat of element n-1
+            const double lp_ll = read_lane(lc.f_in, __builtin_amdgcn_readfirstlane(ll));
+            const double ylast = fma(c.pw[kl + 1], lp_ll * c_last, e_last);
+            const double xl = ylast * c.scal, cf = lc.f_in * cm;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double y0 = fma(c.pw[2 * q + 1], cf, x[2 * q]), y1 = fma(c.pw[2 * q + 2], cf, x[2 * q + 1]);
+                x[2 * q] = (j0 + 2 * q < L.n) ? fma(wg[2 * q], xl, y0) : 0.0;
+                x[2 * q + 1] = (j0 + 2 * q + 1 < L.n) ? fma(wg[2 * q + 1], xl, y1) : 0.0;
+            }
+        }
+        if (USE_G) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = gi[k] + x[k];
         }
         store_row(L.u + (size_t)i * L.ld, sl, x);
     }
@@ -504,7 +729,7 @@ __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, c
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-struct RunList { int n = 0; int32_t *d_start = nullptr, *d_len = nullptr; };
+struct RunList { int n = 0; int32_t *d_start = nullptr, *d_len = nullptr; std::vector<int32_t> h_start, h_len; };
 struct PairList { int n = 0; int32_t *d_fine = nullptr, *d_coarse = nullptr, *d_iota = nullptr; };
 
 struct Level {
@@ -527,6 +752,8 @@ struct mgrit_hip_engine {
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    u64 *chain_gran = nullptr;    // [2][MAX_G][4] granules of the cross-workgroup chain
+    unsigned *chain_err = nullptr;  // pinned, device-mapped: set by a worker whose bounded spin gave up
     double *pinned = nullptr;     // host staging buffer for small read-backs
     size_t pinned_len = 0;
     hipEvent_t ev_read = nullptr;
@@ -547,6 +774,22 @@ void cset_powers(CSet &c, double rho) {
 }
 
 // T = tridiag(-beta, D, -beta) = kappa (I - rho S)(I - rho S^T) + kappa rho^2 e0 e0^T
+// group-local backward scan of the power vector rho^(j'+1), j' < len (zero beyond): serial recurrences
+void build_pt(const CSet &c, int len, double *pt) {
+    std::vector<double> q(GROUP);
+    double p = c.rho;
+    for (int j = 0; j < GROUP; ++j) {
+        q[j] = j < len ? p : 0.0;
+        p = p * c.rho;
+    }
+    double z = q[GROUP - 1];
+    pt[GROUP - 1] = z;
+    for (int j = GROUP - 2; j >= 0; --j) {
+        z = std::fma(c.rho, z, q[j]);
+        pt[j] = z;
+    }
+}
+
 void build_cset_heat1d(CSet &c, std::vector<double> &tab, int n, double fac, double dt) {
     const double beta = dt * fac;
     const double D = dt * (2.0 * fac) + 1.0;
@@ -602,7 +845,7 @@ int dev_upload(Level &lv, hipStream_t st, const std::vector<T> &h, T **out) {
     return 0;
 }
 
-size_t smem_bytes(int G) { return (size_t)8 * G * LANES * sizeof(double2) + (2 * MAX_G + 2 + LANES) * sizeof(double); }
+size_t smem_bytes(int G) { return (size_t)(8 * G * LANES + 2 * 512) * sizeof(double2) + (4 * MAX_G + LANES) * sizeof(double); }
 
 template <typename K>
 int allow_big_lds(K kernel) {
@@ -677,24 +920,38 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     lv.n_csets = (int)uniq.size();
     std::vector<CSet> cs(uniq.size());
     std::vector<double> tabT(uniq.size() * (size_t)E * T, 0.0), tab;  // row storage order per coefficient set
+    std::vector<double> ptT(uniq.size() * (size_t)2 * GROUP, 0.0), pt(GROUP);
     for (size_t q = 0; q < uniq.size(); ++q) {
         std::memset(&cs[q], 0, sizeof(CSet));
-        if (kind == MGRIT_HIP_STEPPER_HEAT1D) build_cset_heat1d(cs[q], tab, n, fac, uniq[q]);
-        else build_cset_advection1d(cs[q], tab, n, fac, uniq[q]);
+        if (kind == MGRIT_HIP_STEPPER_HEAT1D) {
+            build_cset_heat1d(cs[q], tab, n, fac, uniq[q]);
+            build_pt(cs[q], GROUP, pt.data());
+            cs[q].pi_full = pt[0];
+            for (int j = 0; j < GROUP; ++j) ptT[q * (size_t)2 * GROUP + row_pos(j)] = pt[j];
+            build_pt(cs[q], n - ((n - 1) / GROUP) * GROUP, pt.data());
+            cs[q].pi_last = pt[0];
+            for (int j = 0; j < GROUP; ++j) ptT[q * (size_t)2 * GROUP + GROUP + row_pos(j)] = pt[j];
+        } else build_cset_advection1d(cs[q], tab, n, fac, uniq[q]);
         for (int j = 0; j < n; ++j) tabT[q * (size_t)E * T + row_pos(j)] = tab[j];
     }
     std::vector<double> sT((size_t)(K > 0 ? K : 0) * E * T, 0.0), tauv;
     for (int kk = 0; kk < K; ++kk)
         for (int j = 0; j < n; ++j) sT[(size_t)kk * E * T + row_pos(j)] = s[(size_t)kk * n + j];
-    if (K > 0) tauv.assign(tau, tau + (size_t)K * n_pts);
-    int32_t *d_cidx; double *d_dt, *d_tau, *d_sT, *d_tabT; CSet *d_cs;
+    if (K > 0) {  // tc[k][i] = tau_k(t_i) * dt_i
+        tauv.assign(tau, tau + (size_t)K * n_pts);
+        for (int kk = 0; kk < K; ++kk)
+            for (int i = 0; i < n_pts; ++i) tauv[(size_t)kk * n_pts + i] = tauv[(size_t)kk * n_pts + i] * dts[i];
+    }
+    int32_t *d_cidx; double *d_dt, *d_tau, *d_sT, *d_tabT, *d_ptT; CSet *d_cs;
     if ((rc = dev_upload(lv, e->stream, cidx, &d_cidx))) return rc;
     if ((rc = dev_upload(lv, e->stream, dts, &d_dt))) return rc;
     if ((rc = dev_upload(lv, e->stream, tauv, &d_tau))) return rc;
     if ((rc = dev_upload(lv, e->stream, sT, &d_sT))) return rc;
     if ((rc = dev_upload(lv, e->stream, cs, &d_cs))) return rc;
     if ((rc = dev_upload(lv, e->stream, tabT, &d_tabT))) return rc;
-    d.cidx = d_cidx; d.dt = d_dt; d.tau = d_tau; d.cs = d_cs;
+    if ((rc = dev_upload(lv, e->stream, ptT, &d_ptT))) return rc;
+    d.cidx = d_cidx; d.dt = d_dt; d.tc = d_tau; d.cs = d_cs;
+    d.ptP = reinterpret_cast<const double2 *>(d_ptT);
     d.sP = reinterpret_cast<const double2 *>(d_sT);
     d.tabP = reinterpret_cast<const double2 *>(d_tabT);
     lv.set = true;
@@ -779,6 +1036,8 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
         for (void *p : lv.allocs) (void)hipFree(p);
         if (lv.scratch) (void)hipFree(lv.scratch);
     }
+    if (e->chain_gran) (void)hipFree(e->chain_gran);
+    if (e->chain_err) (void)hipHostFree(e->chain_err);
     if (e->pinned) (void)hipHostFree(e->pinned);
     if (e->ev_read) (void)hipEventDestroy(e->ev_read);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -787,10 +1046,18 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
     return 0;
 }
 
+static int chain_status(mgrit_hip_engine *e) {
+    if (e->chain_err && *e->chain_err != 0u) {
+        *e->chain_err = 0u;
+        return fail(MGRIT_HIP_EHIP, "cross-workgroup chain kernel timed out waiting for a peer workgroup (results invalid)");
+    }
+    return 0;
+}
+
 int mgrit_hip_sync(mgrit_hip_engine *e) {
     if (!e) return fail(MGRIT_HIP_EINVAL, "null engine");
     HIP_TRY(hipStreamSynchronize(e->stream));
-    return 0;
+    return chain_status(e);
 }
 
 int mgrit_hip_level_heat1d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int n, int ld,
@@ -836,6 +1103,8 @@ int mgrit_hip_runs_create(mgrit_hip_engine *e, int lvl, int n_runs, const int32_
                         start[r], len[r], lv.dev.n_pts);
     RunList rl;
     rl.n = n_runs;
+    rl.h_start.assign(start, start + n_runs);
+    rl.h_len.assign(len, len + n_runs);
     std::vector<int32_t> hs(start, start + n_runs), hl(len, len + n_runs);
     if ((rc = dev_upload(lv, e->stream, hs, &rl.d_start))) return rc;
     if ((rc = dev_upload(lv, e->stream, hl, &rl.d_len))) return rc;
@@ -879,6 +1148,29 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     if (e->timing) {
         if (!e->ev0) { HIP_TRY(hipEventCreate(&e->ev0)); HIP_TRY(hipEventCreate(&e->ev1)); }
         HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    }
+    if (mode == MGRIT_HIP_RELAX_CHAIN && lv.G > 1) {
+        // sequential chain over several groups: one single-wave workgroup per group, exchange through global granules
+        if (!e->chain_gran) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->chain_gran), sizeof(u64) * 2 * MAX_G * 4));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->chain_err), 64, hipHostMallocMapped));
+            *e->chain_err = 0u;
+        }
+        const bool use_g = lvl > 0;
+        const int fm = force_mode(lv);
+        for (int r = 0; r < rl->n; ++r) {
+            HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 2 * MAX_G * 4, e->stream));
+            const dim3 grid(8 * lv.G), block(LANES);
+            const int st = rl->h_start[r], ln = rl->h_len[r];
+#define CHAIN_CASE(K, F, G_)                                                                                  \
+    if (lv.dev.kind == K && fm == F && use_g == G_)                                                            \
+        hipLaunchKernelGGL((chain_kernel<K, F, G_>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
+#define CHAIN_CASES(K, F) CHAIN_CASE(K, F, false) CHAIN_CASE(K, F, true)
+            FOR_EACH_STEPPER(CHAIN_CASES)
+            HIP_TRY(hipGetLastError());
+        }
+        if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
+        return 0;
     }
     {
         const bool use_g = lvl > 0;
@@ -1018,7 +1310,7 @@ static int wait_pinned(mgrit_hip_engine *e, int n, double *host) {
         if (q != hipErrorNotReady) return fail(MGRIT_HIP_EHIP, "hipEventQuery: %s", hipGetErrorString(q));
     }
     std::memcpy(host, e->pinned, sizeof(double) * (size_t)n);
-    return 0;
+    return chain_status(e);
 }
 
 int mgrit_hip_residual_host(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_host) {
