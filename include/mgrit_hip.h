@@ -87,6 +87,16 @@ int mgrit_hip_jump(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev
 int mgrit_hip_restrict_u(mgrit_hip_engine *e, int lvl, int pairs_id);
 int mgrit_hip_copy_u_to_v(mgrit_hip_engine *e, int lvl_coarse);
 int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id);
+/* The same sweep fused into one pass for the identity transfer (GridTransferCopy) and like steppers on both levels:
+ * triple = (fine slot i of a C-point, fine slot of the PREVIOUS C-point (must be local), coarse slot j). For every triple:
+ * u^{l+1}_j = v^{l+1}_j = u^l_i and g^{l+1}_j as above with v_{j-1} read as u^l at the previous C-point. Pairs whose
+ * predecessor lives on another rank go through restrict_u / copy_pairs_u_to_v / fas_rhs after the exchange. */
+int mgrit_hip_triples_create(mgrit_hip_engine *e, int lvl, int n, const int32_t *fine_idx, const int32_t *prev_fine_idx,
+                             const int32_t *coarse_idx, int *id_out);
+int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id);
+/* v^{l+1}_j = u^{l+1}_j for the coarse slots of a pair list (row-wise part of mgrit.py:520) */
+int mgrit_hip_copy_pairs_u_to_v(mgrit_hip_engine *e, int lvl, int pairs_id);
+
 /* Mgrit.error_correction (mgrit.py:715-726): u^l_i = u^l_i + P(u^{l+1}_j - v^{l+1}_j) */
 int mgrit_hip_error_correction(mgrit_hip_engine *e, int lvl, int pairs_id);
 /* Mgrit.nested_iteration interpolation (mgrit.py:559-563): u^l_i = P(u^{l+1}_j) */

@@ -249,6 +249,29 @@ class HipBackend:
         if pairs:
             check(self.lib.mgrit_hip_fas_rhs(self.h, lvl, self._pair_id(lvl, pairs)))
 
+    # fused FAS residual (identity transfer, like steppers on both levels): see include/mgrit_hip.h
+    def can_fuse_fas(self, lvl):
+        tr = self.mg.transfer_objects[lvl]
+        da, db = self.desc[lvl], self.desc[lvl + 1]
+        same_forcing = len(da.get("forcing_time", [])) == len(db.get("forcing_time", []))
+        return (hasattr(tr, "device_transfer") and int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and
+                da["kind"] == db["kind"] and self.n[lvl] == self.n[lvl + 1] and same_forcing)
+
+    def fas_fused(self, lvl, triples):
+        if not triples:
+            return
+
+        def create():
+            tid = C.c_int(-1)
+            fi, pr, co = (_i32([tr[k] for tr in triples]) for k in range(3))
+            check(self.lib.mgrit_hip_triples_create(self.h, lvl, len(triples), _ptr(fi), _ptr(pr), _ptr(co), C.byref(tid)))
+            return tid.value
+        check(self.lib.mgrit_hip_fas_fused(self.h, lvl, self._handle(self._pairs, lvl, triples, "triples", create)))
+
+    def copy_pairs_u_to_v(self, lvl, pairs):
+        if pairs:
+            check(self.lib.mgrit_hip_copy_pairs_u_to_v(self.h, lvl, self._pair_id(lvl, pairs)))
+
     def error_correction(self, lvl, pairs):
         if pairs:
             check(self.lib.mgrit_hip_error_correction(self.h, lvl, self._pair_id(lvl, pairs)))

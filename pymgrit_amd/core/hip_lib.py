@@ -34,6 +34,10 @@ EXPORTS = {
     "mgrit_hip_restrict_u": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_copy_u_to_v": (C.c_int, [C.c_void_p, C.c_int]),
     "mgrit_hip_fas_rhs": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_triples_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_int)]),
+    "mgrit_hip_fas_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_copy_pairs_u_to_v": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_error_correction": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_interpolate": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_residual_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

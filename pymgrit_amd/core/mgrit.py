@@ -355,6 +355,10 @@ class Mgrit:
         """Inject the C-points and the FAS right-hand side into level lvl+1 (mgrit.py:488-549). op 3 = ghost refresh on
         lvl, op 4 = last local point of lvl+1 to the next owner's ghost."""
         t0 = time.time()
+        if getattr(self.backend, "can_fuse_fas", None) is not None and self.backend.can_fuse_fas(lvl):
+            self._fas_residual_fused(lvl)
+            logging.debug(f"Fas residual on {self.comm_time_rank} took {time.time() - t0} s")
+            return
         self.backend.restrict_u(lvl, self._pairs(lvl, skip_first=False))
         self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
                        recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl])
@@ -365,6 +369,28 @@ class Mgrit:
         self.backend.copy_u_to_v(lvl + 1)
         self.backend.fas_rhs(lvl, self._pairs(lvl, skip_first=True))
         logging.debug(f"Fas residual on {self.comm_time_rank} took {time.time() - t0} s")
+
+    def _fas_residual_fused(self, lvl: int) -> None:
+        """Same sweep as fas_residual with the device backend's fused kernel: every local C-point whose previous
+        C-point is local too is handled in one pass (restriction, clone into v, FAS right-hand side); the first local
+        C-point goes through the separate kernels because its v_{j-1} is the ghost that arrives with op 4."""
+        be = self.backend
+        all_pairs = self._pairs(lvl, skip_first=False)
+        head = self._cached(('pair_head', lvl), lambda: all_pairs[:1])
+        triples = self._cached(('triples', lvl), lambda: [(all_pairs[k][0], all_pairs[k - 1][0], all_pairs[k][1])
+                                                          for k in range(1, len(all_pairs))])
+        self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
+                       recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl])
+        be.restrict_u(lvl, head)
+        be.fas_fused(lvl, triples)
+        self._exchange(lvl + 1,
+                       send_idx=int(self.index_local[lvl + 1][-1]) if self.send_to[lvl + 1] >= 0 else None,
+                       recv_idx=0 if self.get_from[lvl + 1] >= 0 else None,
+                       dest=self.send_to[lvl + 1], src=self.get_from[lvl + 1])
+        be.copy_pairs_u_to_v(lvl, head)
+        if self._ghost[lvl + 1]:  # v ghost = clone of the received u ghost; then the first local pair, unfused
+            be.copy_pairs_u_to_v(lvl, self._cached(('pair_ghost', lvl), lambda: [(all_pairs[0][0], 0)] if all_pairs else []))
+            be.fas_rhs(lvl, head)
 
     def error_correction(self, lvl: int) -> None:
         """u^l at C-points += P(u^{l+1} - v^{l+1}) (mgrit.py:715-726)."""

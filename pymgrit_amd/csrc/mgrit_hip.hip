@@ -560,11 +560,12 @@ __global__ void __launch_bounds__(64) chain_kernel(LevelDev L, int start, int le
                     ok = (unsigned)(g64 >> 32) == epoch;
                 }
                 if (__all(ok)) break;
-                if (++spins > CHAIN_SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                // the error word lives in host memory: look at it rarely (a peer that gave up stops publishing anyway)
+                if (++spins > CHAIN_SPIN_LIMIT ||
+                    ((spins & 0xffffu) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
                     if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     return;  // bounded spin: give up, the host reports the failure
                 }
-                __builtin_amdgcn_s_sleep(1);
             }
         }
         // group (lane & 15) totals: hi/lo halves sit in lanes 4g .. 4g+3
@@ -680,6 +681,50 @@ __global__ void __launch_bounds__(1024) fas_coarse_kernel(LevelDev L, const int3
     store_row(L.g + (size_t)j * L.ld, sl, x);
 }
 
+// fas_residual fused for the identity spatial transfer (GridTransferCopy): per C-point j >= 1 with fine slot i, previous
+// fine C slot ip and coarse slot j (mgrit.py:498-500,520,524-547 in one pass over the data):
+//   u^{l+1}_j = v^{l+1}_j = u^l_i ;  g^{l+1}_j = ((Phi_l(u^l_{i-1}) - u^l_i) + v_j) - Phi_{l+1}(v_{j-1}),  v_{j-1} = u^l_{ip}
+// (lvl > 0: (g^l_i - u^l_i) + Phi_l(u^l_{i-1})). 3-4 vectors read, 3 written per C-point instead of 11-12.
+template <int KIND, int FORCE>
+__global__ void __launch_bounds__(1024) fas_fused_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ fine_idx,
+                                                         const int32_t *__restrict__ prev_idx,
+                                                         const int32_t *__restrict__ coarse_idx, int use_g) {
+    WG_PROLOGUE;
+    const int i = fine_idx[blockIdx.x], ip = prev_idx[blockIdx.x], j = coarse_idx[blockIdx.x];
+    double x[E], w[E];
+    load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
+    load_row(L.u + (size_t)i * L.ld, sl, w);
+    store_row(Lc.u + (size_t)j * Lc.ld, sl, w);
+    store_row(Lc.v + (size_t)j * Lc.ld, sl, w);
+    if (use_g) {
+        double gi[E];
+        load_row(L.g + (size_t)i * L.ld, sl, gi);
+#pragma unroll
+        for (int k = 0; k < E; ++k) w[k] = gi[k] - w[k];
+    }
+    phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+    if (use_g) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = w[k] + x[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
+    }
+    load_row(Lc.v + (size_t)j * Lc.ld, sl, w);  // = u^l_i, written above by this very lane
+#pragma unroll
+    for (int k = 0; k < E; ++k) x[k] = x[k] + w[k];
+    load_row(L.u + (size_t)ip * L.ld, sl, w);   // v_{j-1}
+    {
+        const int par = ctx.parity;
+        ctx_init<KIND, FORCE>(ctx, Lc, t);       // coarse level: its own forcing factor and coefficient sets
+        ctx.parity = par;
+    }
+    phi_apply<KIND, FORCE>(w, ctx, Lc, j, sm, t, lane, wave, G);
+#pragma unroll
+    for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
+    store_row(Lc.g + (size_t)j * Lc.ld, sl, x);
+}
+
 // --- spatial transfer kernels (bandwidth-bound, elementwise over ROW POSITIONS of the destination) ---------------
 // restriction: dst row d_idx[p] <- R(src row s_idx[p]). kind 0 copy (same T: position-wise copy); kind 1 full
 // weighting (examples/example_spatial_coarsening.py:33-55: sol[2i]*1/4 + sol[2i+1]*1/2 + sol[2i+2]*1/4).
@@ -730,7 +775,7 @@ __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, c
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 struct RunList { int n = 0; int32_t *d_start = nullptr, *d_len = nullptr; std::vector<int32_t> h_start, h_len; };
-struct PairList { int n = 0; int32_t *d_fine = nullptr, *d_coarse = nullptr, *d_iota = nullptr; };
+struct PairList { int n = 0; int32_t *d_fine = nullptr, *d_coarse = nullptr, *d_iota = nullptr, *d_prev = nullptr; };
 
 struct Level {
     bool set = false;
@@ -869,7 +914,8 @@ int setup_kernel_attrs() {
     ATTR_RELAX(K, F, false, ROLE_CHAIN) ATTR_RELAX(K, F, true, ROLE_CHAIN)                                           \
     if ((rc = allow_big_lds(residual_kernel<K, F>))) return rc;                                                      \
     if ((rc = allow_big_lds(fas_fine_kernel<K, F>))) return rc;                                                      \
-    if ((rc = allow_big_lds(fas_coarse_kernel<K, F>))) return rc;
+    if ((rc = allow_big_lds(fas_coarse_kernel<K, F>))) return rc;                                                    \
+    if ((rc = allow_big_lds(fas_fused_kernel<K, F>))) return rc;
     FOR_EACH_STEPPER(ATTR_ALL)
     if ((rc = allow_big_lds(jump_kernel))) return rc;
     g_attr_done = true;
@@ -1268,6 +1314,53 @@ int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id) {
         HIP_TRY(hipGetLastError());
     }
     LAUNCH_BY_KIND(fas_coarse_kernel, lc, pl->n, lc.dev, pl->d_coarse);
+    return 0;
+}
+
+int mgrit_hip_triples_create(mgrit_hip_engine *e, int lvl, int n, const int32_t *fine_idx, const int32_t *prev_fine_idx,
+                             const int32_t *coarse_idx, int *id_out) {
+    int rc = mgrit_hip_pairs_create(e, lvl, n, fine_idx, coarse_idx, id_out);
+    if (rc) return rc;
+    Level &lv = e->L[lvl];
+    for (int p = 0; p < n; ++p)
+        if (!prev_fine_idx || prev_fine_idx[p] < 0 || prev_fine_idx[p] >= fine_idx[p] || fine_idx[p] < 1)
+            return fail(MGRIT_HIP_EINVAL, "triple %d: previous fine C slot must be a local slot below the fine slot", p);
+    std::vector<int32_t> hp(prev_fine_idx, prev_fine_idx + n);
+    return dev_upload(lv, e->stream, hp, &lv.pairs[*id_out].d_prev);
+}
+
+int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id) {
+    PairList *pl;
+    int rc = get_pairs(e, lvl, triples_id, &pl);
+    if (rc) return rc;
+    Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
+    if (!pl->d_prev) return fail(MGRIT_HIP_EINVAL, "list %d was not created by mgrit_hip_triples_create", triples_id);
+    if (lf.transfer != MGRIT_HIP_TRANSFER_COPY || lf.dev.kind != lc.dev.kind || force_mode(lf) != force_mode(lc) ||
+        lf.dev.n != lc.dev.n)
+        return fail(MGRIT_HIP_EUNSUPPORTED, "fused FAS residual needs the copy transfer and like steppers on both levels");
+    if (pl->n == 0) return 0;
+    const int use_g = lvl > 0 ? 1 : 0;
+#define FUSED_CASE(K_, F_)                                                                                         \
+    if (lf.dev.kind == K_ && force_mode(lf) == F_)                                                                  \
+        hipLaunchKernelGGL((fas_fused_kernel<K_, F_>), dim3(pl->n), dim3(lf.dev.T), smem_bytes(lf.G), e->stream, lf.dev, \
+                           lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, use_g);
+    FOR_EACH_STEPPER(FUSED_CASE)
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mgrit_hip_copy_pairs_u_to_v(mgrit_hip_engine *e, int lvl, int pairs_id) {
+    PairList *pl;
+    int rc = get_pairs(e, lvl, pairs_id, &pl);
+    if (rc) return rc;
+    Level &lc = e->L[lvl + 1];
+    if ((rc = check_bound(lc, true))) return rc;
+    if (pl->n == 0) return 0;
+    dim3 grid(pl->n, (lc.dev.ld + 255) / 256);
+    hipLaunchKernelGGL(restrict_rows_kernel, grid, dim3(256), 0, e->stream, lc.dev.u, lc.dev.ld, lc.dev.T, pl->d_coarse, lc.dev.v,
+                       lc.dev.ld, lc.dev.T, pl->d_coarse, lc.dev.n, MGRIT_HIP_TRANSFER_COPY);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
