@@ -114,8 +114,9 @@ __device__ __forceinline__ void store_row(double *__restrict__ row, unsigned s0,
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    // bound_ctrl: lanes without a source lane read 0, so "old" is never observed; passing the source avoids a v_mov
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
@@ -151,11 +152,12 @@ struct LaneCoef {
 
 __device__ __forceinline__ LaneCoef lane_coef(const double *lp, int lane) {
     LaneCoef k;
+    // lanes that do not take part in a broadcast stage get a zero coefficient: fma(0, s, a) = a (no select needed)
     const int li = lane & 15;
-    k.f_row = lp[li + 1];
-    k.f_hi = lp[lane >= 32 ? lane - 31 : 0];
-    k.b_row = lp[16 - li];
-    k.b_lo = lp[lane < 32 ? 32 - lane : 0];
+    k.f_row = ((lane >> 4) & 1) ? lp[li + 1] : 0.0;
+    k.f_hi = lane >= 32 ? lp[lane - 31] : 0.0;
+    k.b_row = ((lane >> 4) & 1) ? 0.0 : lp[16 - li];
+    k.b_lo = lane < 32 ? lp[32 - lane] : 0.0;
     k.f_in = lp[lane];
     k.b_in = lp[LANES - 1 - lane];
     return k;
@@ -185,22 +187,18 @@ __device__ __forceinline__ double scan_fwd(double (&x)[E], const Coef &c, const 
 #pragma unroll
     for (int k = 1; k < E; ++k) x[k] = fma(c.rho, x[k - 1], x[k]);
     double a = x[E - 1];
-    const int li = lane & 15;
-    {
-        double v;
-        v = dpp_mov<DPP_ROW_SHR + 1>(a); if (li >= 1) a = fma(c.sc[0], v, a);
-        v = dpp_mov<DPP_ROW_SHR + 2>(a); if (li >= 2) a = fma(c.sc[1], v, a);
-        v = dpp_mov<DPP_ROW_SHR + 4>(a); if (li >= 4) a = fma(c.sc[2], v, a);
-        v = dpp_mov<DPP_ROW_SHR + 8>(a); if (li >= 8) a = fma(c.sc[3], v, a);
-    }
+    // row shifts deliver 0 to lanes without a source (bound_ctrl), and fma(sc, 0, a) = a: no selects in the stages
+    a = fma(c.sc[0], dpp_mov<DPP_ROW_SHR + 1>(a), a);
+    a = fma(c.sc[1], dpp_mov<DPP_ROW_SHR + 2>(a), a);
+    a = fma(c.sc[2], dpp_mov<DPP_ROW_SHR + 4>(a), a);
+    a = fma(c.sc[3], dpp_mov<DPP_ROW_SHR + 8>(a), a);
     {
         const double s15 = read_lane(a, 15), s47 = read_lane(a, 47);
-        if ((lane >> 4) & 1) a = fma(lc.f_row, lane < 32 ? s15 : s47, a);
+        a = fma(lc.f_row, lane < 32 ? s15 : s47, a);
         const double s31 = read_lane(a, 31);
-        if (lane >= 32) a = fma(lc.f_hi, s31, a);
+        a = fma(lc.f_hi, s31, a);
     }
-    double prev = dpp_mov<DPP_WAVE_SHR1>(a);
-    if (lane == 0) prev = 0.0;
+    const double prev = dpp_mov<DPP_WAVE_SHR1>(a);  // lane 0 has no source lane: 0
 #pragma unroll
     for (int k = 0; k < E; ++k) x[k] = fma(c.pw[k + 1], prev, x[k]);
     return read_lane(a, LANES - 1);
@@ -211,22 +209,17 @@ __device__ __forceinline__ double scan_bwd(double (&x)[E], const Coef &c, const 
 #pragma unroll
     for (int k = E - 2; k >= 0; --k) x[k] = fma(c.rho, x[k + 1], x[k]);
     double a = x[0];
-    const int li = lane & 15;
-    {
-        double v;
-        v = dpp_mov<DPP_ROW_SHL + 1>(a); if (li + 1 < 16) a = fma(c.sc[0], v, a);
-        v = dpp_mov<DPP_ROW_SHL + 2>(a); if (li + 2 < 16) a = fma(c.sc[1], v, a);
-        v = dpp_mov<DPP_ROW_SHL + 4>(a); if (li + 4 < 16) a = fma(c.sc[2], v, a);
-        v = dpp_mov<DPP_ROW_SHL + 8>(a); if (li + 8 < 16) a = fma(c.sc[3], v, a);
-    }
+    a = fma(c.sc[0], dpp_mov<DPP_ROW_SHL + 1>(a), a);
+    a = fma(c.sc[1], dpp_mov<DPP_ROW_SHL + 2>(a), a);
+    a = fma(c.sc[2], dpp_mov<DPP_ROW_SHL + 4>(a), a);
+    a = fma(c.sc[3], dpp_mov<DPP_ROW_SHL + 8>(a), a);
     {
         const double s16 = read_lane(a, 16), s48 = read_lane(a, 48);
-        if (((lane >> 4) & 1) == 0) a = fma(lc.b_row, lane < 32 ? s16 : s48, a);
+        a = fma(lc.b_row, lane < 32 ? s16 : s48, a);
         const double s32 = read_lane(a, 32);
-        if (lane < 32) a = fma(lc.b_lo, s32, a);
+        a = fma(lc.b_lo, s32, a);
     }
-    double next = dpp_mov<DPP_WAVE_SHL1>(a);
-    if (lane == LANES - 1) next = 0.0;
+    const double next = dpp_mov<DPP_WAVE_SHL1>(a);  // lane 63 has no source lane: 0
 #pragma unroll
     for (int k = 0; k < E; ++k) x[k] = fma(c.pw[E - k], next, x[k]);
     return read_lane(a, 0);
@@ -255,16 +248,22 @@ __device__ __forceinline__ void ctx_init(StepCtx &ctx, const LevelDev &L, int t)
     }
 }
 
+// SGPR = true: 1024-thread kernels are VGPR-bound, keep the scalars in SGPRs. SGPR = false: the single-wave chain
+// workers have VGPRs to spare and no use for SGPR spill traffic.
+template <bool SGPR>
+__device__ __forceinline__ double uni(double v) { return SGPR ? to_sgpr(v) : v; }
+
+template <bool SGPR = true>
 __device__ __forceinline__ void load_coef(Coef &c, const CSet *g) {
-    c.rho = to_sgpr(g->rho); c.ik = to_sgpr(g->ik); c.scal = to_sgpr(g->scal);
-    c.pi_full = to_sgpr(g->pi_full); c.pi_last = to_sgpr(g->pi_last);
-    c.gcp[0] = to_sgpr(g->gc);
+    c.rho = uni<SGPR>(g->rho); c.ik = uni<SGPR>(g->ik); c.scal = uni<SGPR>(g->scal);
+    c.pi_full = uni<SGPR>(g->pi_full); c.pi_last = uni<SGPR>(g->pi_last);
+    c.gcp[0] = uni<SGPR>(g->gc);
 #pragma unroll
     for (int k = 1; k < 4; ++k) c.gcp[k] = c.gcp[k - 1] * c.gcp[k - 1];
 #pragma unroll
-    for (int k = 0; k <= E; ++k) c.pw[k] = to_sgpr(g->pw[k]);
+    for (int k = 0; k <= E; ++k) c.pw[k] = uni<SGPR>(g->pw[k]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) c.sc[k] = to_sgpr(g->sc[k]);
+    for (int k = 0; k < 4; ++k) c.sc[k] = uni<SGPR>(g->sc[k]);
 }
 
 // d <- u + dt*b(x, t_i), forcing folded as fma(s_k, tau_k*dt, .)  (L.tc[k][i] = tau_k(t_i)*dt_i)
@@ -289,20 +288,18 @@ __device__ __forceinline__ void add_forcing(double (&x)[E], const StepCtx &ctx, 
 
 // Cross-group carries. Lane g (g < 16) of each row holds the value of group g; inclusive
 // Kogge-Stone scans over the row with coefficients gc^(2^s).
-__device__ __forceinline__ double cross_fwd(double a, const Coef &c, int li) {
-    double v;
-    v = dpp_mov<DPP_ROW_SHR + 1>(a); if (li >= 1) a = fma(c.gcp[0], v, a);
-    v = dpp_mov<DPP_ROW_SHR + 2>(a); if (li >= 2) a = fma(c.gcp[1], v, a);
-    v = dpp_mov<DPP_ROW_SHR + 4>(a); if (li >= 4) a = fma(c.gcp[2], v, a);
-    v = dpp_mov<DPP_ROW_SHR + 8>(a); if (li >= 8) a = fma(c.gcp[3], v, a);
+__device__ __forceinline__ double cross_fwd(double a, const Coef &c) {
+    a = fma(c.gcp[0], dpp_mov<DPP_ROW_SHR + 1>(a), a);
+    a = fma(c.gcp[1], dpp_mov<DPP_ROW_SHR + 2>(a), a);
+    a = fma(c.gcp[2], dpp_mov<DPP_ROW_SHR + 4>(a), a);
+    a = fma(c.gcp[3], dpp_mov<DPP_ROW_SHR + 8>(a), a);
     return a;
 }
-__device__ __forceinline__ double cross_bwd(double a, const Coef &c, int li) {
-    double v;
-    v = dpp_mov<DPP_ROW_SHL + 1>(a); if (li + 1 < 16) a = fma(c.gcp[0], v, a);
-    v = dpp_mov<DPP_ROW_SHL + 2>(a); if (li + 2 < 16) a = fma(c.gcp[1], v, a);
-    v = dpp_mov<DPP_ROW_SHL + 4>(a); if (li + 4 < 16) a = fma(c.gcp[2], v, a);
-    v = dpp_mov<DPP_ROW_SHL + 8>(a); if (li + 8 < 16) a = fma(c.gcp[3], v, a);
+__device__ __forceinline__ double cross_bwd(double a, const Coef &c) {
+    a = fma(c.gcp[0], dpp_mov<DPP_ROW_SHL + 1>(a), a);
+    a = fma(c.gcp[1], dpp_mov<DPP_ROW_SHL + 2>(a), a);
+    a = fma(c.gcp[2], dpp_mov<DPP_ROW_SHL + 4>(a), a);
+    a = fma(c.gcp[3], dpp_mov<DPP_ROW_SHL + 8>(a), a);
     return a;
 }
 
@@ -310,13 +307,11 @@ __device__ __forceinline__ double cross_bwd(double a, const Coef &c, int li) {
 __device__ __forceinline__ void heat_chains(const Coef &c, double A, double B, int G, int wave, int lane, double &cm,
                                             double &zin, double &zf0) {
     const int li = lane & 15;
-    const double I = cross_fwd(A, c, li);
-    double C = dpp_mov<DPP_ROW_SHR + 1>(I);
-    if (li == 0) C = 0.0;
+    const double I = cross_fwd(A, c);
+    const double C = dpp_mov<DPP_ROW_SHR + 1>(I);   // exclusive: lane 0 of the row reads 0
     const double Bt = li < G ? fma(C, li == G - 1 ? c.pi_last : c.pi_full, B) : 0.0;
-    const double J = cross_bwd(Bt, c, li);
-    double Jn = dpp_mov<DPP_ROW_SHL + 1>(J);
-    if (li == 15) Jn = 0.0;
+    const double J = cross_bwd(Bt, c);
+    const double Jn = dpp_mov<DPP_ROW_SHL + 1>(J);  // Zf_{g+1}: lane 15 of the row reads 0
     const int w = __builtin_amdgcn_readfirstlane(wave);
     cm = read_lane(C, w);
     zin = read_lane(Jn, w);
@@ -325,10 +320,8 @@ __device__ __forceinline__ void heat_chains(const Coef &c, double A, double B, i
 
 // advection: forward carries only. Returns C_wave; c_last = C_{G-1}.
 __device__ __forceinline__ double fwd_chain(const Coef &c, double A, int G, int wave, int lane, double &c_last) {
-    const int li = lane & 15;
-    const double I = cross_fwd(A, c, li);
-    double C = dpp_mov<DPP_ROW_SHR + 1>(I);
-    if (li == 0) C = 0.0;
+    const double I = cross_fwd(A, c);
+    const double C = dpp_mov<DPP_ROW_SHR + 1>(I);
     c_last = read_lane(C, __builtin_amdgcn_readfirstlane(G - 1));
     return read_lane(C, __builtin_amdgcn_readfirstlane(wave));
 }
@@ -488,20 +481,22 @@ __global__ void __launch_bounds__(64) chain_kernel(LevelDev L, int start, int le
     const int wave = blockIdx.x >> 3, lane = threadIdx.x, G = L.T >> 6, t = wave * LANES + lane, li = lane & 15;
     const unsigned sl = slot0(t);
     const int j0 = t * E;
-    double x[E], s0[E], wg[E], pt[E], gi[E];
+    double x[E], s0[E], wg[E], pt[E], gi[E], gn[E];
     Coef c;
     LaneCoef lc;
     int cur = -1;
     if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) load_row(reinterpret_cast<const double *>(L.sP), sl, s0);
     load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
+    if (USE_G) load_row(L.g + (size_t)start * L.ld, sl, gi);
     for (int i = start; i < start + len; ++i) {
         const unsigned epoch = (unsigned)(i - start + 1);
         u64 *slots = gran + (size_t)(epoch & 1) * MAX_G * 4;
-        if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);  // in flight during the local scans and the exchange
+        // g of the NEXT step: a whole step of latency hiding (HBM ~2 us vs ~2 us per step)
+        if (USE_G && i + 1 < start + len) load_row(L.g + (size_t)(i + 1) * L.ld, sl, gn);
         const int ci = __builtin_amdgcn_readfirstlane(L.cidx[i]);
         if (ci != cur) {
             const CSet *g = L.cs + ci;
-            load_coef(c, g);
+            load_coef<false>(c, g);
             lc = lane_coef(g->lp, lane);
             load_row(reinterpret_cast<const double *>(L.tabP + (size_t)ci * 8 * L.T), sl, wg);
             if (KIND == MGRIT_HIP_STEPPER_HEAT1D)
@@ -559,6 +554,9 @@ __global__ void __launch_bounds__(64) chain_kernel(LevelDev L, int start, int le
                     mine = (unsigned)g64;
                     ok = (unsigned)(g64 >> 32) == epoch;
                 }
+#ifdef MGRIT_EXPERIMENT_NO_WAIT
+                break;
+#endif
                 if (__all(ok)) break;
                 // the error word lives in host memory: look at it rarely (a peer that gave up stops publishing anyway)
                 if (++spins > CHAIN_SPIN_LIMIT ||
@@ -596,7 +594,10 @@ __global__ void __launch_bounds__(64) chain_kernel(LevelDev L, int start, int le
         }
         if (USE_G) {
 #pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = gi[k] + x[k];
+            for (int k = 0; k < E; ++k) {
+                x[k] = gi[k] + x[k];
+                gi[k] = gn[k];
+            }
         }
         store_row(L.u + (size_t)i * L.ld, sl, x);
     }

@@ -8,7 +8,7 @@ def one_level(nt, nx, forcing=True):
     t0 = np.linspace(0, 2.0 * (nt - 1) / 4096, nt)
     kw = dict(rhs_separable=[(bench.rhs_space, bench.rhs_time)]) if forcing else {}
     return Mgrit([Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=bench.init_cond, t_interval=t0, **kw)], nested_iteration=False, max_iter=1, logging_lvl=30)
-for nx in (16384, 8192, 4096, 1024):
+for nx in ((16384, 8192, 4096, 1024) if __name__ == "__main__" else ()):
     for forcing in (True, False):
         mg = one_level(4097, nx, forcing)
         ms = timeit(lambda: mg.forward_solve(0), 3)
