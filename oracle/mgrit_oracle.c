@@ -6,6 +6,7 @@
  *   src/pymgrit/heat/heat_1d.py:177-217                 (Heat1D backward-Euler step)
  *   src/pymgrit/advection/advection_1d.py:101-143       (Advection1D backward-Euler step)
  *   src/pymgrit/dahlquist/dahlquist.py:88-111           (Dahlquist steps)
+ *   src/pymgrit/heat/heat_2d.py:250-366                 (Heat2D theta-scheme step)
  *   examples/example_spatial_coarsening.py:33-82        (full-weighting / linear transfer)
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this file. The product
@@ -22,6 +23,8 @@
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: every fused multiply-add below is an explicit fma()).
  */
+#define _USE_MATH_DEFINES
+#define _GNU_SOURCE
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -323,7 +326,7 @@ double orc_sumsq_spec(const double *r, int n) {
 /* ================================================================================================
  * Steppers
  * ============================================================================================== */
-enum { ORC_DAHLQUIST = 0, ORC_HEAT1D = 1, ORC_ADVECTION1D = 2 };
+enum { ORC_DAHLQUIST = 0, ORC_HEAT1D = 1, ORC_ADVECTION1D = 2, ORC_HEAT2D = 3 };
 enum { ORC_BE = 0, ORC_FE = 1, ORC_TR = 2, ORC_MR = 3 };
 
 typedef struct {
@@ -335,6 +338,11 @@ typedef struct {
     double *tau;           /* [K][nt] */
     orc_cset *csets; int n_csets, cap_csets;
     double *w1, *w2;       /* work (padded) */
+    /* heat2d (heat_2d.py:147-366): full nx x ny grid incl. the rim; interior mi x mj, padded to Mi x Mj (multiples of 64) */
+    int nx, ny, mi, mj, Mi, Mj, has_w;
+    double fx, fy, theta;
+    double *bc, *W, *Qx, *Qy, *lx, *ly, *dinv, *X0, *X1;
+    double dinv_dt;
 } orc_stepper;
 
 static orc_cset *get_cset(orc_stepper *st, double dt) {
@@ -489,6 +497,124 @@ static void dahlquist_step(const orc_stepper *st, double t_start, double t_stop,
 }
 
 /* ================================================================================================
+ * Heat2D (heat_2d.py:250-366). The reference solves (I + theta*dt*L) u = b with SuperLU on every step; the restatement
+ * uses the fast-diagonalisation identity  U = Qx ((Qx B Qy) o D) Qy  on the interior (Qx, Qy: orthogonal symmetric
+ * sine-transform matrices; D = 1/(1 + theta*dt*(lx_k + ly_l))). Every product is a dot product accumulated with fma in
+ * ascending k from 0 -- exactly what a chain of v_mfma_f64_16x16x4 instructions computes.
+ * Layouts: X = Qx.B is stored TRANSPOSED ([j][i']), so all four products read "symmetric matrix times row-major matrix".
+ * ============================================================================================== */
+static void h2d_tables(orc_stepper *st) {
+    int mi = st->mi, mj = st->mj, Mi = st->Mi, Mj = st->Mj;
+    st->Qx = (double *)calloc((size_t)Mi * Mi, sizeof(double));
+    st->Qy = (double *)calloc((size_t)Mj * Mj, sizeof(double));
+    st->lx = (double *)calloc((size_t)Mi, sizeof(double));
+    st->ly = (double *)calloc((size_t)Mj, sizeof(double));
+    double sx = sqrt(2.0 / (mi + 1)), sy = sqrt(2.0 / (mj + 1));
+    for (int i = 0; i < mi; ++i) {
+        for (int k = 0; k < mi; ++k) {
+            long r = ((long)(i + 1) * (k + 1)) % (2L * (mi + 1));
+            st->Qx[(size_t)i * Mi + k] = sx * sin(M_PI * (double)r / (double)(mi + 1));
+        }
+        double h = sin(M_PI * (double)(i + 1) / (2.0 * (mi + 1)));
+        st->lx[i] = 4.0 * st->fx * h * h;
+    }
+    for (int i = 0; i < mj; ++i) {
+        for (int k = 0; k < mj; ++k) {
+            long r = ((long)(i + 1) * (k + 1)) % (2L * (mj + 1));
+            st->Qy[(size_t)i * Mj + k] = sy * sin(M_PI * (double)r / (double)(mj + 1));
+        }
+        double h = sin(M_PI * (double)(i + 1) / (2.0 * (mj + 1)));
+        st->ly[i] = 4.0 * st->fy * h * h;
+    }
+    st->dinv = (double *)calloc((size_t)Mi * Mj, sizeof(double));
+    st->X0 = (double *)calloc((size_t)Mi * Mj, sizeof(double));
+    st->X1 = (double *)calloc((size_t)Mi * Mj, sizeof(double));
+    st->dinv_dt = -1.0;
+}
+
+/* out[n][m] = sum_k A[m][k] * B[k][n]   (A: M x M symmetric table, ldA = M ; B: M x N ; out: N x M) */
+static void h2d_gemm_t(const double *A, int M, const double *B, int N, double *out) {
+    for (int n = 0; n < N; ++n)
+        for (int m = 0; m < M; ++m) {
+            double c = 0.0;
+            for (int k = 0; k < M; ++k) c = fma(A[(size_t)m * M + k], B[(size_t)k * N + n], c);
+            out[(size_t)n * M + m] = c;
+        }
+}
+
+static double h2d_lap(const orc_stepper *st, const double *u, int gi, int gj) {
+    int ny = st->ny;
+    double acc = (2.0 * (st->fx + st->fy)) * u[(size_t)gi * ny + gj];
+    acc = fma(-st->fx, u[(size_t)(gi - 1) * ny + gj], acc);
+    acc = fma(-st->fx, u[(size_t)(gi + 1) * ny + gj], acc);
+    acc = fma(-st->fy, u[(size_t)gi * ny + gj - 1], acc);
+    acc = fma(-st->fy, u[(size_t)gi * ny + gj + 1], acc);
+    return acc;
+}
+
+static void heat2d_step(orc_stepper *st, int nt, int i_stop, double t_start, double t_stop, const double *u, double *out) {
+    int nx = st->nx, ny = st->ny, mi = st->mi, mj = st->mj, Mi = st->Mi, Mj = st->Mj;
+    double dt = t_stop - t_start, th = st->theta;
+    if (th == 0.0) { /* FE: heat_2d.py:346-356; boundary = BC + old boundary (quirk of the reference) */
+        for (int gi = 0; gi < nx; ++gi)
+            for (int gj = 0; gj < ny; ++gj) {
+                size_t p = (size_t)gi * ny + gj;
+                if (gi == 0 || gj == 0 || gi == nx - 1 || gj == ny - 1) { out[p] = st->bc[p] + u[p]; continue; }
+                double v = fma(-dt, h2d_lap(st, u, gi, gj), u[p]);
+                for (int k = 0; k < st->K; ++k)
+                    v = fma(st->s[((size_t)k * mi + (gi - 1)) * mj + (gj - 1)], dt * st->tau[(size_t)k * nt + i_stop - 1], v);
+                out[p] = v;
+            }
+        return;
+    }
+    double thdt = th * dt, thdt1 = (1.0 - th) * dt;
+    if (st->dinv_dt != dt) {
+        for (int a = 0; a < mi; ++a)
+            for (int b = 0; b < mj; ++b) st->dinv[(size_t)a * Mj + b] = 1.0 / (1.0 + thdt * (st->lx[a] + st->ly[b]));
+        st->dinv_dt = dt;
+    }
+    double *B = st->X0, *X = st->X1;
+    memset(B, 0, sizeof(double) * (size_t)Mi * Mj);
+    for (int a = 0; a < mi; ++a)
+        for (int b = 0; b < mj; ++b) {
+            size_t p = (size_t)(a + 1) * ny + (b + 1);
+            double v;
+            if (th == 1.0) {
+                v = u[p];
+                for (int k = 0; k < st->K; ++k) v = fma(st->s[((size_t)k * mi + a) * mj + b], st->tau[(size_t)k * nt + i_stop] * dt, v);
+            } else {
+                v = fma(-thdt, h2d_lap(st, u, a + 1, b + 1), u[p]);
+                for (int k = 0; k < st->K; ++k)
+                    v = fma(st->s[((size_t)k * mi + a) * mj + b],
+                            thdt * st->tau[(size_t)k * nt + i_stop] + thdt1 * st->tau[(size_t)k * nt + i_stop - 1], v);
+            }
+            if (st->has_w) v = fma(thdt, st->W[(size_t)a * mj + b], v);
+            B[(size_t)a * Mj + b] = v;
+        }
+    h2d_gemm_t(st->Qx, Mi, B, Mj, X);                                   /* X[j][i'] = (Qx B)^T           */
+    h2d_gemm_t(st->Qy, Mj, X, Mi, B);                                   /* B[i'][j'] = (Qx B) Qy         */
+    for (size_t q = 0; q < (size_t)Mi * Mj; ++q) B[q] = B[q] * st->dinv[q];
+    h2d_gemm_t(st->Qx, Mi, B, Mj, X);                                   /* X[j'][i] = (Qx B)^T           */
+    h2d_gemm_t(st->Qy, Mj, X, Mi, B);                                   /* B[i][j]  = U                  */
+    for (int gi = 0; gi < nx; ++gi)
+        for (int gj = 0; gj < ny; ++gj) {
+            size_t p = (size_t)gi * ny + gj;
+            out[p] = (gi == 0 || gj == 0 || gi == nx - 1 || gj == ny - 1) ? st->bc[p] : B[(size_t)(gi - 1) * Mj + (gj - 1)];
+        }
+}
+
+/* sum of squares, 2-D reduction tree of the spec: per grid row an fma chain over its ny values, then the rows in order */
+double orc_sumsq_rows(const double *r, int nx, int ny) {
+    double tot = 0.0;
+    for (int i = 0; i < nx; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < ny; ++j) acc = fma(r[(size_t)i * ny + j], r[(size_t)i * ny + j], acc);
+        tot = tot + acc;
+    }
+    return tot;
+}
+
+/* ================================================================================================
  * Problem / solver state (single rank: the reference is bit-identical for every P)
  * ============================================================================================== */
 typedef struct {
@@ -525,6 +651,7 @@ orc_problem *orc_problem_create(int n_levels) {
 static void free_stepper(orc_stepper *st) {
     for (int i = 0; i < st->n_csets; ++i) free(st->csets[i].tab);
     free(st->csets); free(st->s); free(st->tau); free(st->w1); free(st->w2);
+    free(st->bc); free(st->W); free(st->Qx); free(st->Qy); free(st->lx); free(st->ly); free(st->dinv); free(st->X0); free(st->X1);
 }
 
 void orc_problem_destroy(orc_problem *p) {
@@ -578,6 +705,40 @@ void orc_problem_set_level_dahlquist(orc_problem *p, int lvl, int nt, const doub
     st->kind = ORC_DAHLQUIST; st->fac = lambda; st->method = method;
 }
 
+/* bc: nx*ny boundary values (zero inside); S: [K][mi][mj] forcing space factors on the interior; tau: [K][nt] */
+void orc_problem_set_level_heat2d(orc_problem *p, int lvl, int nt, const double *t, int nx, int ny, double fx, double fy,
+                                  double theta, const double *bc, int K, const double *S, const double *tau,
+                                  const double *u0) {
+    level_common(p, lvl, nt, t, nx * ny, u0);
+    orc_stepper *st = &p->L[lvl].st;
+    st->kind = ORC_HEAT2D; st->variant = 1; st->K = K;
+    st->nx = nx; st->ny = ny; st->mi = nx - 2; st->mj = ny - 2;
+    st->Mi = ((st->mi + 63) / 64) * 64; st->Mj = ((st->mj + 63) / 64) * 64;
+    st->fx = fx; st->fy = fy; st->theta = theta;
+    st->bc = (double *)malloc(sizeof(double) * (size_t)nx * ny);
+    memcpy(st->bc, bc, sizeof(double) * (size_t)nx * ny);
+    st->W = (double *)calloc((size_t)st->mi * st->mj, sizeof(double));
+    st->has_w = 0;
+    for (int a = 0; a < st->mi; ++a)
+        for (int b = 0; b < st->mj; ++b) {
+            double w = 0.0;
+            if (a == 0) w += fx * bc[(size_t)0 * ny + b + 1];
+            if (a == st->mi - 1) w += fx * bc[(size_t)(nx - 1) * ny + b + 1];
+            if (b == 0) w += fy * bc[(size_t)(a + 1) * ny + 0];
+            if (b == st->mj - 1) w += fy * bc[(size_t)(a + 1) * ny + ny - 1];
+            st->W[(size_t)a * st->mj + b] = w;
+            if (w != 0.0) st->has_w = 1;
+        }
+    if (K > 0) {
+        size_t ns = (size_t)K * st->mi * st->mj;
+        st->s = (double *)malloc(sizeof(double) * ns);
+        st->tau = (double *)malloc(sizeof(double) * (size_t)K * nt);
+        memcpy(st->s, S, sizeof(double) * ns);
+        memcpy(st->tau, tau, sizeof(double) * (size_t)K * nt);
+    }
+    h2d_tables(st);
+}
+
 void orc_problem_set_transfer(orc_problem *p, int lvl, int kind) { p->L[lvl].transfer = kind; }
 
 void orc_problem_set_options(orc_problem *p, double weight_c, const int32_t *cf_iter, int cycle_type, int nested,
@@ -601,6 +762,7 @@ static void phi(orc_problem *p, int lvl, int i, const double *u_in, double *out)
         if (L->st.variant) advection1d_step_spec(&L->st, dt, u_in, out);
         else advection1d_step_natural(&L->st, dt, u_in, out);
         break;
+    case ORC_HEAT2D: heat2d_step(&L->st, L->nt, i, t_start, t_stop, u_in, out); break;
     default: dahlquist_step(&L->st, t_start, t_stop, u_in, out);
     }
 }
@@ -771,6 +933,7 @@ void orc_nested_iteration(orc_problem *p) {
 }
 
 static double vec_norm(const orc_problem *p, const double *r, int n) {
+    if (p->norm_spec && p->L[0].st.kind == ORC_HEAT2D) return sqrt(orc_sumsq_rows(r, p->L[0].st.nx, p->L[0].st.ny));
     if (p->norm_spec) return sqrt(orc_sumsq_spec(r, n));
     double s = 0.0;
     for (int j = 0; j < n; ++j) s += r[j] * r[j];

@@ -44,6 +44,10 @@ def lib():
                                                    dp, dp, dp, C.c_int]
         L.orc_problem_set_level_advection1d.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, C.c_double, dp,
                                                         C.c_int]
+        L.orc_problem_set_level_heat2d.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                                   C.c_double, dp, C.c_int, dp, dp, dp]
+        L.orc_sumsq_rows.restype = C.c_double
+        L.orc_sumsq_rows.argtypes = [dp, C.c_int, C.c_int]
         L.orc_problem_set_level_dahlquist.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_double, C.c_int,
                                                       C.c_double]
         L.orc_problem_set_transfer.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -140,6 +144,8 @@ class OracleProblem:
        {"kind": "heat1d", "t": array, "n": int, "fac": a/dx^2, "s": [K][n] or None, "tau": [K][nt] or None, "u0": [n]}
        {"kind": "advection1d", "t": array, "n": int, "fac": c/dx, "u0": [n]}
        {"kind": "dahlquist", "t": array, "lambda": float, "method": "BE", "u0": float}
+       {"kind": "heat2d", "t": array, "nx", "ny", "fx", "fy", "theta", "bc": [nx][ny], "S": [K][nx-2][ny-2], "tau": [K][nt],
+        "u0": [nx][ny]}
     """
 
     def __init__(self, levels, transfer=None, variant=1, weight_c=1.0, cf_iter=1, cycle_type='V', nested_iteration=True,
@@ -165,6 +171,16 @@ class OracleProblem:
                 u0 = _f64(s["u0"])
                 L.orc_problem_set_level_advection1d(self.h, lvl, t.size, _dp(t), n, float(s["fac"]), _dp(u0),
                                                     int(variant))
+            elif s["kind"] == "heat2d":
+                nx, ny = int(s["nx"]), int(s["ny"])
+                n = nx * ny
+                Sx = np.asarray(s.get("S", np.zeros((0, nx - 2, ny - 2))), dtype=np.float64).reshape(-1, nx - 2, ny - 2)
+                K = Sx.shape[0]
+                sa = _f64(Sx) if K else np.zeros(1)
+                ta = _f64(np.asarray(s["tau"]).reshape(K, t.size)) if K else np.zeros(1)
+                bc, u0 = _f64(s["bc"]), _f64(np.asarray(s["u0"]).ravel())
+                L.orc_problem_set_level_heat2d(self.h, lvl, t.size, _dp(t), nx, ny, float(s["fx"]), float(s["fy"]),
+                                               float(s["theta"]), _dp(bc), K, _dp(sa), _dp(ta), _dp(u0))
             elif s["kind"] == "dahlquist":
                 n = 1
                 L.orc_problem_set_level_dahlquist(self.h, lvl, t.size, _dp(t), float(s["lambda"]),

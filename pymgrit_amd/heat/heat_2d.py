@@ -1,0 +1,227 @@
+"""2-D heat equation  u_t - a(u_xx + u_yy) = b(x,y,t)  on a rectangle with Dirichlet BCs: Vector + Application.
+
+Drop-in for the reference's ``pymgrit.heat.heat_2d`` (reference src/pymgrit/heat/heat_2d.py:20-366): same constructor,
+the state is the full ``nx x ny`` grid including the boundary values, theta-scheme time stepping (BE, CN, FE), the
+reference's boundary-assignment order at the corners (heat_2d.py:244-247,316-319) and its FE quirk (boundary values are
+added to the BC, heat_2d.py:346-356).
+
+The reference factorises a 5-point matrix with SuperLU on every step (5 s per step at 512^2). Here the interior solve
+uses the fast-diagonalisation identity  (I + theta*dt*(Lx (x) I + I (x) Ly))^-1 B = Qx ((Qx B Qy) o D) Qy  with the
+sine-transform matrices Qx, Qy: four dense FP64 GEMMs per step, which run on the MFMA units on MI355X
+(``device_stepper()``); ``step`` below is the same algorithm in numpy for the plugin / inspection path.
+The device path needs the forcing in declarative form ``b(x,y,t) = sum_k S_k(x,y)*tau_k(t)``: pass
+``rhs_separable=[(S_fn(x,y), tau_fn(t)), ...]``; a plain ``rhs`` is accepted when it is (numerically) rank <= 2 in time
+of the form S0(x,y) + S1(x,y)*t or rank one.
+"""
+from typing import Callable, Union
+
+import numpy as np
+
+from pymgrit_amd.core.application import Application
+from pymgrit_amd.core.vector import Vector
+
+
+class VectorHeat2D(Vector):
+    def __init__(self, nx, ny):
+        super().__init__()
+        self.nx, self.ny = nx, ny
+        self.values = np.zeros((self.nx, self.ny))
+
+    def _new(self, values):
+        out = VectorHeat2D(self.nx, self.ny)
+        out.set_values(values)
+        return out
+
+    def __add__(self, other):
+        return self._new(self.get_values() + other.get_values())
+
+    def __sub__(self, other):
+        return self._new(self.get_values() - other.get_values())
+
+    def __mul__(self, other):
+        return self._new(self.get_values() * other)
+
+    def norm(self):
+        return np.linalg.norm(self.values)
+
+    def clone(self):
+        return self._new(self.get_values())
+
+    def clone_zero(self):
+        return VectorHeat2D(self.nx, self.ny)
+
+    def clone_rand(self):
+        return self._new(np.random.rand(self.nx, self.ny))
+
+    def set_values(self, values):
+        self.values = values
+
+    def get_values(self):
+        return self.values
+
+    def pack(self):
+        return self.values
+
+    def unpack(self, values):
+        self.values = values
+
+
+def _as_bc(value, name):
+    if isinstance(value, (float, int)):
+        return lambda s, _v=value: _v
+    if callable(value):
+        return value
+    raise Exception("Choose float, int or function for boundary condition " + name)
+
+
+def sine_matrix(m):
+    """Orthogonal symmetric DST-I matrix Q[i,k] = sqrt(2/(m+1)) sin(pi (i+1)(k+1)/(m+1)); tridiag(-1,2,-1) = Q L Q."""
+    idx = np.arange(1, m + 1)
+    r = np.outer(idx, idx) % (2 * (m + 1))
+    return np.sqrt(2.0 / (m + 1)) * np.sin(np.pi * r / (m + 1))
+
+
+def sine_eigenvalues(m, f):
+    k = np.arange(1, m + 1)
+    return 4.0 * f * np.sin(np.pi * k / (2.0 * (m + 1))) ** 2
+
+
+class Heat2D(Application):
+    def __init__(self, x_start: float, x_end: float, y_start: float, y_end: float, nx: int, ny: int, a: float,
+                 rhs: Callable = lambda x, y, t: 0 * x * y, init_cond: Callable = lambda x, y: x * y * 0,
+                 method: str = 'BE', bc_left: Union[int, float, Callable] = 0, bc_right: Union[int, float, Callable] = 0,
+                 bc_bottom: Union[int, float, Callable] = 0, bc_top: Union[int, float, Callable] = 0,
+                 rhs_separable=None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.x_start, self.x_end, self.y_start, self.y_end = x_start, x_end, y_start, y_end
+        self.x = np.linspace(x_start, x_end, nx)
+        self.y = np.linspace(y_start, y_end, ny)
+        self.x_2d = self.x[:, np.newaxis]
+        self.y_2d = self.y[np.newaxis, :]
+        self.nx, self.ny = nx, ny
+        self.dx = self.x[1] - self.x[0]
+        self.dy = self.y[1] - self.y[0]
+        self.a = a
+        self._separable = list(rhs_separable) if rhs_separable is not None else None
+        if self._separable is not None:
+            terms = self._separable
+
+            def rhs(x, y, t, _terms=terms):
+                total = _terms[0][0](x, y) * _terms[0][1](t)
+                for s_fn, tau_fn in _terms[1:]:
+                    total = total + s_fn(x, y) * tau_fn(t)
+                return total
+        self.rhs = rhs
+        thetas = {'BE': 1, 'FE': 0, 'CN': 0.5}
+        if method not in thetas:
+            raise Exception("Unknown method. Choose BE (Backward Euler), FE (Forward Euler) or CN (Crank-Nicolson")
+        self.method, self.theta = method, thetas[method]
+        self.bc_left, self.bc_right = _as_bc(bc_left, 'bc_left'), _as_bc(bc_right, 'bc_right')
+        self.bc_bottom, self.bc_top = _as_bc(bc_bottom, 'bc_bottom'), _as_bc(bc_top, 'bc_top')
+        self.fx, self.fy = self.a / self.dx ** 2, self.a / self.dy ** 2
+        self.vector_template = VectorHeat2D(self.nx, self.ny)
+        self.init_cond = init_cond
+        self.vector_t_start = VectorHeat2D(self.nx, self.ny)
+        init = np.array(self.init_cond(self.x_2d, self.y_2d), dtype=np.float64) * np.ones((nx, ny))
+        self._set_bc(init)
+        self.vector_t_start.set_values(init)
+        self._fd = None
+        self._device_desc = None
+
+    # ---- boundary handling (assignment order of the reference: left, right, bottom, top) -----------------------
+    def _set_bc(self, arr):
+        arr[:, 0] = self.bc_left(self.x)
+        arr[:, -1] = self.bc_right(self.x)
+        arr[-1, :] = self.bc_bottom(self.y)
+        arr[0, :] = self.bc_top(self.y)
+
+    def boundary_values(self):
+        """nx x ny array: BC values on the rim, zero inside."""
+        bc = np.zeros((self.nx, self.ny))
+        self._set_bc(bc)
+        return bc
+
+    def boundary_coupling(self):
+        """W (interior, (nx-2) x (ny-2)): fx*(BC above + BC below) + fy*(BC left + BC right) for the interior points next
+        to the rim; the implicit solve sees theta*dt*W on its right-hand side."""
+        bc = self.boundary_values()
+        w = np.zeros((self.nx - 2, self.ny - 2))
+        w[0, :] += self.fx * bc[0, 1:-1]
+        w[-1, :] += self.fx * bc[-1, 1:-1]
+        w[:, 0] += self.fy * bc[1:-1, 0]
+        w[:, -1] += self.fy * bc[1:-1, -1]
+        return w
+
+    def _laplace_apply(self, u):
+        """L u on the full grid with zero boundary rows (heat_2d.py:250-287)."""
+        out = np.zeros_like(u)
+        c = u[1:-1, 1:-1]
+        out[1:-1, 1:-1] = (2 * (self.fx + self.fy)) * c - self.fx * (u[:-2, 1:-1] + u[2:, 1:-1]) \
+            - self.fy * (u[1:-1, :-2] + u[1:-1, 2:])
+        return out
+
+    def _fast_diag(self):
+        if self._fd is None:
+            mi, mj = self.nx - 2, self.ny - 2
+            self._fd = (sine_matrix(mi), sine_matrix(mj), sine_eigenvalues(mi, self.fx)[:, None] +
+                        sine_eigenvalues(mj, self.fy)[None, :])
+        return self._fd
+
+    def step(self, u_start: VectorHeat2D, t_start: float, t_stop: float) -> VectorHeat2D:
+        dt = t_stop - t_start
+        old = np.asarray(u_start.get_values(), dtype=np.float64)
+        xi, yi = self.x_2d[1:-1], self.y_2d[:, 1:-1]
+        if self.theta == 0:
+            new = self.boundary_values()
+            new += old - dt * self._laplace_apply(old)          # boundary entries: BC + old (reference quirk)
+            new[1:-1, 1:-1] += dt * self.rhs(x=xi, y=yi, t=t_start)
+        else:
+            if self.theta == 1:
+                b = old[1:-1, 1:-1] + dt * self.rhs(x=xi, y=yi, t=t_stop)
+            else:
+                b = (old - self.theta * dt * self._laplace_apply(old))[1:-1, 1:-1] \
+                    + self.theta * dt * self.rhs(x=xi, y=yi, t=t_stop) + (1 - self.theta) * dt * self.rhs(x=xi, y=yi, t=t_start)
+            b = b + self.theta * dt * self.boundary_coupling()
+            qx, qy, lam = self._fast_diag()
+            inner = qx @ (((qx @ b) @ qy) / (1.0 + self.theta * dt * lam)) @ qy
+            new = self.boundary_values()
+            new[1:-1, 1:-1] = inner
+        ret = VectorHeat2D(self.nx, self.ny)
+        ret.set_values(new)
+        return ret
+
+    # ---- device description -------------------------------------------------------------------------------------
+    def _detect_separable(self):
+        """rhs(x,y,t) = S0(x,y) + S1(x,y)*t (covers constant-in-time and linear-in-time forcings) or zero."""
+        xi, yi = self.x_2d[1:-1], self.y_2d[:, 1:-1]
+        shape = (self.nx - 2, self.ny - 2)
+        ts = [float(self.t[0]), float(self.t[len(self.t) // 2]), float(self.t[-1])]
+        f = [np.asarray(self.rhs(x=xi, y=yi, t=tt), dtype=np.float64) * np.ones(shape) for tt in ts]
+        scale = max(np.max(np.abs(v)) for v in f)
+        if scale == 0.0:
+            return []
+        s1 = (f[2] - f[0]) / (ts[2] - ts[0])
+        s0 = f[0] - s1 * ts[0]
+        if np.max(np.abs(s0 + s1 * ts[1] - f[1])) > 1e-12 * scale:
+            raise Exception('Heat2D: rhs(x,y,t) is not of the form S0(x,y) + S1(x,y)*t; pass rhs_separable=[(S_fn, tau_fn), '
+                            '...] to run on the MI355X engine')
+        terms = [(s0, lambda t: 1.0)]
+        if np.max(np.abs(s1)) > 0:
+            terms.append((s1, lambda t: t))
+        return terms
+
+    def device_stepper(self):
+        if self._device_desc is None:
+            xi, yi = self.x_2d[1:-1], self.y_2d[:, 1:-1]
+            shape = (self.nx - 2, self.ny - 2)
+            if self._separable is not None:
+                terms = [(np.asarray(s_fn(xi, yi), dtype=np.float64) * np.ones(shape), tau_fn)
+                         for s_fn, tau_fn in self._separable]
+            else:
+                terms = self._detect_separable()
+            self._device_desc = {
+                "kind": "heat2d", "n": self.nx * self.ny, "nx": self.nx, "ny": self.ny, "fx": self.fx, "fy": self.fy,
+                "theta": float(self.theta), "bc": self.boundary_values(),
+                "forcing_space": np.array([s for s, _ in terms], dtype=np.float64).reshape(len(terms), *shape),
+                "forcing_time": [tau for _, tau in terms]}
+        return self._device_desc

@@ -296,6 +296,68 @@ def make_solve(big=True):
     return out
 
 
+# --------------------------------------------------------------------------------------------------
+# Heat2D fixtures (heat_2d.py): Phi known answers for BE/CN/FE with and without boundary values, small MGRIT solves
+# --------------------------------------------------------------------------------------------------
+H2D_X_END, H2D_Y_END, H2D_A = 0.75, 1.5, 3.5
+
+
+def h2d_rhs(x, y, t):   # forcing of examples/example_heat_2d.py:36-46
+    return 5 * x * (H2D_X_END - x) * y * (H2D_Y_END - y) + 10 * H2D_A * t * (y * (H2D_Y_END - y) + x * (H2D_X_END - x))
+
+
+def h2d_input(x, y, k):
+    return np.sin(3 * x + 0.3 * k) * np.cos(2 * y) + 0.1 * x * y
+
+
+H2D_BC = dict(bc_left=1.5, bc_right=lambda s: 2 + s, bc_top=-1.0, bc_bottom=lambda s: s * s)
+
+
+def make_heat2d():
+    from pymgrit.heat.heat_2d import Heat2D, VectorHeat2D
+    meta, arrays = {"phi": [], "solve": {}}, {}
+    k = 0
+    for method in ("BE", "CN", "FE"):
+        for with_bc in (False, True):
+            for nx, ny in ((9, 12), (20, 17)):
+                kw = H2D_BC if with_bc else {}
+                app = Heat2D(x_start=0, x_end=H2D_X_END, y_start=0, y_end=H2D_Y_END, nx=nx, ny=ny, a=H2D_A, rhs=h2d_rhs,
+                             method=method, t_start=0, t_stop=1, nt=33, **kw)
+                u = VectorHeat2D(nx, ny)
+                u.set_values(h2d_input(app.x_2d, app.y_2d, k) * np.ones((nx, ny)))
+                out = app.step(u, app.t[3], app.t[4]).get_values()
+                key = f"h2d_phi_{k}"
+                arrays[key] = np.asarray(out).reshape(nx, ny)
+                meta["phi"].append({"key": key, "method": method, "bc": with_bc, "nx": nx, "ny": ny, "k": k, "i_stop": 4})
+                k += 1
+
+    def levels(nx, ny, nts, method="BE", with_bc=False, a=H2D_A):
+        kw = H2D_BC if with_bc else {}
+        t0 = np.linspace(0, 1, nts[0])
+        ts = [t0]
+        for n in nts[1:]:
+            ts.append(ts[-1][::(len(ts[-1]) - 1) // (n - 1)])
+        return [Heat2D(x_start=0, x_end=H2D_X_END, y_start=0, y_end=H2D_Y_END, nx=nx, ny=ny, a=a, rhs=h2d_rhs,
+                       method=method, t_interval=t, **kw) for t in ts]
+
+    def solve(name, prob, **kw):
+        m = Mgrit(problem=prob, logging_lvl=QUIET, **kw)
+        info = m.solve()
+        meta["solve"][name] = {"conv": [float(c) for c in info["conv"]]}
+        arrays["h2d_solve_" + name] = np.asarray(m.u[0][len(prob[0].t) - 1].get_values())
+
+    # examples/example_heat_2d.py shrunk (55x125x33 there); without nested iteration so that a history exists
+    solve("example_small", levels(17, 21, [33, 17]), cycle_type='V', nested_iteration=False, tol=1e-9, max_iter=8)
+    solve("be_3lvl_F_bc", levels(12, 10, [65, 17, 5], with_bc=True), cycle_type='F', tol=1e-9, max_iter=8)
+    solve("cn_2lvl", levels(12, 10, [65, 33], method="CN", a=0.1), tol=1e-9, max_iter=8, nested_iteration=False)
+    solve("be_weight_bc", levels(10, 14, [33, 9], with_bc=True), weight_c=1.2, tol=1e-9, max_iter=8, nested_iteration=False)
+    solve("fe_2lvl", levels(8, 8, [257, 65], method="FE", a=0.05), tol=1e-9, max_iter=6, nested_iteration=False)
+    with open(os.path.join(HERE, "heat2d.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    np.savez_compressed(os.path.join(HERE, "heat2d.npz"), **arrays)
+    print("wrote heat2d fixtures", {k: v["conv"][:2] for k, v in meta["solve"].items()})
+
+
 def ref_results():
     res = {}
     d = os.path.join(REF, "tests", "mpi", "results")
@@ -308,6 +370,9 @@ def ref_results():
 
 def main():
     os.makedirs(HERE, exist_ok=True)
+    if "--only-heat2d" in sys.argv:
+        make_heat2d()
+        return
     big = "--small" not in sys.argv
     lay = make_layout()
     with open(os.path.join(HERE, "layout.json"), "w") as f:
@@ -319,6 +384,7 @@ def main():
     sol = make_solve(big)
     with open(os.path.join(HERE, "solve.json"), "w") as f:
         json.dump(sol, f, separators=(",", ":"))
+    make_heat2d()
     res, kats = ref_results()
     with open(os.path.join(HERE, "ref_results.json"), "w") as f:
         json.dump({"tests_mpi_results": res}, f, indent=1)

@@ -36,3 +36,26 @@ class OracleApp(Application):
         out = self.vec(self.n)
         out.set_values(self._problem().phi(0, i, u_start.get_values()))
         return out
+
+
+class OracleApp2D(Application):
+    """Heat2D level spec -> plugin Application whose step is the oracle's fast-diagonalisation Phi"""
+
+    def __init__(self, orc, spec):
+        from pymgrit_amd.heat.heat_2d import VectorHeat2D
+        super().__init__(t_interval=np.asarray(spec["t"], dtype=np.float64))
+        self.spec, self.nx, self.ny = spec, int(spec["nx"]), int(spec["ny"])
+        self.vec = VectorHeat2D
+        self.vector_template = VectorHeat2D(self.nx, self.ny)
+        self.vector_t_start = VectorHeat2D(self.nx, self.ny)
+        self.vector_t_start.set_values(np.asarray(spec["u0"], dtype=np.float64).reshape(self.nx, self.ny).copy())
+        self._orc, self._p = orc, None
+
+    def step(self, u_start, t_start, t_stop):
+        if self._p is None:
+            self._p = self._orc.OracleProblem([self.spec])
+        i = int(np.searchsorted(self.t, t_stop))
+        assert self.t[i] == t_stop and self.t[i - 1] == t_start
+        out = self.vec(self.nx, self.ny)
+        out.set_values(self._p.phi(0, i, np.asarray(u_start.get_values()).ravel()).reshape(self.nx, self.ny))
+        return out
