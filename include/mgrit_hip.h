@@ -26,7 +26,7 @@ extern "C" {
 typedef struct mgrit_hip_engine mgrit_hip_engine;
 
 enum { MGRIT_HIP_OK = 0, MGRIT_HIP_EINVAL = -1, MGRIT_HIP_EHIP = -2, MGRIT_HIP_ENODEV = -3, MGRIT_HIP_EUNSUPPORTED = -4 };
-enum { MGRIT_HIP_STEPPER_HEAT1D = 1, MGRIT_HIP_STEPPER_ADVECTION1D = 2 };
+enum { MGRIT_HIP_STEPPER_HEAT1D = 1, MGRIT_HIP_STEPPER_ADVECTION1D = 2, MGRIT_HIP_STEPPER_HEAT2D = 3 };
 enum { MGRIT_HIP_TRANSFER_COPY = 0, MGRIT_HIP_TRANSFER_HEAT1D = 1 };
 enum { MGRIT_HIP_RELAX_F = 0, MGRIT_HIP_RELAX_C = 1, MGRIT_HIP_RELAX_CHAIN = 2 };
 
@@ -54,6 +54,13 @@ int mgrit_hip_level_heat1d(mgrit_hip_engine *e, int lvl, int n_pts_local, const 
 /* Replaces Advection1D.compute_matrix/step (advection/advection_1d.py:101-143): (I + dt*fac*(I - S_periodic)) x = u */
 int mgrit_hip_level_advection1d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int n, int ld,
                                 double fac);
+/* Replaces Heat2D.__init__/compute_matrix/compute_rhs/step (heat/heat_2d.py:147-366): theta-scheme (theta = 1 BE, 0.5 CN,
+ * 0 FE) on the full nx x ny grid (row-major, x slow); rows of the slabs hold the grid in natural order, ld >= nx*ny a
+ * multiple of 16. bc: nx*ny boundary values (zero inside, corner order of heat_2d.py:244-247); forcing on the interior
+ * b(x,y,t_i) = sum_k S[k][(nx-2)*(ny-2)] * tau[k][i]. The implicit solve is a fast diagonalisation: four batched FP64 GEMMs
+ * on the matrix cores per step. */
+int mgrit_hip_level_heat2d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int nx, int ny, int ld,
+                           double fx, double fy, double theta, const double *bc, int K, const double *S, const double *tau);
 /* Device slabs u, v, g of Mgrit.create_u_v_g (mgrit.py:840-858); v and g may be NULL on level 0. */
 int mgrit_hip_level_bind(mgrit_hip_engine *e, int lvl, double *u, double *v, double *g);
 /* Spatial transfer between lvl and lvl+1: GridTransferCopy (core/grid_transfer_copy.py:23-47) or the full-weighting

@@ -72,8 +72,11 @@ class HipBackend:
         check(self.lib.mgrit_hip_create(C.byref(self.h), mg.lvl_max, C.c_void_p(self.stream.cuda_stream)))
         self.desc = [p.device_stepper() for p in mg.problem]
         self.n = [int(d["n"]) for d in self.desc]
-        self.ld = [hip_lib.row_stride(n) for n in self.n]
-        self.perm = [torch.from_numpy(hip_lib.row_permutation(n)).to(self.device) for n in self.n]
+        # 1-D steppers: lane-blocked rows; Heat2D: the nx x ny grid in natural row-major order
+        self.ld = [((n + 15) // 16) * 16 if d["kind"] == "heat2d" else hip_lib.row_stride(n)
+                   for n, d in zip(self.n, self.desc)]
+        self.perm = [torch.arange(n, device=self.device) if d["kind"] == "heat2d" else
+                     torch.from_numpy(hip_lib.row_permutation(n)).to(self.device) for n, d in zip(self.n, self.desc)]
         self.U, self.V, self.G = [], [], []
         self._runs, self._pairs = {}, {}
         self._described = [False] * mg.lvl_max
@@ -105,6 +108,17 @@ class HipBackend:
                                                   _ptr(s), _ptr(tau)))
         elif d["kind"] == "advection1d":
             check(self.lib.mgrit_hip_level_advection1d(self.h, lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"])))
+        elif d["kind"] == "heat2d":
+            nx, ny = int(d["nx"]), int(d["ny"])
+            S = np.ascontiguousarray(np.asarray(d["forcing_space"], dtype=np.float64).reshape(-1, (nx - 2) * (ny - 2)))
+            K = S.shape[0]
+            tau = np.zeros((K, n_pts))
+            for k in range(K):
+                tau[k] = [d["forcing_time"][k](tt) for tt in t_local]
+            tau = np.ascontiguousarray(tau)
+            bc = np.ascontiguousarray(np.asarray(d["bc"], dtype=np.float64).ravel())
+            check(self.lib.mgrit_hip_level_heat2d(self.h, lvl, n_pts, _ptr(t_local), nx, ny, ld, float(d["fx"]), float(d["fy"]),
+                                                  float(d["theta"]), _ptr(bc), K, _ptr(S), _ptr(tau)))
         else:
             raise MgritHipError(f"unknown device stepper kind {d['kind']!r}")
         u = torch.zeros((n_pts, ld), dtype=torch.float64, device=self.device)
@@ -255,7 +269,8 @@ class HipBackend:
         da, db = self.desc[lvl], self.desc[lvl + 1]
         same_forcing = len(da.get("forcing_time", [])) == len(db.get("forcing_time", []))
         return (hasattr(tr, "device_transfer") and int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and
-                da["kind"] == db["kind"] and self.n[lvl] == self.n[lvl + 1] and same_forcing)
+                da["kind"] == db["kind"] and da["kind"] in ("heat1d", "advection1d") and
+                self.n[lvl] == self.n[lvl + 1] and same_forcing)
 
     def fas_fused(self, lvl, triples):
         if not triples:

@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -772,14 +773,231 @@ __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, c
     f[pos] = mode == 0 ? val : f[pos] + val;
 }
 
+// ===============================================================================================================
+// Heat2D (heat/heat_2d.py:250-366): theta-scheme on the full nx x ny grid. Interior solve by fast diagonalisation
+//   U = Qx ((Qx B Qy) o D) Qy,  Qx, Qy orthogonal symmetric sine-transform matrices,
+// i.e. four dense FP64 GEMMs per step, batched over all time points a sweep updates at once. The GEMMs run on the matrix
+// cores with v_mfma_f64_16x16x4_f64, which accumulates its four k-products as a sequential fma chain (verified on gfx950):
+// a K loop in ascending order without split-K is bit-identical to the oracle's plain fma dot product.
+// Every product has the form  out[n][m] = sum_k A[k][m] * B[k][n]  (A symmetric table, output stored transposed), so
+// all operands are read along their contiguous dimension and the four steps chain without any explicit transpose.
+// ===============================================================================================================
+enum { H2D_OP_F = 0, H2D_OP_C = 1, H2D_OP_FAS_FINE = 2, H2D_OP_FAS_COARSE = 3, H2D_OP_RESIDUAL = 4, H2D_OP_JUMP = 5 };
+
+struct H2DDev {
+    int nx, ny, mi, mj, Mi, Mj, K, n_pts, ld, has_w;
+    double fx, fy, theta;
+    const double *bc;    // [nx*ny] boundary values (zero inside)
+    const double *W;     // [Mi][Mj] boundary coupling (zero padded)
+    const double *S;     // [K][Mi][Mj] forcing space factors (zero padded)
+    const double *tstop; // [K][n_pts] tau_k(t_i)
+    const double *dt;    // [n_pts]
+};
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// out[b][n][m] (* dinv[n][m]) = sum_k A[k][m] * B[b][k][n] ; A: M x M symmetric, B: M x N per batch item, out: N x M.
+// 64x64 tile per workgroup, 4 waves x (32x32 = 2x2 MFMA tiles), K step 16 through LDS (rows padded to 80 doubles:
+// the two k-rows a ds_read_b64 half-wave touches fall into disjoint bank halves).
+template <bool SCALE>
+__global__ void __launch_bounds__(256) h2d_gemm_kernel(const double *__restrict__ A, int M, const double *__restrict__ B,
+                                                       int N, double *__restrict__ out, const double *__restrict__ dinv,
+                                                       size_t bstride) {
+    __shared__ __attribute__((aligned(16))) double As[16][80];
+    __shared__ __attribute__((aligned(16))) double Bs[16][80];
+    __shared__ __attribute__((aligned(16))) double Cs[64][66];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const double *Bb = B + (size_t)blockIdx.z * bstride;
+    double *Ob = out + (size_t)blockIdx.z * bstride;
+    const int wm = (w & 1) * 32, wn = (w >> 1) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+    d4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    const int sr = tid >> 5, sc = (tid & 31) * 2;
+    for (int k0 = 0; k0 < M; k0 += 16) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = sr + 8 * h;
+            *reinterpret_cast<double2 *>(&As[r][sc]) = *reinterpret_cast<const double2 *>(A + (size_t)(k0 + r) * M + m0 + sc);
+            *reinterpret_cast<double2 *>(&Bs[r][sc]) = *reinterpret_cast<const double2 *>(Bb + (size_t)(k0 + r) * N + n0 + sc);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const double a0 = As[kk * 4 + lk][wm + lr], a1 = As[kk * 4 + lk][wm + 16 + lr];
+            const double b0 = Bs[kk * 4 + lk][wn + lr], b1 = Bs[kk * 4 + lk][wn + 16 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D[row = lk + 4r][col = lr] of tile (tm, tn) is element (m = wm + 16 tm + lk + 4r, n = wn + 16 tn + lr): store transposed
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[wn + 16 * tn + lr][wm + 16 * tm + lk + 4 * r] = acc[tm][tn][r];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int n = (tid >> 4) + 16 * p, c = (tid & 15) * 4;
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = Cs[n][c + q];
+        const size_t o = (size_t)(n0 + n) * M + m0 + c;
+        if (SCALE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = v[q] * dinv[o + q];
+        }
+        *reinterpret_cast<double2 *>(Ob + o) = make_double2(v[0], v[1]);
+        *reinterpret_cast<double2 *>(Ob + o + 2) = make_double2(v[2], v[3]);
+    }
+}
+
+__device__ __forceinline__ double h2d_lap(const H2DDev &H, const double *u, int gi, int gj) {
+    const int ny = H.ny;
+    double acc = (2.0 * (H.fx + H.fy)) * u[(size_t)gi * ny + gj];
+    acc = fma(-H.fx, u[(size_t)(gi - 1) * ny + gj], acc);
+    acc = fma(-H.fx, u[(size_t)(gi + 1) * ny + gj], acc);
+    acc = fma(-H.fy, u[(size_t)gi * ny + gj - 1], acc);
+    acc = fma(-H.fy, u[(size_t)gi * ny + gj + 1], acc);
+    return acc;
+}
+
+// right-hand side of the implicit solve on the padded interior: B[b][a][c] (heat_2d.py:289-320)
+__global__ void h2d_rhs_kernel(H2DDev H, const double *__restrict__ slab, const int32_t *__restrict__ in_idx,
+                               const int32_t *__restrict__ step_idx, double *__restrict__ B) {
+    const int b = blockIdx.z, a = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H.Mj) return;
+    double v = 0.0;
+    if (a < H.mi && c < H.mj) {
+        const double *u = slab + (size_t)in_idx[b] * H.ld;
+        const int i = step_idx[b];
+        const double dt = H.dt[i], th = H.theta;
+        const size_t p = (size_t)(a + 1) * H.ny + (c + 1), q = (size_t)a * H.Mj + c;
+        if (th == 1.0) {
+            v = u[p];
+            for (int k = 0; k < H.K; ++k) v = fma(H.S[(size_t)k * H.Mi * H.Mj + q], H.tstop[(size_t)k * H.n_pts + i] * dt, v);
+        } else {
+            const double thdt = th * dt, thdt1 = (1.0 - th) * dt;
+            v = fma(-thdt, h2d_lap(H, u, a + 1, c + 1), u[p]);
+            for (int k = 0; k < H.K; ++k)
+                v = fma(H.S[(size_t)k * H.Mi * H.Mj + q],
+                        thdt * H.tstop[(size_t)k * H.n_pts + i] + thdt1 * H.tstop[(size_t)k * H.n_pts + i - 1], v);
+        }
+        if (H.has_w) v = fma(th * dt, H.W[q], v);
+    }
+    B[((size_t)b * H.Mi + a) * H.Mj + c] = v;
+}
+
+// value of Phi(u_in) at grid point (gi, gj) of batch item b: interior from the GEMM result U (theta > 0) or the explicit
+// stencil (theta = 0, heat_2d.py:346-356 incl. the reference's "BC + old boundary" behaviour)
+__device__ __forceinline__ double h2d_phi_value(const H2DDev &H, const double *U, const double *uin, int step, int b, int gi,
+                                                int gj) {
+    const size_t p = (size_t)gi * H.ny + gj;
+    const bool rim = gi == 0 || gj == 0 || gi == H.nx - 1 || gj == H.ny - 1;
+    if (H.theta == 0.0) {
+        if (rim) return H.bc[p] + uin[p];
+        const double dt = H.dt[step];
+        double v = fma(-dt, h2d_lap(H, uin, gi, gj), uin[p]);
+        for (int k = 0; k < H.K; ++k)
+            v = fma(H.S[(size_t)k * H.Mi * H.Mj + (size_t)(gi - 1) * H.Mj + (gj - 1)], dt * H.tstop[(size_t)k * H.n_pts + step - 1], v);
+        return v;
+    }
+    return rim ? H.bc[p] : U[((size_t)b * H.Mi + (gi - 1)) * H.Mj + (gj - 1)];
+}
+
+// sweep epilogue on full-grid rows: one thread per grid point (ops: see H2D_OP_*)
+__global__ void h2d_finish_kernel(H2DDev H, const double *__restrict__ U, const double *__restrict__ in_slab,
+                                  const int32_t *__restrict__ in_idx, const int32_t *__restrict__ step_idx,
+                                  double *__restrict__ dst_slab, int dst_ld, const int32_t *__restrict__ dst_idx,
+                                  const double *__restrict__ a_slab, const int32_t *__restrict__ a_idx,
+                                  const double *__restrict__ b_slab, const int32_t *__restrict__ b_idx, int op, int use_g,
+                                  double w, double w1) {
+    const int b = blockIdx.z, gi = blockIdx.y, gj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gj >= H.ny) return;
+    const size_t p = (size_t)gi * H.ny + gj;
+    const double *uin = in_slab + (size_t)in_idx[b] * H.ld;
+    const double phi = h2d_phi_value(H, U, uin, step_idx[b], b, gi, gj);
+    double *dst = dst_slab + (size_t)dst_idx[b] * dst_ld;
+    double v;
+    if (op == H2D_OP_F) {
+        v = use_g ? a_slab[(size_t)a_idx[b] * H.ld + p] + phi : phi;                       // [g_i +] Phi
+    } else if (op == H2D_OP_C) {
+        v = use_g ? a_slab[(size_t)a_idx[b] * H.ld + p] + phi : phi;
+        if (w != 1.0) v = v * w + dst[p] * w1;                                             // weighted with the old u_i
+    } else if (op == H2D_OP_FAS_FINE) {
+        const double ui = b_slab[(size_t)b_idx[b] * H.ld + p];
+        v = use_g ? (a_slab[(size_t)a_idx[b] * H.ld + p] - ui) + phi : phi - ui;           // (g_i - u_i) + Phi | Phi - u_i
+    } else {  // H2D_OP_FAS_COARSE: (g_j + v_j) - Phi(v_{j-1})
+        v = (a_slab[(size_t)a_idx[b] * H.ld + p] + b_slab[(size_t)b_idx[b] * H.ld + p]) - phi;
+    }
+    dst[p] = v;
+}
+
+// residual / jump: per grid row an fma chain over its ny values (thread per (item, row)), then the rows in order
+__global__ void h2d_rowsq_kernel(H2DDev H, const double *__restrict__ U, const double *__restrict__ in_slab,
+                                 const int32_t *__restrict__ in_idx, const int32_t *__restrict__ step_idx,
+                                 const double *__restrict__ cmp_slab, const int32_t *__restrict__ cmp_idx, int op,
+                                 double *__restrict__ rowsq) {
+    const int b = blockIdx.y, gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= H.nx) return;
+    const double *uin = in_slab + (size_t)in_idx[b] * H.ld;
+    const double *cmp = cmp_slab + (size_t)cmp_idx[b] * H.ld;
+    double acc = 0.0;
+    for (int gj = 0; gj < H.ny; ++gj) {
+        const size_t p = (size_t)gi * H.ny + gj;
+        const double r = op == H2D_OP_RESIDUAL ? h2d_phi_value(H, U, uin, step_idx[b], b, gi, gj) - cmp[p] : uin[p] - cmp[p];
+        acc = fma(r, r, acc);
+    }
+    rowsq[(size_t)b * H.nx + gi] = acc;
+}
+
+__global__ void h2d_rowsum_kernel(const double *__restrict__ rowsq, int nx, int count, double *__restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    double tot = 0.0;
+    for (int i = 0; i < nx; ++i) tot = tot + rowsq[(size_t)b * nx + i];
+    out[b] = tot;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-struct RunList { int n = 0; int32_t *d_start = nullptr, *d_len = nullptr; std::vector<int32_t> h_start, h_len; };
-struct PairList { int n = 0; int32_t *d_fine = nullptr, *d_coarse = nullptr, *d_iota = nullptr, *d_prev = nullptr; };
+struct H2DPlan { int count = 0; uint64_t dtbits = 0; int32_t *d_in = nullptr, *d_step = nullptr, *d_dst = nullptr, *d_a = nullptr, *d_b = nullptr; };
+struct RunList {
+    int n = 0;
+    int32_t *d_start = nullptr, *d_len = nullptr;
+    std::vector<int32_t> h_start, h_len;
+    std::vector<H2DPlan> h2d_relax, h2d_points;  // Heat2D batch plans (built on first use)
+    bool h2d_relax_built = false, h2d_points_built = false;
+};
+struct PairList {
+    int n = 0;
+    int32_t *d_fine = nullptr, *d_coarse = nullptr, *d_iota = nullptr, *d_prev = nullptr;
+    std::vector<int32_t> h_fine, h_coarse;
+    std::vector<H2DPlan> h2d_fine, h2d_coarse;
+    bool h2d_built = false;
+};
+
+struct H2DHost {
+    H2DDev dev{};
+    std::vector<double> lx, ly, dts;
+    std::map<uint64_t, double *> dinv;   // 1/(1 + theta*dt*(lx_k + ly_l)) per distinct dt, [Mi][Mj]
+    double *Qx = nullptr, *Qy = nullptr, *W0 = nullptr, *W1 = nullptr, *rowsq = nullptr;
+    size_t cap_items = 0;
+};
 
 struct Level {
     bool set = false;
+    H2DHost *h2d = nullptr;
     LevelDev dev{};
     int G = 0, n_csets = 0, transfer = MGRIT_HIP_TRANSFER_COPY;
     std::vector<void *> allocs;
@@ -1005,6 +1223,222 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Heat2D host side: tables, batch plans, the batched Phi pipeline
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int H2D_MAX_BATCH = 1024;  // items per GEMM batch (work buffers: 2 x 1024 x Mi x Mj doubles)
+
+uint64_t dbl_bits(double v) { uint64_t b; std::memcpy(&b, &v, 8); return b; }
+
+template <typename T>
+int dev_upload_raw(Level &lv, hipStream_t st, const T *h, size_t n, T **out) {
+    std::vector<T> tmp(h, h + n);
+    return dev_upload(lv, st, tmp, out);
+}
+
+// group batch items by the time-step size of their step index (one D table per group)
+struct H2DItem { int32_t in, step, dst, a, b; };
+
+int h2d_make_plans(mgrit_hip_engine *e, Level &lv, const std::vector<H2DItem> &items, std::vector<H2DPlan> &plans) {
+    H2DHost &h = *lv.h2d;
+    std::vector<uint64_t> keys;
+    for (const H2DItem &it : items) {
+        const uint64_t k = dbl_bits(h.dts[it.step]);
+        bool seen = false;
+        for (uint64_t q : keys) seen = seen || q == k;
+        if (!seen) keys.push_back(k);
+    }
+    for (uint64_t k : keys) {
+        std::vector<int32_t> vin, vst, vds, va, vb;
+        for (const H2DItem &it : items)
+            if (dbl_bits(h.dts[it.step]) == k) {
+                vin.push_back(it.in); vst.push_back(it.step); vds.push_back(it.dst); va.push_back(it.a); vb.push_back(it.b);
+            }
+        for (size_t off = 0; off < vin.size(); off += H2D_MAX_BATCH) {
+            const size_t cnt = std::min<size_t>(H2D_MAX_BATCH, vin.size() - off);
+            H2DPlan pl;
+            pl.count = (int)cnt;
+            pl.dtbits = k;
+            int rc;
+            if ((rc = dev_upload_raw(lv, e->stream, vin.data() + off, cnt, &pl.d_in))) return rc;
+            if ((rc = dev_upload_raw(lv, e->stream, vst.data() + off, cnt, &pl.d_step))) return rc;
+            if ((rc = dev_upload_raw(lv, e->stream, vds.data() + off, cnt, &pl.d_dst))) return rc;
+            if ((rc = dev_upload_raw(lv, e->stream, va.data() + off, cnt, &pl.d_a))) return rc;
+            if ((rc = dev_upload_raw(lv, e->stream, vb.data() + off, cnt, &pl.d_b))) return rc;
+            plans.push_back(pl);
+        }
+    }
+    return 0;
+}
+
+int h2d_reserve(Level &lv, int count) {
+    H2DHost &h = *lv.h2d;
+    if ((size_t)count <= h.cap_items) return 0;
+    if (h.W0) HIP_TRY(hipFree(h.W0));
+    if (h.W1) HIP_TRY(hipFree(h.W1));
+    if (h.rowsq) HIP_TRY(hipFree(h.rowsq));
+    h.W0 = h.W1 = h.rowsq = nullptr;
+    const size_t per = (size_t)h.dev.Mi * h.dev.Mj;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.W0), sizeof(double) * per * count));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.W1), sizeof(double) * per * count));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.rowsq), sizeof(double) * (size_t)h.dev.nx * count));
+    h.cap_items = count;
+    return 0;
+}
+
+int h2d_dinv(mgrit_hip_engine *e, Level &lv, uint64_t dtbits, double **out) {
+    H2DHost &h = *lv.h2d;
+    auto it = h.dinv.find(dtbits);
+    if (it != h.dinv.end()) { *out = it->second; return 0; }
+    double dt;
+    std::memcpy(&dt, &dtbits, 8);
+    const double thdt = h.dev.theta * dt;
+    std::vector<double> tab((size_t)h.dev.Mi * h.dev.Mj, 0.0);
+    for (int a = 0; a < h.dev.mi; ++a)
+        for (int b = 0; b < h.dev.mj; ++b) tab[(size_t)a * h.dev.Mj + b] = 1.0 / (1.0 + thdt * (h.lx[a] + h.ly[b]));
+    double *d = nullptr;
+    int rc = dev_upload(lv, e->stream, tab, &d);
+    if (rc) return rc;
+    h.dinv[dtbits] = d;
+    *out = d;
+    return 0;
+}
+
+// U (in W0) = interior of Phi applied to the rows in_slab[plan.d_in[b]] for the steps plan.d_step[b]  (theta > 0)
+int h2d_phi_batch(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab) {
+    H2DHost &h = *lv.h2d;
+    const H2DDev &H = h.dev;
+    if (H.theta == 0.0) return 0;  // explicit: evaluated inside the epilogue kernels
+    int rc;
+    if ((rc = h2d_reserve(lv, std::min(H2D_MAX_BATCH, std::max(pl.count, 1))))) return rc;
+    double *dinv = nullptr;
+    if ((rc = h2d_dinv(e, lv, pl.dtbits, &dinv))) return rc;
+    const size_t per = (size_t)H.Mi * H.Mj;
+    hipLaunchKernelGGL(h2d_rhs_kernel, dim3((H.Mj + 255) / 256, H.Mi, pl.count), dim3(256), 0, e->stream, H, in_slab, pl.d_in,
+                       pl.d_step, h.W0);
+    // X1[j][i'] = (Qx B)^T ; X2[i'][j'] = ((Qx B) Qy) o D ; X3[j'][i] = (Qx X2)^T ; U[i][j] = (Qx X2) Qy
+    hipLaunchKernelGGL((h2d_gemm_kernel<false>), dim3(H.Mi / 64, H.Mj / 64, pl.count), dim3(256), 0, e->stream, h.Qx, H.Mi, h.W0,
+                       H.Mj, h.W1, nullptr, per);
+    hipLaunchKernelGGL((h2d_gemm_kernel<true>), dim3(H.Mj / 64, H.Mi / 64, pl.count), dim3(256), 0, e->stream, h.Qy, H.Mj, h.W1,
+                       H.Mi, h.W0, dinv, per);
+    hipLaunchKernelGGL((h2d_gemm_kernel<false>), dim3(H.Mi / 64, H.Mj / 64, pl.count), dim3(256), 0, e->stream, h.Qx, H.Mi, h.W0,
+                       H.Mj, h.W1, nullptr, per);
+    hipLaunchKernelGGL((h2d_gemm_kernel<false>), dim3(H.Mj / 64, H.Mi / 64, pl.count), dim3(256), 0, e->stream, h.Qy, H.Mj, h.W1,
+                       H.Mi, h.W0, nullptr, per);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int h2d_finish(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab, double *dst_slab, int dst_ld,
+               const double *a_slab, const double *b_slab, int op, int use_g, double w) {
+    const H2DDev &H = lv.h2d->dev;
+    hipLaunchKernelGGL(h2d_finish_kernel, dim3((H.ny + 127) / 128, H.nx, pl.count), dim3(128), 0, e->stream, H, lv.h2d->W0, in_slab,
+                       pl.d_in, pl.d_step, dst_slab, dst_ld, pl.d_dst, a_slab, pl.d_a, b_slab, pl.d_b, op, use_g, w, 1.0 - w);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int h2d_relax(mgrit_hip_engine *e, int lvl, RunList *rl, int mode, double weight_c) {
+    Level &lv = e->L[lvl];
+    int rc;
+    if (!rl->h2d_relax_built) {
+        int maxlen = 0;
+        for (int r = 0; r < rl->n; ++r) maxlen = std::max(maxlen, (int)rl->h_len[r]);
+        for (int k = 0; k < maxlen; ++k) {  // step k of every run that is long enough: one batch
+            std::vector<H2DItem> items;
+            for (int r = 0; r < rl->n; ++r)
+                if (rl->h_len[r] > k) {
+                    const int i = rl->h_start[r] + k;
+                    items.push_back({i - 1, i, i, i, i});
+                }
+            std::vector<H2DPlan> plans;
+            if ((rc = h2d_make_plans(e, lv, items, plans))) return rc;
+            for (H2DPlan &p : plans) rl->h2d_relax.push_back(p);
+        }
+        rl->h2d_relax_built = true;
+    }
+    const int op = mode == MGRIT_HIP_RELAX_C ? H2D_OP_C : H2D_OP_F;
+    for (const H2DPlan &pl : rl->h2d_relax) {
+        if ((rc = h2d_phi_batch(e, lv, pl, lv.dev.u))) return rc;
+        if ((rc = h2d_finish(e, lv, pl, lv.dev.u, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, op, lvl > 0 ? 1 : 0, weight_c))) return rc;
+    }
+    return 0;
+}
+
+// per-point sums of squares: Phi(u_{i-1}) - u_i (residual) or u_i - prev_i (jump)
+int h2d_points_sumsq(mgrit_hip_engine *e, int lvl, RunList *rl, const double *prev, double *out) {
+    Level &lv = e->L[lvl];
+    const H2DDev &H = lv.h2d->dev;
+    int rc;
+    if (!rl->h2d_points_built) {
+        std::vector<H2DItem> items;
+        for (int r = 0; r < rl->n; ++r) {
+            const int i = rl->h_start[r];
+            items.push_back({i - 1, i, i, i, i});
+        }
+        if ((rc = h2d_make_plans(e, lv, items, rl->h2d_points))) return rc;
+        rl->h2d_points_built = true;
+        // out[] is written in plan order; plans keep list order only when a single time-step size is present
+        if (rl->h2d_points.size() > (size_t)((rl->n + H2D_MAX_BATCH - 1) / H2D_MAX_BATCH))
+            return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D residual over points with several distinct time-step sizes");
+    }
+    int off = 0;
+    for (const H2DPlan &pl : rl->h2d_points) {
+        if ((rc = h2d_reserve(lv, std::min(H2D_MAX_BATCH, pl.count)))) return rc;
+        if (!prev) {
+            if ((rc = h2d_phi_batch(e, lv, pl, lv.dev.u))) return rc;
+            hipLaunchKernelGGL(h2d_rowsq_kernel, dim3((H.nx + 63) / 64, pl.count), dim3(64), 0, e->stream, H, lv.h2d->W0, lv.dev.u,
+                               pl.d_in, pl.d_step, lv.dev.u, pl.d_dst, H2D_OP_RESIDUAL, lv.h2d->rowsq);
+        } else {
+            hipLaunchKernelGGL(h2d_rowsq_kernel, dim3((H.nx + 63) / 64, pl.count), dim3(64), 0, e->stream, H, lv.h2d->W0, lv.dev.u,
+                               pl.d_dst, pl.d_step, prev, pl.d_dst, H2D_OP_JUMP, lv.h2d->rowsq);
+        }
+        hipLaunchKernelGGL(h2d_rowsum_kernel, dim3((pl.count + 63) / 64), dim3(64), 0, e->stream, lv.h2d->rowsq, H.nx, pl.count,
+                           out + off);
+        HIP_TRY(hipGetLastError());
+        off += pl.count;
+    }
+    return 0;
+}
+
+int h2d_fas_rhs(mgrit_hip_engine *e, int lvl, PairList *pl) {
+    Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    int rc;
+    if (!pl->h2d_built) {
+        std::vector<H2DItem> fine, coarse;
+        for (int p = 0; p < pl->n; ++p) {
+            const int i = pl->h_fine[p], j = pl->h_coarse[p];
+            fine.push_back({i - 1, i, j, i, i});      // dst = g^{l+1}_j, a = g^l_i, b = u^l_i
+            coarse.push_back({j - 1, j, j, j, j});    // in = v_{j-1}, dst = g_j, a = g_j, b = v_j
+        }
+        if ((rc = h2d_make_plans(e, lf, fine, pl->h2d_fine))) return rc;
+        if ((rc = h2d_make_plans(e, lc, coarse, pl->h2d_coarse))) return rc;
+        pl->h2d_built = true;
+    }
+    for (const H2DPlan &q : pl->h2d_fine) {
+        if ((rc = h2d_phi_batch(e, lf, q, lf.dev.u))) return rc;
+        if ((rc = h2d_finish(e, lf, q, lf.dev.u, lc.dev.g, lc.dev.ld, lf.dev.g, lf.dev.u, H2D_OP_FAS_FINE, lvl > 0 ? 1 : 0, 1.0))) return rc;
+    }
+    for (const H2DPlan &q : pl->h2d_coarse) {
+        if ((rc = h2d_phi_batch(e, lc, q, lc.dev.v))) return rc;
+        if ((rc = h2d_finish(e, lc, q, lc.dev.v, lc.dev.g, lc.dev.ld, lc.dev.g, lc.dev.v, H2D_OP_FAS_COARSE, 1, 1.0))) return rc;
+    }
+    return 0;
+}
+
+void h2d_sine_table(int m, int M, double *Q, std::vector<double> &lam, double f) {
+    const double sc = std::sqrt(2.0 / (m + 1));
+    lam.assign(M, 0.0);
+    for (int i = 0; i < m; ++i) {
+        for (int k = 0; k < m; ++k) {
+            const long r = ((long)(i + 1) * (k + 1)) % (2L * (m + 1));
+            Q[(size_t)i * M + k] = sc * std::sin(M_PI * (double)r / (double)(m + 1));
+        }
+        const double hs = std::sin(M_PI * (double)(i + 1) / (2.0 * (m + 1)));
+        lam[i] = 4.0 * f * hs * hs;
+    }
+}
+
 int get_runs(mgrit_hip_engine *e, int lvl, int id, RunList **out) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
@@ -1080,6 +1514,12 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
     if (!e) return 0;
     (void)hipStreamSynchronize(e->stream);
     for (auto &lv : e->L) {
+        if (lv.h2d) {
+            if (lv.h2d->W0) (void)hipFree(lv.h2d->W0);
+            if (lv.h2d->W1) (void)hipFree(lv.h2d->W1);
+            if (lv.h2d->rowsq) (void)hipFree(lv.h2d->rowsq);
+            delete lv.h2d;
+        }
         for (void *p : lv.allocs) (void)hipFree(p);
         if (lv.scratch) (void)hipFree(lv.scratch);
     }
@@ -1117,6 +1557,62 @@ int mgrit_hip_level_advection1d(mgrit_hip_engine *e, int lvl, int n_pts_local, c
     return level_common(e, lvl, MGRIT_HIP_STEPPER_ADVECTION1D, n_pts_local, t_local, n, ld, fac, 0, nullptr, nullptr);
 }
 
+int mgrit_hip_level_heat2d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int nx, int ny, int ld,
+                           double fx, double fy, double theta, const double *bc, int K, const double *S, const double *tau) {
+    int rc = check_level(e, lvl, false);
+    if (rc) return rc;
+    if (nx < 3 || ny < 3 || nx > 2050 || ny > 2050) return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D grid %dx%d outside [3,2050]^2", nx, ny);
+    if (ld < nx * ny || (ld % 16) != 0) return fail(MGRIT_HIP_EINVAL, "ld=%d must be a multiple of 16 and >= nx*ny=%d", ld, nx * ny);
+    if (!(theta == 0.0 || theta == 0.5 || theta == 1.0)) return fail(MGRIT_HIP_EINVAL, "theta must be 0 (FE), 0.5 (CN) or 1 (BE)");
+    if (n_pts_local < 0 || (n_pts_local > 0 && !t_local) || !bc) return fail(MGRIT_HIP_EINVAL, "bad arguments");
+    if (K < 0 || K > 8 || (K > 0 && (!S || !tau))) return fail(MGRIT_HIP_EINVAL, "bad forcing description (K=%d)", K);
+    Level &lv = e->L[lvl];
+    if (lv.set) return fail(MGRIT_HIP_EINVAL, "level %d already described", lvl);
+    H2DHost *h = new H2DHost();
+    lv.h2d = h;
+    H2DDev &H = h->dev;
+    H.nx = nx; H.ny = ny; H.mi = nx - 2; H.mj = ny - 2;
+    H.Mi = ((H.mi + 63) / 64) * 64; H.Mj = ((H.mj + 63) / 64) * 64;
+    H.K = K; H.n_pts = n_pts_local; H.ld = ld; H.fx = fx; H.fy = fy; H.theta = theta;
+    h->dts.assign(n_pts_local > 0 ? n_pts_local : 0, 0.0);
+    for (int i = 1; i < n_pts_local; ++i) h->dts[i] = t_local[i] - t_local[i - 1];
+    // tables
+    std::vector<double> qx((size_t)H.Mi * H.Mi, 0.0), qy((size_t)H.Mj * H.Mj, 0.0);
+    h2d_sine_table(H.mi, H.Mi, qx.data(), h->lx, fx);
+    h2d_sine_table(H.mj, H.Mj, qy.data(), h->ly, fy);
+    std::vector<double> W((size_t)H.Mi * H.Mj, 0.0), Sp((size_t)(K > 0 ? K : 0) * H.Mi * H.Mj, 0.0), bcv(bc, bc + (size_t)nx * ny);
+    H.has_w = 0;
+    for (int a = 0; a < H.mi; ++a)
+        for (int b = 0; b < H.mj; ++b) {
+            double w = 0.0;
+            if (a == 0) w += fx * bc[(size_t)0 * ny + b + 1];
+            if (a == H.mi - 1) w += fx * bc[(size_t)(nx - 1) * ny + b + 1];
+            if (b == 0) w += fy * bc[(size_t)(a + 1) * ny + 0];
+            if (b == H.mj - 1) w += fy * bc[(size_t)(a + 1) * ny + ny - 1];
+            W[(size_t)a * H.Mj + b] = w;
+            if (w != 0.0) H.has_w = 1;
+        }
+    for (int k = 0; k < K; ++k)
+        for (int a = 0; a < H.mi; ++a)
+            for (int b = 0; b < H.mj; ++b) Sp[((size_t)k * H.Mi + a) * H.Mj + b] = S[((size_t)k * H.mi + a) * H.mj + b];
+    std::vector<double> tauv;
+    if (K > 0) tauv.assign(tau, tau + (size_t)K * n_pts_local);
+    double *d_bc, *d_W, *d_S, *d_tau, *d_dt;
+    if ((rc = dev_upload(lv, e->stream, qx, &h->Qx))) return rc;
+    if ((rc = dev_upload(lv, e->stream, qy, &h->Qy))) return rc;
+    if ((rc = dev_upload(lv, e->stream, bcv, &d_bc))) return rc;
+    if ((rc = dev_upload(lv, e->stream, W, &d_W))) return rc;
+    if ((rc = dev_upload(lv, e->stream, Sp, &d_S))) return rc;
+    if ((rc = dev_upload(lv, e->stream, tauv, &d_tau))) return rc;
+    if ((rc = dev_upload(lv, e->stream, h->dts, &d_dt))) return rc;
+    H.bc = d_bc; H.W = d_W; H.S = d_S; H.tstop = d_tau; H.dt = d_dt;
+    lv.dev.kind = MGRIT_HIP_STEPPER_HEAT2D;
+    lv.dev.n = nx * ny; lv.dev.ld = ld; lv.dev.T = 0; lv.dev.n_pts = n_pts_local; lv.dev.K = K;
+    lv.G = 0;
+    lv.set = true;
+    return 0;
+}
+
 int mgrit_hip_level_bind(mgrit_hip_engine *e, int lvl, double *u, double *v, double *g) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
@@ -1133,6 +1629,7 @@ int mgrit_hip_level_transfer(mgrit_hip_engine *e, int lvl, int kind) {
     if (kind == MGRIT_HIP_TRANSFER_COPY) {
         if (nf != nc) return fail(MGRIT_HIP_EINVAL, "copy transfer needs equal DOFs (%d vs %d)", nf, nc);
     } else if (kind == MGRIT_HIP_TRANSFER_HEAT1D) {
+        if (e->L[lvl].h2d || e->L[lvl + 1].h2d) return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D levels support the copy transfer only");
         if (nf != 2 * nc + 1) return fail(MGRIT_HIP_EINVAL, "full-weighting transfer needs n_fine = 2*n_coarse+1 (%d vs %d)", nf, nc);
     } else return fail(MGRIT_HIP_EINVAL, "unknown transfer kind %d", kind);
     e->L[lvl].transfer = kind;
@@ -1174,6 +1671,8 @@ int mgrit_hip_pairs_create(mgrit_hip_engine *e, int lvl, int n_pairs, const int3
                         lv.dev.n_pts, lc.dev.n_pts);
     PairList pl;
     pl.n = n_pairs;
+    pl.h_fine.assign(fine_idx, fine_idx + n_pairs);
+    pl.h_coarse.assign(coarse_idx, coarse_idx + n_pairs);
     std::vector<int32_t> hf(fine_idx, fine_idx + n_pairs), hc(coarse_idx, coarse_idx + n_pairs), iota(n_pairs);
     for (int p = 0; p < n_pairs; ++p) iota[p] = p;
     if ((rc = dev_upload(lv, e->stream, hf, &pl.d_fine))) return rc;
@@ -1192,6 +1691,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     if (mode != MGRIT_HIP_RELAX_F && mode != MGRIT_HIP_RELAX_C && mode != MGRIT_HIP_RELAX_CHAIN) return fail(MGRIT_HIP_EINVAL, "bad relax mode %d", mode);
     if ((rc = check_bound(lv, lvl > 0))) return rc;
     if (rl->n == 0) return 0;
+    if (lv.h2d) return h2d_relax(e, lvl, rl, mode, weight_c);
     if (e->timing) {
         if (!e->ev0) { HIP_TRY(hipEventCreate(&e->ev0)); HIP_TRY(hipEventCreate(&e->ev1)); }
         HIP_TRY(hipEventRecord(e->ev0, e->stream));
@@ -1251,6 +1751,7 @@ int mgrit_hip_residual(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_
     if ((rc = check_bound(lv, false))) return rc;
     if (rl->n == 0) return 0;
     if (!sumsq_out) return fail(MGRIT_HIP_EINVAL, "null output");
+    if (lv.h2d) return h2d_points_sumsq(e, lvl, rl, nullptr, sumsq_out);
     LAUNCH_BY_KIND(residual_kernel, lv, rl->n, lv.dev, rl->d_start, sumsq_out);
     return 0;
 }
@@ -1263,6 +1764,7 @@ int mgrit_hip_jump(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev
     if ((rc = check_bound(lv, false))) return rc;
     if (rl->n == 0) return 0;
     if (!sumsq_out || !prev) return fail(MGRIT_HIP_EINVAL, "null argument");
+    if (lv.h2d) return h2d_points_sumsq(e, lvl, rl, prev, sumsq_out);
     hipLaunchKernelGGL(jump_kernel, dim3(rl->n), dim3(lv.dev.T), smem_bytes(lv.G), e->stream, lv.dev, rl->d_start, prev, sumsq_out);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1299,6 +1801,11 @@ int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id) {
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
     if (pl->n == 0) return 0;
+    if (lf.h2d || lc.h2d) {
+        if (!lf.h2d || !lc.h2d || lf.transfer != MGRIT_HIP_TRANSFER_COPY)
+            return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D levels need Heat2D on both levels and the copy transfer");
+        return h2d_fas_rhs(e, lvl, pl);
+    }
     if (lf.transfer == MGRIT_HIP_TRANSFER_COPY) {
         LAUNCH_BY_KIND(fas_fine_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_coarse, lc.dev.g, lc.dev.ld, lvl > 0 ? 1 : 0);
     } else {
@@ -1337,8 +1844,8 @@ int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id) {
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
     if (!pl->d_prev) return fail(MGRIT_HIP_EINVAL, "list %d was not created by mgrit_hip_triples_create", triples_id);
-    if (lf.transfer != MGRIT_HIP_TRANSFER_COPY || lf.dev.kind != lc.dev.kind || force_mode(lf) != force_mode(lc) ||
-        lf.dev.n != lc.dev.n)
+    if (lf.h2d || lc.h2d || lf.transfer != MGRIT_HIP_TRANSFER_COPY || lf.dev.kind != lc.dev.kind ||
+        force_mode(lf) != force_mode(lc) || lf.dev.n != lc.dev.n)
         return fail(MGRIT_HIP_EUNSUPPORTED, "fused FAS residual needs the copy transfer and like steppers on both levels");
     if (pl->n == 0) return 0;
     const int use_g = lvl > 0 ? 1 : 0;

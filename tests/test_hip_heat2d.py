@@ -1,0 +1,122 @@
+"""GPU parity for Heat2D (BASELINE config 4 family): the MFMA fast-diagonalisation stepper and every sweep on 2-D states
+against the oracle (same arithmetic: fma dot products in ascending k = v_mfma_f64_16x16x4 chains), bit for bit; solves
+against the oracle (1e-10 rel) and the reference fixtures (tests/golden/heat2d.*)."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+H2D = cases.load_json("heat2d.json")
+ARR = np.load(cases.GOLDEN + "/heat2d.npz")
+
+
+def _pair(oracle, prob, **opts):
+    from pymgrit_amd import Mgrit
+    opts.setdefault("nested_iteration", False)
+    mg = Mgrit(prob, logging_lvl=30, **opts)
+    op = oracle.OracleProblem([cases.h2d_level_spec(a) for a in prob], **opts)
+    return mg, op
+
+
+def _randomize(mg, op, seed):
+    rng = np.random.default_rng(seed)
+    for lvl in range(mg.lvl_max):
+        for name, slabs in (("u", mg.backend.U), ("v", mg.backend.V), ("g", mg.backend.G)):
+            if slabs[lvl] is None:
+                continue
+            ref = op.state(name, lvl)
+            ref[:] = rng.standard_normal(ref.shape)
+            mg.backend.set_natural(name, lvl, ref)
+
+
+def _equal(mg, op):
+    for lvl in range(mg.lvl_max):
+        for name, slabs in (("u", mg.backend.U), ("v", mg.backend.V), ("g", mg.backend.G)):
+            if slabs[lvl] is None:
+                continue
+            ref, got = op.state(name, lvl), mg.backend.natural(name, lvl)
+            assert np.array_equal(got, ref), (name, lvl, np.abs(got - ref).max())
+
+
+SHAPES = [("BE", False, 9, 12), ("BE", True, 20, 17), ("CN", True, 12, 10), ("FE", False, 8, 8), ("BE", True, 66, 67),
+          ("CN", False, 70, 40), ("BE", False, 130, 131)]
+
+
+@pytest.mark.parametrize("method,with_bc,nx,ny", SHAPES, ids=[f"{m}-bc{int(b)}-{x}x{y}" for m, b, x, y in SHAPES])
+def test_sweeps_bit_exact(oracle, method, with_bc, nx, ny):
+    assert torch.cuda.is_available()
+    a = 0.05 if method == "FE" else cases.H2D_A
+    prob = [cases.h2d_app(nx, ny, t, method, with_bc, a) for t in cases.h2d_grids([33, 9, 3])]
+    for w in (1.0, 1.3):
+        mg, op = _pair(oracle, prob, weight_c=w)
+        _randomize(mg, op, nx + ny)
+        for lvl in range(mg.lvl_max - 1):
+            mg.f_relax(lvl); op.f_relax(lvl)
+            _equal(mg, op)
+            mg.c_relax(lvl); op.c_relax(lvl)
+            _equal(mg, op)
+            mg.fas_residual(lvl); op.fas_residual(lvl)
+            _equal(mg, op)
+        mg.forward_solve(mg.lvl_max - 1); op.forward_solve(mg.lvl_max - 1)
+        _equal(mg, op)
+        for lvl in range(mg.lvl_max - 2, -1, -1):
+            mg.error_correction(lvl); op.error_correction(lvl)
+            _equal(mg, op)
+        got, ref = np.array(mg.compute_residual()), op.residual_norms()
+        assert np.array_equal(got, ref), np.abs(got - ref).max()
+
+
+@pytest.mark.parametrize("name", sorted(cases.H2D_SOLVE))
+def test_solve_matches_oracle_and_reference(oracle, name):
+    from pymgrit_amd import Mgrit
+    prob, opts = cases.h2d_solve_problem(name)
+    mg = Mgrit(prob, logging_lvl=30, **opts)
+    conv = mg.solve()["conv"]
+    op = oracle.OracleProblem([cases.h2d_level_spec(a) for a in prob], **opts)
+    oconv = op.solve()
+    assert len(conv) == len(oconv) and np.max(np.abs(conv - oconv) / oconv) <= 1e-10, (conv, oconv)
+    ref = np.array(H2D["solve"][name]["conv"])
+    assert np.all(np.abs(conv - ref) <= 1e-9 * ref + 2e-11), (conv, ref)
+    assert np.array_equal(mg.backend.natural("u", 0), op.state("u", 0))
+    last = mg.u[0][len(prob[0].t) - 1].get_values()
+    refu = ARR["h2d_solve_" + name]
+    assert last.shape == refu.shape and np.abs(last - refu).max() <= 1e-11 * max(1.0, np.abs(refu).max())
+
+
+def test_reference_unit_test_kats_on_gpu():
+    """reference tests/heat/test_heat_2d.py:230-293 through the GPU engine: one step of a 1-level hierarchy"""
+    from pymgrit_amd import Mgrit
+    from pymgrit_amd.heat.heat_2d import Heat2D
+    from test_heat2d_cpu import REF_KAT
+    for method in ("BE", "CN", "FE"):
+        app = Heat2D(a=1, x_start=0, x_end=1, y_start=3, y_end=4, nx=5, ny=5, method=method, rhs=lambda x, y, t: 2 * x * y,
+                     t_start=0, t_stop=1, nt=11)
+        mg = Mgrit([app], logging_lvl=30)   # nested iteration on one level = time stepping
+        np.testing.assert_almost_equal(mg.u[0][1].get_values(), np.array(REF_KAT[method]))
+
+
+def test_config4_size_properties():
+    """512x512 states (config 4 spatial size), short time grid: F-relax is idempotent, leaves zero residual at F-points,
+    and with zero forcing / zero BC Phi is linear under exact scaling by a power of two."""
+    from pymgrit_amd import Mgrit
+    from pymgrit_amd.heat.heat_2d import Heat2D
+    ts = cases.h2d_grids([33, 5])
+    prob = [Heat2D(x_start=0, x_end=1, y_start=0, y_end=1, nx=512, ny=512, a=1.0, method="BE", t_interval=t) for t in ts]
+    mg = Mgrit(prob, nested_iteration=False, logging_lvl=30)
+    U = mg.backend.U[0]
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    c = torch.randn((len(ts[1]), 512, 512), generator=gen, dtype=torch.float64)
+    c[:, 0, :] = 0; c[:, -1, :] = 0; c[:, :, 0] = 0; c[:, :, -1] = 0
+    U[::8, :512 * 512] = c.reshape(len(ts[1]), -1).to(U.device)
+    mg.f_relax(0)
+    first = U.clone()
+    mg.f_relax(0)
+    assert torch.equal(first, U)
+    fpts = [int(i) for i in np.sort(mg.index_local_f[0])]
+    assert max(mg.backend.residual_norms(fpts)) == 0.0
+    U[::8, :512 * 512] = (4.0 * c).reshape(len(ts[1]), -1).to(U.device)
+    mg.f_relax(0)
+    assert torch.equal(first * 4.0, U)
