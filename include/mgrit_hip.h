@@ -27,7 +27,7 @@ typedef struct mgrit_hip_engine mgrit_hip_engine;
 
 enum { MGRIT_HIP_OK = 0, MGRIT_HIP_EINVAL = -1, MGRIT_HIP_EHIP = -2, MGRIT_HIP_ENODEV = -3, MGRIT_HIP_EUNSUPPORTED = -4 };
 enum { MGRIT_HIP_STEPPER_HEAT1D = 1, MGRIT_HIP_STEPPER_ADVECTION1D = 2, MGRIT_HIP_STEPPER_HEAT2D = 3 };
-enum { MGRIT_HIP_TRANSFER_COPY = 0, MGRIT_HIP_TRANSFER_HEAT1D = 1 };
+enum { MGRIT_HIP_TRANSFER_COPY = 0, MGRIT_HIP_TRANSFER_HEAT1D = 1, MGRIT_HIP_TRANSFER_PERIODIC1D = 2 };
 enum { MGRIT_HIP_RELAX_F = 0, MGRIT_HIP_RELAX_C = 1, MGRIT_HIP_RELAX_CHAIN = 2 };
 
 int mgrit_hip_abi_version(void);
@@ -64,7 +64,8 @@ int mgrit_hip_level_heat2d(mgrit_hip_engine *e, int lvl, int n_pts_local, const 
 /* Device slabs u, v, g of Mgrit.create_u_v_g (mgrit.py:840-858); v and g may be NULL on level 0. */
 int mgrit_hip_level_bind(mgrit_hip_engine *e, int lvl, double *u, double *v, double *g);
 /* Spatial transfer between lvl and lvl+1: GridTransferCopy (core/grid_transfer_copy.py:23-47) or the full-weighting
- * / linear-interpolation pair of examples/example_spatial_coarsening.py:33-82 (fine n = 2*coarse n + 1). */
+ * / linear-interpolation pair of examples/example_spatial_coarsening.py:33-82 (fine n = 2*coarse n + 1), or its periodic
+ * analogue for Advection1D grids (fine n = 2*coarse n; no reference class exists, BASELINE config 5). */
 int mgrit_hip_level_transfer(mgrit_hip_engine *e, int lvl, int kind);
 
 /*

@@ -773,12 +773,23 @@ void orc_phi(orc_problem *p, int lvl, int i, const double *u_in, double *out) { 
 /* examples/example_spatial_coarsening.py:33-55 / :58-82 ; kind 0: GridTransferCopy (grid_transfer_copy.py:23-47) */
 static void restrict_vec(int kind, const double *f, int nf, double *c, int nc) {
     if (kind == 0) { memcpy(c, f, sizeof(double) * (size_t)nc); return; }
-    (void)nf;
+    if (kind == 2) { /* periodic full weighting, nf = 2*nc (pymgrit_amd/advection/grid_transfer_advection.py) */
+        for (int i = 0; i < nc; ++i)
+            c[i] = f[(2 * i - 1 + nf) % nf] * 1.0 / 4.0 + f[2 * i] * 1.0 / 2.0 + f[(2 * i + 1) % nf] * 1.0 / 4.0;
+        return;
+    }
     for (int i = 0; i < nc; ++i) c[i] = f[2 * i] * 1.0 / 4.0 + f[2 * i + 1] * 1.0 / 2.0 + f[2 * i + 2] * 1.0 / 4.0;
 }
 
 static void interp_vec(int kind, const double *c, int nc, double *f, int nf) {
     if (kind == 0) { memcpy(f, c, sizeof(double) * (size_t)nf); return; }
+    if (kind == 2) { /* periodic linear interpolation */
+        for (int i = 0; i < nc; ++i) {
+            f[2 * i] = 0.0 + c[i];
+            f[2 * i + 1] = (0.0 + 1.0 / 2.0 * c[i]) + 1.0 / 2.0 * c[(i + 1) % nc];
+        }
+        return;
+    }
     for (int j = 0; j < nf; ++j) f[j] = 0.0;
     for (int i = 0; i < nc; ++i) {
         f[2 * i] += 1.0 / 2.0 * c[i];

@@ -740,8 +740,14 @@ __global__ void restrict_rows_kernel(const double *__restrict__ src, int src_ld,
     if (kind == MGRIT_HIP_TRANSFER_COPY) { c[pos] = f[pos]; return; }
     const int i = row_nat(pos);
     double r = 0.0;
-    if (i < n_c)
-        r = f[row_pos(2 * i)] * 1.0 / 4.0 + f[row_pos(2 * i + 1)] * 1.0 / 2.0 + f[row_pos(2 * i + 2)] * 1.0 / 4.0;
+    if (i < n_c) {
+        if (kind == MGRIT_HIP_TRANSFER_HEAT1D)
+            r = f[row_pos(2 * i)] * 1.0 / 4.0 + f[row_pos(2 * i + 1)] * 1.0 / 2.0 + f[row_pos(2 * i + 2)] * 1.0 / 4.0;
+        else {  // periodic full weighting, n_f = 2 n_c
+            const int nf = 2 * n_c;
+            r = f[row_pos((2 * i - 1 + nf) % nf)] * 1.0 / 4.0 + f[row_pos(2 * i)] * 1.0 / 2.0 + f[row_pos((2 * i + 1) % nf)] * 1.0 / 4.0;
+        }
+    }
     c[pos] = r;
 }
 
@@ -762,7 +768,11 @@ __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, c
     } else {
         const int j = row_nat(pos);
         if (j >= n_f) return;  // padding stays zero
-        if (j & 1) val = 0.0 + at(row_pos(j >> 1));
+        if (kind == MGRIT_HIP_TRANSFER_PERIODIC1D) {
+            const int i = j >> 1;
+            if (j & 1) val = (0.0 + 1.0 / 2.0 * at(row_pos(i))) + 1.0 / 2.0 * at(row_pos((i + 1) % n_c));
+            else val = 0.0 + at(row_pos(i));
+        } else if (j & 1) val = 0.0 + at(row_pos(j >> 1));
         else {
             const int i = j >> 1;
             val = 0.0;
@@ -1631,6 +1641,9 @@ int mgrit_hip_level_transfer(mgrit_hip_engine *e, int lvl, int kind) {
     } else if (kind == MGRIT_HIP_TRANSFER_HEAT1D) {
         if (e->L[lvl].h2d || e->L[lvl + 1].h2d) return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D levels support the copy transfer only");
         if (nf != 2 * nc + 1) return fail(MGRIT_HIP_EINVAL, "full-weighting transfer needs n_fine = 2*n_coarse+1 (%d vs %d)", nf, nc);
+    } else if (kind == MGRIT_HIP_TRANSFER_PERIODIC1D) {
+        if (e->L[lvl].h2d || e->L[lvl + 1].h2d) return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D levels support the copy transfer only");
+        if (nf != 2 * nc) return fail(MGRIT_HIP_EINVAL, "periodic transfer needs n_fine = 2*n_coarse (%d vs %d)", nf, nc);
     } else return fail(MGRIT_HIP_EINVAL, "unknown transfer kind %d", kind);
     e->L[lvl].transfer = kind;
     return 0;

@@ -358,6 +358,55 @@ def make_heat2d():
     print("wrote heat2d fixtures", {k: v["conv"][:2] for k, v in meta["solve"].items()})
 
 
+# --------------------------------------------------------------------------------------------------
+# Advection1D with periodic spatial coarsening (BASELINE config 5 shrunk). The reference has no periodic transfer class;
+# the fixture runs the REFERENCE Mgrit with a user GridTransfer that states the periodic full-weighting / linear
+# arithmetic on the reference's own vector class.
+# --------------------------------------------------------------------------------------------------
+def make_advection_sc():
+    from pymgrit.core.grid_transfer import GridTransfer
+
+    class PeriodicTransfer(GridTransfer):
+        def restriction(self, u):
+            f = u.get_values()
+            n = len(f)
+            ret = np.zeros(n // 2)
+            for i in range(n // 2):
+                ret[i] = f[(2 * i - 1) % n] * 1 / 4 + f[2 * i] * 1 / 2 + f[(2 * i + 1) % n] * 1 / 4
+            out = VectorAdvection1D(n // 2)
+            out.set_values(ret)
+            return out
+
+        def interpolation(self, u):
+            c = u.get_values()
+            nc = len(c)
+            ret = np.zeros(2 * nc)
+            for i in range(nc):
+                ret[2 * i] += c[i]
+                ret[2 * i + 1] += 1 / 2 * c[i]
+                ret[(2 * i - 1) % (2 * nc)] += 1 / 2 * c[i]
+            out = VectorAdvection1D(2 * nc)
+            out.set_values(ret)
+            return out
+
+    out = {}
+    t0 = np.linspace(0, 2, 129)
+    for name, nxs, strides, kw in (("adv_sc_F", [129, 65, 33, 33], [2, 2, 2], dict(cycle_type='F', max_iter=8)),
+                                   ("adv_sc_V", [65, 33], [4], dict(max_iter=8, nested_iteration=False))):
+        ts = [t0]
+        for st in strides:
+            ts.append(ts[-1][::st])
+        prob = [Advection1D(c=1, x_start=-1, x_end=1, nx=nx, t_interval=t) for nx, t in zip(nxs, ts)]
+        tr = [PeriodicTransfer() if nxs[k] != nxs[k + 1] else GridTransferCopy() for k in range(len(nxs) - 1)]
+        m = Mgrit(problem=prob, transfer=tr, logging_lvl=QUIET, **kw)
+        info = m.solve()
+        out[name] = {"nx": nxs, "strides": strides, "conv": [float(c) for c in info["conv"]],
+                     "u_last": np.asarray(m.u[0][128].get_values()).tolist()}
+    with open(os.path.join(HERE, "advection_sc.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("wrote advection_sc", {k: v["conv"][:3] for k, v in out.items()})
+
+
 def ref_results():
     res = {}
     d = os.path.join(REF, "tests", "mpi", "results")
@@ -373,6 +422,9 @@ def main():
     if "--only-heat2d" in sys.argv:
         make_heat2d()
         return
+    if "--only-advection-sc" in sys.argv:
+        make_advection_sc()
+        return
     big = "--small" not in sys.argv
     lay = make_layout()
     with open(os.path.join(HERE, "layout.json"), "w") as f:
@@ -385,6 +437,7 @@ def main():
     with open(os.path.join(HERE, "solve.json"), "w") as f:
         json.dump(sol, f, separators=(",", ":"))
     make_heat2d()
+    make_advection_sc()
     res, kats = ref_results()
     with open(os.path.join(HERE, "ref_results.json"), "w") as f:
         json.dump({"tests_mpi_results": res}, f, indent=1)
