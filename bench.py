@@ -79,6 +79,61 @@ def cpu_baseline(nx, seconds_target=12.0):
                       f"incl. residual check, {el:.1f} s, host has {os.cpu_count()} cores"}
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet, FP64 matrix (the on-box guide lists no f64 MFMA row)
+
+
+def bench_heat2d(args):
+    """Secondary workload (not the driver's default): BASELINE configs[3] = heat_2d nx=ny=512, nt=16385, 2-level m=8.
+    Reports the V-cycle throughput and the MFMA roofline of the level-0 F-relax sweep (per Phi: 4 GEMMs of 512^3 padded
+    = 8*512^3 flops on v_mfma_f64_16x16x4_f64, plus the O(n^2) rhs / epilogue kernels inside the timed launch)."""
+    import torch
+    from pymgrit_amd import Heat2D, Mgrit
+    torch.cuda.set_device(0)
+    nx, nt0 = args.nx2d, args.nt2d
+    t0 = np.linspace(0, 1, nt0)
+    prob = [Heat2D(x_start=0, x_end=1, y_start=0, y_end=1, nx=nx, ny=nx, a=1.0, method="BE",
+                   init_cond=lambda x, y: np.sin(np.pi * x) * np.sin(np.pi * y), t_interval=t) for t in (t0, t0[::8])]
+    mg = Mgrit(prob, cf_iter=1, nested_iteration=False, max_iter=1, tol=0.0, logging_lvl=30)
+    be = mg.backend
+    dof = nx * nx
+    counts = phi_counts([nt0, (nt0 - 1) // 8 + 1], [8])
+
+    def cycle(it):
+        mg.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True)
+        mg.convergence_criterion(iteration=1)
+    cycle(0)
+    for _ in range(args.warmup):
+        cycle(1)
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        cycle(1)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    f_runs = mg._f_runs(0)
+    n_f = sum(r[1] for r in f_runs)
+    be.set_timing(True)
+    ms = []
+    for _ in range(3):
+        be.relax(0, f_runs, 'F')
+        ms.append(be.last_kernel_ms())
+    be.set_timing(False)
+    f_ms = float(np.mean(ms[1:]))
+    M = ((nx - 2 + 63) // 64) * 64
+    tflops = n_f * 8.0 * M ** 3 / (f_ms * 1e-3) / 1e12
+    out = {"metric": "time-point-DOF updates/sec per MGRIT V-cycle", "value": sum(c * dof for c in counts) * args.steps / elapsed,
+           "unit": "time-point-DOF updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"heat_2d nx=ny={nx} nt={nt0} 2-level m=8 FCF V-cycle + residual check (BASELINE configs[3])",
+                      "phi_per_cycle_by_level": counts, "dof": dof},
+           "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "kernel": "level-0 F-relax = per Phi 4 x h2d_gemm_kernel (f64 MFMA) + rhs + epilogue",
+                        "launch_ms": f_ms, "us_per_phi": 1e3 * f_ms / n_f}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,7 +144,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "smoke-test the N>1 path with several ranks on ONE GPU)")
+    ap.add_argument("--workload", default="heat1d", choices=["heat1d", "heat2d"],
+                    help="heat1d = BASELINE configs[2] (default, the driver's run); heat2d = configs[3] on one GPU")
+    ap.add_argument("--nx2d", type=int, default=512)
+    ap.add_argument("--nt2d", type=int, default=16385)
     args = ap.parse_args()
+    if args.workload == "heat2d":
+        return bench_heat2d(args)
 
     import torch
     import torch.distributed as dist

@@ -1704,10 +1704,14 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     if (mode != MGRIT_HIP_RELAX_F && mode != MGRIT_HIP_RELAX_C && mode != MGRIT_HIP_RELAX_CHAIN) return fail(MGRIT_HIP_EINVAL, "bad relax mode %d", mode);
     if ((rc = check_bound(lv, lvl > 0))) return rc;
     if (rl->n == 0) return 0;
-    if (lv.h2d) return h2d_relax(e, lvl, rl, mode, weight_c);
     if (e->timing) {
         if (!e->ev0) { HIP_TRY(hipEventCreate(&e->ev0)); HIP_TRY(hipEventCreate(&e->ev1)); }
         HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    }
+    if (lv.h2d) {
+        if ((rc = h2d_relax(e, lvl, rl, mode, weight_c))) return rc;
+        if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
+        return 0;
     }
     if (mode == MGRIT_HIP_RELAX_CHAIN && lv.G > 1) {
         // sequential chain over several groups: one single-wave workgroup per group, exchange through global granules
