@@ -13,6 +13,14 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def build_problem(case_name, mode):
     import cases
+    if case_name.startswith("h2d:"):
+        prob, opts = cases.h2d_solve_problem(case_name[4:])
+        return prob, None, opts
+    if case_name.startswith("advsc:"):
+        from pymgrit_amd import Advection1D as A1, GridTransferAdvection as GA, GridTransferCopy as GC
+        rec, nxs, ts, transfer, opts = cases.adv_sc_case(case_name[6:])
+        return ([A1(c=1, x_start=-1, x_end=1, nx=nx, t_interval=t) for nx, t in zip(nxs, ts)],
+                [GA() if k == 2 else GC() for k in transfer], opts)
     from pymgrit_amd import Advection1D, Dahlquist, GridTransferCopy, GridTransferHeat, Heat1D
     c = cases.solve_cases()[case_name]
     tr = None

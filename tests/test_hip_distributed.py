@@ -9,7 +9,8 @@ from test_distributed import launch
 pytestmark = pytest.mark.gpu
 
 CASES = [("heat_nx33_V_nested", [2, 3]), ("heat_nx257_nt257", [2]), ("heat_nx33_F_nonested", [3]),
-         ("heat_nx33_V_jump", [2]), ("heat_spatial_coarsening", [2]), ("advection_3lvl_F", [2])]
+         ("heat_nx33_V_jump", [2]), ("heat_spatial_coarsening", [2]), ("advection_3lvl_F", [2]),
+         ("h2d:be_3lvl_F_bc", [2, 3]), ("h2d:cn_2lvl", [2]), ("advsc:adv_sc_F", [3])]
 
 
 @pytest.mark.parametrize("case,sizes", CASES, ids=[c for c, _ in CASES])

@@ -82,6 +82,7 @@ GRIDS3 = [cases.lin(2, 65), cases.lin(2, 17), cases.lin(2, 5)]
 SWEEP_SHAPES = [
     ("heat", 5, GRIDS3), ("heat", 33, GRIDS3), ("heat", 1024, GRIDS3), ("heat", 1027, GRIDS3), ("heat", 2050, GRIDS3),
     ("heat", 4099, GRIDS3), ("heat", 16384, [cases.lin(2, 17), cases.lin(2, 5), cases.lin(2, 3)]),
+    ("heat", 16386, [cases.lin(2, 9), cases.lin(2, 5), cases.lin(2, 3)]),        # n = 16384: the largest supported state
     ("heat", 300, [cases.lin(5, 101), cases.lin(5, 51), cases.lin(5, 26)]),      # several distinct dt per level
     ("advection", 6, GRIDS3), ("advection", 129, GRIDS3), ("advection", 1026, GRIDS3), ("advection", 8193, GRIDS3),
 ]
@@ -294,3 +295,13 @@ def test_full_size_properties_config3(oracle):
         for k in range(1, 4):
             x = op.phi(0, 4 * c_idx + k, x)
             assert np.array_equal(U[4 * c_idx + k][perm].cpu().numpy(), x), (c_idx, k)
+
+
+def test_unsupported_sizes_fail_loudly():
+    """states beyond the register-resident limit (n > 16384) are rejected with an error, never computed elsewhere"""
+    _need_gpu()
+    from pymgrit_amd import Mgrit
+    from pymgrit_amd.core.hip_lib import MgritHipError
+    prob = heat_problem(20000, [cases.lin(2, 9), cases.lin(2, 3)])
+    with pytest.raises(MgritHipError):
+        Mgrit(prob, logging_lvl=30)
