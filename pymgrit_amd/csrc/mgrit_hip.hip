@@ -813,9 +813,13 @@ template <bool SCALE>
 __global__ void __launch_bounds__(256) h2d_gemm_kernel(const double *__restrict__ A, int M, const double *__restrict__ B,
                                                        int N, double *__restrict__ out, const double *__restrict__ dinv,
                                                        size_t bstride) {
-    __shared__ __attribute__((aligned(16))) double As[16][80];
-    __shared__ __attribute__((aligned(16))) double Bs[16][80];
-    __shared__ __attribute__((aligned(16))) double Cs[64][66];
+    // one LDS block, two uses: the A/B staging tiles of the K loop (2 x 32 x 80 doubles) and, after the loop, the 64 x 66
+    // transposition tile of the epilogue. 40 KB per workgroup -> 4 workgroups per CU.
+    constexpr int BK = 32, LDT = 80;
+    __shared__ __attribute__((aligned(16))) double smem[2 * BK * LDT];
+    double(*As)[LDT] = reinterpret_cast<double(*)[LDT]>(smem);
+    double(*Bs)[LDT] = reinterpret_cast<double(*)[LDT]>(smem + BK * LDT);
+    double(*Cs)[66] = reinterpret_cast<double(*)[66]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
     const double *Bb = B + (size_t)blockIdx.z * bstride;
@@ -828,16 +832,16 @@ __global__ void __launch_bounds__(256) h2d_gemm_kernel(const double *__restrict_
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
     const int sr = tid >> 5, sc = (tid & 31) * 2;
-    for (int k0 = 0; k0 < M; k0 += 16) {
+    for (int k0 = 0; k0 < M; k0 += BK) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < BK / 8; ++h) {
             const int r = sr + 8 * h;
             *reinterpret_cast<double2 *>(&As[r][sc]) = *reinterpret_cast<const double2 *>(A + (size_t)(k0 + r) * M + m0 + sc);
             *reinterpret_cast<double2 *>(&Bs[r][sc]) = *reinterpret_cast<const double2 *>(Bb + (size_t)(k0 + r) * N + n0 + sc);
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < BK / 4; ++kk) {
             const double a0 = As[kk * 4 + lk][wm + lr], a1 = As[kk * 4 + lk][wm + 16 + lr];
             const double b0 = Bs[kk * 4 + lk][wn + lr], b1 = Bs[kk * 4 + lk][wn + 16 + lr];
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
