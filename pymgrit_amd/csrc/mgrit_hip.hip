@@ -134,6 +134,7 @@ struct Smem {
     double *ga;     // [2][MAX_G] forward group totals A_g, double-buffered by step parity
     double *gb;     // [2][MAX_G] backward group totals B_g (advection: slot [p][0] carries y-hat of the last real element)
     double *lp;     // [LANES] rho^(E*l) of the current coefficient set
+    double *red;    // [MAX_G] per-wave partial sums of block_sumsq (own slots: persistent kernels reuse the others)
 };
 
 // wave-uniform scalar coefficients of the current coefficient set, forced into SGPRs (readfirstlane)
@@ -178,6 +179,7 @@ __device__ __forceinline__ Smem carve_smem(char *base, int T) {
     s.ga = tail;
     s.gb = tail + 2 * MAX_G;
     s.lp = tail + 4 * MAX_G;
+    s.red = tail + 4 * MAX_G + LANES;
     return s;
 }
 
@@ -415,11 +417,11 @@ __device__ __forceinline__ double block_sumsq(const double (&r)[E], const Smem &
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
     __syncthreads();
-    if (lane == 0) sm.ga[wave] = acc;
+    if (lane == 0) sm.red[wave] = acc;
     __syncthreads();
     double tot = 0.0;
     if (t == 0)
-        for (int g = 0; g < G; ++g) tot = tot + sm.ga[g];
+        for (int g = 0; g < G; ++g) tot = tot + sm.red[g];
     return tot;
 }
 
@@ -441,25 +443,29 @@ enum { ROLE_F = 0, ROLE_C = 1, ROLE_C_WEIGHTED = 2, ROLE_CHAIN = 3 };
 
 template <int KIND, int FORCE, bool USE_G, int ROLE>
 __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *__restrict__ run_start,
-                                                     const int32_t *__restrict__ run_len, double w, double w1) {
+                                                     const int32_t *__restrict__ run_len, int n_runs, double w, double w1) {
     WG_PROLOGUE;
-    const int start = run_start[blockIdx.x], len = run_len[blockIdx.x];
-    double x[E], gi[E];
-    load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
-    for (int i = start; i < start + len; ++i) {
-        if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);  // in flight while Phi runs
-        phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
-        if (USE_G) {
+    // persistent workgroups: the grid is sized to the chip (not to the run list), each workgroup walks the runs with
+    // stride gridDim.x and keeps the coefficient tables of its current time-step size in LDS / SGPRs across runs
+    for (int r = blockIdx.x; r < n_runs; r += gridDim.x) {
+        const int start = run_start[r], len = run_len[r];
+        double x[E], gi[E];
+        load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
+        for (int i = start; i < start + len; ++i) {
+            if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);  // in flight while Phi runs
+            phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+            if (USE_G) {
 #pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = gi[k] + x[k];
-        }
-        if (ROLE == ROLE_C_WEIGHTED) {
-            double uo[E];
-            load_row(L.u + (size_t)i * L.ld, sl, uo);
+                for (int k = 0; k < E; ++k) x[k] = gi[k] + x[k];
+            }
+            if (ROLE == ROLE_C_WEIGHTED) {
+                double uo[E];
+                load_row(L.u + (size_t)i * L.ld, sl, uo);
 #pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = x[k] * w + uo[k] * w1;
+                for (int k = 0; k < E; ++k) x[k] = x[k] * w + uo[k] * w1;
+            }
+            store_row(L.u + (size_t)i * L.ld, sl, x);
         }
-        store_row(L.u + (size_t)i * L.ld, sl, x);
     }
 }
 
@@ -606,18 +612,20 @@ __global__ void __launch_bounds__(64) chain_kernel(LevelDev L, int start, int le
 
 // compute_residual (mgrit.py:387-413): out[run] = || Phi(u_{i-1}) - u_i ||^2
 template <int KIND, int FORCE>
-__global__ void __launch_bounds__(1024) residual_kernel(LevelDev L, const int32_t *__restrict__ run_start,
+__global__ void __launch_bounds__(1024) residual_kernel(LevelDev L, const int32_t *__restrict__ run_start, int n_runs,
                                                         double *__restrict__ out) {
     WG_PROLOGUE;
-    const int i = run_start[blockIdx.x];
-    double x[E], ui[E];
-    load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
-    load_row(L.u + (size_t)i * L.ld, sl, ui);
-    phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+    for (int r = blockIdx.x; r < n_runs; r += gridDim.x) {  // persistent workgroups, tables stay resident
+        const int i = run_start[r];
+        double x[E], ui[E];
+        load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
+        load_row(L.u + (size_t)i * L.ld, sl, ui);
+        phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
 #pragma unroll
-    for (int k = 0; k < E; ++k) x[k] = x[k] - ui[k];
-    const double tot = block_sumsq(x, sm, t, lane, wave, G);
-    if (t == 0) out[blockIdx.x] = tot;
+        for (int k = 0; k < E; ++k) x[k] = x[k] - ui[k];
+        const double tot = block_sumsq(x, sm, t, lane, wave, G);
+        if (t == 0) out[r] = tot;
+    }
 }
 
 // compute_jump (mgrit.py:372-385): out[run] = || u_i - prev_i ||^2
@@ -1123,7 +1131,7 @@ int dev_upload(Level &lv, hipStream_t st, const std::vector<T> &h, T **out) {
     return 0;
 }
 
-size_t smem_bytes(int G) { return (size_t)(8 * G * LANES + 2 * 512) * sizeof(double2) + (4 * MAX_G + LANES) * sizeof(double); }
+size_t smem_bytes(int G) { return (size_t)(8 * G * LANES + 2 * 512) * sizeof(double2) + (5 * MAX_G + LANES) * sizeof(double); }
 
 template <typename K>
 int allow_big_lds(K kernel) {
@@ -1476,6 +1484,13 @@ int check_bound(const Level &lv, bool need_vg) {
     return 0;
 }
 
+// grid of persistent workgroups: as many as stay resident on the chip (LDS- and thread-limited), at most one per item
+int persistent_grid(const Level &lv, int n_items) {
+    const size_t lds = smem_bytes(lv.G);
+    const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / lv.dev.T));
+    return std::min(n_items, 256 * per_cu);
+}
+
 int force_mode(const Level &lv) { return lv.dev.kind != MGRIT_HIP_STEPPER_HEAT1D ? 0 : lv.dev.K == 0 ? 0 : lv.dev.K == 1 ? 1 : 2; }
 
 #define LAUNCH_CASE(kernel, K_, F_, lv, grid, ...)                                                               \
@@ -1747,12 +1762,14 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
                          : (weight_c != 1.0)           ? ROLE_C_WEIGHTED
                                                        : ROLE_C;
         const double w = weight_c, w1 = 1.0 - weight_c;
-        const dim3 grid(rl->n), block(lv.dev.T);
+        // persistent grid: as many workgroups as stay resident (LDS- and thread-limited), at most one per run
         const size_t lds = smem_bytes(lv.G);
+        const dim3 grid(persistent_grid(lv, rl->n)), block(lv.dev.T);
         const int fm = force_mode(lv);
 #define RELAX_CASE(K, F, G_, R)                                                                                    \
     if (lv.dev.kind == K && fm == F && use_g == G_ && role == R)                                                    \
-        hipLaunchKernelGGL((relax_kernel<K, F, G_, R>), grid, block, lds, e->stream, lv.dev, rl->d_start, rl->d_len, w, w1);
+        hipLaunchKernelGGL((relax_kernel<K, F, G_, R>), grid, block, lds, e->stream, lv.dev, rl->d_start, rl->d_len, rl->n, \
+                           w, w1);
 #define RELAX_CASES(K, F)                                                                                          \
     RELAX_CASE(K, F, false, ROLE_F) RELAX_CASE(K, F, true, ROLE_F) RELAX_CASE(K, F, false, ROLE_C)                  \
     RELAX_CASE(K, F, true, ROLE_C) RELAX_CASE(K, F, false, ROLE_C_WEIGHTED) RELAX_CASE(K, F, true, ROLE_C_WEIGHTED) \
@@ -1773,7 +1790,7 @@ int mgrit_hip_residual(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_
     if (rl->n == 0) return 0;
     if (!sumsq_out) return fail(MGRIT_HIP_EINVAL, "null output");
     if (lv.h2d) return h2d_points_sumsq(e, lvl, rl, nullptr, sumsq_out);
-    LAUNCH_BY_KIND(residual_kernel, lv, rl->n, lv.dev, rl->d_start, sumsq_out);
+    LAUNCH_BY_KIND(residual_kernel, lv, persistent_grid(lv, rl->n), lv.dev, rl->d_start, rl->n, sumsq_out);
     return 0;
 }
 
