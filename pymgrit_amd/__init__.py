@@ -1,16 +1,22 @@
-"""pymgrit_amd: MI355X-native MGRIT relaxation engine behind PyMGRIT's Application / Vector / GridTransfer plugin API
-and ``Mgrit(...).solve()`` surface (reference src/pymgrit/__init__.py:1-17 for the export list)."""
-from .advection.advection_1d import Advection1D
-from .advection.grid_transfer_advection import GridTransferAdvection
-from .core.application import Application
-from .core.grid_transfer import GridTransfer
-from .core.grid_transfer_copy import GridTransferCopy
-from .core.mgrit import Mgrit
-from .core.simple_setup_problem import simple_setup_problem
-from .core.vector import Vector
-from .dahlquist.dahlquist import Dahlquist
-from .heat.heat_1d import Heat1D
-from .heat.heat_2d import Heat2D
-from .heat.grid_transfer_heat import GridTransferHeat
+"""pymgrit_amd -- MI355X-native MGRIT relaxation engine behind PyMGRIT's plugin API.
 
-__all__ = [s for s in dir() if not s.startswith('_')]
+Same public names as the reference package for everything on the hot path (``Mgrit``, ``Application``, ``Vector``,
+``GridTransfer``, ``GridTransferCopy``, ``simple_setup_problem``, ``Dahlquist``, ``Heat1D``, ``Heat2D``, ``Advection1D``)
+plus the two spatial-coarsening transfers that run as HIP kernels.
+"""
+from pymgrit_amd.core.application import Application
+from pymgrit_amd.core.vector import Vector
+from pymgrit_amd.core.grid_transfer import GridTransfer
+from pymgrit_amd.core.grid_transfer_copy import GridTransferCopy
+from pymgrit_amd.core.simple_setup_problem import simple_setup_problem
+from pymgrit_amd.core.mgrit import Mgrit
+
+from pymgrit_amd.dahlquist.dahlquist import Dahlquist
+from pymgrit_amd.heat.heat_1d import Heat1D
+from pymgrit_amd.heat.heat_2d import Heat2D
+from pymgrit_amd.heat.grid_transfer_heat import GridTransferHeat
+from pymgrit_amd.advection.advection_1d import Advection1D
+from pymgrit_amd.advection.grid_transfer_advection import GridTransferAdvection
+
+__all__ = ["Application", "Vector", "GridTransfer", "GridTransferCopy", "simple_setup_problem", "Mgrit", "Dahlquist",
+           "Heat1D", "Heat2D", "GridTransferHeat", "Advection1D", "GridTransferAdvection"]

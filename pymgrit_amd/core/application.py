@@ -45,21 +45,8 @@ class Application(object, metaclass=MetaApplication):
             self.t_start, self.t_end, self.nt = t_start, t_stop, nt
             self.t = np.linspace(self.t_start, self.t_end, nt)
 
-    @property
-    def vector_template(self) -> Vector:
-        return self._vector_template
-
-    @vector_template.setter
-    def vector_template(self, value: Vector) -> None:
-        self._vector_template = value
-
-    @property
-    def vector_t_start(self) -> Vector:
-        return self._vector_t_start
-
-    @vector_t_start.setter
-    def vector_t_start(self, value: Vector) -> None:
-        self._vector_t_start = value
+    # vector_template (prototype of a per-time-point state) and vector_t_start (initial condition) are plain attributes
+    # that every subclass assigns in its __init__; MetaApplication verifies their presence right after construction.
 
     @abstractmethod
     def step(self, u_start: Vector, t_start: float, t_stop: float) -> Vector:

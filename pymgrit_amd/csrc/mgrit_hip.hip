@@ -495,12 +495,21 @@ __global__ void __launch_bounds__(64) chain_kernel(LevelDev L, int start, int le
     if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) load_row(reinterpret_cast<const double *>(L.sP), sl, s0);
     load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
     if (USE_G) load_row(L.g + (size_t)start * L.ld, sl, gi);
+    // per-step scalars (coefficient-set index, forcing coefficient) are fetched one step ahead as well: a dependent
+    // global load at the top of every step would sit on the serial critical path
+    int ci_next = L.cidx[start];
+    double tc_next = (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) ? L.tc[start] : 0.0;
     for (int i = start; i < start + len; ++i) {
         const unsigned epoch = (unsigned)(i - start + 1);
         u64 *slots = gran + (size_t)(epoch & 1) * MAX_G * 4;
+        const int ci = __builtin_amdgcn_readfirstlane(ci_next);
+        const double tc_i = tc_next;
         // g of the NEXT step: a whole step of latency hiding (HBM ~2 us vs ~2 us per step)
-        if (USE_G && i + 1 < start + len) load_row(L.g + (size_t)(i + 1) * L.ld, sl, gn);
-        const int ci = __builtin_amdgcn_readfirstlane(L.cidx[i]);
+        if (i + 1 < start + len) {
+            if (USE_G) load_row(L.g + (size_t)(i + 1) * L.ld, sl, gn);
+            ci_next = L.cidx[i + 1];
+            if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) tc_next = L.tc[i + 1];
+        }
         if (ci != cur) {
             const CSet *g = L.cs + ci;
             load_coef<false>(c, g);
@@ -513,9 +522,8 @@ __global__ void __launch_bounds__(64) chain_kernel(LevelDev L, int start, int le
         double v0, v1 = 0.0;  // the two published values of this worker
         if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
             if (FORCE == 1) {
-                const double c0 = L.tc[i];
 #pragma unroll
-                for (int k = 0; k < E; ++k) x[k] = fma(s0[k], c0, x[k]);
+                for (int k = 0; k < E; ++k) x[k] = fma(s0[k], tc_i, x[k]);
             } else if (FORCE == 2) {
                 for (int kk = 0; kk < L.K; ++kk) {
                     const double ck = L.tc[(size_t)kk * L.n_pts + i];
@@ -571,6 +579,9 @@ __global__ void __launch_bounds__(64) chain_kernel(LevelDev L, int start, int le
                     if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     return;  // bounded spin: give up, the host reports the failure
                 }
+#ifdef MGRIT_CHAIN_SLEEP
+                __builtin_amdgcn_s_sleep(MGRIT_CHAIN_SLEEP);
+#endif
             }
         }
         // group (lane & 15) totals: hi/lo halves sit in lanes 4g .. 4g+3

@@ -1,6 +1,9 @@
-"""Dahlquist test problem u' = lambda*u, u(0) = 1 (scalar ODE). Drop-in for the reference's
-``pymgrit.dahlquist.dahlquist`` (reference src/pymgrit/dahlquist/dahlquist.py:12-111). A scalar state has nothing to
-offload: this Application carries no device description and runs on the plugin path (BASELINE config 1: CPU plumbing)."""
+"""Dahlquist test problem u' = lambda*u, u(0) = 1: scalar state, four one-step methods.
+
+API mirror of the reference's ``pymgrit.dahlquist.dahlquist`` (reference src/pymgrit/dahlquist/dahlquist.py:12-111).
+A scalar has nothing to offload: this Application carries no device description and always runs on the plugin path
+(BASELINE config 1 is the CPU plumbing case).
+"""
 import numpy as np
 
 from pymgrit_amd.core.application import Application
@@ -8,42 +11,53 @@ from pymgrit_amd.core.vector import Vector
 
 
 class VectorDahlquist(Vector):
+    """One float per time point."""
+
     def __init__(self, value):
         super().__init__()
         self.value = value
 
+    # value-semantics algebra
     def __add__(self, other):
-        return VectorDahlquist(self.get_values() + other.get_values())
+        return type(self)(self.value + other.get_values())
 
     def __sub__(self, other):
-        return VectorDahlquist(self.get_values() - other.get_values())
+        return type(self)(self.value - other.get_values())
 
-    def __mul__(self, other):
-        return VectorDahlquist(self.get_values() * other)
+    def __mul__(self, factor):
+        return type(self)(self.value * factor)
 
     def norm(self):
         return np.linalg.norm(self.value)
 
+    # construction
     def clone(self):
-        return VectorDahlquist(self.value)
+        return type(self)(self.value)
 
     def clone_zero(self):
-        return VectorDahlquist(0)
+        return type(self)(0)
 
     def clone_rand(self):
-        return VectorDahlquist(np.random.rand(1)[0])
+        return type(self)(np.random.rand(1)[0])
+
+    # data access / exchange payload: the float itself
+    def get_values(self):
+        return self.value
 
     def set_values(self, value):
         self.value = value
 
-    def get_values(self):
-        return self.value
+    pack = get_values
+    unpack = set_values
 
-    def pack(self):
-        return self.value
 
-    def unpack(self, value):
-        self.value = value
+def _amplification(method, z):
+    """u_new = amp(z) * u for BE / FE / TR, z = dt*lambda (dahlquist.py:99-105)."""
+    if method == 'BE':
+        return 1 / (1 - z)
+    if method == 'FE':
+        return 1 + z
+    return (1 + z / 2) / (1 - z / 2)
 
 
 class Dahlquist(Application):
@@ -51,25 +65,20 @@ class Dahlquist(Application):
 
     def __init__(self, constant_lambda=-1, method='BE', *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.vector_template = VectorDahlquist(0)
-        self.vector_t_start = VectorDahlquist(1)
-        self.lambda_value = constant_lambda
         if method not in self.METHODS:
             raise Exception('Unknown method. Choose BE (Backward Euler), FE (Forward Euler), TR (Trapezoidal rule) '
                             'or MR (implicit mid-point rule)')
         self.method = method
+        self.lambda_value = constant_lambda
+        self.vector_t_start = VectorDahlquist(1)
+        self.vector_template = VectorDahlquist(0)
 
     def step(self, u_start: VectorDahlquist, t_start: float, t_stop: float) -> VectorDahlquist:
-        """BE / FE / TR closed forms; MR as written in the reference (its k1 hard-codes lambda = -1)."""
+        dt = t_stop - t_start
+        z = dt * self.lambda_value
         u = u_start.get_values()
-        z = (t_stop - t_start) * self.lambda_value
-        if self.method == 'BE':
-            new = 1 / (1 - z) * u
-        elif self.method == 'FE':
-            new = (1 + z) * u
-        elif self.method == 'TR':
-            new = (1 + z / 2) / (1 - z / 2) * u
-        else:
-            k1 = -1 / (1 - z / 2) * u
-            new = u + (t_stop - t_start) * k1
-        return VectorDahlquist(new)
+        if self.method == 'MR':
+            # implicit mid-point rule exactly as the reference writes it: the slope hard-codes lambda = -1
+            slope = -1 / (1 - z / 2) * u
+            return VectorDahlquist(u + dt * slope)
+        return VectorDahlquist(_amplification(self.method, z) * u)
