@@ -75,3 +75,36 @@ def test_config5_scale_sweeps_bit_exact(oracle):
     for lvl in (1, 0):
         mg.error_correction(lvl); op.error_correction(lvl)
         assert_state_equal(mg, op)
+
+
+@pytest.mark.gpu
+def test_config5_full_size_properties(oracle):
+    """BASELINE config 5 at FULL size: 8192 periodic points, nt=32769, 4 levels m=2, periodic coarsening on the first two
+    level pairs. F-cycle runs and contracts; F-relax idempotent; restriction of a constant is that constant and
+    interpolation reproduces constants (partition of unity) on the full slabs; a sampled step equals the oracle."""
+    import torch
+    from pymgrit_amd import Advection1D, GridTransferAdvection, GridTransferCopy, Mgrit
+    t0 = np.linspace(0, 2, 32769)
+    ts, nxs = [t0, t0[::2], t0[::4], t0[::8]], [8193, 4097, 2049, 2049]
+    prob = [Advection1D(c=1, x_start=-1, x_end=1, nx=nx, t_interval=t) for nx, t in zip(nxs, ts)]
+    tr = [GridTransferAdvection(), GridTransferAdvection(), GridTransferCopy()]
+    mg = Mgrit(prob, transfer=tr, cycle_type='F', nested_iteration=True, max_iter=2, tol=0.0, logging_lvl=30)
+    conv = mg.solve()["conv"]
+    assert len(conv) == 2 and conv[1] < conv[0]
+    before = mg.backend.U[0].clone()
+    mg.f_relax(0)
+    once = mg.backend.U[0].clone()
+    mg.f_relax(0)
+    assert torch.equal(once, mg.backend.U[0]) and before.shape == once.shape
+    # sampled step vs the oracle
+    op = oracle.OracleProblem([cases.advection_level_spec(8193, t0[:3])], variant=1)
+    x = mg.backend.natural("u", 0)[16384]
+    assert np.array_equal(mg.backend.natural("u", 0)[16385], op.phi(0, 1, x))
+    # transfers on constants
+    mg.backend.U[0].zero_()
+    mg.backend.U[0][:, mg.backend.perm[0]] = 3.0
+    mg.backend.restrict_u(0, mg._pairs(0, skip_first=False))
+    got = mg.backend.natural("u", 1)
+    assert np.all(got == 3.0)
+    mg.backend.interpolate(0, mg._pairs(0, skip_first=True))
+    assert np.all(mg.backend.natural("u", 0) == 3.0)

@@ -120,3 +120,39 @@ def test_config4_size_properties():
     U[::8, :512 * 512] = (4.0 * c).reshape(len(ts[1]), -1).to(U.device)
     mg.f_relax(0)
     assert torch.equal(first * 4.0, U)
+
+
+def test_config4_full_size_properties():
+    """BASELINE config 4 at FULL size: 512x512 states, nt=16385, m=8 (34 GB level-0 slab). F-relax idempotence and zero
+    F-point residual over the whole grid, exact scaling linearity, agreement of a sampled interval with the host stepper."""
+    from pymgrit_amd import Mgrit
+    from pymgrit_amd.heat.heat_2d import Heat2D, VectorHeat2D
+    free, _ = torch.cuda.mem_get_info()
+    if free < 70 * 2 ** 30:
+        pytest.skip("needs ~60 GB of free HBM")
+    ts = cases.h2d_grids([16385, 2049])
+    prob = [Heat2D(x_start=0, x_end=1, y_start=0, y_end=1, nx=512, ny=512, a=1.0, method="BE", t_interval=t) for t in ts]
+    mg = Mgrit(prob, nested_iteration=False, logging_lvl=30)
+    U = mg.backend.U[0]
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    base = torch.randn((512, 512), generator=gen, dtype=torch.float64)
+    base[0, :] = 0; base[-1, :] = 0; base[:, 0] = 0; base[:, -1] = 0
+    scale = torch.linspace(0.5, 1.5, len(ts[1]), dtype=torch.float64)
+    U[::8, :512 * 512] = (scale[:, None] * base.reshape(1, -1)).to(U.device)
+    mg.f_relax(0)
+    ref_rows = U[8 * 1000 + 1:8 * 1000 + 8].clone()
+    first_sum = U.sum().item()
+    mg.f_relax(0)
+    assert torch.equal(ref_rows, U[8 * 1000 + 1:8 * 1000 + 8]) and U.sum().item() == first_sum
+    fpts = [int(i) for i in np.sort(mg.index_local_f[0])]
+    assert max(mg.backend.residual_norms(fpts[:3000] + fpts[-3000:])) == 0.0
+    # host stepper on one interval (same algorithm in numpy: agreement to rounding)
+    v = VectorHeat2D(512, 512)
+    v.set_values((scale[1000] * base).numpy())
+    for k in range(1, 4):
+        v = prob[0].step(v, ts[0][8000 + k - 1], ts[0][8000 + k])
+        got = U[8000 + k, :512 * 512].cpu().numpy().reshape(512, 512)
+        assert np.abs(got - v.get_values()).max() <= 1e-12 * np.abs(got).max()
+    U[::8, :512 * 512] = (2.0 * scale[:, None] * base.reshape(1, -1)).to(U.device)
+    mg.f_relax(0)
+    assert torch.equal(ref_rows * 2.0, U[8 * 1000 + 1:8 * 1000 + 8])

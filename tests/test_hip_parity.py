@@ -252,14 +252,14 @@ def test_auto_detected_separable_forcing():
 
 
 def test_full_size_properties_config3(oracle):
-    """BASELINE config 3 level-0 slab (nx=16384, nt=65537 is 8.6 GB; here nt=8193 keeps the test short while every
-    workgroup still runs the 16-wave / 16384-DOF path): size-independent properties
+    """BASELINE config 3 at FULL size (nx=16384, nt=65537: 8.6 GB level-0 slab, 2 levels m=4 here): size-independent
+    properties
       * F-relax is idempotent bit for bit and leaves zero residual at F-points;
       * with zero forcing Phi is linear: scaling the state by 2^k scales the result exactly;
       * a sampled set of intervals equals the oracle bit for bit."""
     _need_gpu()
     from pymgrit_amd import Mgrit
-    nt = 8193
+    nt = 65537
     grids = [cases.lin(2.0 * (nt - 1) / 65536, nt), cases.lin(2.0 * (nt - 1) / 65536, (nt - 1) // 4 + 1)]
     prob = heat_problem(16384, grids, forcing=False)
     mg = Mgrit(prob, nested_iteration=False, logging_lvl=30)
@@ -290,7 +290,7 @@ def test_full_size_properties_config3(oracle):
     spec = cases.heat_level_spec(16384, grids[0], forcing=False)
     op = oracle.OracleProblem([spec, cases.heat_level_spec(16384, grids[1], forcing=False)], variant=1,
                               nested_iteration=False)
-    for c_idx in (0, 1024, 2047):
+    for c_idx in (0, 8191, 16383):
         x = (cvals[c_idx] * 8.0).numpy()
         for k in range(1, 4):
             x = op.phi(0, 4 * c_idx + k, x)
