@@ -1190,7 +1190,7 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
                     MGRIT_HIP_MAX_N);
     if (ld != mgrit_hip_row_stride(n)) return fail(MGRIT_HIP_EINVAL, "ld=%d must equal mgrit_hip_row_stride(n=%d)=%d", ld, n, mgrit_hip_row_stride(n));
     if (n_pts < 0 || (n_pts > 0 && !t_local)) return fail(MGRIT_HIP_EINVAL, "bad local time grid");
-    if (K < 0 || K > 8 || (K > 0 && (!s || !tau))) return fail(MGRIT_HIP_EINVAL, "bad forcing description (K=%d)", K);
+    if (K < 0 || K > 8 || (K > 0 && (!s || (n_pts > 0 && !tau)))) return fail(MGRIT_HIP_EINVAL, "bad forcing description (K=%d)", K);
     if ((rc = setup_kernel_attrs())) return rc;
     Level &lv = e->L[lvl];
     if (lv.set) return fail(MGRIT_HIP_EINVAL, "level %d already described", lvl);
@@ -1490,6 +1490,8 @@ int get_pairs(mgrit_hip_engine *e, int lvl, int id, PairList **out) {
 }
 
 int check_bound(const Level &lv, bool need_vg) {
+    const int n_pts = lv.dev.n_pts;
+    if (n_pts == 0) return 0;   // a rank that owns no point of this level has nothing to bind
     if (!lv.dev.u) return fail(MGRIT_HIP_EINVAL, "state slabs not bound");
     if (need_vg && (!lv.dev.v || !lv.dev.g)) return fail(MGRIT_HIP_EINVAL, "v/g slabs not bound");
     return 0;
@@ -1605,7 +1607,7 @@ int mgrit_hip_level_heat2d(mgrit_hip_engine *e, int lvl, int n_pts_local, const 
     if (ld < nx * ny || (ld % 16) != 0) return fail(MGRIT_HIP_EINVAL, "ld=%d must be a multiple of 16 and >= nx*ny=%d", ld, nx * ny);
     if (!(theta == 0.0 || theta == 0.5 || theta == 1.0)) return fail(MGRIT_HIP_EINVAL, "theta must be 0 (FE), 0.5 (CN) or 1 (BE)");
     if (n_pts_local < 0 || (n_pts_local > 0 && !t_local) || !bc) return fail(MGRIT_HIP_EINVAL, "bad arguments");
-    if (K < 0 || K > 8 || (K > 0 && (!S || !tau))) return fail(MGRIT_HIP_EINVAL, "bad forcing description (K=%d)", K);
+    if (K < 0 || K > 8 || (K > 0 && (!S || (n_pts_local > 0 && !tau)))) return fail(MGRIT_HIP_EINVAL, "bad forcing description (K=%d)", K);
     Level &lv = e->L[lvl];
     if (lv.set) return fail(MGRIT_HIP_EINVAL, "level %d already described", lvl);
     H2DHost *h = new H2DHost();

@@ -22,7 +22,7 @@ def build_problem(case_name, mode):
         return ([A1(c=1, x_start=-1, x_end=1, nx=nx, t_interval=t) for nx, t in zip(nxs, ts)],
                 [GA() if k == 2 else GC() for k in transfer], opts)
     from pymgrit_amd import Advection1D, Dahlquist, GridTransferCopy, GridTransferHeat, Heat1D
-    c = cases.solve_cases()[case_name]
+    c = {**cases.solve_cases(), **cases.extra_cases()}[case_name]
     tr = None
     if c.get("transfer") is not None:
         tr = [GridTransferHeat() if k == 1 else GridTransferCopy() for k in c["transfer"]]

@@ -37,8 +37,11 @@ def launch(world, case, mode="plugin", backend="gloo", timeout=600):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    for r, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    bad = [r for r, p in enumerate(procs) if p.returncode != 0]
+    if bad:
+        # a rank that only saw its peer disappear is an echo of the real failure: show the root cause first
+        root = [r for r in bad if "Connection closed by peer" not in logs[r]] or bad
+        raise AssertionError(f"ranks {bad} failed; rank {root[0]}:\n{logs[root[0]][-3000:]}")
     res = [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(world)]
     conv = res[0]["conv"]
     for r in res[1:]:
@@ -57,6 +60,7 @@ CASES = [
     ("heat_nx33_F_nonested", [3]),
     ("heat_nx33_V_jump", [2]),                  # conv_crit=1
     ("heat_spatial_coarsening", [2]),
+    ("heat_nx33_procs_without_points", [5]),
 ]
 
 
