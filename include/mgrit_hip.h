@@ -22,11 +22,13 @@ extern "C" {
 #define MGRIT_HIP_ABI_VERSION 1
 #define MGRIT_HIP_E 16            /* elements per lane (arithmetic spec) */
 #define MGRIT_HIP_MAX_N 16384     /* max DOFs per time point for the register-resident steppers */
+#define MGRIT_HIP_MAX_N_2PTS 4096 /* two-point steppers: max DOFs per time point of a pair (two coefficient sets in LDS) */
 
 typedef struct mgrit_hip_engine mgrit_hip_engine;
 
 enum { MGRIT_HIP_OK = 0, MGRIT_HIP_EINVAL = -1, MGRIT_HIP_EHIP = -2, MGRIT_HIP_ENODEV = -3, MGRIT_HIP_EUNSUPPORTED = -4 };
-enum { MGRIT_HIP_STEPPER_HEAT1D = 1, MGRIT_HIP_STEPPER_ADVECTION1D = 2, MGRIT_HIP_STEPPER_HEAT2D = 3 };
+enum { MGRIT_HIP_STEPPER_HEAT1D = 1, MGRIT_HIP_STEPPER_ADVECTION1D = 2, MGRIT_HIP_STEPPER_HEAT2D = 3,
+       MGRIT_HIP_STEPPER_HEAT1D_2PTS = 4 };
 enum { MGRIT_HIP_TRANSFER_COPY = 0, MGRIT_HIP_TRANSFER_HEAT1D = 1, MGRIT_HIP_TRANSFER_PERIODIC1D = 2 };
 enum { MGRIT_HIP_RELAX_F = 0, MGRIT_HIP_RELAX_C = 1, MGRIT_HIP_RELAX_CHAIN = 2 };
 
@@ -51,6 +53,14 @@ int mgrit_hip_sync(mgrit_hip_engine *e);
  */
 int mgrit_hip_level_heat1d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int n, int ld,
                            double fac, int K, const double *s, const double *tau);
+/* Replaces Heat1DBDF1.step / Heat1DBDF2.step (heat/heat_1d_2pts_bdf1.py:84-117, heat/heat_1d_2pts_bdf2.py:82-138): a state
+ * is the pair (u(t), u(t + dtau)) of VectorHeat1D2Pts (heat/vector_heat_1d_2pts.py:9-140) stored as one slab row
+ * [first | second], each half laid out like a Heat1D row of n values: ld = 2 * mgrit_hip_row_stride(n). One Phi = two
+ * tridiagonal Toeplitz solves: order 1: backward Euler t_{i-1}+dtau -> t_i -> t_i+dtau; order 2: variable-step BDF2.
+ * Forcing b(x,t) = sum_k s[k][n] * tau_k(t) with tau[k][i] = tau_k(t_i) and tau2[k][i] = tau_k(t_i + dtau). */
+int mgrit_hip_level_heat1d_2pts(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int n, int ld,
+                                double fac, double dtau, int order, int K, const double *s, const double *tau,
+                                const double *tau2);
 /* Replaces Advection1D.compute_matrix/step (advection/advection_1d.py:101-143): (I + dt*fac*(I - S_periodic)) x = u */
 int mgrit_hip_level_advection1d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int n, int ld,
                                 double fac);

@@ -323,10 +323,22 @@ double orc_sumsq_spec(const double *r, int n) {
     return tot;
 }
 
+/* two-point states [first | second] (vector_heat_1d_2pts.py:66-72, norm of the appended halves): the groups of `first`,
+ * then the groups of `second`, one serial sum */
+static double sumsq_groups(const double *r, int n, double tot) {
+    int G = (n + ORC_GROUP - 1) / ORC_GROUP;
+    for (int g = 0; g < G; ++g) {
+        int len = n - g * ORC_GROUP < ORC_GROUP ? n - g * ORC_GROUP : ORC_GROUP;
+        tot = tot + orc_sumsq_spec(r + (size_t)g * ORC_GROUP, len);
+    }
+    return tot;
+}
+double orc_sumsq_spec_2pts(const double *r, int n) { return sumsq_groups(r + n, n, sumsq_groups(r, n, 0.0)); }
+
 /* ================================================================================================
  * Steppers
  * ============================================================================================== */
-enum { ORC_DAHLQUIST = 0, ORC_HEAT1D = 1, ORC_ADVECTION1D = 2, ORC_HEAT2D = 3 };
+enum { ORC_DAHLQUIST = 0, ORC_HEAT1D = 1, ORC_ADVECTION1D = 2, ORC_HEAT2D = 3, ORC_HEAT1D_2PTS = 4 };
 enum { ORC_BE = 0, ORC_FE = 1, ORC_TR = 2, ORC_MR = 3 };
 
 typedef struct {
@@ -336,6 +348,8 @@ typedef struct {
     int K;                 /* separable forcing terms: b(x,t_i) = sum_k s_k(x)*tau_k(t_i) */
     double *s;             /* [K][n] */
     double *tau;           /* [K][nt] */
+    double *tau2;          /* two-point steppers: [K][nt] tau_k(t_i + dtau) */
+    double dtau;           /* two-point steppers: spacing inside a pair; method = BDF order (1 or 2) */
     orc_cset *csets; int n_csets, cap_csets;
     double *w1, *w2;       /* work (padded) */
     /* heat2d (heat_2d.py:147-366): full nx x ny grid incl. the rim; interior mi x mj, padded to Mi x Mj (multiples of 64) */
@@ -354,8 +368,8 @@ static orc_cset *get_cset(orc_stepper *st, double dt) {
     }
     orc_cset *c = &st->csets[st->n_csets++];
     memset(c, 0, sizeof(*c));
-    if (st->kind == ORC_HEAT1D) cset_heat1d(c, st->n, st->fac, dt);
-    else cset_advection1d(c, st->n, st->fac, dt);
+    if (st->kind == ORC_ADVECTION1D) cset_advection1d(c, st->n, st->fac, dt);
+    else cset_heat1d(c, st->n, st->fac, dt);
     return c;
 }
 
@@ -372,12 +386,8 @@ static void heat1d_rhs(const orc_stepper *st, int nt, int i_stop, double dt, con
     }
 }
 
-static void heat1d_step_natural(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out) {
-    int n = st->n;
-    double beta = dt * st->fac, D = dt * (2.0 * st->fac) + 1.0;
-    double *d = st->w1, *cp = st->w2;
-    heat1d_rhs(st, nt, i_stop, dt, u, d);
-    /* Thomas algorithm on tridiag(-beta, D, -beta) */
+/* Thomas algorithm on tridiag(-beta, D, -beta); d is overwritten */
+static void thomas_toeplitz(int n, double beta, double D, double *d, double *cp, double *out) {
     double piv = D;
     cp[0] = -beta / piv; d[0] = d[0] / piv;
     for (int j = 1; j < n; ++j) {
@@ -387,6 +397,12 @@ static void heat1d_step_natural(orc_stepper *st, int nt, int i_stop, double dt, 
     }
     out[n - 1] = d[n - 1];
     for (int j = n - 2; j >= 0; --j) out[j] = d[j] - cp[j] * out[j + 1];
+}
+
+static void heat1d_step_natural(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out) {
+    double beta = dt * st->fac, D = dt * (2.0 * st->fac) + 1.0;
+    heat1d_rhs(st, nt, i_stop, dt, u, st->w1);
+    thomas_toeplitz(st->n, beta, D, st->w1, st->w2, out);
 }
 
 /* Cross-group carries: the <= 16 group totals sit in one row of 16 lanes; inclusive Kogge-Stone
@@ -405,17 +421,10 @@ static void cross_scan(const orc_cset *c, double *a, int backward) {
 
 /* Spec variant of the Heat1D step: every group scans locally forward and backward, ONE exchange of the
  * group totals (A_g, B_g), two short carry chains, then one pass that adds the carries and the rank-one correction. */
-static void heat1d_step_spec(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out) {
-    int n = st->n, NP = padded(n), G = NP / ORC_GROUP;
-    orc_cset *c = get_cset(st, dt);
-    double *d = st->w1;
+/* x = (I + dt*L)^{-1} d for the coefficient set c; d (padded work array, first n entries filled) is overwritten */
+static void heat_solve_spec(const orc_cset *c, int n, double *d, double *out) {
+    int NP = padded(n), G = NP / ORC_GROUP;
     double A[16] = {0}, B[16] = {0}, C[17] = {0}, Zf[17] = {0};
-    /* d = u + dt*b(x, t_i) with the forcing folded as fma(s_k, tau_k*dt, .) */
-    for (int j = 0; j < n; ++j) {
-        double v = u[j];
-        for (int k = 0; k < st->K; ++k) v = fma(st->s[(size_t)k * n + j], st->tau[(size_t)k * nt + i_stop] * dt, v);
-        d[j] = v;
-    }
     for (int j = n; j < NP; ++j) d[j] = 0.0;
     for (int g = 0; g < G; ++g) {
         double *dg = d + (size_t)g * ORC_GROUP;
@@ -443,6 +452,90 @@ static void heat1d_step_spec(orc_stepper *st, int nt, int i_stop, double dt, con
                 out[j] = fma(-z0, c->tab[j], z * c->ik);
             }
         }
+    }
+}
+
+static void heat1d_step_spec(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out) {
+    int n = st->n;
+    orc_cset *c = get_cset(st, dt);
+    double *d = st->w1;
+    /* d = u + dt*b(x, t_i) with the forcing folded as fma(s_k, tau_k*dt, .) */
+    for (int j = 0; j < n; ++j) {
+        double v = u[j];
+        for (int k = 0; k < st->K; ++k) v = fma(st->s[(size_t)k * n + j], st->tau[(size_t)k * nt + i_stop] * dt, v);
+        d[j] = v;
+    }
+    heat_solve_spec(c, n, d, out);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Two-point steppers (heat/heat_1d_2pts_bdf1.py:84-117, heat/heat_1d_2pts_bdf2.py:82-138): a state is the pair
+ * (first, second) = values at t and t + dtau, stored [first | second], n = st->n values each.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { double dt_eff, a, nb, fs; } orc_half;  /* spec coefficients of one half-solve */
+
+/* BDF2 coefficients of heat_1d_2pts_bdf2.py:103-110 for (tau_i, tau_im1), rewritten for the scaled system
+ * (I + L/c) x = rhs/c : dt_eff = 1/c, a = cm1/c, nb = -cm2/c, forcing scale fs = 1/c */
+static orc_half bdf2_half(double tau_i, double tau_im1) {
+    orc_half h;
+    double r = tau_i / tau_im1;
+    double cm2 = (r * r) / (tau_i * (1.0 + r));
+    double cm1 = (1.0 + r) / tau_i;
+    double c = (1.0 + 2.0 * r) / (tau_i * (1.0 + r));
+    double inv = 1.0 / c;
+    h.dt_eff = inv; h.a = cm1 * inv; h.nb = -(cm2 * inv); h.fs = inv;
+    return h;
+}
+
+static void twopts_step_natural(orc_stepper *st, int nt, int i_stop, double t_start, double t_stop, const double *u, double *out) {
+    int n = st->n;
+    const double *first = u, *second = u + n;
+    double *o1 = out, *o2 = out + n, *d = st->w1;
+    double dtau = st->dtau;
+    for (int half = 0; half < 2; ++half) {
+        const double *tau = half ? st->tau2 : st->tau;
+        const double *x_old = half ? second : first, *x_new = half ? o1 : second;  /* values two / one point back */
+        if (st->method == 1) {  /* spsolve(tau*L + I, x_new + rhs*tau) */
+            double tl = half ? dtau : t_stop - t_start - dtau;
+            for (int j = 0; j < n; ++j) {
+                double f = 0.0;
+                if (st->K > 0) { f = st->s[j] * tau[i_stop]; for (int k = 1; k < st->K; ++k) f = f + st->s[(size_t)k * n + j] * tau[(size_t)k * nt + i_stop]; }
+                d[j] = st->K > 0 ? x_new[j] + f * tl : x_new[j];
+            }
+            thomas_toeplitz(n, tl * st->fac, tl * (2.0 * st->fac) + 1.0, d, st->w2, half ? o2 : o1);
+        } else {                /* spsolve(L + coeff*I, rhs - coeffm2*x_old + coeffm1*x_new) */
+            double tau_i = half ? dtau : t_stop - t_start - dtau, tau_im1 = half ? t_stop - t_start - dtau : dtau;
+            double r = tau_i / tau_im1;
+            double cm2 = (r * r) / (tau_i * (1.0 + r)), cm1 = (1.0 + r) / tau_i, c = (1.0 + 2.0 * r) / (tau_i * (1.0 + r));
+            for (int j = 0; j < n; ++j) {
+                double f = 0.0;
+                if (st->K > 0) { f = st->s[j] * tau[i_stop]; for (int k = 1; k < st->K; ++k) f = f + st->s[(size_t)k * n + j] * tau[(size_t)k * nt + i_stop]; }
+                d[j] = f - cm2 * x_old[j] + cm1 * x_new[j];
+            }
+            thomas_toeplitz(n, st->fac, 2.0 * st->fac + c, d, st->w2, half ? o2 : o1);
+        }
+    }
+}
+
+/* Spec variant: each half-solve is base -> forcing fma chain -> heat_solve_spec with the coefficient set of dt_eff.
+ * BDF1: base = x_new, forcing scale = tau_l (the half's step). BDF2: base = fma(a, x_new, nb*x_old), see bdf2_half. */
+static void twopts_step_spec(orc_stepper *st, int nt, int i_stop, double t_start, double t_stop, const double *u, double *out) {
+    int n = st->n;
+    const double *first = u, *second = u + n;
+    double *o1 = out, *o2 = out + n, *d = st->w1;
+    double dtau = st->dtau, tl0 = t_stop - t_start - dtau;
+    for (int half = 0; half < 2; ++half) {
+        const double *tau = half ? st->tau2 : st->tau;
+        const double *x_old = half ? second : first, *x_new = half ? o1 : second;
+        orc_half h;
+        if (st->method == 1) { h.dt_eff = half ? dtau : tl0; h.a = 1.0; h.nb = 0.0; h.fs = h.dt_eff; }
+        else h = half ? bdf2_half(dtau, tl0) : bdf2_half(tl0, dtau);
+        for (int j = 0; j < n; ++j) {
+            double v = st->method == 1 ? x_new[j] : fma(h.a, x_new[j], h.nb * x_old[j]);
+            for (int k = 0; k < st->K; ++k) v = fma(st->s[(size_t)k * n + j], tau[(size_t)k * nt + i_stop] * h.fs, v);
+            d[j] = v;
+        }
+        heat_solve_spec(get_cset(st, h.dt_eff), n, d, half ? o2 : o1);
     }
 }
 
@@ -650,7 +743,7 @@ orc_problem *orc_problem_create(int n_levels) {
 
 static void free_stepper(orc_stepper *st) {
     for (int i = 0; i < st->n_csets; ++i) free(st->csets[i].tab);
-    free(st->csets); free(st->s); free(st->tau); free(st->w1); free(st->w2);
+    free(st->csets); free(st->s); free(st->tau); free(st->tau2); free(st->w1); free(st->w2);
     free(st->bc); free(st->W); free(st->Qx); free(st->Qy); free(st->lx); free(st->ly); free(st->dinv); free(st->X0); free(st->X1);
 }
 
@@ -688,6 +781,24 @@ void orc_problem_set_level_heat1d(orc_problem *p, int lvl, int nt, const double 
         st->tau = (double *)malloc(sizeof(double) * (size_t)K * nt);
         memcpy(st->s, s, sizeof(double) * (size_t)K * n);
         memcpy(st->tau, tau, sizeof(double) * (size_t)K * nt);
+    }
+}
+
+/* two-point heat stepper: n values per time point of the pair (state = 2n), order = 1 (BDF1) or 2 (BDF2);
+ * tau: [K][nt] tau_k(t_i), tau2: [K][nt] tau_k(t_i + dtau); u0: [2n] */
+void orc_problem_set_level_heat1d_2pts(orc_problem *p, int lvl, int nt, const double *t, int n, double fac, double dtau,
+                                       int order, int K, const double *s, const double *tau, const double *tau2,
+                                       const double *u0, int variant) {
+    level_common(p, lvl, nt, t, 2 * n, u0);
+    orc_stepper *st = &p->L[lvl].st;
+    st->kind = ORC_HEAT1D_2PTS; st->variant = variant; st->fac = fac; st->K = K; st->n = n; st->dtau = dtau; st->method = order;
+    if (K > 0) {
+        st->s = (double *)malloc(sizeof(double) * (size_t)K * n);
+        st->tau = (double *)malloc(sizeof(double) * (size_t)K * nt);
+        st->tau2 = (double *)malloc(sizeof(double) * (size_t)K * nt);
+        memcpy(st->s, s, sizeof(double) * (size_t)K * n);
+        memcpy(st->tau, tau, sizeof(double) * (size_t)K * nt);
+        memcpy(st->tau2, tau2, sizeof(double) * (size_t)K * nt);
     }
 }
 
@@ -763,6 +874,10 @@ static void phi(orc_problem *p, int lvl, int i, const double *u_in, double *out)
         else advection1d_step_natural(&L->st, dt, u_in, out);
         break;
     case ORC_HEAT2D: heat2d_step(&L->st, L->nt, i, t_start, t_stop, u_in, out); break;
+    case ORC_HEAT1D_2PTS:
+        if (L->st.variant) twopts_step_spec(&L->st, L->nt, i, t_start, t_stop, u_in, out);
+        else twopts_step_natural(&L->st, L->nt, i, t_start, t_stop, u_in, out);
+        break;
     default: dahlquist_step(&L->st, t_start, t_stop, u_in, out);
     }
 }
@@ -945,6 +1060,7 @@ void orc_nested_iteration(orc_problem *p) {
 
 static double vec_norm(const orc_problem *p, const double *r, int n) {
     if (p->norm_spec && p->L[0].st.kind == ORC_HEAT2D) return sqrt(orc_sumsq_rows(r, p->L[0].st.nx, p->L[0].st.ny));
+    if (p->norm_spec && p->L[0].st.kind == ORC_HEAT1D_2PTS) return sqrt(orc_sumsq_spec_2pts(r, n / 2));
     if (p->norm_spec) return sqrt(orc_sumsq_spec(r, n));
     double s = 0.0;
     for (int j = 0; j < n; ++j) s += r[j] * r[j];

@@ -42,6 +42,10 @@ def lib():
         L.orc_problem_destroy.argtypes = [C.c_void_p]
         L.orc_problem_set_level_heat1d.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_int,
                                                    dp, dp, dp, C.c_int]
+        L.orc_problem_set_level_heat1d_2pts.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_double,
+                                                        C.c_int, C.c_int, dp, dp, dp, dp, C.c_int]
+        L.orc_sumsq_spec_2pts.restype = C.c_double
+        L.orc_sumsq_spec_2pts.argtypes = [dp, C.c_int]
         L.orc_problem_set_level_advection1d.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, C.c_double, dp,
                                                         C.c_int]
         L.orc_problem_set_level_heat2d.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, C.c_int, C.c_double, C.c_double,
@@ -122,6 +126,11 @@ def sumsq_spec(r):
     return lib().orc_sumsq_spec(_dp(r), r.size)
 
 
+def sumsq_spec_2pts(r):
+    r = _f64(np.asarray(r).ravel())
+    return lib().orc_sumsq_spec_2pts(_dp(r), r.size // 2)
+
+
 def restrict(kind, f, nc):
     f = _f64(f)
     c = np.zeros(nc)
@@ -142,6 +151,8 @@ METHODS = {"BE": 0, "FE": 1, "TR": 2, "MR": 3}
 class OracleProblem:
     """Single-rank MGRIT oracle over a level hierarchy. Level specs are dicts:
        {"kind": "heat1d", "t": array, "n": int, "fac": a/dx^2, "s": [K][n] or None, "tau": [K][nt] or None, "u0": [n]}
+       {"kind": "heat1d_2pts", "t": array, "n": int (per time point of the pair), "fac", "dtau", "order": 1|2, "s", "tau",
+        "tau2": [K][nt] tau_k(t_i + dtau), "u0": [2][n]}   (state = [first | second])
        {"kind": "advection1d", "t": array, "n": int, "fac": c/dx, "u0": [n]}
        {"kind": "dahlquist", "t": array, "lambda": float, "method": "BE", "u0": float}
        {"kind": "heat2d", "t": array, "nx", "ny", "fx", "fy", "theta", "bc": [nx][ny], "S": [K][nx-2][ny-2], "tau": [K][nt],
@@ -166,6 +177,17 @@ class OracleProblem:
                 u0 = _f64(s["u0"])
                 L.orc_problem_set_level_heat1d(self.h, lvl, t.size, _dp(t), n, float(s["fac"]), K, _dp(sa), _dp(ta),
                                                _dp(u0), int(variant))
+            elif s["kind"] == "heat1d_2pts":
+                m = int(s["n"])
+                n = 2 * m
+                K = 0 if s.get("s") is None else int(np.asarray(s["s"]).reshape(-1, m).shape[0])
+                sa = _f64(np.asarray(s["s"]).reshape(K, m)) if K else np.zeros(1)
+                ta = _f64(np.asarray(s["tau"]).reshape(K, t.size)) if K else np.zeros(1)
+                tb = _f64(np.asarray(s["tau2"]).reshape(K, t.size)) if K else np.zeros(1)
+                u0 = _f64(np.asarray(s["u0"]).ravel())
+                assert u0.size == n
+                L.orc_problem_set_level_heat1d_2pts(self.h, lvl, t.size, _dp(t), m, float(s["fac"]), float(s["dtau"]),
+                                                    int(s["order"]), K, _dp(sa), _dp(ta), _dp(tb), _dp(u0), int(variant))
             elif s["kind"] == "advection1d":
                 n = int(s["n"])
                 u0 = _f64(s["u0"])

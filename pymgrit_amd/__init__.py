@@ -1,8 +1,8 @@
 """pymgrit_amd -- MI355X-native MGRIT relaxation engine behind PyMGRIT's plugin API.
 
 Same public names as the reference package for everything on the hot path (``Mgrit``, ``Application``, ``Vector``,
-``GridTransfer``, ``GridTransferCopy``, ``simple_setup_problem``, ``Dahlquist``, ``Heat1D``, ``Heat2D``, ``Advection1D``)
-plus the two spatial-coarsening transfers that run as HIP kernels.
+``GridTransfer``, ``GridTransferCopy``, ``simple_setup_problem``, ``Dahlquist``, ``Heat1D``, ``Heat1DBDF1``, ``Heat1DBDF2``,
+``Heat2D``, ``Advection1D``) plus the two spatial-coarsening transfers that run as HIP kernels.
 """
 from pymgrit_amd.core.application import Application
 from pymgrit_amd.core.vector import Vector
@@ -13,10 +13,12 @@ from pymgrit_amd.core.mgrit import Mgrit
 
 from pymgrit_amd.dahlquist.dahlquist import Dahlquist
 from pymgrit_amd.heat.heat_1d import Heat1D
+from pymgrit_amd.heat.heat_1d_2pts_bdf1 import Heat1DBDF1
+from pymgrit_amd.heat.heat_1d_2pts_bdf2 import Heat1DBDF2
 from pymgrit_amd.heat.heat_2d import Heat2D
 from pymgrit_amd.heat.grid_transfer_heat import GridTransferHeat
 from pymgrit_amd.advection.advection_1d import Advection1D
 from pymgrit_amd.advection.grid_transfer_advection import GridTransferAdvection
 
 __all__ = ["Application", "Vector", "GridTransfer", "GridTransferCopy", "simple_setup_problem", "Mgrit", "Dahlquist",
-           "Heat1D", "Heat2D", "GridTransferHeat", "Advection1D", "GridTransferAdvection"]
+           "Heat1D", "Heat1DBDF1", "Heat1DBDF2", "Heat2D", "GridTransferHeat", "Advection1D", "GridTransferAdvection"]

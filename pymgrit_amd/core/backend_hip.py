@@ -47,11 +47,11 @@ class SlabVectorList:
             return [self[k] for k in range(*i.indices(len(self)))]
         vec = self.template.clone_zero()
         host = self.slab[self._row(int(i))][self.perm].cpu().numpy()
-        vec.set_values(host.reshape(np.shape(vec.get_values())).copy())
+        vec.unpack(host.reshape(np.shape(vec.pack())).copy())   # pack()/unpack(): the Vector's own flat payload form
         return vec
 
     def __setitem__(self, i, vec):
-        vals = np.ascontiguousarray(np.asarray(vec.get_values(), dtype=np.float64)).ravel()
+        vals = np.ascontiguousarray(np.asarray(vec.pack(), dtype=np.float64)).ravel()
         self.slab[self._row(int(i))][self.perm] = torch.from_numpy(vals).to(self.slab.device)
 
     def __iter__(self):
@@ -73,10 +73,19 @@ class HipBackend:
         self.desc = [p.device_stepper() for p in mg.problem]
         self.n = [int(d["n"]) for d in self.desc]
         # 1-D steppers: lane-blocked rows; Heat2D: the nx x ny grid in natural row-major order
-        self.ld = [((n + 15) // 16) * 16 if d["kind"] == "heat2d" else hip_lib.row_stride(n)
-                   for n, d in zip(self.n, self.desc)]
-        self.perm = [torch.arange(n, device=self.device) if d["kind"] == "heat2d" else
-                     torch.from_numpy(hip_lib.row_permutation(n)).to(self.device) for n, d in zip(self.n, self.desc)]
+        # two-point states: the row is [first | second], each half lane-blocked like a 1-D row of n values
+        self.ld = [((n + 15) // 16) * 16 if d["kind"] == "heat2d" else
+                   (2 if d["kind"] == "heat1d_2pts" else 1) * hip_lib.row_stride(n) for n, d in zip(self.n, self.desc)]
+        self.perm = []
+        for n, d in zip(self.n, self.desc):
+            if d["kind"] == "heat2d":
+                perm = np.arange(n)
+            elif d["kind"] == "heat1d_2pts":
+                half = hip_lib.row_permutation(n)
+                perm = np.concatenate((half, half + hip_lib.row_stride(n)))
+            else:
+                perm = hip_lib.row_permutation(n)
+            self.perm.append(torch.from_numpy(np.asarray(perm, dtype=np.int64)).to(self.device))
         self.U, self.V, self.G = [], [], []
         self._runs, self._pairs = {}, {}
         self._described = [False] * mg.lvl_max
@@ -106,6 +115,16 @@ class HipBackend:
             tau = np.ascontiguousarray(tau)
             check(self.lib.mgrit_hip_level_heat1d(self.h, lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"]), K,
                                                   _ptr(s), _ptr(tau)))
+        elif d["kind"] == "heat1d_2pts":
+            s = np.ascontiguousarray(np.asarray(d.get("forcing_space", np.zeros((0, n))), dtype=np.float64).reshape(-1, n))
+            K = s.shape[0]
+            tau, tau2 = np.zeros((K, n_pts)), np.zeros((K, n_pts))
+            for k in range(K):
+                tau[k] = [d["forcing_time"][k](tt) for tt in t_local]
+                tau2[k] = [d["forcing_time"][k](tt + d["dtau"]) for tt in t_local]
+            check(self.lib.mgrit_hip_level_heat1d_2pts(self.h, lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"]),
+                                                       float(d["dtau"]), int(d["order"]), K, _ptr(s),
+                                                       _ptr(np.ascontiguousarray(tau)), _ptr(np.ascontiguousarray(tau2))))
         elif d["kind"] == "advection1d":
             check(self.lib.mgrit_hip_level_advection1d(self.h, lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"])))
         elif d["kind"] == "heat2d":
@@ -127,7 +146,7 @@ class HipBackend:
             host = np.zeros((n_pts, ld))
             perm = self.perm[lvl].cpu().numpy()
             for i in range(n_pts):  # clone_rand per time point, in time order (heat_1d.py:88-96)
-                host[i, perm] = np.asarray(tmpl.clone_rand().get_values(), dtype=np.float64).ravel()
+                host[i, perm] = np.asarray(tmpl.clone_rand().pack(), dtype=np.float64).ravel()
             u.copy_(torch.from_numpy(host))
         v = g = None
         if lvl > 0:

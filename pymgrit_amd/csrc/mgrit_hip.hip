@@ -79,6 +79,8 @@ struct LevelDev {
     const CSet *cs;       // [n_csets]
     const double2 *tabP;  // [n_csets][ld/2] rank-one correction table, row storage order
     const double2 *ptP;   // [n_csets][2][512] heat: group-local backward scan of rho^(j'+1) (full group, last group)
+    const int32_t *cidx2; // two-point steppers: [n_pts][2] coefficient sets of the two half-solves (then tc is [K][n_pts][2])
+    const double *hc;     // two-point BDF2: [n_pts][4] = (a, nb) of the first and of the second half-solve
     int n, ld, T, n_pts, K, kind;
 };
 
@@ -338,6 +340,27 @@ __device__ __forceinline__ void heat_finish(double (&x)[E], const Coef &c, doubl
     x[2 * q + 1] = fma(-z0, w.y, z_1 * c.ik);
 }
 
+// x <- (I + dt L)^{-1} x for the coefficient set resident in c / lc / sm: group-local scans,
+// one exchange of the group totals through the LDS slots ga/gb (one barrier), carries + rank-one correction
+__device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const LaneCoef &lc, const Smem &sm, double *ga,
+                                           double *gb, int n, int t, int lane, int wave, int G) {
+    const int j0 = t * E, li = lane & 15;
+    const double a = scan_fwd(x, c, lc, lane);
+#pragma unroll
+    for (int k = 0; k < E; ++k)
+        if (j0 + k >= n) x[k] = 0.0;
+    const double b = scan_bwd(x, c, lc, lane);
+    if (lane == 0) { ga[wave] = a; gb[wave] = b; }
+    __syncthreads();
+    double cm, zin, zf0;
+    heat_chains(c, li < G ? ga[li] : 0.0, li < G ? gb[li] : 0.0, G, wave, lane, cm, zin, zf0);
+    const double z0 = zf0 * c.ik;
+    const double cb = lc.b_in * zin;
+    const double2 *pt = sm.pt + (wave == G - 1 ? 512 : 0) + lane;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) heat_finish(x, c, cm, cb, z0, q, sm.tab[slot0(t) + q * 64], pt[q * 64]);
+}
+
 // x <- Phi(x) for the step (i-1 -> i) of level L, one workgroup holding the whole vector (heat_1d.py:198-217 /
 // advection_1d.py:129-143; arithmetic: DESIGN.md section 3). One workgroup barrier per application.
 template <int KIND, int FORCE>
@@ -365,20 +388,7 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const Le
     double *ga = sm.ga + par * MAX_G, *gb = sm.gb + par * MAX_G;
     if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
         add_forcing<FORCE>(x, ctx, L, i, t);
-        const double a = scan_fwd(x, c, lc, lane);
-#pragma unroll
-        for (int k = 0; k < E; ++k)
-            if (j0 + k >= L.n) x[k] = 0.0;
-        const double b = scan_bwd(x, c, lc, lane);
-        if (lane == 0) { ga[wave] = a; gb[wave] = b; }
-        __syncthreads();
-        double cm, zin, zf0;
-        heat_chains(c, li < G ? ga[li] : 0.0, li < G ? gb[li] : 0.0, G, wave, lane, cm, zin, zf0);
-        const double z0 = zf0 * c.ik;
-        const double cb = lc.b_in * zin;
-        const double2 *pt = sm.pt + (wave == G - 1 ? 512 : 0) + lane;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) heat_finish(x, c, cm, cb, z0, q, sm.tab[slot0(t) + q * 64], pt[q * 64]);
+        heat_solve(x, c, lc, sm, ga, gb, L.n, t, lane, wave, G);
     } else {
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] * c.ik;
@@ -802,6 +812,8 @@ __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, c
     f[pos] = mode == 0 ? val : f[pos] + val;
 }
 
+#include "mgrit_hip_2pts.inc"
+
 // ===============================================================================================================
 // Heat2D (heat/heat_2d.py:250-366): theta-scheme on the full nx x ny grid. Interior solve by fast diagonalisation
 //   U = Qx ((Qx B Qy) o D) Qy,  Qx, Qy orthogonal symmetric sine-transform matrices,
@@ -1029,6 +1041,7 @@ struct H2DHost {
 };
 
 struct Level {
+    int order = 0;   // two-point steppers: BDF order (1 or 2)
     bool set = false;
     H2DHost *h2d = nullptr;
     LevelDev dev{};
@@ -1144,16 +1157,21 @@ int dev_upload(Level &lv, hipStream_t st, const std::vector<T> &h, T **out) {
 
 size_t smem_bytes(int G) { return (size_t)(8 * G * LANES + 2 * 512) * sizeof(double2) + (5 * MAX_G + LANES) * sizeof(double); }
 
+constexpr int MAX_G2 = MGRIT_HIP_MAX_N_2PTS / GROUP;  // two-point steppers: waves per half
+size_t smem2_bytes(int G) { return (size_t)2 * (8 * G * LANES + 2 * 512) * sizeof(double2) + (6 * MAX_G + 2 * LANES) * sizeof(double); }
+
 template <typename K>
-int allow_big_lds(K kernel) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem_bytes(MAX_G)));
+int allow_big_lds(K kernel, size_t bytes = smem_bytes(MAX_G)) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
 }
 
 // Dispatch tables over the template space: kind (heat1d, advection1d) x forcing mode (0, 1, 2; advection has none).
 #define FOR_EACH_STEPPER(X) X(MGRIT_HIP_STEPPER_HEAT1D, 0) X(MGRIT_HIP_STEPPER_HEAT1D, 1) X(MGRIT_HIP_STEPPER_HEAT1D, 2) \
     X(MGRIT_HIP_STEPPER_ADVECTION1D, 0)
+
+// two-point steppers: BDF order (1, 2) x forcing mode (0, 1, 2)
+#define FOR_EACH_2PTS(X) X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2)
 
 bool g_attr_done = false;
 int setup_kernel_attrs() {
@@ -1170,6 +1188,16 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(fas_fused_kernel<K, F>))) return rc;
     FOR_EACH_STEPPER(ATTR_ALL)
     if ((rc = allow_big_lds(jump_kernel))) return rc;
+#define ATTR_2PTS(O, F)                                                                                              \
+    if ((rc = allow_big_lds(relax2_kernel<O, F, false, false>, smem2_bytes(MAX_G2)))) return rc;                     \
+    if ((rc = allow_big_lds(relax2_kernel<O, F, true, false>, smem2_bytes(MAX_G2)))) return rc;                      \
+    if ((rc = allow_big_lds(relax2_kernel<O, F, false, true>, smem2_bytes(MAX_G2)))) return rc;                      \
+    if ((rc = allow_big_lds(relax2_kernel<O, F, true, true>, smem2_bytes(MAX_G2)))) return rc;                       \
+    if ((rc = allow_big_lds(residual2_kernel<O, F>, smem2_bytes(MAX_G2)))) return rc;                                \
+    if ((rc = allow_big_lds(fas_fine2_kernel<O, F>, smem2_bytes(MAX_G2)))) return rc;                                \
+    if ((rc = allow_big_lds(fas_coarse2_kernel<O, F>, smem2_bytes(MAX_G2)))) return rc;
+    FOR_EACH_2PTS(ATTR_2PTS)
+    if ((rc = allow_big_lds(jump2_kernel, smem2_bytes(MAX_G2)))) return rc;
     g_attr_done = true;
     return 0;
 }
@@ -1249,6 +1277,107 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     if ((rc = dev_upload(lv, e->stream, tabT, &d_tabT))) return rc;
     if ((rc = dev_upload(lv, e->stream, ptT, &d_ptT))) return rc;
     d.cidx = d_cidx; d.dt = d_dt; d.tc = d_tau; d.cs = d_cs;
+    d.ptP = reinterpret_cast<const double2 *>(d_ptT);
+    d.sP = reinterpret_cast<const double2 *>(d_sT);
+    d.tabP = reinterpret_cast<const double2 *>(d_tabT);
+    lv.set = true;
+    return 0;
+}
+
+// BDF2 coefficients of heat_1d_2pts_bdf2.py:103-110 for the pair of step sizes (tau_i, tau_im1), rewritten for the scaled
+// system (I + L/c) x = rhs/c (the oracle's bdf2_half is the same text)
+struct HalfCoef { double dt_eff, a, nb, fs; };
+HalfCoef bdf2_half(double tau_i, double tau_im1) {
+    HalfCoef h;
+    const double r = tau_i / tau_im1;
+    const double cm2 = (r * r) / (tau_i * (1.0 + r));
+    const double cm1 = (1.0 + r) / tau_i;
+    const double c = (1.0 + 2.0 * r) / (tau_i * (1.0 + r));
+    const double inv = 1.0 / c;
+    h.dt_eff = inv; h.a = cm1 * inv; h.nb = -(cm2 * inv); h.fs = inv;
+    return h;
+}
+
+int level_heat1d_2pts(mgrit_hip_engine *e, int lvl, int n_pts, const double *t_local, int n, int ld, double fac, double dtau,
+                      int order, int K, const double *s, const double *tau, const double *tau2) {
+    int rc = check_level(e, lvl, false);
+    if (rc) return rc;
+    if (n < 1 || n > MGRIT_HIP_MAX_N_2PTS)
+        return fail(MGRIT_HIP_EUNSUPPORTED, "n=%d DOFs per time point outside [1,%d] (two-point stepper)", n, MGRIT_HIP_MAX_N_2PTS);
+    if (ld != 2 * mgrit_hip_row_stride(n)) return fail(MGRIT_HIP_EINVAL, "ld=%d must equal 2*mgrit_hip_row_stride(n=%d)=%d", ld, n, 2 * mgrit_hip_row_stride(n));
+    if (order != 1 && order != 2) return fail(MGRIT_HIP_EINVAL, "BDF order must be 1 or 2");
+    if (n_pts < 0 || (n_pts > 0 && !t_local)) return fail(MGRIT_HIP_EINVAL, "bad local time grid");
+    if (K < 0 || K > 8 || (K > 0 && (!s || (n_pts > 0 && (!tau || !tau2))))) return fail(MGRIT_HIP_EINVAL, "bad forcing description (K=%d)", K);
+    if ((rc = setup_kernel_attrs())) return rc;
+    Level &lv = e->L[lvl];
+    if (lv.set) return fail(MGRIT_HIP_EINVAL, "level %d already described", lvl);
+    const int G = (n + GROUP - 1) / GROUP, T = G * LANES;
+    lv.G = G;
+    lv.order = order;
+    LevelDev &d = lv.dev;
+    d.n = n; d.ld = ld; d.T = T; d.n_pts = n_pts; d.K = K; d.kind = MGRIT_HIP_STEPPER_HEAT1D_2PTS;
+    const size_t np = n_pts > 0 ? n_pts : 0;
+    std::vector<double> uniq, hc(np * 4, 0.0), fs(np * 2, 0.0), dts(np, 0.0);
+    std::vector<int32_t> cidx2(np * 2, 0);
+    auto set_of = [&](double dt_eff) -> int {
+        for (size_t q = 0; q < uniq.size(); ++q)
+            if (std::memcmp(&uniq[q], &dt_eff, sizeof(double)) == 0) return (int)q;
+        uniq.push_back(dt_eff);
+        return (int)uniq.size() - 1;
+    };
+    for (int i = 1; i < n_pts; ++i) {
+        const double t_start = t_local[i - 1], t_stop = t_local[i];
+        dts[i] = t_stop - t_start;
+        const double tl0 = t_stop - t_start - dtau;
+        HalfCoef h[2];
+        if (order == 1) {
+            h[0].dt_eff = tl0; h[1].dt_eff = dtau;
+            for (int q = 0; q < 2; ++q) { h[q].a = 1.0; h[q].nb = 0.0; h[q].fs = h[q].dt_eff; }
+        } else {
+            h[0] = bdf2_half(tl0, dtau);
+            h[1] = bdf2_half(dtau, tl0);
+        }
+        for (int q = 0; q < 2; ++q) {
+            cidx2[2 * (size_t)i + q] = set_of(h[q].dt_eff);
+            hc[4 * (size_t)i + 2 * q] = h[q].a;
+            hc[4 * (size_t)i + 2 * q + 1] = h[q].nb;
+            fs[2 * (size_t)i + q] = h[q].fs;
+        }
+        if (uniq.size() > 4096) return fail(MGRIT_HIP_EUNSUPPORTED, "more than 4096 distinct time-step sizes on level %d", lvl);
+    }
+    lv.n_csets = (int)uniq.size();
+    std::vector<CSet> cs(uniq.size());
+    std::vector<double> tabT(uniq.size() * (size_t)E * T, 0.0), tab;
+    std::vector<double> ptT(uniq.size() * (size_t)2 * GROUP, 0.0), pt(GROUP);
+    for (size_t q = 0; q < uniq.size(); ++q) {
+        std::memset(&cs[q], 0, sizeof(CSet));
+        build_cset_heat1d(cs[q], tab, n, fac, uniq[q]);
+        build_pt(cs[q], GROUP, pt.data());
+        cs[q].pi_full = pt[0];
+        for (int j = 0; j < GROUP; ++j) ptT[q * (size_t)2 * GROUP + row_pos(j)] = pt[j];
+        build_pt(cs[q], n - ((n - 1) / GROUP) * GROUP, pt.data());
+        cs[q].pi_last = pt[0];
+        for (int j = 0; j < GROUP; ++j) ptT[q * (size_t)2 * GROUP + GROUP + row_pos(j)] = pt[j];
+        for (int j = 0; j < n; ++j) tabT[q * (size_t)E * T + row_pos(j)] = tab[j];
+    }
+    std::vector<double> sT((size_t)(K > 0 ? K : 0) * E * T, 0.0), tc((size_t)(K > 0 ? K : 0) * np * 2, 0.0);
+    for (int kk = 0; kk < K; ++kk) {
+        for (int j = 0; j < n; ++j) sT[(size_t)kk * E * T + row_pos(j)] = s[(size_t)kk * n + j];
+        for (int i = 1; i < n_pts; ++i) {   // tc[k][i][half] = tau_k(t_i [+ dtau]) * forcing scale of the half
+            tc[((size_t)kk * np + i) * 2] = tau[(size_t)kk * n_pts + i] * fs[2 * (size_t)i];
+            tc[((size_t)kk * np + i) * 2 + 1] = tau2[(size_t)kk * n_pts + i] * fs[2 * (size_t)i + 1];
+        }
+    }
+    int32_t *d_cidx2; double *d_dt, *d_tc, *d_sT, *d_tabT, *d_ptT, *d_hc; CSet *d_cs;
+    if ((rc = dev_upload(lv, e->stream, cidx2, &d_cidx2))) return rc;
+    if ((rc = dev_upload(lv, e->stream, dts, &d_dt))) return rc;
+    if ((rc = dev_upload(lv, e->stream, tc, &d_tc))) return rc;
+    if ((rc = dev_upload(lv, e->stream, sT, &d_sT))) return rc;
+    if ((rc = dev_upload(lv, e->stream, cs, &d_cs))) return rc;
+    if ((rc = dev_upload(lv, e->stream, tabT, &d_tabT))) return rc;
+    if ((rc = dev_upload(lv, e->stream, ptT, &d_ptT))) return rc;
+    if ((rc = dev_upload(lv, e->stream, hc, &d_hc))) return rc;
+    d.cidx = nullptr; d.cidx2 = d_cidx2; d.hc = d_hc; d.dt = d_dt; d.tc = d_tc; d.cs = d_cs;
     d.ptP = reinterpret_cast<const double2 *>(d_ptT);
     d.sP = reinterpret_cast<const double2 *>(d_sT);
     d.tabP = reinterpret_cast<const double2 *>(d_tabT);
@@ -1498,13 +1627,30 @@ int check_bound(const Level &lv, bool need_vg) {
 }
 
 // grid of persistent workgroups: as many as stay resident on the chip (LDS- and thread-limited), at most one per item
+bool is_2pts(const Level &lv) { return lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D_2PTS; }
+
 int persistent_grid(const Level &lv, int n_items) {
-    const size_t lds = smem_bytes(lv.G);
+    const size_t lds = is_2pts(lv) ? smem2_bytes(lv.G) : smem_bytes(lv.G);
     const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / lv.dev.T));
     return std::min(n_items, 256 * per_cu);
 }
 
-int force_mode(const Level &lv) { return lv.dev.kind != MGRIT_HIP_STEPPER_HEAT1D ? 0 : lv.dev.K == 0 ? 0 : lv.dev.K == 1 ? 1 : 2; }
+int force_mode(const Level &lv) {
+    if (lv.dev.kind != MGRIT_HIP_STEPPER_HEAT1D && lv.dev.kind != MGRIT_HIP_STEPPER_HEAT1D_2PTS) return 0;
+    return lv.dev.K == 0 ? 0 : lv.dev.K == 1 ? 1 : 2;
+}
+
+// two-point kernels: template space BDF order x forcing mode
+#define LAUNCH2_CASE(kernel, O_, F_, lv, grid, ...)                                                              \
+    if ((lv).order == O_ && force_mode(lv) == F_)                                                                 \
+        hipLaunchKernelGGL((kernel<O_, F_>), dim3(grid), dim3((lv).dev.T), smem2_bytes((lv).G), e->stream, __VA_ARGS__);
+#define LAUNCH2_BY_ORDER(kernel, lv, grid, ...)                                                                  \
+    do {                                                                                                         \
+        LAUNCH2_CASE(kernel, 1, 0, lv, grid, __VA_ARGS__) LAUNCH2_CASE(kernel, 1, 1, lv, grid, __VA_ARGS__)       \
+        LAUNCH2_CASE(kernel, 1, 2, lv, grid, __VA_ARGS__) LAUNCH2_CASE(kernel, 2, 0, lv, grid, __VA_ARGS__)       \
+        LAUNCH2_CASE(kernel, 2, 1, lv, grid, __VA_ARGS__) LAUNCH2_CASE(kernel, 2, 2, lv, grid, __VA_ARGS__)       \
+        HIP_TRY(hipGetLastError());                                                                              \
+    } while (0)
 
 #define LAUNCH_CASE(kernel, K_, F_, lv, grid, ...)                                                               \
     if ((lv).dev.kind == K_ && force_mode(lv) == F_)                                                              \
@@ -1594,6 +1740,12 @@ int mgrit_hip_level_heat1d(mgrit_hip_engine *e, int lvl, int n_pts_local, const 
     return level_common(e, lvl, MGRIT_HIP_STEPPER_HEAT1D, n_pts_local, t_local, n, ld, fac, K, s, tau);
 }
 
+int mgrit_hip_level_heat1d_2pts(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int n, int ld,
+                                double fac, double dtau, int order, int K, const double *s, const double *tau,
+                                const double *tau2) {
+    return level_heat1d_2pts(e, lvl, n_pts_local, t_local, n, ld, fac, dtau, order, K, s, tau, tau2);
+}
+
 int mgrit_hip_level_advection1d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int n, int ld,
                                 double fac) {
     return level_common(e, lvl, MGRIT_HIP_STEPPER_ADVECTION1D, n_pts_local, t_local, n, ld, fac, 0, nullptr, nullptr);
@@ -1668,6 +1820,8 @@ int mgrit_hip_level_transfer(mgrit_hip_engine *e, int lvl, int kind) {
     if (rc) return rc;
     if (lvl + 1 >= e->n_levels || !e->L[lvl + 1].set) return fail(MGRIT_HIP_EINVAL, "describe level %d before its transfer", lvl + 1);
     const int nf = e->L[lvl].dev.n, nc = e->L[lvl + 1].dev.n;
+    if (is_2pts(e->L[lvl]) != is_2pts(e->L[lvl + 1]) || (is_2pts(e->L[lvl]) && kind != MGRIT_HIP_TRANSFER_COPY))
+        return fail(MGRIT_HIP_EUNSUPPORTED, "two-point levels pair with two-point levels through the copy transfer only");
     if (kind == MGRIT_HIP_TRANSFER_COPY) {
         if (nf != nc) return fail(MGRIT_HIP_EINVAL, "copy transfer needs equal DOFs (%d vs %d)", nf, nc);
     } else if (kind == MGRIT_HIP_TRANSFER_HEAT1D) {
@@ -1745,6 +1899,22 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
         if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
         return 0;
     }
+    if (is_2pts(lv)) {
+        const bool use_g = lvl > 0, weighted = mode == MGRIT_HIP_RELAX_C && weight_c != 1.0;
+        const double w = weight_c, w1 = 1.0 - weight_c;
+        const dim3 grid(persistent_grid(lv, rl->n)), block(lv.dev.T);
+        const int fm = force_mode(lv);
+#define RELAX2_CASE(O, F, G_, W_)                                                                                  \
+    if (lv.order == O && fm == F && use_g == G_ && weighted == W_)                                                  \
+        hipLaunchKernelGGL((relax2_kernel<O, F, G_, W_>), grid, block, smem2_bytes(lv.G), e->stream, lv.dev, rl->d_start, \
+                           rl->d_len, rl->n, w, w1);
+#define RELAX2_CASES(O, F) RELAX2_CASE(O, F, false, false) RELAX2_CASE(O, F, true, false) RELAX2_CASE(O, F, false, true) \
+    RELAX2_CASE(O, F, true, true)
+        FOR_EACH_2PTS(RELAX2_CASES)
+        HIP_TRY(hipGetLastError());
+        if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
+        return 0;
+    }
     if (mode == MGRIT_HIP_RELAX_CHAIN && lv.G > 1) {
         // sequential chain over several groups: one single-wave workgroup per group, exchange through global granules
         if (!e->chain_gran) {
@@ -1803,7 +1973,8 @@ int mgrit_hip_residual(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_
     if (rl->n == 0) return 0;
     if (!sumsq_out) return fail(MGRIT_HIP_EINVAL, "null output");
     if (lv.h2d) return h2d_points_sumsq(e, lvl, rl, nullptr, sumsq_out);
-    LAUNCH_BY_KIND(residual_kernel, lv, persistent_grid(lv, rl->n), lv.dev, rl->d_start, rl->n, sumsq_out);
+    if (is_2pts(lv)) LAUNCH2_BY_ORDER(residual2_kernel, lv, persistent_grid(lv, rl->n), lv.dev, rl->d_start, rl->n, sumsq_out);
+    else LAUNCH_BY_KIND(residual_kernel, lv, persistent_grid(lv, rl->n), lv.dev, rl->d_start, rl->n, sumsq_out);
     return 0;
 }
 
@@ -1816,7 +1987,10 @@ int mgrit_hip_jump(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev
     if (rl->n == 0) return 0;
     if (!sumsq_out || !prev) return fail(MGRIT_HIP_EINVAL, "null argument");
     if (lv.h2d) return h2d_points_sumsq(e, lvl, rl, prev, sumsq_out);
-    hipLaunchKernelGGL(jump_kernel, dim3(rl->n), dim3(lv.dev.T), smem_bytes(lv.G), e->stream, lv.dev, rl->d_start, prev, sumsq_out);
+    if (is_2pts(lv))
+        hipLaunchKernelGGL(jump2_kernel, dim3(rl->n), dim3(lv.dev.T), smem2_bytes(lv.G), e->stream, lv.dev, rl->d_start, prev, sumsq_out);
+    else
+        hipLaunchKernelGGL(jump_kernel, dim3(rl->n), dim3(lv.dev.T), smem_bytes(lv.G), e->stream, lv.dev, rl->d_start, prev, sumsq_out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1857,6 +2031,13 @@ int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id) {
             return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D levels need Heat2D on both levels and the copy transfer");
         return h2d_fas_rhs(e, lvl, pl);
     }
+    if (is_2pts(lf) || is_2pts(lc)) {
+        if (!is_2pts(lf) || !is_2pts(lc) || lf.transfer != MGRIT_HIP_TRANSFER_COPY)
+            return fail(MGRIT_HIP_EUNSUPPORTED, "two-point levels pair with two-point levels through the copy transfer only");
+        LAUNCH2_BY_ORDER(fas_fine2_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_coarse, lc.dev.g, lc.dev.ld, lvl > 0 ? 1 : 0);
+        LAUNCH2_BY_ORDER(fas_coarse2_kernel, lc, pl->n, lc.dev, pl->d_coarse);
+        return 0;
+    }
     if (lf.transfer == MGRIT_HIP_TRANSFER_COPY) {
         LAUNCH_BY_KIND(fas_fine_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_coarse, lc.dev.g, lc.dev.ld, lvl > 0 ? 1 : 0);
     } else {
@@ -1895,7 +2076,7 @@ int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id) {
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
     if (!pl->d_prev) return fail(MGRIT_HIP_EINVAL, "list %d was not created by mgrit_hip_triples_create", triples_id);
-    if (lf.h2d || lc.h2d || lf.transfer != MGRIT_HIP_TRANSFER_COPY || lf.dev.kind != lc.dev.kind ||
+    if (lf.h2d || lc.h2d || is_2pts(lf) || is_2pts(lc) || lf.transfer != MGRIT_HIP_TRANSFER_COPY || lf.dev.kind != lc.dev.kind ||
         force_mode(lf) != force_mode(lc) || lf.dev.n != lc.dev.n)
         return fail(MGRIT_HIP_EUNSUPPORTED, "fused FAS residual needs the copy transfer and like steppers on both levels");
     if (pl->n == 0) return 0;

@@ -69,6 +69,54 @@ def _zero_init(x):
     return x * 0
 
 
+def thomas_toeplitz(beta, diag, d):
+    """Solve tridiag(-beta, diag, -beta) x = d (the matrices of heat_1d.py:177-217 are of this form)."""
+    n = d.shape[0]
+    cp, dp = np.empty(n), np.empty(n)
+    piv = diag
+    cp[0], dp[0] = -beta / piv, d[0] / piv
+    for j in range(1, n):
+        piv = diag + beta * cp[j - 1]
+        cp[j] = -beta / piv
+        dp[j] = (d[j] + beta * dp[j - 1]) / piv
+    out = np.empty(n)
+    out[-1] = dp[-1]
+    for j in range(n - 2, -1, -1):
+        out[j] = dp[j] - cp[j] * out[j + 1]
+    return out
+
+
+def detect_separable(rhs, x, t, who='Heat1D'):
+    """Find (s, tau) with rhs(x,t) = s(x)*tau(t) to rounding, or K=0 for a zero forcing."""
+    nx = x.shape[0]
+    probes = np.unique(np.concatenate((t[:1], t[len(t) // 3:len(t) // 3 + 1], t[len(t) // 2:len(t) // 2 + 1], t[-1:])))
+    samples = [np.asarray(rhs(x, float(tp)), dtype=np.float64) * np.ones(nx) for tp in probes]
+    norms = [np.max(np.abs(s)) for s in samples]
+    if max(norms) == 0.0:
+        return [], []
+    s_vec = samples[int(np.argmax(norms))]
+    piv = int(np.argmax(np.abs(s_vec)))
+    xp = x[piv:piv + 1]
+
+    def tau_fn(tt, _xp=xp, _den=s_vec[piv]):
+        return float(np.asarray(rhs(_xp, tt), dtype=np.float64).ravel()[0]) / _den
+    for tp, smp in zip(probes, samples):
+        if np.max(np.abs(smp - s_vec * tau_fn(float(tp)))) > 1e-12 * max(norms):
+            raise Exception(f'{who}: rhs(x,t) is not of the separable form s(x)*tau(t); pass rhs_separable=[(s_fn, '
+                            'tau_fn), ...] to run on the MI355X engine')
+    return [s_vec], [tau_fn]
+
+
+def separable_rhs(terms):
+    """rhs(x, t) = sum_k s_k(x) * tau_k(t) from a list of (s_fn, tau_fn) pairs."""
+    def rhs(x, t, _terms=tuple(terms)):
+        total = _terms[0][0](x) * _terms[0][1](t)
+        for s_fn, tau_fn in _terms[1:]:
+            total = total + s_fn(x) * tau_fn(t)
+        return total
+    return rhs
+
+
 class Heat1D(Application):
     def __init__(self, x_start, x_end, nx, a, init_cond=_zero_init, rhs=_zero_rhs, rhs_separable=None, *args, **kwargs):
         """
@@ -88,13 +136,7 @@ class Heat1D(Application):
         self.fac = self.a / self.dx ** 2
         self._separable = list(rhs_separable) if rhs_separable is not None else None
         if self._separable is not None:
-            terms = self._separable
-
-            def rhs(x, t, _terms=terms):
-                total = _terms[0][0](x) * _terms[0][1](t)
-                for s_fn, tau_fn in _terms[1:]:
-                    total = total + s_fn(x) * tau_fn(t)
-                return total
+            rhs = separable_rhs(self._separable)
         self.rhs = rhs
         self.init_cond = init_cond
         self.vector_template = VectorHeat1D(self.nx)
@@ -106,45 +148,13 @@ class Heat1D(Application):
     def step(self, u_start: VectorHeat1D, t_start: float, t_stop: float) -> VectorHeat1D:
         dt = t_stop - t_start
         d = u_start.get_values() + self.rhs(self.x, t_stop) * dt
-        beta, diag = dt * self.fac, dt * (2 * self.fac) + 1
-        n = self.nx
-        cp, dp = np.empty(n), np.empty(n)
-        piv = diag
-        cp[0], dp[0] = -beta / piv, d[0] / piv
-        for j in range(1, n):
-            piv = diag + beta * cp[j - 1]
-            cp[j] = -beta / piv
-            dp[j] = (d[j] + beta * dp[j - 1]) / piv
-        out = np.empty(n)
-        out[-1] = dp[-1]
-        for j in range(n - 2, -1, -1):
-            out[j] = dp[j] - cp[j] * out[j + 1]
-        ret = VectorHeat1D(n)
-        ret.set_values(out)
+        ret = VectorHeat1D(self.nx)
+        ret.set_values(thomas_toeplitz(dt * self.fac, dt * (2 * self.fac) + 1, d))
         return ret
 
     # ---- device description ------------------------------------------------------------------------------------
     def _detect_separable(self):
-        """Find (s, tau) with rhs(x,t) = s(x)*tau(t) to rounding, or K=0 for a zero forcing."""
-        probes = np.unique(np.concatenate((self.t[:1], self.t[len(self.t) // 3:len(self.t) // 3 + 1],
-                                           self.t[len(self.t) // 2:len(self.t) // 2 + 1], self.t[-1:])))
-        samples = [np.asarray(self.rhs(self.x, float(tp)), dtype=np.float64) * np.ones(self.nx) for tp in probes]
-        norms = [np.max(np.abs(s)) for s in samples]
-        if max(norms) == 0.0:
-            return [], []
-        k = int(np.argmax(norms))
-        s_vec, t_ref = samples[k], float(probes[k])
-        piv = int(np.argmax(np.abs(s_vec)))
-        xp = self.x[piv:piv + 1]
-
-        def tau_fn(t, _xp=xp, _den=s_vec[piv]):
-            return float(np.asarray(self.rhs(_xp, t), dtype=np.float64).ravel()[0]) / _den
-        for tp, smp in zip(probes, samples):
-            if np.max(np.abs(smp - s_vec * tau_fn(float(tp)))) > 1e-12 * max(norms):
-                raise Exception('Heat1D: rhs(x,t) is not of the separable form s(x)*tau(t); pass rhs_separable=[(s_fn, '
-                                'tau_fn), ...] to run on the MI355X engine')
-        del t_ref
-        return [s_vec], [tau_fn]
+        return detect_separable(self.rhs, self.x, self.t, type(self).__name__)
 
     def device_stepper(self):
         """Declarative Phi for libmgrit_hip (include/mgrit_hip.h: mgrit_hip_level_heat1d)."""

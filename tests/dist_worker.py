@@ -16,6 +16,13 @@ def build_problem(case_name, mode):
     if case_name.startswith("h2d:"):
         prob, opts = cases.h2d_solve_problem(case_name[4:])
         return prob, None, opts
+    if case_name.startswith("bdf:"):
+        c = cases.BDF_CASES[case_name[4:]]
+        prob = cases.bdf_levels(c["nx"], c["n_pairs"], c["orders"], c["coarsening"], c["forcing"])
+        if mode == "plugin":
+            for p in prob:
+                p.device_stepper = lambda: None   # host steppers through the plugin backend
+        return prob, None, dict(c["kw"])
     if case_name.startswith("advsc:"):
         from pymgrit_amd import Advection1D as A1, GridTransferAdvection as GA, GridTransferCopy as GC
         rec, nxs, ts, transfer, opts = cases.adv_sc_case(case_name[6:])
@@ -58,8 +65,7 @@ def run(rank, world, port, case_name, mode, out_dir, backend):
     mg = Mgrit(prob, transfer=tr, logging_lvl=30, **opts)
     conv = mg.solve()["conv"]
     owned = [int(i) for i in mg.index_local[0]]
-    vals = np.array([np.asarray(mg.u[0][i].get_values(), dtype=np.float64).ravel() for i in owned])
-    first = int(mg.cpts[0][0]) if False else None
+    vals = np.array([np.asarray(mg.u[0][i].pack(), dtype=np.float64).ravel() for i in owned])
     t_owned = np.asarray(mg.t[0])[owned]
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), conv=conv, u=vals, t=t_owned)
     if world > 1:

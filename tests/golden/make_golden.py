@@ -407,6 +407,66 @@ def make_advection_sc():
     print("wrote advection_sc", {k: v["conv"][:3] for k, v in out.items()})
 
 
+# --------------------------------------------------------------------------------------------------
+# Two-point BDF applications (heat_1d_2pts_bdf1.py / heat_1d_2pts_bdf2.py, example_heat_1d_bdf2.py)
+# --------------------------------------------------------------------------------------------------
+def bdf_rhs2(x, t):      # a second forcing form: two separable terms
+    return rhs(x, t) + np.sin(2 * np.pi * x) * t
+
+
+def make_bdf():
+    from pymgrit.heat.heat_1d_2pts_bdf1 import Heat1DBDF1
+    from pymgrit.heat.heat_1d_2pts_bdf2 import Heat1DBDF2
+    cls = {1: Heat1DBDF1, 2: Heat1DBDF2}
+
+    def levels(nx, n_pairs, orders, coarsening, forcing):
+        """pairs (t, t + dtau) on n_pairs points of [0, 2], levels coarsened by `coarsening` (example_heat_1d_bdf2.py:56-66)"""
+        dtau = 2.0 / (2 * (n_pairs - 1))
+        t = np.linspace(0, 2, n_pairs)
+        out = []
+        for lvl, order in enumerate(orders):
+            f = {"zero": lambda x, tt: x * 0, "one": rhs, "two": bdf_rhs2}[forcing]
+            out.append(cls[order](x_start=0, x_end=1, nx=nx, a=1, dtau=dtau, rhs=f, init_cond=init_cond,
+                                  t_interval=t[::coarsening ** lvl]))
+        return out
+
+    out = {"phi": {}, "solve": {}}
+    # single Phi applications on a fixed input pair, uniform and non-uniform pair spacing
+    x = np.linspace(0, 1, 35)[1:-1]
+    for order in (1, 2):
+        for forcing in ("zero", "one", "two"):
+            app = levels(35, 17, [order], 2, forcing)[0]
+            v = app.vector_template.clone_zero()
+            v.set_values(heat_input(x, 0), heat_input(x, 1), app.vector_template.dtau)
+            for name, (ta, tb) in {"uniform": (app.t[3], app.t[4]), "wide": (app.t[2], app.t[6])}.items():
+                r = app.step(v, float(ta), float(tb))
+                out["phi"][f"bdf{order}_{forcing}_{name}"] = {
+                    "t_start": float(ta), "t_stop": float(tb),
+                    "first": np.asarray(r.get_values()[0]).tolist(), "second": np.asarray(r.get_values()[1]).tolist()}
+            out["phi"][f"bdf{order}_{forcing}_t0"] = {"first": np.asarray(app.vector_t_start.get_values()[0]).tolist(),
+                                                      "second": np.asarray(app.vector_t_start.get_values()[1]).tolist()}
+    cases = {
+        "bdf2_example_small": dict(nx=35, n_pairs=33, orders=[2, 1, 1], coarsening=2, forcing="one", kw=dict(tol=1e-9, max_iter=10)),
+        "bdf1_2lvl_m4": dict(nx=35, n_pairs=33, orders=[1, 1], coarsening=4, forcing="one", kw=dict(tol=1e-9, max_iter=10)),
+        "bdf2_2lvl_F_two": dict(nx=19, n_pairs=33, orders=[2, 2, 1], coarsening=2, forcing="two",
+                                kw=dict(tol=1e-9, max_iter=10, cycle_type='F', nested_iteration=False)),
+        "bdf2_weighted_jump": dict(nx=19, n_pairs=17, orders=[2, 1], coarsening=2, forcing="zero",
+                                   kw=dict(tol=1e-9, max_iter=8, weight_c=1.2, conv_crit=1)),
+    }
+    for name, c in cases.items():
+        prob = levels(c["nx"], c["n_pairs"], c["orders"], c["coarsening"], c["forcing"])
+        m = Mgrit(problem=prob, logging_lvl=QUIET, **c["kw"])
+        info = m.solve()
+        rec = {"conv": [float(v) for v in info["conv"]], "samples": {}}
+        for i in (1, (c["n_pairs"] - 1) // 2, c["n_pairs"] - 1):
+            a, b, _ = m.u[0][i].get_values()
+            rec["samples"][str(i)] = [np.asarray(a).tolist(), np.asarray(b).tolist()]
+        out["solve"][name] = rec
+    with open(os.path.join(HERE, "bdf.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("wrote bdf", {k: v["conv"][:3] for k, v in out["solve"].items()})
+
+
 def ref_results():
     res = {}
     d = os.path.join(REF, "tests", "mpi", "results")
@@ -425,6 +485,9 @@ def main():
     if "--only-advection-sc" in sys.argv:
         make_advection_sc()
         return
+    if "--only-bdf" in sys.argv:
+        make_bdf()
+        return
     big = "--small" not in sys.argv
     lay = make_layout()
     with open(os.path.join(HERE, "layout.json"), "w") as f:
@@ -438,6 +501,7 @@ def main():
         json.dump(sol, f, separators=(",", ":"))
     make_heat2d()
     make_advection_sc()
+    make_bdf()
     res, kats = ref_results()
     with open(os.path.join(HERE, "ref_results.json"), "w") as f:
         json.dump({"tests_mpi_results": res}, f, indent=1)

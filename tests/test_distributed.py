@@ -61,6 +61,7 @@ CASES = [
     ("heat_nx33_V_jump", [2]),                  # conv_crit=1
     ("heat_spatial_coarsening", [2]),
     ("heat_nx33_procs_without_points", [5]),
+    ("bdf:bdf2_example_small", [3]),
 ]
 
 

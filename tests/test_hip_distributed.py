@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 CASES = [("heat_nx33_V_nested", [2, 3]), ("heat_nx257_nt257", [2]), ("heat_nx33_F_nonested", [3]),
          ("heat_nx33_V_jump", [2]), ("heat_spatial_coarsening", [2]), ("advection_3lvl_F", [2]),
          ("h2d:be_3lvl_F_bc", [2, 3, 7]), ("h2d:cn_2lvl", [2]), ("advsc:adv_sc_F", [3]),
-         ("heat_nx33_procs_without_points", [5])]   # first factor 16: ranks that own no coarse point at all
+         ("heat_nx33_procs_without_points", [5]), ("bdf:bdf2_example_small", [2, 3]), ("bdf:bdf2_weighted_jump", [3])]   # first factor 16: ranks that own no coarse point at all
 
 
 @pytest.mark.parametrize("case,sizes", CASES, ids=[c for c, _ in CASES])
