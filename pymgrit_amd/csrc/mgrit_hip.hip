@@ -488,146 +488,182 @@ __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *
 // step's epoch, then finishes locally. One exchange per step, the arithmetic is exactly that of phi_apply.
 // Workers are the blocks with blockIdx % 8 == 0 (observed to share an XCD: speed only, never correctness); all other
 // blocks exit at once. Granules are double-buffered by epoch parity; every spin is bounded and reports through *err.
+// Each granule is published twice: to the write-through set (sc1 store: leaves the XCD's L2, visible chip-wide -- the set
+// correctness rests on) and to a plain-stored set that stays in the writer's L2, where the sc1 poll of a worker on the same
+// XCD finds it without a trip over the fabric (MI355X_MICROARCH.md, visibility table: stores of each flavour). A stale
+// plain-stored granule can only carry an older epoch, so it is never mistaken for data; the poll alternates between the sets.
 // ---------------------------------------------------------------------------------------------------------------
 typedef unsigned long long u64;
 constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 26;
 
+// state of one chain worker that survives across steps
+struct ChainCtx {
+    Coef c;
+    LaneCoef lc;
+    double s0[E], wg[E], pt[E];
+    int cur;
+    int ci_a, ci_b;        // coefficient-set index of the next step and of the one after it
+    double tc_a, tc_b;     // forcing coefficient, likewise
+};
+
+// One step of the chain. g_cur = g of this step (loaded one step ago), g_nxt = receives g of the next step. All vector
+// loads for later steps are issued BEHIND the poll: s_waitcnt vmcnt(0) in front of the poll result would otherwise wait for
+// them (vmcnt retires in order), putting an HBM round trip on the serial path of every step.
+// Returns false when the bounded spin gave up.
+template <int KIND, int FORCE, bool USE_G>
+__device__ __forceinline__ bool chain_step(const LevelDev &L, ChainCtx &k, double (&x)[E], const double (&g_cur)[E],
+                                           double (&g_nxt)[E], int i, int start, int len, u64 *gran, unsigned *err, int wave,
+                                           int lane, int G, int t, unsigned sl) {
+    const int j0 = t * E, li = lane & 15;
+    const unsigned epoch = (unsigned)(i - start + 1);
+    u64 *slots = gran + (size_t)(epoch & 1) * MAX_G * 4;
+    const int ci = __builtin_amdgcn_readfirstlane(k.ci_a);
+    const double tc_i = k.tc_a;
+    k.ci_a = k.ci_b;
+    k.tc_a = k.tc_b;
+    if (ci != k.cur) {
+        const CSet *g = L.cs + ci;
+        load_coef<false>(k.c, g);
+        k.lc = lane_coef(g->lp, lane);
+        load_row(reinterpret_cast<const double *>(L.tabP + (size_t)ci * 8 * L.T), sl, k.wg);
+        if (KIND == MGRIT_HIP_STEPPER_HEAT1D)
+            load_row(reinterpret_cast<const double *>(L.ptP + (size_t)ci * 1024 + (wave == G - 1 ? 512 : 0)), (unsigned)lane, k.pt);
+        k.cur = ci;
+    }
+    const Coef &c = k.c;
+    const LaneCoef &lc = k.lc;
+    double v0, v1 = 0.0;  // the two published values of this worker
+    if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
+        if (FORCE == 1) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) x[q] = fma(k.s0[q], tc_i, x[q]);
+        } else if (FORCE == 2) {
+            for (int kk = 0; kk < L.K; ++kk) {
+                const double ck = L.tc[(size_t)kk * L.n_pts + i];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const double2 sv = L.sP[(size_t)kk * 8 * L.T + sl + q * 64];
+                    x[2 * q] = fma(sv.x, ck, x[2 * q]);
+                    x[2 * q + 1] = fma(sv.y, ck, x[2 * q + 1]);
+                }
+            }
+        }
+        v0 = scan_fwd(x, c, lc, lane);
+#pragma unroll
+        for (int q = 0; q < E; ++q)
+            if (j0 + q >= L.n) x[q] = 0.0;
+        v1 = scan_bwd(x, c, lc, lane);
+    } else {
+#pragma unroll
+        for (int q = 0; q < E; ++q) x[q] = x[q] * c.ik;
+        v0 = scan_fwd(x, c, lc, lane);
+        const int jl = L.n - 1;
+        double y = 0.0;
+#pragma unroll
+        for (int q = 0; q < E; ++q)
+            if (j0 + q == jl) y = x[q];
+        v1 = read_lane(y, __builtin_amdgcn_readfirstlane((jl % GROUP) / E));  // only meaningful on the last worker
+    }
+    // ---- publish: 4 granules {epoch, 32-bit half}, each to both sets
+    if (lane < 4) {
+        const double v = lane < 2 ? v0 : v1;
+        const unsigned half = (lane & 1) ? (unsigned)__double2loint(v) : (unsigned)__double2hiint(v);
+        __hip_atomic_store(slots + 2 * MAX_G * 4 + wave * 4 + lane, ((u64)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(slots + wave * 4 + lane, ((u64)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- sweep: lane q watches granule (worker q>>2, item q&3)
+    unsigned mine = 0;
+    {
+        const bool watch = (lane >> 2) < G;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+            if (watch) {
+                // every 8th sweep looks at the write-through set (guaranteed to become visible), the others at the
+                // plain-stored set (an L2 hit when the writer shares this XCD)
+                const u64 *src = (spins & 7u) == 7u ? slots + lane : slots + 2 * MAX_G * 4 + lane;
+                const u64 g64 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mine = (unsigned)g64;
+                ok = (unsigned)(g64 >> 32) == epoch;
+            }
+#ifdef MGRIT_EXPERIMENT_NO_WAIT
+            break;
+#endif
+            if (__all(ok)) break;
+            // the error word lives in host memory: look at it rarely (a peer that gave up stops publishing anyway)
+            if (++spins > CHAIN_SPIN_LIMIT ||
+                ((spins & 0xffffu) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
+                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return false;  // bounded spin: give up, the host reports the failure
+            }
+#ifdef MGRIT_CHAIN_SLEEP
+            __builtin_amdgcn_s_sleep(MGRIT_CHAIN_SLEEP);
+#endif
+        }
+    }
+    // ---- loads for the steps to come, a whole step ahead of the next poll
+    if (i + 1 < start + len) {
+        if (USE_G) load_row(L.g + (size_t)(i + 1) * L.ld, sl, g_nxt);
+        if (i + 2 < start + len) {
+            k.ci_b = L.cidx[i + 2];
+            if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) k.tc_b = L.tc[i + 2];
+        }
+    }
+    // group (lane & 15) totals: hi/lo halves sit in lanes 4g .. 4g+3
+    const int src = (li < G ? li : 0) * 4;
+    const double A = __hiloint2double((int)__shfl(mine, src), (int)__shfl(mine, src + 1));
+    const double B = __hiloint2double((int)__shfl(mine, src + 2), (int)__shfl(mine, src + 3));
+    if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
+        double cm, zin, zf0;
+        heat_chains(c, li < G ? A : 0.0, li < G ? B : 0.0, G, wave, lane, cm, zin, zf0);
+        const double z0 = zf0 * c.ik, cb = lc.b_in * zin;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            heat_finish(x, c, cm, cb, z0, q, make_double2(k.wg[2 * q], k.wg[2 * q + 1]), make_double2(k.pt[2 * q], k.pt[2 * q + 1]));
+    } else {
+        double c_last = 0.0;
+        const double cm = fwd_chain(c, li < G ? A : 0.0, G, wave, lane, c_last);
+        const int jl = L.n - 1, ll = (jl % GROUP) / E, kl = jl % E;
+        const double e_last = read_lane(B, __builtin_amdgcn_readfirstlane(G - 1));  // y-hat of element n-1
+        const double lp_ll = read_lane(lc.f_in, __builtin_amdgcn_readfirstlane(ll));
+        const double ylast = fma(c.pw[kl + 1], lp_ll * c_last, e_last);
+        const double xl = ylast * c.scal, cf = lc.f_in * cm;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double y0 = fma(c.pw[2 * q + 1], cf, x[2 * q]), y1 = fma(c.pw[2 * q + 2], cf, x[2 * q + 1]);
+            x[2 * q] = (j0 + 2 * q < L.n) ? fma(k.wg[2 * q], xl, y0) : 0.0;
+            x[2 * q + 1] = (j0 + 2 * q + 1 < L.n) ? fma(k.wg[2 * q + 1], xl, y1) : 0.0;
+        }
+    }
+    if (USE_G) {
+#pragma unroll
+        for (int q = 0; q < E; ++q) x[q] = g_cur[q] + x[q];
+    }
+    store_row(L.u + (size_t)i * L.ld, sl, x);
+    return true;
+}
+
 template <int KIND, int FORCE, bool USE_G>
 __global__ void __launch_bounds__(64) chain_kernel(LevelDev L, int start, int len, u64 *gran, unsigned *err) {
     if (blockIdx.x & 7) return;
-    const int wave = blockIdx.x >> 3, lane = threadIdx.x, G = L.T >> 6, t = wave * LANES + lane, li = lane & 15;
+    const int wave = blockIdx.x >> 3, lane = threadIdx.x, G = L.T >> 6, t = wave * LANES + lane;
     const unsigned sl = slot0(t);
-    const int j0 = t * E;
-    double x[E], s0[E], wg[E], pt[E], gi[E], gn[E];
-    Coef c;
-    LaneCoef lc;
-    int cur = -1;
-    if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) load_row(reinterpret_cast<const double *>(L.sP), sl, s0);
+    double x[E], ga[E], gb[E];
+    ChainCtx k;
+    k.cur = -1;
+    if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) load_row(reinterpret_cast<const double *>(L.sP), sl, k.s0);
     load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
-    if (USE_G) load_row(L.g + (size_t)start * L.ld, sl, gi);
-    // per-step scalars (coefficient-set index, forcing coefficient) are fetched one step ahead as well: a dependent
-    // global load at the top of every step would sit on the serial critical path
-    int ci_next = L.cidx[start];
-    double tc_next = (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) ? L.tc[start] : 0.0;
-    for (int i = start; i < start + len; ++i) {
-        const unsigned epoch = (unsigned)(i - start + 1);
-        u64 *slots = gran + (size_t)(epoch & 1) * MAX_G * 4;
-        const int ci = __builtin_amdgcn_readfirstlane(ci_next);
-        const double tc_i = tc_next;
-        // g of the NEXT step: a whole step of latency hiding (HBM ~2 us vs ~2 us per step)
-        if (i + 1 < start + len) {
-            if (USE_G) load_row(L.g + (size_t)(i + 1) * L.ld, sl, gn);
-            ci_next = L.cidx[i + 1];
-            if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) tc_next = L.tc[i + 1];
-        }
-        if (ci != cur) {
-            const CSet *g = L.cs + ci;
-            load_coef<false>(c, g);
-            lc = lane_coef(g->lp, lane);
-            load_row(reinterpret_cast<const double *>(L.tabP + (size_t)ci * 8 * L.T), sl, wg);
-            if (KIND == MGRIT_HIP_STEPPER_HEAT1D)
-                load_row(reinterpret_cast<const double *>(L.ptP + (size_t)ci * 1024 + (wave == G - 1 ? 512 : 0)), (unsigned)lane, pt);
-            cur = ci;
-        }
-        double v0, v1 = 0.0;  // the two published values of this worker
-        if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
-            if (FORCE == 1) {
-#pragma unroll
-                for (int k = 0; k < E; ++k) x[k] = fma(s0[k], tc_i, x[k]);
-            } else if (FORCE == 2) {
-                for (int kk = 0; kk < L.K; ++kk) {
-                    const double ck = L.tc[(size_t)kk * L.n_pts + i];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const double2 sv = L.sP[(size_t)kk * 8 * L.T + sl + q * 64];
-                        x[2 * q] = fma(sv.x, ck, x[2 * q]);
-                        x[2 * q + 1] = fma(sv.y, ck, x[2 * q + 1]);
-                    }
-                }
-            }
-            v0 = scan_fwd(x, c, lc, lane);
-#pragma unroll
-            for (int k = 0; k < E; ++k)
-                if (j0 + k >= L.n) x[k] = 0.0;
-            v1 = scan_bwd(x, c, lc, lane);
-        } else {
-#pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = x[k] * c.ik;
-            v0 = scan_fwd(x, c, lc, lane);
-            const int jl = L.n - 1;
-            double y = 0.0;
-#pragma unroll
-            for (int k = 0; k < E; ++k)
-                if (j0 + k == jl) y = x[k];
-            v1 = read_lane(y, __builtin_amdgcn_readfirstlane((jl % GROUP) / E));  // only meaningful on the last worker
-        }
-        // ---- publish: 4 granules {epoch, 32-bit half}
-        if (lane < 4) {
-            const double v = lane < 2 ? v0 : v1;
-            const unsigned half = (lane & 1) ? (unsigned)__double2loint(v) : (unsigned)__double2hiint(v);
-            __hip_atomic_store(slots + wave * 4 + lane, ((u64)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- sweep: lane k watches granule (worker k>>2, item k&3)
-        unsigned mine = 0;
-        {
-            const bool watch = (lane >> 2) < G;
-            unsigned spins = 0;
-            for (;;) {
-                bool ok = true;
-                if (watch) {
-                    const u64 g64 = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    mine = (unsigned)g64;
-                    ok = (unsigned)(g64 >> 32) == epoch;
-                }
-#ifdef MGRIT_EXPERIMENT_NO_WAIT
-                break;
-#endif
-                if (__all(ok)) break;
-                // the error word lives in host memory: look at it rarely (a peer that gave up stops publishing anyway)
-                if (++spins > CHAIN_SPIN_LIMIT ||
-                    ((spins & 0xffffu) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
-                    if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    return;  // bounded spin: give up, the host reports the failure
-                }
-#ifdef MGRIT_CHAIN_SLEEP
-                __builtin_amdgcn_s_sleep(MGRIT_CHAIN_SLEEP);
-#endif
-            }
-        }
-        // group (lane & 15) totals: hi/lo halves sit in lanes 4g .. 4g+3
-        const int src = (li < G ? li : 0) * 4;
-        const double A = __hiloint2double((int)__shfl(mine, src), (int)__shfl(mine, src + 1));
-        const double B = __hiloint2double((int)__shfl(mine, src + 2), (int)__shfl(mine, src + 3));
-        if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
-            double cm, zin, zf0;
-            heat_chains(c, li < G ? A : 0.0, li < G ? B : 0.0, G, wave, lane, cm, zin, zf0);
-            const double z0 = zf0 * c.ik, cb = lc.b_in * zin;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                heat_finish(x, c, cm, cb, z0, q, make_double2(wg[2 * q], wg[2 * q + 1]), make_double2(pt[2 * q], pt[2 * q + 1]));
-        } else {
-            double c_last = 0.0;
-            const double cm = fwd_chain(c, li < G ? A : 0.0, G, wave, lane, c_last);
-            const int jl = L.n - 1, ll = (jl % GROUP) / E, kl = jl % E;
-            const double e_last = read_lane(B, __builtin_amdgcn_readfirstlane(G - 1));  // y-hat of element n-1
-            const double lp_ll = read_lane(lc.f_in, __builtin_amdgcn_readfirstlane(ll));
-            const double ylast = fma(c.pw[kl + 1], lp_ll * c_last, e_last);
-            const double xl = ylast * c.scal, cf = lc.f_in * cm;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double y0 = fma(c.pw[2 * q + 1], cf, x[2 * q]), y1 = fma(c.pw[2 * q + 2], cf, x[2 * q + 1]);
-                x[2 * q] = (j0 + 2 * q < L.n) ? fma(wg[2 * q], xl, y0) : 0.0;
-                x[2 * q + 1] = (j0 + 2 * q + 1 < L.n) ? fma(wg[2 * q + 1], xl, y1) : 0.0;
-            }
-        }
-        if (USE_G) {
-#pragma unroll
-            for (int k = 0; k < E; ++k) {
-                x[k] = gi[k] + x[k];
-                gi[k] = gn[k];
-            }
-        }
-        store_row(L.u + (size_t)i * L.ld, sl, x);
+    if (USE_G) load_row(L.g + (size_t)start * L.ld, sl, ga);
+    const bool f1 = KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1;
+    k.ci_a = L.cidx[start];
+    k.tc_a = f1 ? L.tc[start] : 0.0;
+    k.ci_b = len > 1 ? L.cidx[start + 1] : 0;
+    k.tc_b = (f1 && len > 1) ? L.tc[start + 1] : 0.0;
+    // two steps per trip so that the g buffers swap roles without register copies
+    for (int i = start; i < start + len; i += 2) {
+        if (!chain_step<KIND, FORCE, USE_G>(L, k, x, ga, gb, i, start, len, gran, err, wave, lane, G, t, sl)) return;
+        if (i + 1 < start + len &&
+            !chain_step<KIND, FORCE, USE_G>(L, k, x, gb, ga, i + 1, start, len, gran, err, wave, lane, G, t, sl)) return;
     }
 }
 
@@ -1918,14 +1954,14 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     if (mode == MGRIT_HIP_RELAX_CHAIN && lv.G > 1) {
         // sequential chain over several groups: one single-wave workgroup per group, exchange through global granules
         if (!e->chain_gran) {
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->chain_gran), sizeof(u64) * 2 * MAX_G * 4));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->chain_gran), sizeof(u64) * 4 * MAX_G * 4));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->chain_err), 64, hipHostMallocMapped));
             *e->chain_err = 0u;
         }
         const bool use_g = lvl > 0;
         const int fm = force_mode(lv);
         for (int r = 0; r < rl->n; ++r) {
-            HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 2 * MAX_G * 4, e->stream));
+            HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
             const dim3 grid(8 * lv.G), block(LANES);
             const int st = rl->h_start[r], ln = rl->h_len[r];
 #define CHAIN_CASE(K, F, G_)                                                                                  \
