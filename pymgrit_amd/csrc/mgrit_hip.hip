@@ -511,8 +511,8 @@ struct ChainCtx {
 // them (vmcnt retires in order), putting an HBM round trip on the serial path of every step.
 // Returns false when the bounded spin gave up.
 template <int KIND, int FORCE, bool USE_G>
-__device__ __forceinline__ bool chain_step(const LevelDev &L, ChainCtx &k, double (&x)[E], const double (&g_cur)[E],
-                                           double (&g_nxt)[E], int i, int start, int len, u64 *gran, unsigned *err, int wave,
+__device__ __forceinline__ bool chain_step(const LevelDev &L, ChainCtx &k, double (&x)[E], const double2 *g_slot,
+                                           double2 *x_slot, int i, int start, int len, u64 *gran, unsigned *err, int wave,
                                            int lane, int G, int t, unsigned sl) {
     const int j0 = t * E, li = lane & 15;
     const unsigned epoch = (unsigned)(i - start + 1);
@@ -601,13 +601,10 @@ __device__ __forceinline__ bool chain_step(const LevelDev &L, ChainCtx &k, doubl
 #endif
         }
     }
-    // ---- loads for the steps to come, a whole step ahead of the next poll
-    if (i + 1 < start + len) {
-        if (USE_G) load_row(L.g + (size_t)(i + 1) * L.ld, sl, g_nxt);
-        if (i + 2 < start + len) {
-            k.ci_b = L.cidx[i + 2];
-            if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) k.tc_b = L.tc[i + 2];
-        }
+    // ---- scalars of the step after next, a whole step ahead of the next poll
+    if (i + 2 < start + len) {
+        k.ci_b = L.cidx[i + 2];
+        if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) k.tc_b = L.tc[i + 2];
     }
     // group (lane & 15) totals: hi/lo halves sit in lanes 4g .. 4g+3
     const int src = (li < G ? li : 0) * 4;
@@ -637,34 +634,104 @@ __device__ __forceinline__ bool chain_step(const LevelDev &L, ChainCtx &k, doubl
     }
     if (USE_G) {
 #pragma unroll
-        for (int q = 0; q < E; ++q) x[q] = g_cur[q] + x[q];
+        for (int q = 0; q < 8; ++q) {
+            const double2 gv = g_slot[q * 64 + lane];
+            x[2 * q] = gv.x + x[2 * q];
+            x[2 * q + 1] = gv.y + x[2 * q + 1];
+        }
     }
-    store_row(L.u + (size_t)i * L.ld, sl, x);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x_slot[q * 64 + lane] = make_double2(x[2 * q], x[2 * q + 1]);
     return true;
 }
 
+// The streamer wave of a chain worker: every global load of g and every global store of u of the worker's group goes
+// through this wave and two LDS rings, so the compute wave's vmcnt only ever counts its own granule polls (vmcnt retires in
+// order: a g load or u store in flight in the compute wave would sit in front of every poll result). One workgroup
+// barrier per step hands over g of the next step and x of the previous one.
+//   step s (between barrier s and barrier s+1):  compute reads g_ring[s & 1], writes x_ring[s & 1];
+//   the streamer stores x_ring[(s-1) & 1] to u, moves g of step s+1 from registers into g_ring[(s+1) & 1] and refills
+//   those registers with g of step s+4 (three rows in flight).
+template <bool USE_G>
+__device__ __forceinline__ void stream_step(const LevelDev &L, double (&row)[E], double2 *g_next, const double2 *x_prev,
+                                            int s, int start, int len, unsigned sl, int lane) {
+    __syncthreads();
+    if (s >= 1) {
+        double xr[E];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double2 v = x_prev[q * 64 + lane];
+            xr[2 * q] = v.x;
+            xr[2 * q + 1] = v.y;
+        }
+        store_row(L.u + (size_t)(start + s - 1) * L.ld, sl, xr);
+    }
+    if (USE_G && s + 1 < len) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g_next[q * 64 + lane] = make_double2(row[2 * q], row[2 * q + 1]);
+        if (s + 4 < len) load_row(L.g + (size_t)(start + s + 4) * L.ld, sl, row);
+    }
+}
+
 template <int KIND, int FORCE, bool USE_G>
-__global__ void __launch_bounds__(64) chain_kernel(LevelDev L, int start, int len, u64 *gran, unsigned *err) {
+__global__ void __launch_bounds__(128) chain_kernel(LevelDev L, int start, int len, u64 *gran, unsigned *err) {
     if (blockIdx.x & 7) return;
-    const int wave = blockIdx.x >> 3, lane = threadIdx.x, G = L.T >> 6, t = wave * LANES + lane;
+    __shared__ double2 g_ring[2][512], x_ring[2][512];
+    const int wave = blockIdx.x >> 3, lane = threadIdx.x & 63, G = L.T >> 6, t = wave * LANES + lane;
     const unsigned sl = slot0(t);
-    double x[E], ga[E], gb[E];
+    if (threadIdx.x >= LANES) {  // ---- streamer wave
+        double r0[E], r1[E], r2[E];
+        if (USE_G) {
+            load_row(L.g + (size_t)start * L.ld, sl, r0);
+            if (len > 1) load_row(L.g + (size_t)(start + 1) * L.ld, sl, r1);
+            if (len > 2) load_row(L.g + (size_t)(start + 2) * L.ld, sl, r2);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) g_ring[0][q * 64 + lane] = make_double2(r0[2 * q], r0[2 * q + 1]);
+            if (len > 3) load_row(L.g + (size_t)(start + 3) * L.ld, sl, r0);
+        }
+        // step s moves the register row holding g of step s+1: rows cycle r1, r2, r0; rings alternate -> period 6
+        for (int s = 0; s < len; s += 6) {
+            stream_step<USE_G>(L, r1, g_ring[1], x_ring[1], s, start, len, sl, lane);
+            if (s + 1 < len) stream_step<USE_G>(L, r2, g_ring[0], x_ring[0], s + 1, start, len, sl, lane);
+            if (s + 2 < len) stream_step<USE_G>(L, r0, g_ring[1], x_ring[1], s + 2, start, len, sl, lane);
+            if (s + 3 < len) stream_step<USE_G>(L, r1, g_ring[0], x_ring[0], s + 3, start, len, sl, lane);
+            if (s + 4 < len) stream_step<USE_G>(L, r2, g_ring[1], x_ring[1], s + 4, start, len, sl, lane);
+            if (s + 5 < len) stream_step<USE_G>(L, r0, g_ring[0], x_ring[0], s + 5, start, len, sl, lane);
+        }
+        __syncthreads();  // the compute wave has written the last x
+        {
+            double xr[E];
+            const double2 *xs = x_ring[(len - 1) & 1];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double2 v = xs[q * 64 + lane];
+                xr[2 * q] = v.x;
+                xr[2 * q + 1] = v.y;
+            }
+            store_row(L.u + (size_t)(start + len - 1) * L.ld, sl, xr);
+        }
+        return;
+    }
+    // ---- compute wave
+    double x[E];
     ChainCtx k;
     k.cur = -1;
     if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) load_row(reinterpret_cast<const double *>(L.sP), sl, k.s0);
     load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
-    if (USE_G) load_row(L.g + (size_t)start * L.ld, sl, ga);
     const bool f1 = KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1;
     k.ci_a = L.cidx[start];
     k.tc_a = f1 ? L.tc[start] : 0.0;
     k.ci_b = len > 1 ? L.cidx[start + 1] : 0;
     k.tc_b = (f1 && len > 1) ? L.tc[start + 1] : 0.0;
-    // two steps per trip so that the g buffers swap roles without register copies
     for (int i = start; i < start + len; i += 2) {
-        if (!chain_step<KIND, FORCE, USE_G>(L, k, x, ga, gb, i, start, len, gran, err, wave, lane, G, t, sl)) return;
-        if (i + 1 < start + len &&
-            !chain_step<KIND, FORCE, USE_G>(L, k, x, gb, ga, i + 1, start, len, gran, err, wave, lane, G, t, sl)) return;
+        __syncthreads();
+        if (!chain_step<KIND, FORCE, USE_G>(L, k, x, g_ring[0], x_ring[0], i, start, len, gran, err, wave, lane, G, t, sl)) return;
+        if (i + 1 < start + len) {
+            __syncthreads();
+            if (!chain_step<KIND, FORCE, USE_G>(L, k, x, g_ring[1], x_ring[1], i + 1, start, len, gran, err, wave, lane, G, t, sl)) return;
+        }
     }
+    __syncthreads();
 }
 
 // compute_residual (mgrit.py:387-413): out[run] = || Phi(u_{i-1}) - u_i ||^2
@@ -749,47 +816,58 @@ __global__ void __launch_bounds__(1024) fas_coarse_kernel(LevelDev L, const int3
 }
 
 // fas_residual fused for the identity spatial transfer (GridTransferCopy): per C-point j >= 1 with fine slot i, previous
-// fine C slot ip and coarse slot j (mgrit.py:498-500,520,524-547 in one pass over the data):
+// fine C slot ip and coarse slot j (mgrit.py:498-500,520,524-547):
 //   u^{l+1}_j = v^{l+1}_j = u^l_i ;  g^{l+1}_j = ((Phi_l(u^l_{i-1}) - u^l_i) + v_j) - Phi_{l+1}(v_{j-1}),  v_{j-1} = u^l_{ip}
-// (lvl > 0: (g^l_i - u^l_i) + Phi_l(u^l_{i-1})). 3-4 vectors read, 3 written per C-point instead of 11-12.
+// (lvl > 0: (g^l_i - u^l_i) + Phi_l(u^l_{i-1})). Persistent workgroups in two phases, so that each level's coefficient tables
+// are loaded into LDS once per workgroup instead of twice per C-point: phase 1 applies the fine Phi to all of the
+// workgroup's points (writes u, v and the partial g of the coarse level), phase 2 the coarse Phi (reads u^l_{ip} and the
+// partial g it wrote itself). 4-5 vectors read, 4 written per C-point instead of 11-12.
 template <int KIND, int FORCE>
 __global__ void __launch_bounds__(1024) fas_fused_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ fine_idx,
                                                          const int32_t *__restrict__ prev_idx,
-                                                         const int32_t *__restrict__ coarse_idx, int use_g) {
+                                                         const int32_t *__restrict__ coarse_idx, int n_items, int use_g) {
     WG_PROLOGUE;
-    const int i = fine_idx[blockIdx.x], ip = prev_idx[blockIdx.x], j = coarse_idx[blockIdx.x];
-    double x[E], w[E];
-    load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
-    load_row(L.u + (size_t)i * L.ld, sl, w);
-    store_row(Lc.u + (size_t)j * Lc.ld, sl, w);
-    store_row(Lc.v + (size_t)j * Lc.ld, sl, w);
-    if (use_g) {
-        double gi[E];
-        load_row(L.g + (size_t)i * L.ld, sl, gi);
+    for (int p = blockIdx.x; p < n_items; p += gridDim.x) {
+        const int i = fine_idx[p], j = coarse_idx[p];
+        double x[E], w[E];
+        load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
+        load_row(L.u + (size_t)i * L.ld, sl, w);
+        store_row(Lc.u + (size_t)j * Lc.ld, sl, w);
+        store_row(Lc.v + (size_t)j * Lc.ld, sl, w);
+        if (use_g) {
+            double gi[E];
+            load_row(L.g + (size_t)i * L.ld, sl, gi);
 #pragma unroll
-        for (int k = 0; k < E; ++k) w[k] = gi[k] - w[k];
+            for (int k = 0; k < E; ++k) w[k] = gi[k] - w[k];
+        }
+        phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+        if (use_g) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = w[k] + x[k];
+            load_row(L.u + (size_t)i * L.ld, sl, w);   // u^l_i once more (one live vector less while Phi runs)
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = x[k] + w[k];   // + v_j
+        store_row(Lc.g + (size_t)j * Lc.ld, sl, x);
     }
-    phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
-    if (use_g) {
-#pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = w[k] + x[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
-    }
-    load_row(Lc.v + (size_t)j * Lc.ld, sl, w);  // = u^l_i, written above by this very lane
-#pragma unroll
-    for (int k = 0; k < E; ++k) x[k] = x[k] + w[k];
-    load_row(L.u + (size_t)ip * L.ld, sl, w);   // v_{j-1}
     {
         const int par = ctx.parity;
         ctx_init<KIND, FORCE>(ctx, Lc, t);       // coarse level: its own forcing factor and coefficient sets
         ctx.parity = par;
     }
-    phi_apply<KIND, FORCE>(w, ctx, Lc, j, sm, t, lane, wave, G);
+    for (int p = blockIdx.x; p < n_items; p += gridDim.x) {
+        const int ip = prev_idx[p], j = coarse_idx[p];
+        double x[E], w[E];
+        load_row(L.u + (size_t)ip * L.ld, sl, w);   // v_{j-1}
+        load_row(Lc.g + (size_t)j * Lc.ld, sl, x);  // partial g, written above by this very lane
+        phi_apply<KIND, FORCE>(w, ctx, Lc, j, sm, t, lane, wave, G);
 #pragma unroll
-    for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
-    store_row(Lc.g + (size_t)j * Lc.ld, sl, x);
+        for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
+        store_row(Lc.g + (size_t)j * Lc.ld, sl, x);
+    }
 }
 
 // --- spatial transfer kernels (bandwidth-bound, elementwise over ROW POSITIONS of the destination) ---------------
@@ -1962,7 +2040,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
         const int fm = force_mode(lv);
         for (int r = 0; r < rl->n; ++r) {
             HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
-            const dim3 grid(8 * lv.G), block(LANES);
+            const dim3 grid(8 * lv.G), block(2 * LANES);
             const int st = rl->h_start[r], ln = rl->h_len[r];
 #define CHAIN_CASE(K, F, G_)                                                                                  \
     if (lv.dev.kind == K && fm == F && use_g == G_)                                                            \
@@ -2119,8 +2197,8 @@ int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id) {
     const int use_g = lvl > 0 ? 1 : 0;
 #define FUSED_CASE(K_, F_)                                                                                         \
     if (lf.dev.kind == K_ && force_mode(lf) == F_)                                                                  \
-        hipLaunchKernelGGL((fas_fused_kernel<K_, F_>), dim3(pl->n), dim3(lf.dev.T), smem_bytes(lf.G), e->stream, lf.dev, \
-                           lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, use_g);
+        hipLaunchKernelGGL((fas_fused_kernel<K_, F_>), dim3(persistent_grid(lf, pl->n)), dim3(lf.dev.T), smem_bytes(lf.G),  \
+                           e->stream, lf.dev, lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);
     FOR_EACH_STEPPER(FUSED_CASE)
     HIP_TRY(hipGetLastError());
     return 0;
