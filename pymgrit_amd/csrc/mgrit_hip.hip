@@ -950,10 +950,15 @@ struct H2DDev {
 };
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
 
 // out[b][n][m] (* dinv[n][m]) = sum_k A[k][m] * B[b][k][n] ; A: M x M symmetric, B: M x N per batch item, out: N x M.
 // 64x64 tile per workgroup, 4 waves x (32x32 = 2x2 MFMA tiles), K step 16 through LDS (rows padded to 80 doubles:
 // the two k-rows a ds_read_b64 half-wave touches fall into disjoint bank halves).
+// LDS-only workgroup barrier: __syncthreads() also waits for vmcnt(0) (its fence covers global memory), which would drain
+// the register prefetch of the next K step in front of every barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <bool SCALE>
 __global__ void __launch_bounds__(256) h2d_gemm_kernel(const double *__restrict__ A, int M, const double *__restrict__ B,
                                                        int N, double *__restrict__ out, const double *__restrict__ dinv,
@@ -966,9 +971,14 @@ __global__ void __launch_bounds__(256) h2d_gemm_kernel(const double *__restrict_
     double(*Bs)[LDT] = reinterpret_cast<double(*)[LDT]>(smem + BK * LDT);
     double(*Cs)[66] = reinterpret_cast<double(*)[66]>(smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const double *Bb = B + (size_t)blockIdx.z * bstride;
-    double *Ob = out + (size_t)blockIdx.z * bstride;
+    // grid (n tiles, m tiles, items): workgroups are dealt to the 8 XCDs round-robin by linear id, so with 8 n tiles XCD x
+    // handles the n-block x of every item: that 64-column block of B is fetched from HBM once, by this XCD only, and reused
+    // by the item's m tiles out of its L2, next to the whole A table (2 MB at 512^2) which stays L2-resident.
+    // (Sending all 64 tiles of an item to one XCD instead makes A and two items' B compete for the 4 MB L2: half the rate.)
+    const int item = blockIdx.z;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const double *Bb = B + (size_t)item * bstride;
+    double *Ob = out + (size_t)item * bstride;
     const int wm = (w & 1) * 32, wn = (w >> 1) * 32;
     const int lr = lane & 15, lk = lane >> 4;
     d4_t acc[2][2];
@@ -977,14 +987,28 @@ __global__ void __launch_bounds__(256) h2d_gemm_kernel(const double *__restrict_
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
     const int sr = tid >> 5, sc = (tid & 31) * 2;
+    d2_t ra[BK / 8], rb[BK / 8];
+    const double *Ap = A + (size_t)sr * M + m0 + sc, *Bp = Bb + (size_t)sr * N + n0 + sc;
+#pragma unroll
+    for (int h = 0; h < BK / 8; ++h) {
+        ra[h] = *reinterpret_cast<const d2_t *>(Ap + (size_t)(8 * h) * M);
+        rb[h] = *reinterpret_cast<const d2_t *>(Bp + (size_t)(8 * h) * N);
+    }
     for (int k0 = 0; k0 < M; k0 += BK) {
 #pragma unroll
         for (int h = 0; h < BK / 8; ++h) {
-            const int r = sr + 8 * h;
-            *reinterpret_cast<double2 *>(&As[r][sc]) = *reinterpret_cast<const double2 *>(A + (size_t)(k0 + r) * M + m0 + sc);
-            *reinterpret_cast<double2 *>(&Bs[r][sc]) = *reinterpret_cast<const double2 *>(Bb + (size_t)(k0 + r) * N + n0 + sc);
+            *reinterpret_cast<d2_t *>(&As[sr + 8 * h][sc]) = ra[h];
+            *reinterpret_cast<d2_t *>(&Bs[sr + 8 * h][sc]) = rb[h];
         }
-        __syncthreads();
+        lds_barrier();
+        {   // operands of the next K step: in flight while the matrix cores work on this one (the last trip re-reads its own)
+            const int kn = k0 + BK < M ? k0 + BK : k0;
+#pragma unroll
+            for (int h = 0; h < BK / 8; ++h) {
+                ra[h] = *reinterpret_cast<const d2_t *>(Ap + (size_t)(kn + 8 * h) * M);
+                rb[h] = *reinterpret_cast<const d2_t *>(Bp + (size_t)(kn + 8 * h) * N);
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
             const double a0 = As[kk * 4 + lk][wm + lr], a1 = As[kk * 4 + lk][wm + 16 + lr];
@@ -994,7 +1018,7 @@ __global__ void __launch_bounds__(256) h2d_gemm_kernel(const double *__restrict_
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         }
-        __syncthreads();
+        lds_barrier();
     }
     // D[row = lk + 4r][col = lr] of tile (tm, tn) is element (m = wm + 16 tm + lk + 4r, n = wn + 16 tn + lr): store transposed
 #pragma unroll
@@ -1593,14 +1617,11 @@ int h2d_phi_batch(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const doubl
     hipLaunchKernelGGL(h2d_rhs_kernel, dim3((H.Mj + 255) / 256, H.Mi, pl.count), dim3(256), 0, e->stream, H, in_slab, pl.d_in,
                        pl.d_step, h.W0);
     // X1[j][i'] = (Qx B)^T ; X2[i'][j'] = ((Qx B) Qy) o D ; X3[j'][i] = (Qx X2)^T ; U[i][j] = (Qx X2) Qy
-    hipLaunchKernelGGL((h2d_gemm_kernel<false>), dim3(H.Mi / 64, H.Mj / 64, pl.count), dim3(256), 0, e->stream, h.Qx, H.Mi, h.W0,
-                       H.Mj, h.W1, nullptr, per);
-    hipLaunchKernelGGL((h2d_gemm_kernel<true>), dim3(H.Mj / 64, H.Mi / 64, pl.count), dim3(256), 0, e->stream, h.Qy, H.Mj, h.W1,
-                       H.Mi, h.W0, dinv, per);
-    hipLaunchKernelGGL((h2d_gemm_kernel<false>), dim3(H.Mi / 64, H.Mj / 64, pl.count), dim3(256), 0, e->stream, h.Qx, H.Mi, h.W0,
-                       H.Mj, h.W1, nullptr, per);
-    hipLaunchKernelGGL((h2d_gemm_kernel<false>), dim3(H.Mj / 64, H.Mi / 64, pl.count), dim3(256), 0, e->stream, h.Qy, H.Mj, h.W1,
-                       H.Mi, h.W0, nullptr, per);
+    const dim3 g1(H.Mj / 64, H.Mi / 64, pl.count), g2(H.Mi / 64, H.Mj / 64, pl.count);  // (n tiles, m tiles, items)
+    hipLaunchKernelGGL((h2d_gemm_kernel<false>), g1, dim3(256), 0, e->stream, h.Qx, H.Mi, h.W0, H.Mj, h.W1, nullptr, per);
+    hipLaunchKernelGGL((h2d_gemm_kernel<true>), g2, dim3(256), 0, e->stream, h.Qy, H.Mj, h.W1, H.Mi, h.W0, dinv, per);
+    hipLaunchKernelGGL((h2d_gemm_kernel<false>), g1, dim3(256), 0, e->stream, h.Qx, H.Mi, h.W0, H.Mj, h.W1, nullptr, per);
+    hipLaunchKernelGGL((h2d_gemm_kernel<false>), g2, dim3(256), 0, e->stream, h.Qy, H.Mj, h.W1, H.Mi, h.W0, nullptr, per);
     HIP_TRY(hipGetLastError());
     return 0;
 }
