@@ -97,6 +97,11 @@ __device__ __forceinline__ unsigned slot0(int t) { return (unsigned)(((t >> 6) <
 // ---------------------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------------------
+// LDS-only workgroup barrier. __syncthreads() also waits for vmcnt(0) (its fence covers global memory), which would drain
+// the GEMM's register prefetch of the next K step in front of every barrier. Only the GEMM uses it: in the 1-D steppers it
+// bought nothing measurable (their loads are consumed before the next barrier anyway).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ void load_row(const double *__restrict__ row, unsigned s0, double (&x)[E]) {
     const double2 *r2 = reinterpret_cast<const double2 *>(row) + s0;
 #pragma unroll
@@ -955,10 +960,6 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // out[b][n][m] (* dinv[n][m]) = sum_k A[k][m] * B[b][k][n] ; A: M x M symmetric, B: M x N per batch item, out: N x M.
 // 64x64 tile per workgroup, 4 waves x (32x32 = 2x2 MFMA tiles), K step 16 through LDS (rows padded to 80 doubles:
 // the two k-rows a ds_read_b64 half-wave touches fall into disjoint bank halves).
-// LDS-only workgroup barrier: __syncthreads() also waits for vmcnt(0) (its fence covers global memory), which would drain
-// the register prefetch of the next K step in front of every barrier
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 template <bool SCALE>
 __global__ void __launch_bounds__(256) h2d_gemm_kernel(const double *__restrict__ A, int M, const double *__restrict__ B,
                                                        int N, double *__restrict__ out, const double *__restrict__ dinv,
