@@ -56,6 +56,33 @@ def phi_counts(nts, m_list, first_iteration=False):
     return counts
 
 
+def cycle_phi_counts(nts, m_list, cycle_type='V'):
+    """Phi applications per level of one steady-state cycle (iteration >= 1, cf_iter = 1) + the residual check, obtained by
+    walking the recursion of Mgrit.iteration (reference mgrit.py:261-290); equals phi_counts() for V-cycles."""
+    L = len(nts)
+    N = [n - 1 for n in nts]
+    C = [N[l] // m_list[l] if l < L - 1 else N[l] for l in range(L)]
+    F = [N[l] - C[l] for l in range(L)]
+    counts = [0] * L
+
+    def it(lvl, ctype, first_f):
+        if lvl == L - 1:
+            counts[lvl] += N[lvl]
+            return
+        if first_f and lvl > 0:
+            counts[lvl] += F[lvl]
+        counts[lvl] += C[lvl] + F[lvl]            # C-relax, F-relax
+        counts[lvl] += C[lvl]                     # fas_residual: fine Phi per C-point
+        counts[lvl + 1] += N[lvl + 1]             #               coarse Phi per coarse point
+        it(lvl + 1, ctype, True)
+        counts[lvl] += F[lvl]                     # F-relax after the correction
+        if lvl != 0 and ctype == 'F':
+            it(lvl, 'V', False)
+    it(0, cycle_type, True)
+    counts[0] += C[0]                             # residual check
+    return counts
+
+
 def cpu_baseline(nx, seconds_target=12.0):
     """The parity oracle ("port", variant 0 = plain Thomas) timed single-threaded on this host on a bounded sample of
     the same workload: nx as given, nt=1025, 3-level m=4, V-cycles until ~seconds_target."""
@@ -134,6 +161,59 @@ def bench_heat2d(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_advection(args):
+    """Secondary workload (not the driver's default): BASELINE configs[4] = advection_1d nx=8193 (8192 periodic DOF),
+    nt=32769, F-cycle, 4 levels m=2, spatial coarsening (periodic full weighting / linear interpolation) on the first two
+    level pairs and the copy transfer on the last (mirrors examples/example_spatial_coarsening.py:112-123). Reports the
+    F-cycle throughput and the HBM roofline of the level-0 F-relax launch (16*n bytes per Phi)."""
+    import torch
+    from pymgrit_amd import Advection1D, GridTransferAdvection, GridTransferCopy, Mgrit
+    torch.cuda.set_device(0)
+    nt0 = args.nt_adv
+    t0 = np.linspace(0, 2, nt0)
+    nxs = [8193, 4097, 2049, 2049]
+    prob = [Advection1D(c=1, x_start=-1, x_end=1, nx=nx, t_interval=t0[::2 ** lvl]) for lvl, nx in enumerate(nxs)]
+    transfer = [GridTransferAdvection(), GridTransferAdvection(), GridTransferCopy()]
+    mg = Mgrit(prob, transfer=transfer, cf_iter=1, cycle_type='F', nested_iteration=False, max_iter=1, tol=0.0, logging_lvl=30)
+    be = mg.backend
+
+    def cycle(it):
+        mg.iteration(lvl=0, cycle_type='F', iteration=it, first_f=True)
+        mg.convergence_criterion(iteration=1)
+    cycle(0)
+    for _ in range(args.warmup):
+        cycle(1)
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        cycle(1)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    f_runs = mg._f_runs(0)
+    n_f = sum(r[1] for r in f_runs)
+    be.set_timing(True)
+    ms = []
+    for _ in range(4):
+        be.relax(0, f_runs, 'F')
+        ms.append(be.last_kernel_ms())
+    be.set_timing(False)
+    f_ms = float(np.mean(ms[1:]))
+    dof = nxs[0] - 1
+    achieved = n_f * 16.0 * dof / (f_ms * 1e-3) / 1e9
+    out = {"metric": "time-point-DOF updates/sec per MGRIT F-cycle", "value": None, "unit": "time-point-DOF updates/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"advection_1d nx=8193 nt={nt0} 4-level m=2 F-cycle, spatial coarsening on the first two "
+                                  f"level pairs + residual check (BASELINE configs[4])", "dof_by_level": [n - 1 for n in nxs]},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "relax_kernel<ADVECTION1D,false,ROLE_F> (level-0 F-relax)", "launch_ms": f_ms,
+                        "algorithmic_bytes_per_launch": n_f * 16.0 * dof}}
+    counts = cycle_phi_counts([len(p.t) for p in prob], [2, 2, 2], 'F')
+    out["config"]["phi_per_cycle_by_level"] = counts
+    out["value"] = sum(c * d for c, d in zip(counts, out["config"]["dof_by_level"])) * args.steps / elapsed
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,13 +224,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "smoke-test the N>1 path with several ranks on ONE GPU)")
-    ap.add_argument("--workload", default="heat1d", choices=["heat1d", "heat2d"],
+    ap.add_argument("--nt-adv", dest="nt_adv", type=int, default=32769)
+    ap.add_argument("--workload", default="heat1d", choices=["heat1d", "heat2d", "advection"],
                     help="heat1d = BASELINE configs[2] (default, the driver's run); heat2d = configs[3] on one GPU")
     ap.add_argument("--nx2d", type=int, default=512)
     ap.add_argument("--nt2d", type=int, default=16385)
     args = ap.parse_args()
     if args.workload == "heat2d":
         return bench_heat2d(args)
+    if args.workload == "advection":
+        return bench_advection(args)
 
     import torch
     import torch.distributed as dist
@@ -249,7 +332,8 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle + residual check "
-                               f"(BASELINE configs[2]; time points sharded over {world} GPU(s))",
+                               f"(BASELINE configs[{2 if (nx, nt0) == (16384, 65537) else 1 if (nx, nt0) == (1024, 4097) else '-'}]; "
+                               f"time points sharded over {world} GPU(s))",
                    "phi_per_cycle_by_level": counts, "dof": dof},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
