@@ -106,6 +106,29 @@ def cpu_baseline(nx, seconds_target=12.0):
                       f"incl. residual check, {el:.1f} s, host has {os.cpu_count()} cores"}
 
 
+def iters_to_tol(problem, nx, tol=1e-10):
+    """Second half of BASELINE.json's metric ("iters-to-tol vs CPU ref"): Mgrit.solve() to the reference's default tolerance
+    on the full workload (GPU; tolerance tightened from the reference default 1e-7, which this workload meets after two cycles), and on the bounded sample of cpu_baseline() on both the GPU and the CPU oracle (same
+    arithmetic spec), whose residual histories must agree. Outside every timed region; part of the cpu_baseline leg."""
+    import cases
+    from oracle import oracle as orc
+    from pymgrit_amd import Heat1D, Mgrit
+    mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=True, max_iter=30, tol=tol, logging_lvl=30)
+    conv_full = mg.solve()["conv"]
+    del mg
+    nts = (1025, 257, 65)
+    grids = [cases.lin(2.0 * (nts[0] - 1) / 65536, nt) for nt in nts]
+    small = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=init_cond, rhs_separable=[(rhs_space, rhs_time)], t_interval=g)
+             for g in grids]
+    conv_gpu = Mgrit(small, cf_iter=1, cycle_type='V', nested_iteration=True, max_iter=30, tol=tol, logging_lvl=30).solve()["conv"]
+    conv_cpu = orc.OracleProblem([cases.heat_level_spec(nx, g) for g in grids], variant=1, cf_iter=1, nested_iteration=True,
+                                 max_iter=30, tol=tol).solve()
+    k = min(len(conv_gpu), len(conv_cpu))
+    return {"tol": tol, "full_workload": {"gpu_iters": int(len(conv_full)), "conv_last": float(conv_full[-1])},
+            "sample_nt1025": {"gpu_iters": int(len(conv_gpu)), "cpu_iters": int(len(conv_cpu)),
+                              "max_rel_conv_diff": float(np.max(np.abs(conv_gpu[:k] - conv_cpu[:k]) / np.abs(conv_cpu[:k])))}}
+
+
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet, FP64 matrix (the on-box guide lists no f64 MFMA row)
 
 
@@ -349,6 +372,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx)
+            out["iters_to_tol"] = iters_to_tol(problem, nx)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
