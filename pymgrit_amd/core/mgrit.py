@@ -11,7 +11,8 @@ What stays on the host is control flow only: the cycle recursion (mgrit.py:261-2
 boundaries (mgrit.py:304-331,346-352,397-403,467-484,502-517 -- mpi4py pickled isend/recv replaced by
 torch.distributed point-to-point, RCCL over xGMI for device rows) and the stopping test.
 
-Out of scope this round: local convergence criteria conv_crit 2/3 and their drain protocol.
+Local convergence criteria (conv_crit 2/3) are implemented for one rank; their multi-rank drain protocol is out of scope
+(SURVEY section 8f).
 """
 import logging
 import sys
@@ -94,7 +95,13 @@ class Mgrit:
         self.send_to, self.get_from, self.global_t = [], [], []
         self.t_norm = 1 if t_norm == 1 else None if t_norm == 2 else np.inf
         self.conv_crit = conv_crit
-        self.global_conv_crit = True
+        self.global_conv_crit = conv_crit in (0, 1)
+        self.finished = [False, None]
+        self.pre_finished = [True, 0]   # rank 0 has no predecessor (mgrit.py:224-228)
+        if not self.global_conv_crit and self.comm_time_size > 1:
+            raise Exception('Local convergence criteria (conv_crit 2/3) run on one rank only: their multi-rank drain protocol '
+                            '(mgrit.py:434-455,648-691: ranks leave the solve loop in different iterations) is not '
+                            'implemented; choose 0 (global space-time residual) or 1 (global jump) on several ranks')
         self.save_values_last_iter = None
         self.output_lvl = output_lvl
         self.output_fcn = output_fcn if (output_fcn is not None and callable(output_fcn)) else None
@@ -122,7 +129,7 @@ class Mgrit:
 
         if nested_iteration:
             self.nested_iteration()
-        if self.conv_crit == 1:
+        if self.conv_crit in (1, 3):
             self.backend.save_last()
 
         if self.iter_max == 0:
@@ -155,9 +162,6 @@ class Mgrit:
         if conv_crit not in [0, 1, 2, 3]:
             raise Exception('Unknown convergence criterion. Please choose: 0 (global space-time residual), '
                             '1 (global jump)2 (local space-time residual)3 (local jump)')
-        if conv_crit in (2, 3):
-            raise Exception('Local convergence criteria (conv_crit 2/3) are not implemented in the MI355X engine yet; '
-                            'choose 0 (global space-time residual) or 1 (global jump)')
         if isinstance(cf_iter, int):
             return [cf_iter for _ in range(len(problem))]
         if isinstance(cf_iter, list):
@@ -334,9 +338,14 @@ class Mgrit:
         """Global stopping value (mgrit.py:415-432): the per-point norms of all ranks, in time order, reduced with
         np.linalg.norm(ord=t_norm). gather+bcast of the reference becomes one all-gather of a few floats."""
         t0 = time.time()
-        val = self.compute_residual() if self.conv_crit == 0 else self.compute_jump()
-        parts = self.comm_time.allgather_object([float(x) for x in val])
-        self.conv[iteration] = time_norm(np.array([x for part in parts for x in part]), self.t_norm)
+        val = self.compute_residual() if self.conv_crit in (0, 2) else self.compute_jump()
+        if self.global_conv_crit:
+            parts = self.comm_time.allgather_object([float(x) for x in val])
+            self.conv[iteration] = time_norm(np.array([x for part in parts for x in part]), self.t_norm)
+        else:   # local criterion (mgrit.py:434-455), one rank: every point below the tolerance on its own
+            self.finished = [bool(self.pre_finished[0] and (all(v < self.tol for v in val) or iteration == self.iter_max)),
+                             iteration]
+            self.conv[iteration] = time_norm(np.array([float(x) for x in val]), self.t_norm)
         logging.debug(f"Convergence criterion on {self.comm_time_rank} took {time.time() - t0} s")
 
     def forward_solve(self, lvl: int) -> None:
@@ -435,13 +444,15 @@ class Mgrit:
             self.convergence_criterion(iteration=iteration + 1)
             now, before = self.conv[iteration + 1], self.conv[iteration]
             factor = '-' if iteration == 0 else str(now / before)
-            self.log_info('{0: <7}'.format(f"iter {iteration + 1}") + '{0: <32}'.format(f" | conv: {now}") +
+            label = f" | conv: {now}" if self.global_conv_crit else f" | conv on process {self.comm_time_size - 1}: {now}"
+            self.log_info('{0: <7}'.format(f"iter {iteration + 1}") + '{0: <32}'.format(label) +
                           '{0: <37}'.format(f" | conv factor: {factor}") +
                           '{0: <35}'.format(f" | runtime: {it_stop - it_start} s"))
             if self.output_fcn is not None and self.output_lvl == 2:
                 self.output_fcn(self)
             if now < self.tol or iteration == self.iter_max - 1:
-                break
+                if self.global_conv_crit or (self.finished[0] and self.pre_finished[0]) or iteration == self.iter_max - 1:
+                    break
         self.backend.sync()
         self.comm_time.barrier()
         self.runtime_solve = time.time() - solve_start

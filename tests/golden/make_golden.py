@@ -467,6 +467,22 @@ def make_bdf():
     print("wrote bdf", {k: v["conv"][:3] for k, v in out["solve"].items()})
 
 
+# --------------------------------------------------------------------------------------------------
+# Local convergence criteria (conv_crit 2 / 3, mgrit.py:434-455) on one rank
+# --------------------------------------------------------------------------------------------------
+def make_local_conv():
+    out = {}
+    for crit in (2, 3):
+        d = simple_setup_problem(Dahlquist(t_start=0, t_stop=5, nt=101), level=2, coarsening=2)
+        out[f"dahlquist_crit{crit}"] = run(d, tol=1e-10, conv_crit=crit, sample_pts=(100,))
+        out[f"heat_nx33_crit{crit}"] = run(heat_levels(33, [65, 17, 5]), tol=1e-7, max_iter=12, conv_crit=crit, sample_pts=(64,))
+        out[f"heat_nx33_crit{crit}_maxiter"] = run(heat_levels(33, [65, 17, 5]), tol=1e-14, max_iter=3, conv_crit=crit,
+                                                  sample_pts=(64,))
+    with open(os.path.join(HERE, "local_conv.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("wrote local_conv", {k: len(v["conv"]) for k, v in out.items()})
+
+
 def ref_results():
     res = {}
     d = os.path.join(REF, "tests", "mpi", "results")
@@ -485,6 +501,9 @@ def main():
     if "--only-advection-sc" in sys.argv:
         make_advection_sc()
         return
+    if "--only-local-conv" in sys.argv:
+        make_local_conv()
+        return
     if "--only-bdf" in sys.argv:
         make_bdf()
         return
@@ -502,6 +521,7 @@ def main():
     make_heat2d()
     make_advection_sc()
     make_bdf()
+    make_local_conv()
     res, kats = ref_results()
     with open(os.path.join(HERE, "ref_results.json"), "w") as f:
         json.dump({"tests_mpi_results": res}, f, indent=1)
