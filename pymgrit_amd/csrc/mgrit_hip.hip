@@ -100,7 +100,13 @@ __device__ __forceinline__ unsigned slot0(int t) { return (unsigned)(((t >> 6) <
 // LDS-only workgroup barrier. __syncthreads() also waits for vmcnt(0) (its fence covers global memory), which would drain
 // the GEMM's register prefetch of the next K step in front of every barrier. Only the GEMM uses it: in the 1-D steppers it
 // bought nothing measurable (their loads are consumed before the next barrier anyway).
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (Builtins, not inline asm: an `asm volatile("s_waitcnt lgkmcnt(0); s_barrier")` in this place was observed to let waves
+// read the LDS group totals of a step before they were written in one kernel -- the compiler does not treat an asm
+// string as a barrier when it schedules LDS accesses.)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0), vmcnt / expcnt untouched (gfx9 encoding)
+    __builtin_amdgcn_s_barrier();
+}
 
 __device__ __forceinline__ void load_row(const double *__restrict__ row, unsigned s0, double (&x)[E]) {
     const double2 *r2 = reinterpret_cast<const double2 *>(row) + s0;
