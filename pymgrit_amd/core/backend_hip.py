@@ -261,6 +261,19 @@ class HipBackend:
         self.mg.save_values_last_iter = SlabVectorList(self.prev, self.n[0], self.mg.problem[0].vector_template,
                                                        self.perm[0])
 
+    # -- C-point snapshots of level 0 (pipelined solve, Mgrit._solve_pipelined): rows copied inside HBM ------------
+    def snapshot_cpoints(self, slot, points):
+        if not hasattr(self, "_snap"):
+            self._snap, self._snap_idx = {}, torch.as_tensor(np.asarray(points, dtype=np.int64), device=self.device)
+        if slot not in self._snap:
+            self._snap[slot] = torch.empty((len(points), self.ld[0]), dtype=torch.float64, device=self.device)
+        if len(points):
+            torch.index_select(self.U[0], 0, self._snap_idx, out=self._snap[slot])
+
+    def restore_cpoints(self, slot, points):
+        if len(points):
+            self.U[0].index_copy_(0, self._snap_idx, self._snap[slot])
+
     def jump_norms(self, points):
         out = []
         if len(points):

@@ -69,6 +69,16 @@ class PluginBackend:
     def save_last(self):
         self.mg.save_values_last_iter = [item.clone() for item in self.mg.u[0]]
 
+    # -- C-point snapshots of level 0 (pipelined solve, Mgrit._solve_pipelined) -----------------------
+    def snapshot_cpoints(self, slot, points):
+        if not hasattr(self, "_snap"):
+            self._snap = {}
+        self._snap[slot] = [self.mg.u[0][i].clone() for i in points]
+
+    def restore_cpoints(self, slot, points):
+        for i, vec in zip(points, self._snap[slot]):
+            self.mg.u[0][i] = vec.clone()
+
     def jump_norms(self, points):
         mg = self.mg
         out = [(mg.u[0][i] - mg.save_values_last_iter[i]).norm() for i in points]

@@ -28,9 +28,37 @@ class SerialComm:
     def exchange(self, send=None, recv=None):
         raise RuntimeError("exchange on a size-1 communicator")
 
+    def prepare(self):
+        return None
+
+    def drain(self):
+        return None
+
+
+class _Gather:
+    """Handle of a posted all-gather of per-rank float lists (TorchTimeComm.iallgather_floats)."""
+
+    def __init__(self, work, out, counts_work, counts):
+        self.work, self.out, self.counts_work, self.counts = work, out, counts_work, counts
+
+    def result(self):
+        """blocks until every rank has posted the same gather; returns the per-rank lists in rank order"""
+        self.counts_work.wait()
+        self.work.wait()
+        return [self.out[r, :int(self.counts[r].item())].tolist() for r in range(self.out.shape[0])]
+
 
 class TorchTimeComm:
-    """Nearest-owner point-to-point on a ``torch.distributed`` process group."""
+    """Nearest-owner point-to-point on a ``torch.distributed`` process group.
+
+    Streams of messages that must not wait for each other get their own communicator:
+      * one 2-rank group per pair of neighbouring ranks (r, r+1): a send to the next rank that its receiver has not posted
+        yet (the receiver is still busy with earlier work) must not hold back this rank's receive from the previous rank,
+        which it would on a shared NCCL communicator (one stream, rendezvous sends);
+      * a small gloo group for the convergence values, which travel as host floats and are collected asynchronously
+        (``iallgather_floats``) while the sweeps of the following iterations already run.
+    Sends never block the caller: the payload is copied into a staging buffer that lives until the send has completed
+    (``exchange`` reaps finished sends), so the slab row it came from may be overwritten at once."""
 
     def __init__(self, group=None):
         if not dist.is_initialized():
@@ -39,6 +67,9 @@ class TorchTimeComm:
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
         self.backend = dist.get_backend(group)
+        self._inflight = []
+        self._links = None
+        self._side = None
 
     def Get_rank(self):
         return self.rank
@@ -60,45 +91,87 @@ class TorchTimeComm:
     def _device(self):
         return torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
 
+    # ---- communicators ----------------------------------------------------------------------------------------------
+    def _link(self, a, b):
+        """process group for the pair of ranks (a, b): its own 2-rank group for neighbours, the main group otherwise.
+        Groups are created collectively by all ranks the first time any link is needed."""
+        if self._links is None:
+            self._links = {}
+            for r in range(self.size - 1):   # every rank creates every group, in the same order (new_group is collective)
+                self._links[r] = dist.new_group([self._global(r), self._global(r + 1)], backend=self.backend)
+        lo, hi = min(a, b), max(a, b)
+        return self._links[lo] if hi == lo + 1 else self.group
+
+    def _side_group(self):
+        if self._side is None:
+            self._side = dist.new_group([self._global(r) for r in range(self.size)], backend="gloo")
+        return self._side
+
+    def prepare(self):
+        """create all communicators now (collective; call at the same program point on every rank)"""
+        if self.size > 1:
+            self._link(0, 1)
+            self._side_group()
+
+    # ---- convergence values -------------------------------------------------------------------------------------------
+    def iallgather_floats(self, values, max_count):
+        """post an all-gather of this rank's list of floats (at most max_count per rank, the same bound on all ranks)"""
+        g = self._side_group()
+        mine = torch.zeros(max_count, dtype=torch.float64)
+        mine[:len(values)] = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        out = torch.zeros(self.size * max_count, dtype=torch.float64)   # flat: rank r fills [r*max_count, (r+1)*max_count)
+        counts = torch.zeros(self.size, dtype=torch.int64)
+        cw = dist.all_gather_into_tensor(counts, torch.tensor([len(values)], dtype=torch.int64), group=g, async_op=True)
+        w = dist.all_gather_into_tensor(out, mine, group=g, async_op=True)
+        return _Gather(w, out.view(self.size, max_count), cw, counts)
+
+    # ---- point to point -------------------------------------------------------------------------------------------------
+    def _reap(self, block=False):
+        keep = []
+        for work, staged in self._inflight:
+            if block:
+                work.wait()
+            elif not work.is_completed():
+                keep.append((work, staged))
+        self._inflight = keep
+
+    def drain(self):
+        """wait for every send posted so far (end of a solve)"""
+        self._reap(block=True)
+
     def exchange(self, send=None, recv=None):
         """One exchange point: optionally send ``(payload, dest)`` and/or receive ``(buffer_or_None, src)``.
         Tensors travel as they are (the receive buffer must be a tensor of the same shape); other payloads are
-        pickled. Send and receive of one point are posted together (ncclGroup on RCCL), so a ring of ranks executing
-        the same point cannot deadlock. Returns the received object (the filled tensor, or the unpickled payload)."""
-        ops, result, staged = [], None, None
+        pickled. The send is posted from a staging copy and not waited for; the receive is waited for. Returns the received
+        object (the filled tensor, or the unpickled payload)."""
+        self._reap()
+        result = None
         if send is not None:
             payload, dest = send
+            g = self._link(self.rank, dest)
             if torch.is_tensor(payload):
-                if payload.is_cuda and self.backend != "nccl":  # e.g. gloo: device rows are staged through the host
-                    payload = payload.cpu()
-                ops.append(dist.P2POp(dist.isend, payload, self._global(dest), self.group))
+                staged = payload.detach().cpu() if (payload.is_cuda and self.backend != "nccl") else payload.detach().clone()
+                self._inflight.append((dist.isend(staged, self._global(dest), group=g), staged))
             else:
                 raw = torch.frombuffer(bytearray(pickle.dumps(payload)), dtype=torch.uint8).to(self._device())
                 size = torch.tensor([raw.numel()], dtype=torch.int64, device=self._device())
-                for w in [dist.isend(size, self._global(dest), group=self.group),
-                          dist.isend(raw, self._global(dest), group=self.group)]:
-                    ops.append(w)
+                self._inflight.append((dist.isend(size, self._global(dest), group=g), size))
+                self._inflight.append((dist.isend(raw, self._global(dest), group=g), raw))
         if recv is not None:
             buf, src = recv
+            g = self._link(self.rank, src)
             if torch.is_tensor(buf):
-                if buf.is_cuda and self.backend != "nccl":
-                    staged = torch.empty(buf.shape, dtype=buf.dtype, device="cpu")
-                ops.append(dist.P2POp(dist.irecv, staged if staged is not None else buf, self._global(src), self.group))
+                staged = torch.empty(buf.shape, dtype=buf.dtype, device="cpu") if (buf.is_cuda and self.backend != "nccl") else None
+                dist.irecv(staged if staged is not None else buf, self._global(src), group=g).wait()
+                if staged is not None:
+                    buf.copy_(staged)
                 result = buf
             else:
                 size = torch.zeros(1, dtype=torch.int64, device=self._device())
-                dist.recv(size, self._global(src), group=self.group)
+                dist.irecv(size, self._global(src), group=g).wait()
                 raw = torch.empty(int(size.item()), dtype=torch.uint8, device=self._device())
-                dist.recv(raw, self._global(src), group=self.group)
+                dist.irecv(raw, self._global(src), group=g).wait()
                 result = pickle.loads(raw.cpu().numpy().tobytes())
-        p2p = [o for o in ops if isinstance(o, dist.P2POp)]
-        works = [o for o in ops if not isinstance(o, dist.P2POp)]
-        if p2p:
-            works += dist.batch_isend_irecv(p2p)
-        for w in works:
-            w.wait()
-        if staged is not None:
-            result.copy_(staged)
         return result
 
 

@@ -52,7 +52,8 @@ class Mgrit:
     def __init__(self, problem: List[Application], transfer: List[GridTransfer] = None, weight_c: float = 1.0,
                  max_iter: int = 100, tol: float = 1e-7, nested_iteration: bool = True, cf_iter: int = 1,
                  cycle_type: str = 'V', comm_time=None, comm_space=None, logging_lvl: int = logging.INFO,
-                 output_fcn=None, output_lvl=1, t_norm=2, random_init_guess: bool = False, conv_crit: int = 0) -> None:
+                 output_fcn=None, output_lvl=1, t_norm=2, random_init_guess: bool = False, conv_crit: int = 0,
+                 pipeline_depth: int = None) -> None:
         logging.basicConfig(format='%(levelname)s - %(asctime)s - %(message)s', datefmt='%d-%m-%y %H:%M:%S',
                             level=logging_lvl, stream=sys.stdout)
         if transfer is None:
@@ -69,6 +70,7 @@ class Mgrit:
         self.comm_space_rank = comm_space.Get_rank() if self.spatial_parallel else -99
         self.comm_space_size = comm_space.Get_size() if self.spatial_parallel else 1
 
+        self.comm_time.prepare()
         self.comm_time.barrier()
         setup_start = time.time()
         self.log_info("Start setup")
@@ -103,6 +105,8 @@ class Mgrit:
                             '(mgrit.py:434-455,648-691: ranks leave the solve loop in different iterations) is not '
                             'implemented; choose 0 (global space-time residual) or 1 (global jump) on several ranks')
         self.save_values_last_iter = None
+        self._pipeline_request = pipeline_depth
+        self._pl = None
         self.output_lvl = output_lvl
         self.output_fcn = output_fcn if (output_fcn is not None and callable(output_fcn)) else None
         self._ghost, self._is_c_local = [], []
@@ -432,7 +436,114 @@ class Mgrit:
                 ('convergence criterion', str(self.conv_crit))]
         self.log_info('\n'.join(['Run parameter overview'] + ['  ' + '{0: <25}'.format(k) + ' : ' + v for k, v in rows]))
 
+    # ------------------------------------------------------------------------------------------------
+    # Pipelined solve on several ranks. The coarsest-level solve is a pipeline over the ranks (op 5), so inside ONE
+    # iteration rank r idles while the ranks before it step through their part of the coarsest grid, and again afterwards
+    # until the last rank is done and the global stopping value is known. Nothing but that stopping value keeps rank r
+    # from starting the next iteration early: its sweeps only need its own points and ghost points of rank r-1, which is
+    # ahead of it. So the stopping values are collected asynchronously and looked at `depth` iterations late:
+    #   * before iteration it (0-based) starts, conv[it - depth] must be known; if it is below tol nobody starts it.
+    #     The decision depends only on global values, so every rank executes the same set of iterations and every
+    #     posted message is matched;
+    #   * the result must be the state of the FIRST iteration whose conv is below tol (the reference stops there): each
+    #     iteration ends with F-relax(0), so the level-0 C-points of an iteration determine its whole end state; they
+    #     are snapshotted (a copy of 1/m of u[0]) and on a late stop the solver restores the C-points of the iteration
+    #     before, rebuilds the F-points with one F-relax and repeats that one iteration -- bit-identical to the
+    #     unpipelined run, internal levels included.
+    # ------------------------------------------------------------------------------------------------
+    def pipeline_depth(self) -> int:
+        if self._pipeline_request is not None:
+            want = int(self._pipeline_request)
+        else:
+            want = 3
+        usable = (self.comm_time_size > 1 and self.lvl_max > 1 and self.conv_crit == 0 and
+                  not (self.output_fcn is not None and self.output_lvl == 2) and
+                  type(self).convergence_criterion is Mgrit.convergence_criterion and
+                  type(self).iteration is Mgrit.iteration)
+        return max(want, 0) if usable else 0
+
+    def _pl_state(self):
+        if self._pl is None:
+            depth = self.pipeline_depth()
+            counts = self.comm_time.allgather_object(len(self._c_points(0)))
+            self._pl = {"depth": depth, "executed": 0, "resolved": 0, "pending": {}, "slots": depth + 2,
+                        "max_count": max(max(counts), 1), "snap_points": [int(i) for i in self.index_local_c[0]]}
+            self.backend.snapshot_cpoints(0, self._pl["snap_points"])
+        return self._pl
+
+    def _pl_resolve(self, c):
+        """conv[c] (1-based iteration count) from the gather posted after iteration c"""
+        pl = self._pl
+        while pl["resolved"] < c:
+            k = pl["resolved"] + 1
+            parts = pl["pending"].pop(k).result()
+            self.conv[k] = time_norm(np.array([x for part in parts for x in part]), self.t_norm)
+            factor = '-' if k == 1 else str(self.conv[k] / self.conv[k - 1])
+            self.log_info('{0: <7}'.format(f"iter {k}") + '{0: <32}'.format(f" | conv: {self.conv[k]}") +
+                          '{0: <37}'.format(f" | conv factor: {factor}") + '{0: <35}'.format(" | runtime: pipelined"))
+            pl["resolved"] = k
+        return self.conv[c]
+
+    def _pl_advance(self, n, stop_on_tol=True):
+        """run up to n more iterations; returns the 1-based index of the iteration that met tol (None if none did)"""
+        pl = self._pl_state()
+        depth = pl["depth"]
+        for _ in range(n):
+            it = pl["executed"]
+            if it >= self.iter_max:
+                break
+            gate = it - depth
+            if gate >= 1 and self._pl_resolve(gate) < self.tol and stop_on_tol:
+                return gate
+            self.solve_iter = it + 1
+            self.iteration(lvl=0, cycle_type=self.cycle_type, iteration=it, first_f=True)
+            val = self.compute_residual()
+            pl["pending"][it + 1] = self.comm_time.iallgather_floats(val, pl["max_count"])
+            pl["executed"] = it + 1
+            self.backend.snapshot_cpoints((it + 1) % pl["slots"], pl["snap_points"])
+        return None
+
+    def _pl_finish(self, stop_on_tol=True):
+        """resolve everything posted; roll back to the first iteration below tol. Returns the iteration count kept."""
+        pl = self._pl_state()
+        stop = None
+        for c in range(1, pl["executed"] + 1):    # the first iteration below tol, resolving values only as far as needed
+            if self._pl_resolve(c) < self.tol and stop_on_tol:
+                stop = c
+                break
+        keep = pl["executed"] if stop is None else stop
+        for k in list(pl["pending"]):       # gathers of discarded iterations: complete them (every rank posted them)
+            pl["pending"].pop(k).result()
+        if keep < pl["executed"]:
+            self.backend.restore_cpoints((keep - 1) % pl["slots"], pl["snap_points"])
+            if keep - 1 >= 1:
+                self.f_relax(lvl=0)
+            self.iteration(lvl=0, cycle_type=self.cycle_type, iteration=keep - 1, first_f=True)
+            pl["executed"] = pl["resolved"] = keep
+        self.conv[keep + 1:] = 0.0
+        self.solve_iter = keep
+        return keep
+
+    def _solve_pipelined(self) -> dict:
+        self.log_info("Start solve")
+        solve_start = time.time()
+        self._pl = None
+        self._pl_advance(self.iter_max)
+        self._pl_finish()
+        self.backend.sync()
+        self.comm_time.drain()
+        self.comm_time.barrier()
+        self.runtime_solve = time.time() - solve_start
+        self.log_info(f"Solve took {self.runtime_solve} s")
+        if self.output_fcn is not None and self.output_lvl == 1:
+            self.output_fcn(self)
+        self.ouput_run_information()
+        return {'conv': self.conv[np.where(self.conv != 0)], 'time_setup': self.runtime_setup,
+                'time_solve': self.runtime_solve}
+
     def solve(self) -> dict:
+        if self.pipeline_depth() > 0:
+            return self._solve_pipelined()
         self.log_info("Start solve")
         solve_start = time.time()
         for iteration in range(self.iter_max):
@@ -454,6 +565,7 @@ class Mgrit:
                 if self.global_conv_crit or (self.finished[0] and self.pre_finished[0]) or iteration == self.iter_max - 1:
                     break
         self.backend.sync()
+        self.comm_time.drain()
         self.comm_time.barrier()
         self.runtime_solve = time.time() - solve_start
         self.log_info(f"Solve took {self.runtime_solve} s")
