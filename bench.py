@@ -248,6 +248,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "smoke-test the N>1 path with several ranks on ONE GPU)")
     ap.add_argument("--nt-adv", dest="nt_adv", type=int, default=32769)
+    ap.add_argument("--pipeline-depth", dest="pipeline_depth", type=int, default=None,
+                    help="N>1: how many iterations the stopping value may lag (default: the solver's default, 3; 0 = check "
+                         "after every cycle like the reference's loop)")
     ap.add_argument("--workload", default="heat1d", choices=["heat1d", "heat2d", "advection"],
                     help="heat1d = BASELINE configs[2] (default, the driver's run); heat2d = configs[3] on one GPU")
     ap.add_argument("--nx2d", type=int, default=512)
@@ -283,7 +286,8 @@ def main():
     grids = [t0, t0[::4], t0[::16]]
     problem = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=init_cond, rhs_separable=[(rhs_space, rhs_time)],
                       t_interval=g) for g in grids]
-    mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=False, max_iter=1, tol=0.0, logging_lvl=30)
+    mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=False, max_iter=2 + args.warmup + args.steps, tol=0.0,
+               logging_lvl=30, pipeline_depth=args.pipeline_depth)
     be = mg.backend
     dof = nx - 2
     counts = phi_counts(nts, [4, 4])
@@ -298,14 +302,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    cycle(0)  # iteration 0 (does the extra leading F-relax), then steady-state warm-up
-    for _ in range(args.warmup):
-        cycle(1)
-    fence()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        cycle(1)
-    fence()
+    pipelined = mg.pipeline_depth() > 0   # several ranks: the solver's own pipelined loop (Mgrit._solve_pipelined)
+    if pipelined:
+        # the same steps through the solver's pipelined loop: every step still is one cycle + its stopping value; the values
+        # are gathered asynchronously and ALL of them are resolved inside the timed region (_pl_finish)
+        mg._pl_advance(1 + args.warmup, stop_on_tol=False)
+        mg._pl_finish(stop_on_tol=False)
+        fence()
+        t_start = time.perf_counter()
+        mg._pl_advance(args.steps, stop_on_tol=False)
+        mg._pl_finish(stop_on_tol=False)
+        fence()
+    else:
+        cycle(0)  # iteration 0 (does the extra leading F-relax), then steady-state warm-up
+        for _ in range(args.warmup):
+            cycle(1)
+        fence()
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            cycle(1)
+        fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -357,7 +373,7 @@ def main():
         "config": {"workload": f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle + residual check "
                                f"(BASELINE configs[{2 if (nx, nt0) == (16384, 65537) else 1 if (nx, nt0) == (1024, 4097) else '-'}]; "
                                f"time points sharded over {world} GPU(s))",
-                   "phi_per_cycle_by_level": counts, "dof": dof},
+                   "phi_per_cycle_by_level": counts, "dof": dof, "pipeline_depth": mg.pipeline_depth()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "relax_kernel<HEAT1D,false,ROLE_F> (level-0 F-relax)", "launch_ms": f_ms,

@@ -5,6 +5,7 @@ CPU. Payloads are either device/CPU tensors (sent in place, no pickling) or smal
 """
 import pickle
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -118,7 +119,8 @@ class TorchTimeComm:
         """post an all-gather of this rank's list of floats (at most max_count per rank, the same bound on all ranks)"""
         g = self._side_group()
         mine = torch.zeros(max_count, dtype=torch.float64)
-        mine[:len(values)] = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        if len(values):
+            mine[:len(values)] = torch.from_numpy(np.ascontiguousarray(np.asarray(values, dtype=np.float64)))
         out = torch.zeros(self.size * max_count, dtype=torch.float64)   # flat: rank r fills [r*max_count, (r+1)*max_count)
         counts = torch.zeros(self.size, dtype=torch.int64)
         cw = dist.all_gather_into_tensor(counts, torch.tensor([len(values)], dtype=torch.int64), group=g, async_op=True)

@@ -62,7 +62,11 @@ def run(rank, world, port, case_name, mode, out_dir, backend):
         torch.cuda.set_device(rank % max(torch.cuda.device_count(), 1))
     from pymgrit_amd import Mgrit
     prob, tr, opts = build_problem(case_name, mode)
+    if os.environ.get("MGRIT_TEST_PIPELINE_DEPTH") is not None:
+        opts["pipeline_depth"] = int(os.environ["MGRIT_TEST_PIPELINE_DEPTH"])
     mg = Mgrit(prob, transfer=tr, logging_lvl=30, **opts)
+    if world > 1 and os.environ.get("MGRIT_TEST_PIPELINE_DEPTH") is not None:
+        assert mg.pipeline_depth() == int(os.environ["MGRIT_TEST_PIPELINE_DEPTH"]) or mg.conv_crit != 0
     conv = mg.solve()["conv"]
     owned = [int(i) for i in mg.index_local[0]]
     vals = np.array([np.asarray(mg.u[0][i].pack(), dtype=np.float64).ravel() for i in owned])

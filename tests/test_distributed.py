@@ -22,11 +22,15 @@ def free_port():
     return port
 
 
-def launch(world, case, mode="plugin", backend="gloo", timeout=600):
+def launch(world, case, mode="plugin", backend="gloo", timeout=600, depth=None):
     out = tempfile.mkdtemp(prefix=f"mgrit_{case}_{world}_")
     port = free_port()
+    env = dict(os.environ)
+    env.pop("MGRIT_TEST_PIPELINE_DEPTH", None)
+    if depth is not None:
+        env["MGRIT_TEST_PIPELINE_DEPTH"] = str(depth)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port), case,
-                               mode, out, backend], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               mode, out, backend], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
              for r in range(world)]
     logs = []
     try:
@@ -72,3 +76,20 @@ def test_multi_rank_equals_single_rank(case, sizes):
         conv, u = launch(world, case)
         assert np.array_equal(conv, conv1), (case, world, conv, conv1)
         assert np.array_equal(u, u1), (case, world, np.abs(u - u1).max())
+
+
+PIPELINE_CASES = [   # (case, world, depth): stops by tolerance in the middle of the run, by max_iter, F-cycles, depth 0 = no lag
+    ("dahlquist_config1", 3, 0), ("dahlquist_config1", 3, 1), ("dahlquist_config1", 2, 6),
+    ("heat_nx33_V_nested", 3, 0), ("heat_nx33_V_nested", 3, 1), ("heat_nx33_F_nonested", 2, 2),
+    ("heat_nx5_test_mgrit", 2, 4),   # max_iter = 2: the run ends before the first stopping value would be looked at
+]
+
+
+@pytest.mark.parametrize("case,world,depth", PIPELINE_CASES, ids=[f"{c}-P{w}-d{d}" for c, w, d in PIPELINE_CASES])
+def test_pipelined_solve_is_bit_identical_for_every_depth(case, world, depth):
+    """the stopping value may lag `depth` iterations (Mgrit._solve_pipelined): same residual history, same iteration count,
+    same solution as one rank, whatever the depth -- including the rollback when tol was met `depth` iterations ago"""
+    conv1, u1 = launch(1, case)
+    conv, u = launch(world, case, depth=depth)
+    assert np.array_equal(conv, conv1), (conv, conv1)
+    assert np.array_equal(u, u1)

@@ -24,3 +24,16 @@ def test_sharded_hip_equals_single_rank(case, sizes):
         conv, u = launch(world, case, mode="hip", backend="gloo")
         assert np.array_equal(conv, conv1), (case, world, conv, conv1)
         assert np.array_equal(u, u1), (case, world, np.abs(u - u1).max())
+
+
+@pytest.mark.parametrize("case,world,depth", [("heat_nx33_V_nested", 3, 1), ("heat_nx33_V_nested", 2, 0),
+                                              ("h2d:be_3lvl_F_bc", 2, 2), ("bdf:bdf2_example_small", 3, 4)])
+def test_pipelined_hip_solve_is_bit_identical(case, world, depth):
+    """stopping value examined `depth` iterations late on the HIP path: C-point snapshots / rollback inside HBM"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    conv1, u1 = launch(1, case, mode="hip")
+    conv, u = launch(world, case, mode="hip", backend="gloo", depth=depth)
+    assert np.array_equal(conv, conv1), (conv, conv1)
+    assert np.array_equal(u, u1)
