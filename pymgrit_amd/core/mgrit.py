@@ -70,7 +70,7 @@ class Mgrit:
         self.comm_space_rank = comm_space.Get_rank() if self.spatial_parallel else -99
         self.comm_space_size = comm_space.Get_size() if self.spatial_parallel else 1
 
-        self.comm_time.prepare()
+        getattr(self.comm_time, 'prepare', lambda: None)()   # optional hook of the communicator
         self.comm_time.barrier()
         setup_start = time.time()
         self.log_info("Start setup")
@@ -457,6 +457,7 @@ class Mgrit:
         else:
             want = 3
         usable = (self.comm_time_size > 1 and self.lvl_max > 1 and self.conv_crit == 0 and
+                  hasattr(self.comm_time, "iallgather_floats") and
                   not (self.output_fcn is not None and self.output_lvl == 2) and
                   type(self).convergence_criterion is Mgrit.convergence_criterion and
                   type(self).iteration is Mgrit.iteration)
@@ -531,7 +532,7 @@ class Mgrit:
         self._pl_advance(self.iter_max)
         self._pl_finish()
         self.backend.sync()
-        self.comm_time.drain()
+        getattr(self.comm_time, 'drain', lambda: None)()
         self.comm_time.barrier()
         self.runtime_solve = time.time() - solve_start
         self.log_info(f"Solve took {self.runtime_solve} s")
@@ -565,7 +566,7 @@ class Mgrit:
                 if self.global_conv_crit or (self.finished[0] and self.pre_finished[0]) or iteration == self.iter_max - 1:
                     break
         self.backend.sync()
-        self.comm_time.drain()
+        getattr(self.comm_time, 'drain', lambda: None)()
         self.comm_time.barrier()
         self.runtime_solve = time.time() - solve_start
         self.log_info(f"Solve took {self.runtime_solve} s")
