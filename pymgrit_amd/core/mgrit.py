@@ -15,6 +15,7 @@ Local convergence criteria (conv_crit 2/3) are implemented for one rank; their m
 (SURVEY section 8f).
 """
 import logging
+import os
 import sys
 import time
 from typing import List, Tuple
@@ -454,8 +455,8 @@ class Mgrit:
     def pipeline_depth(self) -> int:
         if self._pipeline_request is not None:
             want = int(self._pipeline_request)
-        else:
-            want = 3
+        else:   # default 3 (covers the lag of 8 ranks); PYMGRIT_AMD_PIPELINE_DEPTH overrides it without touching the script
+            want = int(os.environ.get("PYMGRIT_AMD_PIPELINE_DEPTH", "3"))
         usable = (self.comm_time_size > 1 and self.lvl_max > 1 and self.conv_crit == 0 and
                   hasattr(self.comm_time, "iallgather_floats") and
                   not (self.output_fcn is not None and self.output_lvl == 2) and
