@@ -256,6 +256,29 @@ class HipBackend:
         check(self.lib.mgrit_hip_residual_host(self.h, 0, self._point_run_id(0, points), _ptr(host)))
         return np.sqrt(host).tolist()
 
+    def residual_begin(self, points):
+        """launch the residual kernel and return at once; the per-point sums of squares land in pinned host memory that the
+        kernel writes directly (no copy command), residual_end() waits for the event recorded behind the kernel"""
+        if not len(points):
+            return None
+        if not hasattr(self, "_res_ring"):
+            self._res_ring, self._res_next = [], 0
+        if len(self._res_ring) < 8:
+            self._res_ring.append(torch.empty(len(points), dtype=torch.float64, pin_memory=True))
+        buf = self._res_ring[self._res_next % len(self._res_ring)]
+        self._res_next += 1
+        check(self.lib.mgrit_hip_residual(self.h, 0, self._point_run_id(0, points), C.c_void_p(buf.data_ptr())))
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return buf, ev
+
+    def residual_end(self, handle):
+        if handle is None:
+            return []
+        buf, ev = handle
+        ev.synchronize()
+        return np.sqrt(buf.numpy()).tolist()
+
     def save_last(self):
         self.prev = self.U[0].clone()
         self.mg.save_values_last_iter = SlabVectorList(self.prev, self.n[0], self.mg.problem[0].vector_template,

@@ -66,6 +66,12 @@ class PluginBackend:
         u = self.mg.u[0]
         return [(self._phi(0, u, i) - u[i]).norm() for i in points]
 
+    def residual_begin(self, points):
+        return self.residual_norms(points)
+
+    def residual_end(self, handle):
+        return handle
+
     def save_last(self):
         self.mg.save_values_last_iter = [item.clone() for item in self.mg.u[0]]
 

@@ -468,7 +468,7 @@ class Mgrit:
         if self._pl is None:
             depth = self.pipeline_depth()
             counts = self.comm_time.allgather_object(len(self._c_points(0)))
-            self._pl = {"depth": depth, "executed": 0, "resolved": 0, "pending": {}, "slots": depth + 2,
+            self._pl = {"depth": depth, "executed": 0, "resolved": 0, "pending": {}, "open": None, "slots": depth + 2,
                         "max_count": max(max(counts), 1), "snap_points": [int(i) for i in self.index_local_c[0]]}
             self.backend.snapshot_cpoints(0, self._pl["snap_points"])
         return self._pl
@@ -495,19 +495,36 @@ class Mgrit:
             if it >= self.iter_max:
                 break
             gate = it - depth
-            if gate >= 1 and self._pl_resolve(gate) < self.tol and stop_on_tol:
-                return gate
+            if gate >= 1:
+                if pl.get("open") is not None and pl["open"][0] <= gate:
+                    self._pl_post()   # depth 0: the value looked at is the one of the trip just finished
+                if self._pl_resolve(gate) < self.tol and stop_on_tol:
+                    return gate
             self.solve_iter = it + 1
             self.iteration(lvl=0, cycle_type=self.cycle_type, iteration=it, first_f=True)
-            val = self.compute_residual()
-            pl["pending"][it + 1] = self.comm_time.iallgather_floats(val, pl["max_count"])
+            # residual of this iteration: launched now, read one trip later, so the host never waits for the device to
+            # finish the iteration it has just queued (it stays one iteration ahead of it)
+            self._exchange(0, send_idx=self._last_slot(0) if self.last_is_f_point[0] else None,
+                           recv_idx=0 if self.first_is_c_point[0] else None, dest=self.send_to[0], src=self.get_from[0])
+            handle = self.backend.residual_begin(self._c_points(0))
             pl["executed"] = it + 1
             self.backend.snapshot_cpoints((it + 1) % pl["slots"], pl["snap_points"])
+            self._pl_post()
+            pl["open"] = (it + 1, handle)
         return None
+
+    def _pl_post(self):
+        """hand the residual values of the previous trip to the asynchronous gather"""
+        pl = self._pl
+        if pl.get("open") is not None:
+            c, handle = pl["open"]
+            pl["pending"][c] = self.comm_time.iallgather_floats(self.backend.residual_end(handle), pl["max_count"])
+            pl["open"] = None
 
     def _pl_finish(self, stop_on_tol=True):
         """resolve everything posted; roll back to the first iteration below tol. Returns the iteration count kept."""
         pl = self._pl_state()
+        self._pl_post()
         stop = None
         for c in range(1, pl["executed"] + 1):    # the first iteration below tol, resolving values only as far as needed
             if self._pl_resolve(c) < self.tol and stop_on_tol:
