@@ -249,7 +249,7 @@ def main():
                     "smoke-test the N>1 path with several ranks on ONE GPU)")
     ap.add_argument("--nt-adv", dest="nt_adv", type=int, default=32769)
     ap.add_argument("--pipeline-depth", dest="pipeline_depth", type=int, default=None,
-                    help="N>1: how many iterations the stopping value may lag (default: the solver's default, 3; 0 = check "
+                    help="N>1: how many iterations the stopping value may lag (default: the solver's default, 4; 0 = check "
                          "after every cycle like the reference's loop)")
     ap.add_argument("--workload", default="heat1d", choices=["heat1d", "heat2d", "advection"],
                     help="heat1d = BASELINE configs[2] (default, the driver's run); heat2d = configs[3] on one GPU")

@@ -455,8 +455,8 @@ class Mgrit:
     def pipeline_depth(self) -> int:
         if self._pipeline_request is not None:
             want = int(self._pipeline_request)
-        else:   # default 3 (covers the lag of 8 ranks); PYMGRIT_AMD_PIPELINE_DEPTH overrides it without touching the script
-            want = int(os.environ.get("PYMGRIT_AMD_PIPELINE_DEPTH", "3"))
+        else:   # default 4 (the last of 8 ranks lags about two cycles, its values are posted one trip late); PYMGRIT_AMD_PIPELINE_DEPTH overrides it without touching the script
+            want = int(os.environ.get("PYMGRIT_AMD_PIPELINE_DEPTH", "4"))
         usable = (self.comm_time_size > 1 and self.lvl_max > 1 and self.conv_crit == 0 and
                   hasattr(self.comm_time, "iallgather_floats") and
                   not (self.output_fcn is not None and self.output_lvl == 2) and
