@@ -67,6 +67,15 @@ def run(rank, world, port, case_name, mode, out_dir, backend):
     mg = Mgrit(prob, transfer=tr, logging_lvl=30, **opts)
     if world > 1 and os.environ.get("MGRIT_TEST_PIPELINE_DEPTH") is not None:
         assert mg.pipeline_depth() == int(os.environ["MGRIT_TEST_PIPELINE_DEPTH"]) or mg.conv_crit != 0
+    slow = os.environ.get("MGRIT_TEST_SLOW_RANK")
+    if slow is not None and world > 1 and rank == int(slow) % world:
+        import time
+        relax = mg.backend.relax
+
+        def slow_relax(*a, **k):   # one rank far behind its neighbours: the others run ahead as far as the depth allows
+            time.sleep(0.004)
+            return relax(*a, **k)
+        mg.backend.relax = slow_relax
     conv = mg.solve()["conv"]
     owned = [int(i) for i in mg.index_local[0]]
     vals = np.array([np.asarray(mg.u[0][i].pack(), dtype=np.float64).ravel() for i in owned])

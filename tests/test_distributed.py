@@ -22,13 +22,16 @@ def free_port():
     return port
 
 
-def launch(world, case, mode="plugin", backend="gloo", timeout=600, depth=None):
+def launch(world, case, mode="plugin", backend="gloo", timeout=600, depth=None, slow_rank=None):
     out = tempfile.mkdtemp(prefix=f"mgrit_{case}_{world}_")
     port = free_port()
     env = dict(os.environ)
     env.pop("MGRIT_TEST_PIPELINE_DEPTH", None)
+    env.pop("MGRIT_TEST_SLOW_RANK", None)
     if depth is not None:
         env["MGRIT_TEST_PIPELINE_DEPTH"] = str(depth)
+    if slow_rank is not None:
+        env["MGRIT_TEST_SLOW_RANK"] = str(slow_rank)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port), case,
                                mode, out, backend], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
              for r in range(world)]
@@ -93,3 +96,12 @@ def test_pipelined_solve_is_bit_identical_for_every_depth(case, world, depth):
     conv, u = launch(world, case, depth=depth)
     assert np.array_equal(conv, conv1), (conv, conv1)
     assert np.array_equal(u, u1)
+
+
+@pytest.mark.parametrize("slow_rank", [0, 1, 2])
+def test_pipelined_solve_with_a_rank_far_behind(slow_rank):
+    """one rank sleeps in every sweep: its neighbours run ahead by up to `depth` iterations, several messages per link
+    are in flight, stopping values arrive late -- same results as one rank"""
+    conv1, u1 = launch(1, "heat_nx33_V_nested")
+    conv, u = launch(3, "heat_nx33_V_nested", depth=3, slow_rank=slow_rank)
+    assert np.array_equal(conv, conv1) and np.array_equal(u, u1)
