@@ -490,260 +490,7 @@ __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Sequential chain across workgroups (forward_solve, mgrit.py:459-486, for n > 1024). A single workgroup streaming
-// 24*n bytes per step through one CU is bound by that CU's memory pipe (~31 GB/s measured: 8 us per step at n = 16382).
-// Here group g of the vector (1024 values) lives in its own single-wave workgroup on its own CU; per step every worker
-// scans its group locally, publishes its two group totals as 8-byte {epoch, half} granules (one relaxed agent-scope store
-// each, cdna_hip_programming.md Guideline 16, form R2), sweeps the granules of all workers until every tag carries the
-// step's epoch, then finishes locally. One exchange per step, the arithmetic is exactly that of phi_apply.
-// Workers are the blocks with blockIdx % 8 == 0 (observed to share an XCD: speed only, never correctness); all other
-// blocks exit at once. Granules are double-buffered by epoch parity; every spin is bounded and reports through *err.
-// Each granule is published twice: to the write-through set (sc1 store: leaves the XCD's L2, visible chip-wide -- the set
-// correctness rests on) and to a plain-stored set that stays in the writer's L2, where the sc1 poll of a worker on the same
-// XCD finds it without a trip over the fabric (MI355X_MICROARCH.md, visibility table: stores of each flavour). A stale
-// plain-stored granule can only carry an older epoch, so it is never mistaken for data; the poll alternates between the sets.
-// ---------------------------------------------------------------------------------------------------------------
-typedef unsigned long long u64;
-constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 26;
-
-// state of one chain worker that survives across steps
-struct ChainCtx {
-    Coef c;
-    LaneCoef lc;
-    double s0[E], wg[E], pt[E];
-    int cur;
-    int ci_a, ci_b;        // coefficient-set index of the next step and of the one after it
-    double tc_a, tc_b;     // forcing coefficient, likewise
-};
-
-// One step of the chain. g_cur = g of this step (loaded one step ago), g_nxt = receives g of the next step. All vector
-// loads for later steps are issued BEHIND the poll: s_waitcnt vmcnt(0) in front of the poll result would otherwise wait for
-// them (vmcnt retires in order), putting an HBM round trip on the serial path of every step.
-// Returns false when the bounded spin gave up.
-template <int KIND, int FORCE, bool USE_G>
-__device__ __forceinline__ bool chain_step(const LevelDev &L, ChainCtx &k, double (&x)[E], const double2 *g_slot,
-                                           double2 *x_slot, int i, int start, int len, u64 *gran, unsigned *err, int wave,
-                                           int lane, int G, int t, unsigned sl) {
-    const int j0 = t * E, li = lane & 15;
-    const unsigned epoch = (unsigned)(i - start + 1);
-    u64 *slots = gran + (size_t)(epoch & 1) * MAX_G * 4;
-    const int ci = __builtin_amdgcn_readfirstlane(k.ci_a);
-    const double tc_i = k.tc_a;
-    k.ci_a = k.ci_b;
-    k.tc_a = k.tc_b;
-    if (ci != k.cur) {
-        const CSet *g = L.cs + ci;
-        load_coef<false>(k.c, g);
-        k.lc = lane_coef(g->lp, lane);
-        load_row(reinterpret_cast<const double *>(L.tabP + (size_t)ci * 8 * L.T), sl, k.wg);
-        if (KIND == MGRIT_HIP_STEPPER_HEAT1D)
-            load_row(reinterpret_cast<const double *>(L.ptP + (size_t)ci * 1024 + (wave == G - 1 ? 512 : 0)), (unsigned)lane, k.pt);
-        k.cur = ci;
-    }
-    const Coef &c = k.c;
-    const LaneCoef &lc = k.lc;
-    double v0, v1 = 0.0;  // the two published values of this worker
-    if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
-        if (FORCE == 1) {
-#pragma unroll
-            for (int q = 0; q < E; ++q) x[q] = fma(k.s0[q], tc_i, x[q]);
-        } else if (FORCE == 2) {
-            for (int kk = 0; kk < L.K; ++kk) {
-                const double ck = L.tc[(size_t)kk * L.n_pts + i];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const double2 sv = L.sP[(size_t)kk * 8 * L.T + sl + q * 64];
-                    x[2 * q] = fma(sv.x, ck, x[2 * q]);
-                    x[2 * q + 1] = fma(sv.y, ck, x[2 * q + 1]);
-                }
-            }
-        }
-        v0 = scan_fwd(x, c, lc, lane);
-#pragma unroll
-        for (int q = 0; q < E; ++q)
-            if (j0 + q >= L.n) x[q] = 0.0;
-        v1 = scan_bwd(x, c, lc, lane);
-    } else {
-#pragma unroll
-        for (int q = 0; q < E; ++q) x[q] = x[q] * c.ik;
-        v0 = scan_fwd(x, c, lc, lane);
-        const int jl = L.n - 1;
-        double y = 0.0;
-#pragma unroll
-        for (int q = 0; q < E; ++q)
-            if (j0 + q == jl) y = x[q];
-        v1 = read_lane(y, __builtin_amdgcn_readfirstlane((jl % GROUP) / E));  // only meaningful on the last worker
-    }
-    // ---- publish: 4 granules {epoch, 32-bit half}, each to both sets
-    if (lane < 4) {
-        const double v = lane < 2 ? v0 : v1;
-        const unsigned half = (lane & 1) ? (unsigned)__double2loint(v) : (unsigned)__double2hiint(v);
-        __hip_atomic_store(slots + 2 * MAX_G * 4 + wave * 4 + lane, ((u64)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_store(slots + wave * 4 + lane, ((u64)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // ---- sweep: lane q watches granule (worker q>>2, item q&3)
-    unsigned mine = 0;
-    {
-        const bool watch = (lane >> 2) < G;
-        unsigned spins = 0;
-        for (;;) {
-            bool ok = true;
-            if (watch) {
-                // every 8th sweep looks at the write-through set (guaranteed to become visible), the others at the
-                // plain-stored set (an L2 hit when the writer shares this XCD)
-                const u64 *src = (spins & 7u) == 7u ? slots + lane : slots + 2 * MAX_G * 4 + lane;
-                const u64 g64 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mine = (unsigned)g64;
-                ok = (unsigned)(g64 >> 32) == epoch;
-            }
-#ifdef MGRIT_EXPERIMENT_NO_WAIT
-            break;
-#endif
-            if (__all(ok)) break;
-            // the error word lives in host memory: look at it rarely (a peer that gave up stops publishing anyway)
-            if (++spins > CHAIN_SPIN_LIMIT ||
-                ((spins & 0xffffu) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
-                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                return false;  // bounded spin: give up, the host reports the failure
-            }
-#ifdef MGRIT_CHAIN_SLEEP
-            __builtin_amdgcn_s_sleep(MGRIT_CHAIN_SLEEP);
-#endif
-        }
-    }
-    // ---- scalars of the step after next, a whole step ahead of the next poll
-    if (i + 2 < start + len) {
-        k.ci_b = L.cidx[i + 2];
-        if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) k.tc_b = L.tc[i + 2];
-    }
-    // group (lane & 15) totals: hi/lo halves sit in lanes 4g .. 4g+3
-    const int src = (li < G ? li : 0) * 4;
-    const double A = __hiloint2double((int)__shfl(mine, src), (int)__shfl(mine, src + 1));
-    const double B = __hiloint2double((int)__shfl(mine, src + 2), (int)__shfl(mine, src + 3));
-    if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
-        double cm, zin, zf0;
-        heat_chains(c, li < G ? A : 0.0, li < G ? B : 0.0, G, wave, lane, cm, zin, zf0);
-        const double z0 = zf0 * c.ik, cb = lc.b_in * zin;
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            heat_finish(x, c, cm, cb, z0, q, make_double2(k.wg[2 * q], k.wg[2 * q + 1]), make_double2(k.pt[2 * q], k.pt[2 * q + 1]));
-    } else {
-        double c_last = 0.0;
-        const double cm = fwd_chain(c, li < G ? A : 0.0, G, wave, lane, c_last);
-        const int jl = L.n - 1, ll = (jl % GROUP) / E, kl = jl % E;
-        const double e_last = read_lane(B, __builtin_amdgcn_readfirstlane(G - 1));  // y-hat of element n-1
-        const double lp_ll = read_lane(lc.f_in, __builtin_amdgcn_readfirstlane(ll));
-        const double ylast = fma(c.pw[kl + 1], lp_ll * c_last, e_last);
-        const double xl = ylast * c.scal, cf = lc.f_in * cm;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const double y0 = fma(c.pw[2 * q + 1], cf, x[2 * q]), y1 = fma(c.pw[2 * q + 2], cf, x[2 * q + 1]);
-            x[2 * q] = (j0 + 2 * q < L.n) ? fma(k.wg[2 * q], xl, y0) : 0.0;
-            x[2 * q + 1] = (j0 + 2 * q + 1 < L.n) ? fma(k.wg[2 * q + 1], xl, y1) : 0.0;
-        }
-    }
-    if (USE_G) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const double2 gv = g_slot[q * 64 + lane];
-            x[2 * q] = gv.x + x[2 * q];
-            x[2 * q + 1] = gv.y + x[2 * q + 1];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) x_slot[q * 64 + lane] = make_double2(x[2 * q], x[2 * q + 1]);
-    return true;
-}
-
-// The streamer wave of a chain worker: every global load of g and every global store of u of the worker's group goes
-// through this wave and two LDS rings, so the compute wave's vmcnt only ever counts its own granule polls (vmcnt retires in
-// order: a g load or u store in flight in the compute wave would sit in front of every poll result). One workgroup
-// barrier per step hands over g of the next step and x of the previous one.
-//   step s (between barrier s and barrier s+1):  compute reads g_ring[s & 1], writes x_ring[s & 1];
-//   the streamer stores x_ring[(s-1) & 1] to u, moves g of step s+1 from registers into g_ring[(s+1) & 1] and refills
-//   those registers with g of step s+4 (three rows in flight).
-template <bool USE_G>
-__device__ __forceinline__ void stream_step(const LevelDev &L, double (&row)[E], double2 *g_next, const double2 *x_prev,
-                                            int s, int start, int len, unsigned sl, int lane) {
-    __syncthreads();
-    if (s >= 1) {
-        double xr[E];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const double2 v = x_prev[q * 64 + lane];
-            xr[2 * q] = v.x;
-            xr[2 * q + 1] = v.y;
-        }
-        store_row(L.u + (size_t)(start + s - 1) * L.ld, sl, xr);
-    }
-    if (USE_G && s + 1 < len) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) g_next[q * 64 + lane] = make_double2(row[2 * q], row[2 * q + 1]);
-        if (s + 4 < len) load_row(L.g + (size_t)(start + s + 4) * L.ld, sl, row);
-    }
-}
-
-template <int KIND, int FORCE, bool USE_G>
-__global__ void __launch_bounds__(128) chain_kernel(LevelDev L, int start, int len, u64 *gran, unsigned *err) {
-    if (blockIdx.x & 7) return;
-    __shared__ double2 g_ring[2][512], x_ring[2][512];
-    const int wave = blockIdx.x >> 3, lane = threadIdx.x & 63, G = L.T >> 6, t = wave * LANES + lane;
-    const unsigned sl = slot0(t);
-    if (threadIdx.x >= LANES) {  // ---- streamer wave
-        double r0[E], r1[E], r2[E];
-        if (USE_G) {
-            load_row(L.g + (size_t)start * L.ld, sl, r0);
-            if (len > 1) load_row(L.g + (size_t)(start + 1) * L.ld, sl, r1);
-            if (len > 2) load_row(L.g + (size_t)(start + 2) * L.ld, sl, r2);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) g_ring[0][q * 64 + lane] = make_double2(r0[2 * q], r0[2 * q + 1]);
-            if (len > 3) load_row(L.g + (size_t)(start + 3) * L.ld, sl, r0);
-        }
-        // step s moves the register row holding g of step s+1: rows cycle r1, r2, r0; rings alternate -> period 6
-        for (int s = 0; s < len; s += 6) {
-            stream_step<USE_G>(L, r1, g_ring[1], x_ring[1], s, start, len, sl, lane);
-            if (s + 1 < len) stream_step<USE_G>(L, r2, g_ring[0], x_ring[0], s + 1, start, len, sl, lane);
-            if (s + 2 < len) stream_step<USE_G>(L, r0, g_ring[1], x_ring[1], s + 2, start, len, sl, lane);
-            if (s + 3 < len) stream_step<USE_G>(L, r1, g_ring[0], x_ring[0], s + 3, start, len, sl, lane);
-            if (s + 4 < len) stream_step<USE_G>(L, r2, g_ring[1], x_ring[1], s + 4, start, len, sl, lane);
-            if (s + 5 < len) stream_step<USE_G>(L, r0, g_ring[0], x_ring[0], s + 5, start, len, sl, lane);
-        }
-        __syncthreads();  // the compute wave has written the last x
-        {
-            double xr[E];
-            const double2 *xs = x_ring[(len - 1) & 1];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double2 v = xs[q * 64 + lane];
-                xr[2 * q] = v.x;
-                xr[2 * q + 1] = v.y;
-            }
-            store_row(L.u + (size_t)(start + len - 1) * L.ld, sl, xr);
-        }
-        return;
-    }
-    // ---- compute wave
-    double x[E];
-    ChainCtx k;
-    k.cur = -1;
-    if (KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1) load_row(reinterpret_cast<const double *>(L.sP), sl, k.s0);
-    load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
-    const bool f1 = KIND == MGRIT_HIP_STEPPER_HEAT1D && FORCE == 1;
-    k.ci_a = L.cidx[start];
-    k.tc_a = f1 ? L.tc[start] : 0.0;
-    k.ci_b = len > 1 ? L.cidx[start + 1] : 0;
-    k.tc_b = (f1 && len > 1) ? L.tc[start + 1] : 0.0;
-    for (int i = start; i < start + len; i += 2) {
-        __syncthreads();
-        if (!chain_step<KIND, FORCE, USE_G>(L, k, x, g_ring[0], x_ring[0], i, start, len, gran, err, wave, lane, G, t, sl)) return;
-        if (i + 1 < start + len) {
-            __syncthreads();
-            if (!chain_step<KIND, FORCE, USE_G>(L, k, x, g_ring[1], x_ring[1], i + 1, start, len, gran, err, wave, lane, G, t, sl)) return;
-        }
-    }
-    __syncthreads();
-}
+#include "mgrit_hip_chain.inc"
 
 // compute_residual (mgrit.py:387-413): out[run] = || Phi(u_{i-1}) - u_i ||^2
 template <int KIND, int FORCE>
@@ -939,224 +686,7 @@ __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, c
 
 #include "mgrit_hip_2pts.inc"
 
-// ===============================================================================================================
-// Heat2D (heat/heat_2d.py:250-366): theta-scheme on the full nx x ny grid. Interior solve by fast diagonalisation
-//   U = Qx ((Qx B Qy) o D) Qy,  Qx, Qy orthogonal symmetric sine-transform matrices,
-// i.e. four dense FP64 GEMMs per step, batched over all time points a sweep updates at once. The GEMMs run on the matrix
-// cores with v_mfma_f64_16x16x4_f64, which accumulates its four k-products as a sequential fma chain (verified on gfx950):
-// a K loop in ascending order without split-K is bit-identical to the oracle's plain fma dot product.
-// Every product has the form  out[n][m] = sum_k A[k][m] * B[k][n]  (A symmetric table, output stored transposed), so
-// all operands are read along their contiguous dimension and the four steps chain without any explicit transpose.
-// ===============================================================================================================
-enum { H2D_OP_F = 0, H2D_OP_C = 1, H2D_OP_FAS_FINE = 2, H2D_OP_FAS_COARSE = 3, H2D_OP_RESIDUAL = 4, H2D_OP_JUMP = 5 };
-
-struct H2DDev {
-    int nx, ny, mi, mj, Mi, Mj, K, n_pts, ld, has_w;
-    double fx, fy, theta;
-    const double *bc;    // [nx*ny] boundary values (zero inside)
-    const double *W;     // [Mi][Mj] boundary coupling (zero padded)
-    const double *S;     // [K][Mi][Mj] forcing space factors (zero padded)
-    const double *tstop; // [K][n_pts] tau_k(t_i)
-    const double *dt;    // [n_pts]
-};
-
-typedef double d4_t __attribute__((ext_vector_type(4)));
-typedef double d2_t __attribute__((ext_vector_type(2)));
-
-// out[b][n][m] (* dinv[n][m]) = sum_k A[k][m] * B[b][k][n] ; A: M x M symmetric, B: M x N per batch item, out: N x M.
-// 64x64 tile per workgroup, 4 waves x (32x32 = 2x2 MFMA tiles), K step 16 through LDS (rows padded to 80 doubles:
-// the two k-rows a ds_read_b64 half-wave touches fall into disjoint bank halves).
-template <bool SCALE>
-__global__ void __launch_bounds__(256) h2d_gemm_kernel(const double *__restrict__ A, int M, const double *__restrict__ B,
-                                                       int N, double *__restrict__ out, const double *__restrict__ dinv,
-                                                       size_t bstride) {
-    // one LDS block, two uses: the A/B staging tiles of the K loop (2 x 32 x 80 doubles) and, after the loop, the 64 x 66
-    // transposition tile of the epilogue. 40 KB per workgroup -> 4 workgroups per CU.
-    constexpr int BK = 32, LDT = 80;
-    __shared__ __attribute__((aligned(16))) double smem[2 * BK * LDT];
-    double(*As)[LDT] = reinterpret_cast<double(*)[LDT]>(smem);
-    double(*Bs)[LDT] = reinterpret_cast<double(*)[LDT]>(smem + BK * LDT);
-    double(*Cs)[66] = reinterpret_cast<double(*)[66]>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // grid (n tiles, m tiles, items): workgroups are dealt to the 8 XCDs round-robin by linear id, so with 8 n tiles XCD x
-    // handles the n-block x of every item: that 64-column block of B is fetched from HBM once, by this XCD only, and reused
-    // by the item's m tiles out of its L2, next to the whole A table (2 MB at 512^2) which stays L2-resident.
-    // (Sending all 64 tiles of an item to one XCD instead makes A and two items' B compete for the 4 MB L2: half the rate.)
-    const int item = blockIdx.z;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const double *Bb = B + (size_t)item * bstride;
-    double *Ob = out + (size_t)item * bstride;
-    const int wm = (w & 1) * 32, wn = (w >> 1) * 32;
-    const int lr = lane & 15, lk = lane >> 4;
-    d4_t acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    const int sr = tid >> 5, sc = (tid & 31) * 2;
-    d2_t ra[BK / 8], rb[BK / 8];
-    const double *Ap = A + (size_t)sr * M + m0 + sc, *Bp = Bb + (size_t)sr * N + n0 + sc;
-#pragma unroll
-    for (int h = 0; h < BK / 8; ++h) {
-        ra[h] = *reinterpret_cast<const d2_t *>(Ap + (size_t)(8 * h) * M);
-        rb[h] = *reinterpret_cast<const d2_t *>(Bp + (size_t)(8 * h) * N);
-    }
-    for (int k0 = 0; k0 < M; k0 += BK) {
-#pragma unroll
-        for (int h = 0; h < BK / 8; ++h) {
-            *reinterpret_cast<d2_t *>(&As[sr + 8 * h][sc]) = ra[h];
-            *reinterpret_cast<d2_t *>(&Bs[sr + 8 * h][sc]) = rb[h];
-        }
-        lds_barrier();
-        {   // operands of the next K step: in flight while the matrix cores work on this one (the last trip re-reads its own)
-            const int kn = k0 + BK < M ? k0 + BK : k0;
-#pragma unroll
-            for (int h = 0; h < BK / 8; ++h) {
-                ra[h] = *reinterpret_cast<const d2_t *>(Ap + (size_t)(kn + 8 * h) * M);
-                rb[h] = *reinterpret_cast<const d2_t *>(Bp + (size_t)(kn + 8 * h) * N);
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            const double a0 = As[kk * 4 + lk][wm + lr], a1 = As[kk * 4 + lk][wm + 16 + lr];
-            const double b0 = Bs[kk * 4 + lk][wn + lr], b1 = Bs[kk * 4 + lk][wn + 16 + lr];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        lds_barrier();
-    }
-    // D[row = lk + 4r][col = lr] of tile (tm, tn) is element (m = wm + 16 tm + lk + 4r, n = wn + 16 tn + lr): store transposed
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cs[wn + 16 * tn + lr][wm + 16 * tm + lk + 4 * r] = acc[tm][tn][r];
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int n = (tid >> 4) + 16 * p, c = (tid & 15) * 4;
-        double v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = Cs[n][c + q];
-        const size_t o = (size_t)(n0 + n) * M + m0 + c;
-        if (SCALE) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = v[q] * dinv[o + q];
-        }
-        *reinterpret_cast<double2 *>(Ob + o) = make_double2(v[0], v[1]);
-        *reinterpret_cast<double2 *>(Ob + o + 2) = make_double2(v[2], v[3]);
-    }
-}
-
-__device__ __forceinline__ double h2d_lap(const H2DDev &H, const double *u, int gi, int gj) {
-    const int ny = H.ny;
-    double acc = (2.0 * (H.fx + H.fy)) * u[(size_t)gi * ny + gj];
-    acc = fma(-H.fx, u[(size_t)(gi - 1) * ny + gj], acc);
-    acc = fma(-H.fx, u[(size_t)(gi + 1) * ny + gj], acc);
-    acc = fma(-H.fy, u[(size_t)gi * ny + gj - 1], acc);
-    acc = fma(-H.fy, u[(size_t)gi * ny + gj + 1], acc);
-    return acc;
-}
-
-// right-hand side of the implicit solve on the padded interior: B[b][a][c] (heat_2d.py:289-320)
-__global__ void h2d_rhs_kernel(H2DDev H, const double *__restrict__ slab, const int32_t *__restrict__ in_idx,
-                               const int32_t *__restrict__ step_idx, double *__restrict__ B) {
-    const int b = blockIdx.z, a = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= H.Mj) return;
-    double v = 0.0;
-    if (a < H.mi && c < H.mj) {
-        const double *u = slab + (size_t)in_idx[b] * H.ld;
-        const int i = step_idx[b];
-        const double dt = H.dt[i], th = H.theta;
-        const size_t p = (size_t)(a + 1) * H.ny + (c + 1), q = (size_t)a * H.Mj + c;
-        if (th == 1.0) {
-            v = u[p];
-            for (int k = 0; k < H.K; ++k) v = fma(H.S[(size_t)k * H.Mi * H.Mj + q], H.tstop[(size_t)k * H.n_pts + i] * dt, v);
-        } else {
-            const double thdt = th * dt, thdt1 = (1.0 - th) * dt;
-            v = fma(-thdt, h2d_lap(H, u, a + 1, c + 1), u[p]);
-            for (int k = 0; k < H.K; ++k)
-                v = fma(H.S[(size_t)k * H.Mi * H.Mj + q],
-                        thdt * H.tstop[(size_t)k * H.n_pts + i] + thdt1 * H.tstop[(size_t)k * H.n_pts + i - 1], v);
-        }
-        if (H.has_w) v = fma(th * dt, H.W[q], v);
-    }
-    B[((size_t)b * H.Mi + a) * H.Mj + c] = v;
-}
-
-// value of Phi(u_in) at grid point (gi, gj) of batch item b: interior from the GEMM result U (theta > 0) or the explicit
-// stencil (theta = 0, heat_2d.py:346-356 incl. the reference's "BC + old boundary" behaviour)
-__device__ __forceinline__ double h2d_phi_value(const H2DDev &H, const double *U, const double *uin, int step, int b, int gi,
-                                                int gj) {
-    const size_t p = (size_t)gi * H.ny + gj;
-    const bool rim = gi == 0 || gj == 0 || gi == H.nx - 1 || gj == H.ny - 1;
-    if (H.theta == 0.0) {
-        if (rim) return H.bc[p] + uin[p];
-        const double dt = H.dt[step];
-        double v = fma(-dt, h2d_lap(H, uin, gi, gj), uin[p]);
-        for (int k = 0; k < H.K; ++k)
-            v = fma(H.S[(size_t)k * H.Mi * H.Mj + (size_t)(gi - 1) * H.Mj + (gj - 1)], dt * H.tstop[(size_t)k * H.n_pts + step - 1], v);
-        return v;
-    }
-    return rim ? H.bc[p] : U[((size_t)b * H.Mi + (gi - 1)) * H.Mj + (gj - 1)];
-}
-
-// sweep epilogue on full-grid rows: one thread per grid point (ops: see H2D_OP_*)
-__global__ void h2d_finish_kernel(H2DDev H, const double *__restrict__ U, const double *__restrict__ in_slab,
-                                  const int32_t *__restrict__ in_idx, const int32_t *__restrict__ step_idx,
-                                  double *__restrict__ dst_slab, int dst_ld, const int32_t *__restrict__ dst_idx,
-                                  const double *__restrict__ a_slab, const int32_t *__restrict__ a_idx,
-                                  const double *__restrict__ b_slab, const int32_t *__restrict__ b_idx, int op, int use_g,
-                                  double w, double w1) {
-    const int b = blockIdx.z, gi = blockIdx.y, gj = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gj >= H.ny) return;
-    const size_t p = (size_t)gi * H.ny + gj;
-    const double *uin = in_slab + (size_t)in_idx[b] * H.ld;
-    const double phi = h2d_phi_value(H, U, uin, step_idx[b], b, gi, gj);
-    double *dst = dst_slab + (size_t)dst_idx[b] * dst_ld;
-    double v;
-    if (op == H2D_OP_F) {
-        v = use_g ? a_slab[(size_t)a_idx[b] * H.ld + p] + phi : phi;                       // [g_i +] Phi
-    } else if (op == H2D_OP_C) {
-        v = use_g ? a_slab[(size_t)a_idx[b] * H.ld + p] + phi : phi;
-        if (w != 1.0) v = v * w + dst[p] * w1;                                             // weighted with the old u_i
-    } else if (op == H2D_OP_FAS_FINE) {
-        const double ui = b_slab[(size_t)b_idx[b] * H.ld + p];
-        v = use_g ? (a_slab[(size_t)a_idx[b] * H.ld + p] - ui) + phi : phi - ui;           // (g_i - u_i) + Phi | Phi - u_i
-    } else {  // H2D_OP_FAS_COARSE: (g_j + v_j) - Phi(v_{j-1})
-        v = (a_slab[(size_t)a_idx[b] * H.ld + p] + b_slab[(size_t)b_idx[b] * H.ld + p]) - phi;
-    }
-    dst[p] = v;
-}
-
-// residual / jump: per grid row an fma chain over its ny values (thread per (item, row)), then the rows in order
-__global__ void h2d_rowsq_kernel(H2DDev H, const double *__restrict__ U, const double *__restrict__ in_slab,
-                                 const int32_t *__restrict__ in_idx, const int32_t *__restrict__ step_idx,
-                                 const double *__restrict__ cmp_slab, const int32_t *__restrict__ cmp_idx, int op,
-                                 double *__restrict__ rowsq) {
-    const int b = blockIdx.y, gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= H.nx) return;
-    const double *uin = in_slab + (size_t)in_idx[b] * H.ld;
-    const double *cmp = cmp_slab + (size_t)cmp_idx[b] * H.ld;
-    double acc = 0.0;
-    for (int gj = 0; gj < H.ny; ++gj) {
-        const size_t p = (size_t)gi * H.ny + gj;
-        const double r = op == H2D_OP_RESIDUAL ? h2d_phi_value(H, U, uin, step_idx[b], b, gi, gj) - cmp[p] : uin[p] - cmp[p];
-        acc = fma(r, r, acc);
-    }
-    rowsq[(size_t)b * H.nx + gi] = acc;
-}
-
-__global__ void h2d_rowsum_kernel(const double *__restrict__ rowsq, int nx, int count, double *__restrict__ out) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= count) return;
-    double tot = 0.0;
-    for (int i = 0; i < nx; ++i) tot = tot + rowsq[(size_t)b * nx + i];
-    out[b] = tot;
-}
+#include "mgrit_hip_heat2d.inc"
 
 // ---------------------------------------------------------------------------------------------------------------
 // host side
