@@ -119,6 +119,13 @@ int mgrit_hip_copy_pairs_u_to_v(mgrit_hip_engine *e, int lvl, int pairs_id);
 int mgrit_hip_error_correction(mgrit_hip_engine *e, int lvl, int pairs_id);
 /* Mgrit.nested_iteration interpolation (mgrit.py:559-563): u^l_i = P(u^{l+1}_j) */
 int mgrit_hip_interpolate(mgrit_hip_engine *e, int lvl, int pairs_id);
+/* Mgrit.error_correction followed by Mgrit.f_relax (mgrit.py:715-726, then 292-333, as Mgrit.iteration calls them,
+ * mgrit.py:283-284) in one pass, for 1-D steppers and the identity transfer: a run list whose run r additionally names the
+ * coarse slot coarse_idx[r] of its predecessor C-point (-1: predecessor is a ghost or is not corrected). The predecessor
+ * receives u += u^{l+1}_j - v^{l+1}_j and is written back, then the run's points follow as in mgrit_hip_relax mode F. */
+int mgrit_hip_ec_runs_create(mgrit_hip_engine *e, int lvl, int n_runs, const int32_t *start, const int32_t *len,
+                             const int32_t *coarse_idx, int *id_out);
+int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id);
 
 /* Same two reductions with the result delivered to HOST memory (sumsq_host[r], r < n_runs) when the call returns: the
  * device->host leg of Mgrit.convergence_criterion (mgrit.py:425-432). */

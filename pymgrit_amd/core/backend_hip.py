@@ -342,6 +342,24 @@ class HipBackend:
         if pairs:
             check(self.lib.mgrit_hip_copy_pairs_u_to_v(self.h, lvl, self._pair_id(lvl, pairs)))
 
+    def can_fuse_ec(self, lvl):
+        tr = self.mg.transfer_objects[lvl]
+        da, db = self.desc[lvl], self.desc[lvl + 1]
+        return (hasattr(tr, "device_transfer") and int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and
+                da["kind"] == db["kind"] and da["kind"] in ("heat1d", "advection1d") and self.n[lvl] == self.n[lvl + 1])
+
+    def ec_relax(self, lvl, triples):
+        """error correction of the C-point in front of each run + the run's F-relaxation in one launch"""
+        if not triples:
+            return
+
+        def create():
+            rid = C.c_int(-1)
+            st, ln, co = _i32([t[0] for t in triples]), _i32([t[1] for t in triples]), _i32([t[2] for t in triples])
+            check(self.lib.mgrit_hip_ec_runs_create(self.h, lvl, len(triples), _ptr(st), _ptr(ln), _ptr(co), C.byref(rid)))
+            return rid.value
+        check(self.lib.mgrit_hip_ec_relax(self.h, lvl, self._handle(self._runs, lvl, triples, "ecruns", create)))
+
     def error_correction(self, lvl, pairs):
         if pairs:
             check(self.lib.mgrit_hip_error_correction(self.h, lvl, self._pair_id(lvl, pairs)))

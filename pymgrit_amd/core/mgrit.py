@@ -289,15 +289,20 @@ class Mgrit:
             self.f_relax(lvl=lvl)
         self.fas_residual(lvl=lvl)
         self.iteration(lvl=lvl + 1, cycle_type=cycle_type, iteration=iteration, first_f=True)
-        self.error_correction(lvl=lvl)
-        self.f_relax(lvl=lvl)
+        if self._can_fuse_ec(lvl):
+            self._ec_f_relax(lvl)
+        else:
+            self.error_correction(lvl=lvl)
+            self.f_relax(lvl=lvl)
         if lvl != 0 and cycle_type == 'F':
             self.iteration(lvl=lvl, cycle_type='V', iteration=iteration, first_f=False)
 
-    def f_relax(self, lvl: int) -> None:
+    def f_relax(self, lvl: int, ec: bool = False) -> None:
         """F-relaxation (mgrit.py:292-333): every F-interval is propagated from its preceding point. Exchange:
         op 0 = last local C-point to the next owner's ghost; op 1 = hand-off inside an F-interval that straddles a
-        rank boundary (comm_front / comm_back)."""
+        rank boundary (comm_front / comm_back).
+        ec=True (internal, Mgrit._ec_f_relax): the launches also apply the error correction to the C-point in front of
+        each interval; the sweep order and the exchange points are those of the plain relaxation."""
         t0 = time.time()
         self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_c_point[lvl] else None,
                        recv_idx=0 if self.first_is_f_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl])
@@ -306,20 +311,43 @@ class Mgrit:
             front, back = self.comm_front[lvl], self.comm_back[lvl]
             if front and back and len(runs) == 1:
                 self._exchange(lvl, recv_idx=0, src=self.get_from[lvl])
-                self.backend.relax(lvl, runs, 'F')
+                self._relax_f(lvl, 'f_all', runs, ec)
                 self._exchange(lvl, send_idx=self._last_slot(lvl), dest=self.send_to[lvl])
             elif not front and not back:
-                self.backend.relax(lvl, runs, 'F')
+                self._relax_f(lvl, 'f_all', runs, ec)
             else:
                 lo, hi = (1 if front else 0), (len(runs) - 1 if back else len(runs))
                 if back:  # the interval feeding the next rank goes first
-                    self.backend.relax(lvl, self._cached(('f_last', lvl), lambda: runs[-1:]), 'F')
+                    self._relax_f(lvl, 'f_last', self._cached(('f_last', lvl), lambda: runs[-1:]), ec)
                     self._exchange(lvl, send_idx=self._last_slot(lvl), dest=self.send_to[lvl])
-                self.backend.relax(lvl, self._cached(('f_mid', lvl), lambda: runs[lo:hi]), 'F')
+                self._relax_f(lvl, 'f_mid', self._cached(('f_mid', lvl), lambda: runs[lo:hi]), ec)
                 if front:
                     self._exchange(lvl, recv_idx=0, src=self.get_from[lvl])
-                    self.backend.relax(lvl, self._cached(('f_first', lvl), lambda: runs[:1]), 'F')
+                    self._relax_f(lvl, 'f_first', self._cached(('f_first', lvl), lambda: runs[:1]), ec)
         logging.debug(f"F-relax on {self.comm_time_rank} took {time.time() - t0} s")
+
+    def _relax_f(self, lvl, tag, runs, ec):
+        if not ec:
+            self.backend.relax(lvl, runs, 'F')
+            return
+        def build():   # (start, length, coarse slot of the corrected C-point in front of the run, or -1)
+            coarse_of = dict(self._pairs(lvl, skip_first=True))
+            return [(st, ln, coarse_of.get(st - 1, -1)) for st, ln in runs]
+        self.backend.ec_relax(lvl, self._cached(('ec_' + tag, lvl), build))
+
+    def _can_fuse_ec(self, lvl):
+        return (getattr(self.backend, "can_fuse_ec", None) is not None and self.backend.can_fuse_ec(lvl) and
+                type(self).error_correction is Mgrit.error_correction and type(self).f_relax is Mgrit.f_relax)
+
+    def _ec_f_relax(self, lvl: int) -> None:
+        """error_correction(lvl) then f_relax(lvl) (mgrit.py:283-284) with the correction of every C-point that is followed
+        by a local F-interval folded into that interval's launch; the remaining C-points (the last local point, C-points
+        followed by another C-point) are corrected up front -- in particular before op 0 sends the last local C-point."""
+        def leftover():
+            fused = {st - 1 for st, _ in self._f_runs(lvl)}
+            return [p for p in self._pairs(lvl, skip_first=True) if p[0] not in fused]
+        self.backend.error_correction(lvl, self._cached(('ec_left', lvl), leftover))
+        self.f_relax(lvl, ec=True)
 
     def c_relax(self, lvl: int) -> None:
         """C-relaxation (mgrit.py:335-370); op 2 = last local F-point to the next owner's ghost."""

@@ -490,6 +490,39 @@ __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *
     }
 }
 
+// error_correction + f_relax in one pass for the identity transfer (mgrit.py:715-726 followed by 292-333): a run whose
+// predecessor is a corrected C-point applies the correction itself -- u_c = u_c + (u^{l+1}_j - v^{l+1}_j), same operation
+// order as interp_rows_kernel -- writes the C-point back and goes on with the F-points, so the C-point travels through HBM
+// once instead of twice. ec_coarse[r] = coarse slot j of run r's predecessor, or -1 (ghost / uncorrected predecessor).
+template <int KIND, int FORCE, bool USE_G>
+__global__ void __launch_bounds__(1024) ecf_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ run_start,
+                                                   const int32_t *__restrict__ run_len, const int32_t *__restrict__ ec_coarse,
+                                                   int n_runs) {
+    WG_PROLOGUE;
+    for (int r = blockIdx.x; r < n_runs; r += gridDim.x) {
+        const int start = run_start[r], len = run_len[r], j = ec_coarse[r];
+        double x[E], gi[E];
+        load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
+        if (j >= 0) {
+            double uc[E];
+            load_row(Lc.u + (size_t)j * Lc.ld, sl, uc);
+            load_row(Lc.v + (size_t)j * Lc.ld, sl, gi);
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = x[k] + (uc[k] - gi[k]);
+            store_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
+        }
+        for (int i = start; i < start + len; ++i) {
+            if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);
+            phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+            if (USE_G) {
+#pragma unroll
+                for (int k = 0; k < E; ++k) x[k] = gi[k] + x[k];
+            }
+            store_row(L.u + (size_t)i * L.ld, sl, x);
+        }
+    }
+}
+
 #include "mgrit_hip_chain.inc"
 
 // compute_residual (mgrit.py:387-413): out[run] = || Phi(u_{i-1}) - u_i ||^2
@@ -694,7 +727,7 @@ __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, c
 struct H2DPlan { int count = 0; uint64_t dtbits = 0; int32_t *d_in = nullptr, *d_step = nullptr, *d_dst = nullptr, *d_a = nullptr, *d_b = nullptr; };
 struct RunList {
     int n = 0;
-    int32_t *d_start = nullptr, *d_len = nullptr;
+    int32_t *d_start = nullptr, *d_len = nullptr, *d_ec = nullptr;  // d_ec: mgrit_hip_ec_runs_create only
     std::vector<int32_t> h_start, h_len;
     std::vector<H2DPlan> h2d_relax, h2d_points;  // Heat2D batch plans (built on first use)
     bool h2d_relax_built = false, h2d_points_built = false;
@@ -860,7 +893,9 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(residual_kernel<K, F>))) return rc;                                                      \
     if ((rc = allow_big_lds(fas_fine_kernel<K, F>))) return rc;                                                      \
     if ((rc = allow_big_lds(fas_coarse_kernel<K, F>))) return rc;                                                    \
-    if ((rc = allow_big_lds(fas_fused_kernel<K, F>))) return rc;
+    if ((rc = allow_big_lds(fas_fused_kernel<K, F>))) return rc;                                                     \
+    if ((rc = allow_big_lds(ecf_kernel<K, F, false>))) return rc;                                                    \
+    if ((rc = allow_big_lds(ecf_kernel<K, F, true>))) return rc;
     FOR_EACH_STEPPER(ATTR_ALL)
     if ((rc = allow_big_lds(jump_kernel))) return rc;
 #define ATTR_2PTS(O, F)                                                                                              \
@@ -1792,6 +1827,48 @@ static int interp_common(mgrit_hip_engine *e, int lvl, int pairs_id, int mode) {
 
 int mgrit_hip_error_correction(mgrit_hip_engine *e, int lvl, int pairs_id) { return interp_common(e, lvl, pairs_id, 1); }
 int mgrit_hip_interpolate(mgrit_hip_engine *e, int lvl, int pairs_id) { return interp_common(e, lvl, pairs_id, 0); }
+
+int mgrit_hip_ec_runs_create(mgrit_hip_engine *e, int lvl, int n_runs, const int32_t *start, const int32_t *len,
+                             const int32_t *coarse_idx, int *id_out) {
+    int rc = mgrit_hip_runs_create(e, lvl, n_runs, start, len, id_out);
+    if (rc) return rc;
+    if (lvl + 1 >= e->n_levels || !e->L[lvl + 1].set) return fail(MGRIT_HIP_EINVAL, "level %d has no coarser level", lvl);
+    if (n_runs > 0 && !coarse_idx) return fail(MGRIT_HIP_EINVAL, "null coarse index list");
+    Level &lv = e->L[lvl];
+    for (int r = 0; r < n_runs; ++r)
+        if (coarse_idx[r] < -1 || coarse_idx[r] >= e->L[lvl + 1].dev.n_pts)
+            return fail(MGRIT_HIP_EINVAL, "run %d: coarse slot %d outside [-1,%d)", r, coarse_idx[r], e->L[lvl + 1].dev.n_pts);
+    std::vector<int32_t> h(coarse_idx, coarse_idx + n_runs);
+    return dev_upload(lv, e->stream, h, &lv.runs[*id_out].d_ec);
+}
+
+int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id) {
+    RunList *rl;
+    int rc = get_runs(e, lvl, ec_runs_id, &rl);
+    if (rc) return rc;
+    if (!rl->d_ec) return fail(MGRIT_HIP_EINVAL, "list %d was not created by mgrit_hip_ec_runs_create", ec_runs_id);
+    Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
+    if (lf.h2d || lc.h2d || is_2pts(lf) || is_2pts(lc) || lf.transfer != MGRIT_HIP_TRANSFER_COPY || lf.dev.n != lc.dev.n)
+        return fail(MGRIT_HIP_EUNSUPPORTED, "fused correction + F-relaxation needs 1-D steppers and the copy transfer");
+    if (rl->n == 0) return 0;
+    if (e->timing) {
+        if (!e->ev0) { HIP_TRY(hipEventCreate(&e->ev0)); HIP_TRY(hipEventCreate(&e->ev1)); }
+        HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    }
+    const bool use_g = lvl > 0;
+    const int fm = force_mode(lf);
+    const dim3 grid(persistent_grid(lf, rl->n)), block(lf.dev.T);
+#define ECF_CASE(K, F, G_)                                                                                          \
+    if (lf.dev.kind == K && fm == F && use_g == G_)                                                                 \
+        hipLaunchKernelGGL((ecf_kernel<K, F, G_>), grid, block, smem_bytes(lf.G), e->stream, lf.dev, lc.dev, rl->d_start,  \
+                           rl->d_len, rl->d_ec, rl->n);
+#define ECF_CASES(K, F) ECF_CASE(K, F, false) ECF_CASE(K, F, true)
+    FOR_EACH_STEPPER(ECF_CASES)
+    HIP_TRY(hipGetLastError());
+    if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
+    return 0;
+}
 
 // Host read-back of per-run scalars without any copy command: the kernels store straight into pinned, device-mapped
 // host memory and the host spins on an event recorded behind the kernel. (A D2H copy command issued after a long mostly
