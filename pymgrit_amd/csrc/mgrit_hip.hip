@@ -460,7 +460,7 @@ extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
 // f_relax / c_relax / forward_solve (mgrit.py:292-370,459-486). ROLE only separates the launches by purpose (distinct
 // kernel symbols in rocprof traces; the weighted C-relaxation is the only one that re-reads the old u_i).
-enum { ROLE_F = 0, ROLE_C = 1, ROLE_C_WEIGHTED = 2, ROLE_CHAIN = 3 };
+enum { ROLE_F = 0, ROLE_C = 1, ROLE_C_WEIGHTED = 2 };
 
 template <int KIND, int FORCE, bool USE_G, int ROLE>
 __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *__restrict__ run_start,
@@ -889,7 +889,6 @@ int setup_kernel_attrs() {
 #define ATTR_ALL(K, F)                                                                                              \
     ATTR_RELAX(K, F, false, ROLE_F) ATTR_RELAX(K, F, true, ROLE_F) ATTR_RELAX(K, F, false, ROLE_C)                   \
     ATTR_RELAX(K, F, true, ROLE_C) ATTR_RELAX(K, F, false, ROLE_C_WEIGHTED) ATTR_RELAX(K, F, true, ROLE_C_WEIGHTED)  \
-    ATTR_RELAX(K, F, false, ROLE_CHAIN) ATTR_RELAX(K, F, true, ROLE_CHAIN)                                           \
     if ((rc = allow_big_lds(residual_kernel<K, F>))) return rc;                                                      \
     if ((rc = allow_big_lds(fas_fine_kernel<K, F>))) return rc;                                                      \
     if ((rc = allow_big_lds(fas_coarse_kernel<K, F>))) return rc;                                                    \
@@ -1622,8 +1621,8 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
         if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
         return 0;
     }
-    if (mode == MGRIT_HIP_RELAX_CHAIN && lv.G > 1) {
-        // sequential chain over several groups: one single-wave workgroup per group, exchange through global granules
+    if (mode == MGRIT_HIP_RELAX_CHAIN) {
+        // sequential chain: one two-wave workgroup (compute + streamer) per group, exchange through global granules
         if (!e->chain_gran) {
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->chain_gran), sizeof(u64) * 4 * MAX_G * 4));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->chain_err), 64, hipHostMallocMapped));
@@ -1635,10 +1634,11 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
             const dim3 grid(8 * lv.G), block(2 * LANES);
             const int st = rl->h_start[r], ln = rl->h_len[r];
-#define CHAIN_CASE(K, F, G_)                                                                                  \
-    if (lv.dev.kind == K && fm == F && use_g == G_)                                                            \
-        hipLaunchKernelGGL((chain_kernel<K, F, G_>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
-#define CHAIN_CASES(K, F) CHAIN_CASE(K, F, false) CHAIN_CASE(K, F, true)
+#define CHAIN_CASE(K, F, G_, S_)                                                                              \
+    if (lv.dev.kind == K && fm == F && use_g == G_ && (lv.G == 1) == S_)                                       \
+        hipLaunchKernelGGL((chain_kernel<K, F, G_, S_>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
+#define CHAIN_CASES(K, F) CHAIN_CASE(K, F, false, false) CHAIN_CASE(K, F, true, false) CHAIN_CASE(K, F, false, true) \
+    CHAIN_CASE(K, F, true, true)
             FOR_EACH_STEPPER(CHAIN_CASES)
             HIP_TRY(hipGetLastError());
         }
@@ -1647,10 +1647,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     }
     {
         const bool use_g = lvl > 0;
-        const int role = mode == MGRIT_HIP_RELAX_CHAIN ? ROLE_CHAIN
-                         : mode == MGRIT_HIP_RELAX_F   ? ROLE_F
-                         : (weight_c != 1.0)           ? ROLE_C_WEIGHTED
-                                                       : ROLE_C;
+        const int role = mode == MGRIT_HIP_RELAX_F ? ROLE_F : (weight_c != 1.0) ? ROLE_C_WEIGHTED : ROLE_C;
         const double w = weight_c, w1 = 1.0 - weight_c;
         // persistent grid: as many workgroups as stay resident (LDS- and thread-limited), at most one per run
         const size_t lds = smem_bytes(lv.G);
@@ -1662,8 +1659,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
                            w, w1);
 #define RELAX_CASES(K, F)                                                                                          \
     RELAX_CASE(K, F, false, ROLE_F) RELAX_CASE(K, F, true, ROLE_F) RELAX_CASE(K, F, false, ROLE_C)                  \
-    RELAX_CASE(K, F, true, ROLE_C) RELAX_CASE(K, F, false, ROLE_C_WEIGHTED) RELAX_CASE(K, F, true, ROLE_C_WEIGHTED) \
-    RELAX_CASE(K, F, false, ROLE_CHAIN) RELAX_CASE(K, F, true, ROLE_CHAIN)
+    RELAX_CASE(K, F, true, ROLE_C) RELAX_CASE(K, F, false, ROLE_C_WEIGHTED) RELAX_CASE(K, F, true, ROLE_C_WEIGHTED)
         FOR_EACH_STEPPER(RELAX_CASES)
         HIP_TRY(hipGetLastError());
     }
