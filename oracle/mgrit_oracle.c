@@ -399,10 +399,16 @@ static void thomas_toeplitz(int n, double beta, double D, double *d, double *cp,
     for (int j = n - 2; j >= 0; --j) out[j] = d[j] - cp[j] * out[j + 1];
 }
 
-static void heat1d_step_natural(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out) {
+/* scratch passed in: the threaded sweeps of the timing path (orc_problem_set_threads) give every thread its own */
+static void heat1d_step_natural_ws(const orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out,
+                                   double *w1, double *w2) {
     double beta = dt * st->fac, D = dt * (2.0 * st->fac) + 1.0;
-    heat1d_rhs(st, nt, i_stop, dt, u, st->w1);
-    thomas_toeplitz(st->n, beta, D, st->w1, st->w2, out);
+    heat1d_rhs(st, nt, i_stop, dt, u, w1);
+    thomas_toeplitz(st->n, beta, D, w1, w2, out);
+}
+
+static void heat1d_step_natural(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out) {
+    heat1d_step_natural_ws(st, nt, i_stop, dt, u, out, st->w1, st->w2);
 }
 
 /* Cross-group carries: the <= 16 group totals sit in one row of 16 lanes; inclusive Kogge-Stone
@@ -731,12 +737,14 @@ typedef struct {
     double *save_last;      /* conv_crit 1: clone of u[0] */
     double *tmp1, *tmp2, *tmp3;
     int64_t phi_count[ORC_MAX_LEVELS];
+    int threads;            /* > 1: the independent loops of the sweeps run on that many OpenMP threads (timing only; same
+                               arithmetic, same results). Heat1D natural variant with copy transfers only. */
 } orc_problem;
 
 orc_problem *orc_problem_create(int n_levels) {
     orc_problem *p = (orc_problem *)calloc(1, sizeof(orc_problem));
     p->n_levels = n_levels; p->weight_c = 1.0; p->nested = 1; p->t_norm = 2; p->max_iter = 100; p->tol = 1e-7;
-    p->norm_spec = 1;
+    p->norm_spec = 1; p->threads = 1;
     for (int l = 0; l < ORC_MAX_LEVELS; ++l) p->cf_iter[l] = 1;
     return p;
 }
@@ -852,6 +860,23 @@ void orc_problem_set_level_heat2d(orc_problem *p, int lvl, int nt, const double 
 
 void orc_problem_set_transfer(orc_problem *p, int lvl, int kind) { p->L[lvl].transfer = kind; }
 
+/* Threaded sweeps for the CPU baseline of bench.py: the F-intervals / C-points of a sweep are independent -- the same
+ * independence the reference's mpi4py path exploits across ranks (mgrit.py:313-331) -- so they are split over OpenMP
+ * threads. Returns the thread count in effect (1 when the hierarchy is not all Heat1D / natural variant / copy transfer,
+ * or the library was built without OpenMP). */
+int orc_problem_set_threads(orc_problem *p, int threads) {
+    p->threads = 1;
+#ifdef _OPENMP
+    int ok = threads > 1;
+    for (int l = 0; l < p->n_levels; ++l)
+        if (p->L[l].st.kind != ORC_HEAT1D || p->L[l].st.variant != 0 || (l < p->n_levels - 1 && p->L[l].transfer != 0)) ok = 0;
+    if (ok) p->threads = threads;
+#else
+    (void)threads;
+#endif
+    return p->threads;
+}
+
 void orc_problem_set_options(orc_problem *p, double weight_c, const int32_t *cf_iter, int cycle_type, int nested,
                              int t_norm, int conv_crit, int max_iter, double tol, int norm_spec) {
     p->weight_c = weight_c; p->cycle_type = cycle_type; p->nested = nested; p->t_norm = t_norm;
@@ -950,9 +975,133 @@ double *orc_state_ptr(orc_problem *p, int which, int lvl) {
 
 int64_t orc_phi_count(orc_problem *p, int lvl) { return p->phi_count[lvl]; }
 
+#ifdef _OPENMP
+#include <omp.h>
+/* ---- threaded variants (timing path): identical arithmetic, one interval / C-point per loop trip ---- */
+static void phi_ws(orc_problem *p, int lvl, int i, const double *u_in, double *out, double *w1, double *w2) {
+    orc_level *L = &p->L[lvl];
+    heat1d_step_natural_ws(&L->st, L->nt, i, L->t[i] - L->t[i - 1], u_in, out, w1, w2);
+}
+
+static int has_adjacent_c(const orc_level *L) {
+    for (int i = 1; i < L->nt; ++i) if (L->is_c[i] && L->is_c[i - 1] && i - 1 > 0) return 1;
+    return 0;
+}
+
+static void f_relax_mt(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl];
+    int n = L->n, np = padded(n);
+#pragma omp parallel num_threads(p->threads)
+    {
+        double *w = (double *)malloc(sizeof(double) * 3 * (size_t)np), *w1 = w, *w2 = w + np, *tmp = w + 2 * np;
+#pragma omp for schedule(static)
+        for (int i = 1; i < L->nt; ++i) {
+            if (L->is_c[i] || !L->is_c[i - 1]) continue;       /* i = first F-point of an interval */
+            for (int k = i; k < L->nt && !L->is_c[k]; ++k) {
+                if (lvl == 0) phi_ws(p, lvl, k, ROW(L->u, L, k - 1), ROW(L->u, L, k), w1, w2);
+                else {
+                    phi_ws(p, lvl, k, ROW(L->u, L, k - 1), tmp, w1, w2);
+                    double *uk = ROW(L->u, L, k); const double *gk = ROW(L->g, L, k);
+                    for (int j = 0; j < n; ++j) uk[j] = gk[j] + tmp[j];
+                }
+            }
+        }
+        free(w);
+    }
+}
+
+static void c_relax_mt(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl];
+    int n = L->n, np = padded(n);
+    double wt = p->weight_c, w1c = 1.0 - p->weight_c;
+#pragma omp parallel num_threads(p->threads)
+    {
+        double *w = (double *)malloc(sizeof(double) * 3 * (size_t)np), *w1 = w, *w2 = w + np, *tmp = w + 2 * np;
+#pragma omp for schedule(static)
+        for (int i = 1; i < L->nt; ++i) {
+            if (!L->is_c[i]) continue;
+            phi_ws(p, lvl, i, ROW(L->u, L, i - 1), tmp, w1, w2);
+            double *ui = ROW(L->u, L, i);
+            if (lvl == 0) for (int j = 0; j < n; ++j) ui[j] = tmp[j] * wt + ui[j] * w1c;
+            else { const double *gi = ROW(L->g, L, i); for (int j = 0; j < n; ++j) ui[j] = (gi[j] + tmp[j]) * wt + ui[j] * w1c; }
+        }
+        free(w);
+    }
+}
+
+static void fas_residual_mt(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl], *C = &p->L[lvl + 1];
+    int n = L->n, np = padded(n);
+    int *cidx = (int *)malloc(sizeof(int) * (size_t)C->nt), nc = 0;
+    for (int i = 0; i < L->nt; ++i) if (L->is_c[i]) cidx[nc++] = i;
+#pragma omp parallel for schedule(static) num_threads(p->threads)
+    for (int j = 0; j < nc; ++j) {
+        memcpy(ROW(C->u, C, j), ROW(L->u, L, cidx[j]), sizeof(double) * (size_t)n);
+        memcpy(ROW(C->v, C, j), ROW(L->u, L, cidx[j]), sizeof(double) * (size_t)n);
+    }
+#pragma omp parallel num_threads(p->threads)
+    {
+        double *w = (double *)malloc(sizeof(double) * 4 * (size_t)np), *w1 = w, *w2 = w + np, *a = w + 2 * np, *b = w + 3 * np;
+#pragma omp for schedule(static)
+        for (int j = 1; j < nc; ++j) {
+            int i = cidx[j];
+            phi_ws(p, lvl, i, ROW(L->u, L, i - 1), a, w1, w2);
+            const double *ui = ROW(L->u, L, i);
+            if (lvl == 0) for (int k = 0; k < n; ++k) a[k] = a[k] - ui[k];
+            else { const double *gi = ROW(L->g, L, i); for (int k = 0; k < n; ++k) a[k] = gi[k] - ui[k] + a[k]; }
+            phi_ws(p, lvl + 1, j, ROW(C->v, C, j - 1), b, w1, w2);
+            double *gj = ROW(C->g, C, j); const double *vj = ROW(C->v, C, j);
+            for (int k = 0; k < n; ++k) gj[k] = a[k] + vj[k] - b[k];
+        }
+        free(w);
+    }
+    free(cidx);
+}
+
+static void error_correction_mt(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl], *C = &p->L[lvl + 1];
+    int n = L->n;
+    int *cidx = (int *)malloc(sizeof(int) * (size_t)C->nt), nc = 0;
+    for (int i = 0; i < L->nt; ++i) if (L->is_c[i]) cidx[nc++] = i;
+#pragma omp parallel for schedule(static) num_threads(p->threads)
+    for (int j = 1; j < nc; ++j) {
+        const double *uj = ROW(C->u, C, j), *vj = ROW(C->v, C, j);
+        double *ui = ROW(L->u, L, cidx[j]);
+        for (int k = 0; k < n; ++k) { double e = uj[k] - vj[k]; ui[k] = ui[k] + e; }
+    }
+    free(cidx);
+}
+
+static int compute_residual_mt(orc_problem *p, double *r_norm) {
+    orc_level *L = &p->L[0];
+    int n = L->n, np = padded(n);
+    int *cidx = (int *)malloc(sizeof(int) * (size_t)L->nt), nc = 0;
+    for (int i = 1; i < L->nt; ++i) if (L->is_c[i]) cidx[nc++] = i;
+#pragma omp parallel num_threads(p->threads)
+    {
+        double *w = (double *)malloc(sizeof(double) * 3 * (size_t)np), *w1 = w, *w2 = w + np, *tmp = w + 2 * np;
+#pragma omp for schedule(static)
+        for (int c = 0; c < nc; ++c) {
+            int i = cidx[c];
+            phi_ws(p, 0, i, ROW(L->u, L, i - 1), tmp, w1, w2);
+            const double *ui = ROW(L->u, L, i);
+            double ss = 0.0;
+            for (int j = 0; j < n; ++j) { double r = tmp[j] - ui[j]; ss += r * r; }
+            r_norm[c] = sqrt(ss);
+        }
+        free(w);
+    }
+    free(cidx);
+    return nc;
+}
+#endif
+
 /* mgrit.py:292-333 (single rank: intervals are independent, ascending inside an interval) */
 void orc_f_relax(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl];
+#ifdef _OPENMP
+    if (p->threads > 1) { f_relax_mt(p, lvl); return; }
+#endif
     for (int i = 1; i < L->nt; ++i) {
         if (L->is_c[i]) continue;
         if (lvl == 0) phi(p, lvl, i, ROW(L->u, L, i - 1), ROW(L->u, L, i));
@@ -968,6 +1117,9 @@ void orc_f_relax(orc_problem *p, int lvl) {
 void orc_c_relax(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl];
     double w = p->weight_c, w1 = 1.0 - p->weight_c;
+#ifdef _OPENMP
+    if (p->threads > 1 && !has_adjacent_c(L)) { c_relax_mt(p, lvl); return; }
+#endif
     for (int i = 1; i < L->nt; ++i) {
         if (!L->is_c[i]) continue;
         phi(p, lvl, i, ROW(L->u, L, i - 1), p->tmp1);
@@ -994,6 +1146,9 @@ void orc_forward_solve(orc_problem *p, int lvl) {
 void orc_fas_residual(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl], *C = &p->L[lvl + 1];
     int j = 0;
+#ifdef _OPENMP
+    if (p->threads > 1) { fas_residual_mt(p, lvl); return; }
+#endif
     for (int i = 0; i < L->nt; ++i) if (L->is_c[i]) { restrict_vec(L->transfer, ROW(L->u, L, i), L->n, ROW(C->u, C, j), C->n); ++j; }
     memcpy(C->v, C->u, sizeof(double) * (size_t)C->nt * (size_t)C->n);
     j = 0;
@@ -1018,6 +1173,9 @@ void orc_fas_residual(orc_problem *p, int lvl) {
 void orc_error_correction(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl], *C = &p->L[lvl + 1];
     int j = 0;
+#ifdef _OPENMP
+    if (p->threads > 1) { error_correction_mt(p, lvl); return; }
+#endif
     for (int i = 0; i < L->nt; ++i) {
         if (!L->is_c[i]) continue;
         if (j != 0) {
@@ -1071,6 +1229,9 @@ static double vec_norm(const orc_problem *p, const double *r, int n) {
 int orc_compute_residual(orc_problem *p, double *r_norm) {
     orc_level *L = &p->L[0];
     int cnt = 0;
+#ifdef _OPENMP
+    if (p->threads > 1 && !p->norm_spec) return compute_residual_mt(p, r_norm);
+#endif
     for (int i = 1; i < L->nt; ++i) {
         if (!L->is_c[i]) continue;
         phi(p, 0, i, ROW(L->u, L, i - 1), p->tmp1);

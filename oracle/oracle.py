@@ -55,6 +55,8 @@ def lib():
         L.orc_problem_set_level_dahlquist.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_double, C.c_int,
                                                       C.c_double]
         L.orc_problem_set_transfer.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_problem_set_threads.restype = C.c_int
+        L.orc_problem_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.orc_problem_set_options.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
                                               C.c_int, C.c_int, C.c_double, C.c_int]
         L.orc_problem_init_state.argtypes = [C.c_void_p]
@@ -227,6 +229,10 @@ class OracleProblem:
             self.L.orc_problem_destroy(self.h)
         except Exception:
             pass
+
+    def set_threads(self, threads):
+        """threaded sweeps for timing (bench.py cpu_baseline): returns the thread count in effect"""
+        return int(self.L.orc_problem_set_threads(self.h, int(threads)))
 
     def state(self, which, lvl):
         """numpy view (no copy) of slab 'u' | 'v' | 'g' on level lvl, shape [nt][n]."""
