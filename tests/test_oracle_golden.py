@@ -218,3 +218,21 @@ def test_phi_work_model(oracle):
     p = oracle.OracleProblem(levels, variant=0, nested_iteration=False, max_iter=2, tol=0.0)
     p.solve()
     assert [p.phi_count(l) for l in range(3)] == [12288 + 9216, 2 * 3840, 2 * 512]
+
+
+def test_threaded_sweeps_equal_serial_sweeps(oracle):
+    """the OpenMP path of the oracle (timing only, bench.py cpu_baseline) leaves every result bit-identical"""
+    nts = (129, 33, 9)
+    def build(threads):
+        p = oracle.OracleProblem([cases.heat_level_spec(259, cases.lin(0.01, nt)) for nt in nts], variant=0,
+                                 nested_iteration=True, max_iter=3, tol=0.0, norm_spec=False, weight_c=1.2)
+        assert p.set_threads(threads) == threads
+        return p
+    a, b = build(1), build(4)
+    ca, cb = a.solve(), b.solve()
+    assert np.array_equal(ca, cb)
+    for lvl in range(3):
+        for which in ("u", "v", "g") if lvl else ("u",):
+            assert np.array_equal(a.state(which, lvl), b.state(which, lvl))
+    spec = oracle.OracleProblem([cases.heat_level_spec(259, cases.lin(0.01, nt)) for nt in nts], variant=1)
+    assert spec.set_threads(4) == 1   # only the natural variant is threaded
