@@ -737,6 +737,7 @@ typedef struct {
     double *save_last;      /* conv_crit 1: clone of u[0] */
     double *tmp1, *tmp2, *tmp3;
     int64_t phi_count[ORC_MAX_LEVELS];
+    int at_k;               /* > 0: AT-MGRIT (core/at_mgrit.py): truncated local solves of distance k on the coarsest level */
     int threads;            /* > 1: the independent loops of the sweeps run on that many OpenMP threads (timing only; same
                                arithmetic, same results). Heat1D natural variant with copy transfers only. */
 } orc_problem;
@@ -1142,6 +1143,30 @@ void orc_forward_solve(orc_problem *p, int lvl) {
     }
 }
 
+/* AtMgrit.forward_solve, one rank (at_mgrit.py:79-87): every coarsest-level point p is recomputed from the OLD value k-1
+ * points back by k-1 steps with the FAS right-hand side; the points are independent of each other. One level: nothing
+ * happens (at_mgrit.py:45). */
+void orc_at_forward_solve(orc_problem *p, int lvl, int k) {
+    orc_level *L = &p->L[lvl];
+    if (p->n_levels == 1) return;
+    size_t sz = (size_t)L->nt * (size_t)L->n;
+    double *old = (double *)malloc(sizeof(double) * sz), *tmp = (double *)malloc(sizeof(double) * (size_t)L->n);
+    memcpy(old, L->u, sizeof(double) * sz);
+    for (int pt = 0; pt < L->nt; ++pt) {
+        int s0 = pt - k + 1 > 0 ? pt - k + 1 : 0;
+        double *cur = ROW(L->u, L, pt);
+        memcpy(cur, old + (size_t)s0 * (size_t)L->n, sizeof(double) * (size_t)L->n);
+        for (int i = (pt - k + 2 > 1 ? pt - k + 2 : 1); i <= pt; ++i) {
+            phi(p, lvl, i, cur, tmp);
+            const double *gi = ROW(L->g, L, i);
+            for (int j = 0; j < L->n; ++j) cur[j] = gi[j] + tmp[j];
+        }
+    }
+    free(old); free(tmp);
+}
+
+void orc_problem_set_at(orc_problem *p, int k) { p->at_k = k; }
+
 /* mgrit.py:488-549 */
 void orc_fas_residual(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl], *C = &p->L[lvl + 1];
@@ -1191,7 +1216,7 @@ void orc_error_correction(orc_problem *p, int lvl) {
 
 /* mgrit.py:261-290 */
 void orc_iteration(orc_problem *p, int lvl, int cycle_type, int iteration, int first_f) {
-    if (lvl == p->n_levels - 1) { orc_forward_solve(p, lvl); return; }
+    if (lvl == p->n_levels - 1) { if (p->at_k > 0) orc_at_forward_solve(p, lvl, p->at_k); else orc_forward_solve(p, lvl); return; }
     if ((lvl > 0 || (iteration == 0 && lvl == 0)) && first_f) orc_f_relax(p, lvl);
     for (int k = 0; k < p->cf_iter[lvl]; ++k) { orc_c_relax(p, lvl); orc_f_relax(p, lvl); }
     orc_fas_residual(p, lvl);
@@ -1203,7 +1228,7 @@ void orc_iteration(orc_problem *p, int lvl, int cycle_type, int iteration, int f
 
 /* mgrit.py:551-566 */
 void orc_nested_iteration(orc_problem *p) {
-    orc_forward_solve(p, p->n_levels - 1);
+    if (p->at_k > 0) orc_at_forward_solve(p, p->n_levels - 1, p->at_k); else orc_forward_solve(p, p->n_levels - 1);
     for (int lvl = p->n_levels - 2; lvl >= 0; --lvl) {
         orc_level *L = &p->L[lvl], *C = &p->L[lvl + 1];
         int j = 0;

@@ -55,6 +55,8 @@ def lib():
         L.orc_problem_set_level_dahlquist.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_double, C.c_int,
                                                       C.c_double]
         L.orc_problem_set_transfer.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_problem_set_at.argtypes = [C.c_void_p, C.c_int]
+        L.orc_at_forward_solve.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_problem_set_threads.restype = C.c_int
         L.orc_problem_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.orc_problem_set_options.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
@@ -229,6 +231,12 @@ class OracleProblem:
             self.L.orc_problem_destroy(self.h)
         except Exception:
             pass
+
+    def set_at(self, k):
+        """AT-MGRIT: truncated coarsest-level solves of distance k (core/at_mgrit.py)"""
+        self.L.orc_problem_set_at(self.h, int(k))
+
+    def at_forward_solve(self, lvl, k): self.L.orc_at_forward_solve(self.h, lvl, int(k))
 
     def set_threads(self, threads):
         """threaded sweeps for timing (bench.py cpu_baseline): returns the thread count in effect"""

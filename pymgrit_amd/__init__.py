@@ -1,6 +1,6 @@
 """pymgrit_amd -- MI355X-native MGRIT relaxation engine behind PyMGRIT's plugin API.
 
-Same public names as the reference package for everything on the hot path (``Mgrit``, ``Application``, ``Vector``,
+Same public names as the reference package for everything on the hot path (``Mgrit``, ``AtMgrit``, ``Application``, ``Vector``,
 ``GridTransfer``, ``GridTransferCopy``, ``simple_setup_problem``, ``Dahlquist``, ``Heat1D``, ``Heat1DBDF1``, ``Heat1DBDF2``,
 ``Heat2D``, ``Advection1D``) plus the two spatial-coarsening transfers that run as HIP kernels.
 """
@@ -10,6 +10,7 @@ from pymgrit_amd.core.grid_transfer import GridTransfer
 from pymgrit_amd.core.grid_transfer_copy import GridTransferCopy
 from pymgrit_amd.core.simple_setup_problem import simple_setup_problem
 from pymgrit_amd.core.mgrit import Mgrit
+from pymgrit_amd.core.at_mgrit import AtMgrit
 
 from pymgrit_amd.dahlquist.dahlquist import Dahlquist
 from pymgrit_amd.heat.heat_1d import Heat1D
@@ -20,5 +21,5 @@ from pymgrit_amd.heat.grid_transfer_heat import GridTransferHeat
 from pymgrit_amd.advection.advection_1d import Advection1D
 from pymgrit_amd.advection.grid_transfer_advection import GridTransferAdvection
 
-__all__ = ["Application", "Vector", "GridTransfer", "GridTransferCopy", "simple_setup_problem", "Mgrit", "Dahlquist",
+__all__ = ["Application", "Vector", "GridTransfer", "GridTransferCopy", "simple_setup_problem", "Mgrit", "AtMgrit", "Dahlquist",
            "Heat1D", "Heat1DBDF1", "Heat1DBDF2", "Heat2D", "GridTransferHeat", "Advection1D", "GridTransferAdvection"]

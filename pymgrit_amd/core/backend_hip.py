@@ -342,6 +342,12 @@ class HipBackend:
         if pairs:
             check(self.lib.mgrit_hip_copy_pairs_u_to_v(self.h, lvl, self._pair_id(lvl, pairs)))
 
+    def at_forward_solve(self, lvl, k):
+        """AtMgrit.forward_solve (at_mgrit.py:79-87), one rank: truncated, mutually independent coarsest-level solves"""
+        if self.mg.comm_time_size > 1:
+            raise MgritHipError("AT-MGRIT on the HIP engine runs on one rank (several ranks: host applications only)")
+        check(self.lib.mgrit_hip_at_solve(self.h, lvl, int(k)))
+
     def can_fuse_ec(self, lvl):
         tr = self.mg.transfer_objects[lvl]
         da, db = self.desc[lvl], self.desc[lvl + 1]

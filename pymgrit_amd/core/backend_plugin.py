@@ -66,6 +66,38 @@ class PluginBackend:
         u = self.mg.u[0]
         return [(self._phi(0, u, i) - u[i]).norm() for i in points]
 
+    # -- AT-MGRIT (core/at_mgrit.py:37-87) ---------------------------------------------------------------
+    def at_forward_solve(self, lvl, k):
+        """every coarsest-level point from the OLD value k-1 points back, k-1 steps with the FAS right-hand side. Several
+        ranks: the (u, g) rows of the level are gathered first (the reference gathers the same rows, one per rank, over its
+        black/green communicators and therefore allows one coarsest point per rank only; any distribution works here)."""
+        mg = self.mg
+        t, tmpl = mg.global_t[lvl], mg.problem[lvl].vector_template
+        n = len(t)
+        if mg.comm_time_size == 1:
+            old, g, owned = [v.clone() for v in mg.u[lvl]], mg.g[lvl], list(range(n))
+            local_of = {p: p for p in owned}
+        else:
+            mine = {int(gi): (mg.u[lvl][int(li)].pack(), mg.g[lvl][int(li)].pack())
+                    for gi, li in zip(mg.cpts[lvl], mg.index_local[lvl])}
+            rows = {}
+            for part in mg.comm_time.allgather_object(mine):
+                rows.update(part)
+
+            def vec(payload):
+                v = tmpl.clone_zero()
+                v.unpack(payload)
+                return v
+            old = [vec(rows[p][0]) for p in range(n)]
+            g = [vec(rows[p][1]) for p in range(n)]
+            owned = [int(gi) for gi in mg.cpts[lvl]]
+            local_of = {int(gi): int(li) for gi, li in zip(mg.cpts[lvl], mg.index_local[lvl])}
+        for p in owned:
+            cur = old[max(0, p - k + 1)]
+            for i in range(max(1, p - k + 2), p + 1):
+                cur = g[i] + mg.step[lvl](u_start=cur, t_start=t[i - 1], t_stop=t[i])
+            mg.u[lvl][local_of[p]] = cur
+
     def residual_begin(self, points):
         return self.residual_norms(points)
 

@@ -27,6 +27,7 @@ EXPORTS = {
                                               C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgrit_hip_ec_runs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mgrit_hip_ec_relax": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_at_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_level_advection1d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]),
     "mgrit_hip_level_heat2d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                          C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -523,6 +523,26 @@ __global__ void __launch_bounds__(1024) ecf_kernel(LevelDev L, LevelDev Lc, cons
     }
 }
 
+// AtMgrit.forward_solve (core/at_mgrit.py:79-87): point p of the coarsest level is recomputed from the OLD value k-1
+// points back by k-1 steps with the FAS right-hand side; all points are independent (that is the point of AT-MGRIT: no
+// sequential coarsest-level solve). u_old = a copy of the u slab taken before the launch.
+template <int KIND, int FORCE>
+__global__ void __launch_bounds__(1024) at_kernel(LevelDev L, const double *__restrict__ u_old, int k) {
+    WG_PROLOGUE;
+    for (int p = 1 + blockIdx.x; p < L.n_pts; p += gridDim.x) {
+        const int s = p - k + 1 > 0 ? p - k + 1 : 0;
+        double x[E], gi[E];
+        load_row(u_old + (size_t)s * L.ld, sl, x);
+        for (int i = s + 1; i <= p; ++i) {
+            load_row(L.g + (size_t)i * L.ld, sl, gi);
+            phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+#pragma unroll
+            for (int q = 0; q < E; ++q) x[q] = gi[q] + x[q];
+        }
+        store_row(L.u + (size_t)p * L.ld, sl, x);
+    }
+}
+
 #include "mgrit_hip_chain.inc"
 
 // compute_residual (mgrit.py:387-413): out[run] = || Phi(u_{i-1}) - u_i ||^2
@@ -894,7 +914,8 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(fas_coarse_kernel<K, F>))) return rc;                                                    \
     if ((rc = allow_big_lds(fas_fused_kernel<K, F>))) return rc;                                                     \
     if ((rc = allow_big_lds(ecf_kernel<K, F, false>))) return rc;                                                    \
-    if ((rc = allow_big_lds(ecf_kernel<K, F, true>))) return rc;
+    if ((rc = allow_big_lds(ecf_kernel<K, F, true>))) return rc;                                                     \
+    if ((rc = allow_big_lds(at_kernel<K, F>))) return rc;
     FOR_EACH_STEPPER(ATTR_ALL)
     if ((rc = allow_big_lds(jump_kernel))) return rc;
 #define ATTR_2PTS(O, F)                                                                                              \
@@ -1823,6 +1844,27 @@ static int interp_common(mgrit_hip_engine *e, int lvl, int pairs_id, int mode) {
 
 int mgrit_hip_error_correction(mgrit_hip_engine *e, int lvl, int pairs_id) { return interp_common(e, lvl, pairs_id, 1); }
 int mgrit_hip_interpolate(mgrit_hip_engine *e, int lvl, int pairs_id) { return interp_common(e, lvl, pairs_id, 0); }
+
+int mgrit_hip_at_solve(mgrit_hip_engine *e, int lvl, int k) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    Level &lv = e->L[lvl];
+    if (k < 1) return fail(MGRIT_HIP_EINVAL, "distance k=%d must be at least 1", k);
+    if (lvl == 0) return fail(MGRIT_HIP_EINVAL, "the truncated solve runs on a coarse level (it uses g)");
+    if ((rc = check_bound(lv, true))) return rc;
+    if (lv.h2d || is_2pts(lv)) return fail(MGRIT_HIP_EUNSUPPORTED, "AT-MGRIT coarsest solve: 1-D single-point steppers only");
+    if (lv.dev.n_pts < 2) return 0;
+    const size_t rows = (size_t)lv.dev.n_pts;
+    if (lv.scratch_rows < rows) {
+        if (lv.scratch) HIP_TRY(hipFree(lv.scratch));
+        lv.scratch = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lv.scratch), sizeof(double) * rows * lv.dev.ld));
+        lv.scratch_rows = rows;
+    }
+    HIP_TRY(hipMemcpyAsync(lv.scratch, lv.dev.u, sizeof(double) * rows * lv.dev.ld, hipMemcpyDeviceToDevice, e->stream));
+    LAUNCH_BY_KIND(at_kernel, lv, persistent_grid(lv, lv.dev.n_pts - 1), lv.dev, lv.scratch, k);
+    return 0;
+}
 
 int mgrit_hip_ec_runs_create(mgrit_hip_engine *e, int lvl, int n_runs, const int32_t *start, const int32_t *len,
                              const int32_t *coarse_idx, int *id_out) {

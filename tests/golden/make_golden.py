@@ -483,6 +483,34 @@ def make_local_conv():
     print("wrote local_conv", {k: len(v["conv"]) for k, v in out.items()})
 
 
+# --------------------------------------------------------------------------------------------------
+# AT-MGRIT (core/at_mgrit.py), one rank
+# --------------------------------------------------------------------------------------------------
+def make_at_mgrit():
+    from pymgrit.core.at_mgrit import AtMgrit
+    out = {}
+
+    def run_at(problem, k, sample_pts=(), **kw):
+        kw.setdefault("logging_lvl", QUIET)
+        m = AtMgrit(problem=problem, k=k, **kw)
+        info = m.solve()
+        rec = {"conv": [float(c) for c in info["conv"]], "samples": {}}
+        for i in sample_pts:
+            rec["samples"][str(i)] = np.asarray(m.u[0][i].get_values(), dtype=float).ravel().tolist()
+        return rec
+    for k in (1, 2, 3, 5):
+        out[f"heat_nx33_k{k}"] = run_at(heat_levels(33, [65, 17, 5]), k, tol=1e-9, max_iter=8, sample_pts=(1, 33, 64))
+    out["heat_nx33_k3_nonested_F"] = run_at(heat_levels(33, [129, 33, 9]), 3, tol=1e-9, max_iter=8, nested_iteration=False,
+                                            cycle_type='F', sample_pts=(128,))
+    out["heat_nx33_2lvl_k4_w13"] = run_at(heat_levels(33, [65, 17]), 4, tol=1e-9, max_iter=8, weight_c=1.3, sample_pts=(64,))
+    out["heat_nx33_k2_jump"] = run_at(heat_levels(33, [65, 17, 5]), 2, tol=1e-9, max_iter=8, conv_crit=1, sample_pts=(64,))
+    d = simple_setup_problem(Dahlquist(t_start=0, t_stop=5, nt=101), level=3, coarsening=2)
+    out["dahlquist_k4"] = run_at(d, 4, tol=1e-10, sample_pts=(100,))
+    with open(os.path.join(HERE, "at_mgrit.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("wrote at_mgrit", {k: len(v["conv"]) for k, v in out.items()})
+
+
 def ref_results():
     res = {}
     d = os.path.join(REF, "tests", "mpi", "results")
@@ -500,6 +528,9 @@ def main():
         return
     if "--only-advection-sc" in sys.argv:
         make_advection_sc()
+        return
+    if "--only-at-mgrit" in sys.argv:
+        make_at_mgrit()
         return
     if "--only-local-conv" in sys.argv:
         make_local_conv()
@@ -522,6 +553,7 @@ def main():
     make_advection_sc()
     make_bdf()
     make_local_conv()
+    make_at_mgrit()
     res, kats = ref_results()
     with open(os.path.join(HERE, "ref_results.json"), "w") as f:
         json.dump({"tests_mpi_results": res}, f, indent=1)
