@@ -151,8 +151,9 @@ FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet, FP64 matrix (the on-box gu
 
 def bench_heat2d(args):
     """Secondary workload (not the driver's default): BASELINE configs[3] = heat_2d nx=ny=512, nt=16385, 2-level m=8.
-    Reports the V-cycle throughput and the MFMA roofline of the level-0 F-relax sweep (per Phi: 4 GEMMs of 512^3 padded
-    = 8*512^3 flops on v_mfma_f64_16x16x4_f64, plus the O(n^2) rhs / epilogue kernels inside the timed launch)."""
+    Reports the V-cycle throughput and the MFMA roofline of the level-0 F-relax sweep (per Phi: four half-size sine
+    transforms = 4*512*512*512 flops at 512^2 on v_mfma_f64_16x16x4_f64 -- the even/odd split halves the 8*512^3 of four
+    full products --, plus the O(n^2) rhs / epilogue kernels inside the timed launch)."""
     import torch
     from pymgrit_amd import Heat2D, Mgrit
     torch.cuda.set_device(0)
@@ -186,8 +187,9 @@ def bench_heat2d(args):
         ms.append(be.last_kernel_ms())
     be.set_timing(False)
     f_ms = float(np.mean(ms[1:]))
-    M = ((nx - 2 + 63) // 64) * 64
-    tflops = n_f * 8.0 * M ** 3 / (f_ms * 1e-3) / 1e12
+    HP = (((nx - 2 + 1) // 2 + 63) // 64) * 64      # padded half size of an axis; P = 2 HP slots
+    flops_per_phi = 4.0 * (2 * HP) * (2 * HP) * (HP + HP)   # four half-size transforms: 2 MACs x P x P x HP each way per axis
+    tflops = n_f * flops_per_phi / (f_ms * 1e-3) / 1e12
     out = {"metric": "time-point-DOF updates/sec per MGRIT V-cycle", "value": sum(c * dof for c in counts) * args.steps / elapsed,
            "unit": "time-point-DOF updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -196,7 +198,8 @@ def bench_heat2d(args):
                       "phi_per_cycle_by_level": counts, "dof": dof},
            "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                        "kernel": "level-0 F-relax = per Phi 4 x h2d_gemm_kernel (f64 MFMA) + rhs + epilogue",
+                        "kernel": "level-0 F-relax = per Phi 2 x h2d_fwd_kernel + 2 x h2d_inv_kernel (f64 MFMA, half-size transforms) + rhs + epilogue",
+                        "flops_per_phi": flops_per_phi,
                         "launch_ms": f_ms, "us_per_phi": 1e3 * f_ms / n_f}}
     print(json.dumps(out), flush=True)
 

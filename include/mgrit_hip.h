@@ -67,8 +67,8 @@ int mgrit_hip_level_advection1d(mgrit_hip_engine *e, int lvl, int n_pts_local, c
 /* Replaces Heat2D.__init__/compute_matrix/compute_rhs/step (heat/heat_2d.py:147-366): theta-scheme (theta = 1 BE, 0.5 CN,
  * 0 FE) on the full nx x ny grid (row-major, x slow); rows of the slabs hold the grid in natural order, ld >= nx*ny a
  * multiple of 16. bc: nx*ny boundary values (zero inside, corner order of heat_2d.py:244-247); forcing on the interior
- * b(x,y,t_i) = sum_k S[k][(nx-2)*(ny-2)] * tau[k][i]. The implicit solve is a fast diagonalisation: four batched FP64 GEMMs
- * on the matrix cores per step. */
+ * b(x,y,t_i) = sum_k S[k][(nx-2)*(ny-2)] * tau[k][i]. The implicit solve is a fast diagonalisation: four batched half-size
+ * sine transforms (even/odd split of the sine matrix) on the FP64 matrix cores per step. */
 int mgrit_hip_level_heat2d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int nx, int ny, int ld,
                            double fx, double fy, double theta, const double *bc, int K, const double *S, const double *tau);
 /* Device slabs u, v, g of Mgrit.create_u_v_g (mgrit.py:840-858); v and g may be NULL on level 0. */

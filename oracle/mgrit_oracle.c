@@ -353,9 +353,11 @@ typedef struct {
     orc_cset *csets; int n_csets, cap_csets;
     double *w1, *w2;       /* work (padded) */
     /* heat2d (heat_2d.py:147-366): full nx x ny grid incl. the rim; interior mi x mj, padded to Mi x Mj (multiples of 64) */
-    int nx, ny, mi, mj, Mi, Mj, has_w;
+    int nx, ny, mi, mj, Mi, Mj, has_w;   /* Mi = 2*HPx, Mj = 2*HPy: one padded length for the natural and the spectral layout */
+    int HPx, HPy;                        /* padded half sizes: even modes in slots [0, HP), odd modes in [HP, 2 HP) */
+    double *Fxe, *Fxo, *Fye, *Fyo;       /* folded sine tables [HP][HP]: Fe[k][e] = Q[k][2e], Fo[k][o] = Q[k][2o+1] */
     double fx, fy, theta;
-    double *bc, *W, *Qx, *Qy, *lx, *ly, *dinv, *X0, *X1;
+    double *bc, *W, *lx, *ly, *dinv, *X0, *X1;
     double dinv_dt;
 } orc_stepper;
 
@@ -602,43 +604,75 @@ static void dahlquist_step(const orc_stepper *st, double t_start, double t_stop,
  * ascending k from 0 -- exactly what a chain of v_mfma_f64_16x16x4 instructions computes.
  * Layouts: X = Qx.B is stored TRANSPOSED ([j][i']), so all four products read "symmetric matrix times row-major matrix".
  * ============================================================================================== */
+/* One even/odd split of the sine transform. Q[i][k] = s sin(pi (i+1)(k+1)/(m+1)) satisfies
+ * Q[m-1-i][k] = (-1)^k Q[i][k], so with the folded inputs xe[k] = x[k] + x[m-1-k], xo[k] = x[k] - x[m-1-k] (k < floor(m/2);
+ * for odd m the centre element joins xe unchanged) the even modes need only Fe = Q[k][2e] and the odd modes only
+ * Fo = Q[k][2o+1], k < ceil(m/2): half the multiplications of the full product. */
+static void h2d_axis_tables(int m, int HP, double f, double **Fe, double **Fo, double **lam_spec) {
+    int hE = (m + 1) / 2, hO = m / 2;
+    double sc = sqrt(2.0 / (m + 1));
+    *Fe = (double *)calloc((size_t)HP * HP, sizeof(double));
+    *Fo = (double *)calloc((size_t)HP * HP, sizeof(double));
+    *lam_spec = (double *)calloc((size_t)2 * HP, sizeof(double));
+    for (int k = 0; k < hE; ++k) {
+        for (int e = 0; e < hE; ++e) {
+            long r = ((long)(k + 1) * (2 * e + 1)) % (2L * (m + 1));
+            (*Fe)[(size_t)k * HP + e] = sc * sin(M_PI * (double)r / (double)(m + 1));
+        }
+        if (k < hO)
+            for (int o = 0; o < hO; ++o) {
+                long r = ((long)(k + 1) * (2 * o + 2)) % (2L * (m + 1));
+                (*Fo)[(size_t)k * HP + o] = sc * sin(M_PI * (double)r / (double)(m + 1));
+            }
+    }
+    for (int e = 0; e < hE; ++e) { double h = sin(M_PI * (double)(2 * e + 1) / (2.0 * (m + 1))); (*lam_spec)[e] = 4.0 * f * h * h; }
+    for (int o = 0; o < hO; ++o) { double h = sin(M_PI * (double)(2 * o + 2) / (2.0 * (m + 1))); (*lam_spec)[HP + o] = 4.0 * f * h * h; }
+}
+
 static void h2d_tables(orc_stepper *st) {
-    int mi = st->mi, mj = st->mj, Mi = st->Mi, Mj = st->Mj;
-    st->Qx = (double *)calloc((size_t)Mi * Mi, sizeof(double));
-    st->Qy = (double *)calloc((size_t)Mj * Mj, sizeof(double));
-    st->lx = (double *)calloc((size_t)Mi, sizeof(double));
-    st->ly = (double *)calloc((size_t)Mj, sizeof(double));
-    double sx = sqrt(2.0 / (mi + 1)), sy = sqrt(2.0 / (mj + 1));
-    for (int i = 0; i < mi; ++i) {
-        for (int k = 0; k < mi; ++k) {
-            long r = ((long)(i + 1) * (k + 1)) % (2L * (mi + 1));
-            st->Qx[(size_t)i * Mi + k] = sx * sin(M_PI * (double)r / (double)(mi + 1));
-        }
-        double h = sin(M_PI * (double)(i + 1) / (2.0 * (mi + 1)));
-        st->lx[i] = 4.0 * st->fx * h * h;
-    }
-    for (int i = 0; i < mj; ++i) {
-        for (int k = 0; k < mj; ++k) {
-            long r = ((long)(i + 1) * (k + 1)) % (2L * (mj + 1));
-            st->Qy[(size_t)i * Mj + k] = sy * sin(M_PI * (double)r / (double)(mj + 1));
-        }
-        double h = sin(M_PI * (double)(i + 1) / (2.0 * (mj + 1)));
-        st->ly[i] = 4.0 * st->fy * h * h;
-    }
+    int Mi = st->Mi, Mj = st->Mj;
+    h2d_axis_tables(st->mi, st->HPx, st->fx, &st->Fxe, &st->Fxo, &st->lx);   /* lx, ly: eigenvalues in spectral slot order */
+    h2d_axis_tables(st->mj, st->HPy, st->fy, &st->Fye, &st->Fyo, &st->ly);
     st->dinv = (double *)calloc((size_t)Mi * Mj, sizeof(double));
     st->X0 = (double *)calloc((size_t)Mi * Mj, sizeof(double));
     st->X1 = (double *)calloc((size_t)Mi * Mj, sizeof(double));
     st->dinv_dt = -1.0;
 }
 
-/* out[n][m] = sum_k A[m][k] * B[k][n]   (A: M x M symmetric table, ldA = M ; B: M x N ; out: N x M) */
-static void h2d_gemm_t(const double *A, int M, const double *B, int N, double *out) {
-    for (int n = 0; n < N; ++n)
-        for (int m = 0; m < M; ++m) {
+/* forward half transform along the rows of B (natural index k, m real rows, 2 HP stored): out[n][slot], slot = e or HP + o */
+static void h2d_fwd(const double *Fe, const double *Fo, int m, int HP, const double *B, int N, double *out) {
+    int hE = (m + 1) / 2, hO = m / 2, P = 2 * HP;
+    for (int n = 0; n < N; ++n) {
+        for (int e = 0; e < HP; ++e) {
             double c = 0.0;
-            for (int k = 0; k < M; ++k) c = fma(A[(size_t)m * M + k], B[(size_t)k * N + n], c);
-            out[(size_t)n * M + m] = c;
+            for (int k = 0; k < hE; ++k) {
+                double x = k < hO ? B[(size_t)k * N + n] + B[(size_t)(m - 1 - k) * N + n] : B[(size_t)k * N + n];
+                c = fma(Fe[(size_t)k * HP + e], x, c);
+            }
+            out[(size_t)n * P + e] = c;
         }
+        for (int o = 0; o < HP; ++o) {
+            double c = 0.0;
+            for (int k = 0; k < hO; ++k)
+                c = fma(Fo[(size_t)k * HP + o], B[(size_t)k * N + n] - B[(size_t)(m - 1 - k) * N + n], c);
+            out[(size_t)n * P + HP + o] = c;
+        }
+    }
+}
+
+/* inverse half transform along the rows of B (spectral slots): out[n][i] = Pe + Po, out[n][m-1-i] = Pe - Po */
+static void h2d_inv(const double *Fe, const double *Fo, int m, int HP, const double *B, int N, double *out) {
+    int hE = (m + 1) / 2, hO = m / 2, P = 2 * HP;
+    for (int n = 0; n < N; ++n) {
+        for (int i = 0; i < P; ++i) out[(size_t)n * P + i] = 0.0;
+        for (int i = 0; i < hE; ++i) {
+            double pe = 0.0, po = 0.0;
+            for (int e = 0; e < hE; ++e) pe = fma(Fe[(size_t)i * HP + e], B[(size_t)e * N + n], pe);
+            for (int o = 0; o < hO; ++o) po = fma(Fo[(size_t)i * HP + o], B[(size_t)(HP + o) * N + n], po);
+            out[(size_t)n * P + i] = pe + po;
+            if (i < hO) out[(size_t)n * P + (m - 1 - i)] = pe - po;
+        }
+    }
 }
 
 static double h2d_lap(const orc_stepper *st, const double *u, int gi, int gj) {
@@ -667,9 +701,15 @@ static void heat2d_step(orc_stepper *st, int nt, int i_stop, double t_start, dou
         return;
     }
     double thdt = th * dt, thdt1 = (1.0 - th) * dt;
-    if (st->dinv_dt != dt) {
-        for (int a = 0; a < mi; ++a)
-            for (int b = 0; b < mj; ++b) st->dinv[(size_t)a * Mj + b] = 1.0 / (1.0 + thdt * (st->lx[a] + st->ly[b]));
+    if (st->dinv_dt != dt) {   /* spectral slot order on both axes; slots without a mode stay 0 */
+        int hxe = (mi + 1) / 2, hxo = mi / 2, hye = (mj + 1) / 2, hyo = mj / 2;
+        memset(st->dinv, 0, sizeof(double) * (size_t)Mi * Mj);
+        for (int a = 0; a < Mi; ++a) {
+            if (!((a < hxe) || (a >= st->HPx && a < st->HPx + hxo))) continue;
+            for (int b = 0; b < Mj; ++b)
+                if ((b < hye) || (b >= st->HPy && b < st->HPy + hyo))
+                    st->dinv[(size_t)a * Mj + b] = 1.0 / (1.0 + thdt * (st->lx[a] + st->ly[b]));
+        }
         st->dinv_dt = dt;
     }
     double *B = st->X0, *X = st->X1;
@@ -690,11 +730,11 @@ static void heat2d_step(orc_stepper *st, int nt, int i_stop, double t_start, dou
             if (st->has_w) v = fma(thdt, st->W[(size_t)a * mj + b], v);
             B[(size_t)a * Mj + b] = v;
         }
-    h2d_gemm_t(st->Qx, Mi, B, Mj, X);                                   /* X[j][i'] = (Qx B)^T           */
-    h2d_gemm_t(st->Qy, Mj, X, Mi, B);                                   /* B[i'][j'] = (Qx B) Qy         */
+    h2d_fwd(st->Fxe, st->Fxo, mi, st->HPx, B, Mj, X);                   /* X[j][i'] : x to spectral slots, transposed */
+    h2d_fwd(st->Fye, st->Fyo, mj, st->HPy, X, Mi, B);                   /* B[i'][j']: y to spectral slots             */
     for (size_t q = 0; q < (size_t)Mi * Mj; ++q) B[q] = B[q] * st->dinv[q];
-    h2d_gemm_t(st->Qx, Mi, B, Mj, X);                                   /* X[j'][i] = (Qx B)^T           */
-    h2d_gemm_t(st->Qy, Mj, X, Mi, B);                                   /* B[i][j]  = U                  */
+    h2d_inv(st->Fxe, st->Fxo, mi, st->HPx, B, Mj, X);                   /* X[j'][i] : x back                          */
+    h2d_inv(st->Fye, st->Fyo, mj, st->HPy, X, Mi, B);                   /* B[i][j]  = U                               */
     for (int gi = 0; gi < nx; ++gi)
         for (int gj = 0; gj < ny; ++gj) {
             size_t p = (size_t)gi * ny + gj;
@@ -753,7 +793,7 @@ orc_problem *orc_problem_create(int n_levels) {
 static void free_stepper(orc_stepper *st) {
     for (int i = 0; i < st->n_csets; ++i) free(st->csets[i].tab);
     free(st->csets); free(st->s); free(st->tau); free(st->tau2); free(st->w1); free(st->w2);
-    free(st->bc); free(st->W); free(st->Qx); free(st->Qy); free(st->lx); free(st->ly); free(st->dinv); free(st->X0); free(st->X1);
+    free(st->bc); free(st->W); free(st->Fxe); free(st->Fxo); free(st->Fye); free(st->Fyo); free(st->lx); free(st->ly); free(st->dinv); free(st->X0); free(st->X1);
 }
 
 void orc_problem_destroy(orc_problem *p) {
@@ -833,7 +873,8 @@ void orc_problem_set_level_heat2d(orc_problem *p, int lvl, int nt, const double 
     orc_stepper *st = &p->L[lvl].st;
     st->kind = ORC_HEAT2D; st->variant = 1; st->K = K;
     st->nx = nx; st->ny = ny; st->mi = nx - 2; st->mj = ny - 2;
-    st->Mi = ((st->mi + 63) / 64) * 64; st->Mj = ((st->mj + 63) / 64) * 64;
+    st->HPx = (((st->mi + 1) / 2 + 63) / 64) * 64; st->HPy = (((st->mj + 1) / 2 + 63) / 64) * 64;
+    st->Mi = 2 * st->HPx; st->Mj = 2 * st->HPy;
     st->fx = fx; st->fy = fy; st->theta = theta;
     st->bc = (double *)malloc(sizeof(double) * (size_t)nx * ny);
     memcpy(st->bc, bc, sizeof(double) * (size_t)nx * ny);

@@ -764,7 +764,10 @@ struct H2DHost {
     H2DDev dev{};
     std::vector<double> lx, ly, dts;
     std::map<uint64_t, double *> dinv;   // 1/(1 + theta*dt*(lx_k + ly_l)) per distinct dt, [Mi][Mj]
-    double *Qx = nullptr, *Qy = nullptr, *W0 = nullptr, *W1 = nullptr, *rowsq = nullptr;
+    int HPx = 0, HPy = 0;                // padded half sizes (spectral slots: even modes [0, HP), odd modes [HP, 2 HP))
+    double *Fxe = nullptr, *Fxo = nullptr, *FxeT = nullptr, *FxoT = nullptr;   // folded sine tables [HP][HP] and transposes
+    double *Fye = nullptr, *Fyo = nullptr, *FyeT = nullptr, *FyoT = nullptr;
+    double *W0 = nullptr, *W1 = nullptr, *rowsq = nullptr;
     size_t cap_items = 0;
 };
 
@@ -1185,9 +1188,14 @@ int h2d_dinv(mgrit_hip_engine *e, Level &lv, uint64_t dtbits, double **out) {
     double dt;
     std::memcpy(&dt, &dtbits, 8);
     const double thdt = h.dev.theta * dt;
-    std::vector<double> tab((size_t)h.dev.Mi * h.dev.Mj, 0.0);
-    for (int a = 0; a < h.dev.mi; ++a)
-        for (int b = 0; b < h.dev.mj; ++b) tab[(size_t)a * h.dev.Mj + b] = 1.0 / (1.0 + thdt * (h.lx[a] + h.ly[b]));
+    std::vector<double> tab((size_t)h.dev.Mi * h.dev.Mj, 0.0);   // spectral slot order on both axes, 0 where no mode lives
+    const int hxe = (h.dev.mi + 1) / 2, hxo = h.dev.mi / 2, hye = (h.dev.mj + 1) / 2, hyo = h.dev.mj / 2;
+    for (int a = 0; a < h.dev.Mi; ++a) {
+        if (!((a < hxe) || (a >= h.HPx && a < h.HPx + hxo))) continue;
+        for (int b = 0; b < h.dev.Mj; ++b)
+            if ((b < hye) || (b >= h.HPy && b < h.HPy + hyo))
+                tab[(size_t)a * h.dev.Mj + b] = 1.0 / (1.0 + thdt * (h.lx[a] + h.ly[b]));
+    }
     double *d = nullptr;
     int rc = dev_upload(lv, e->stream, tab, &d);
     if (rc) return rc;
@@ -1208,12 +1216,13 @@ int h2d_phi_batch(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const doubl
     const size_t per = (size_t)H.Mi * H.Mj;
     hipLaunchKernelGGL(h2d_rhs_kernel, dim3((H.Mj + 255) / 256, H.Mi, pl.count), dim3(256), 0, e->stream, H, in_slab, pl.d_in,
                        pl.d_step, h.W0);
-    // X1[j][i'] = (Qx B)^T ; X2[i'][j'] = ((Qx B) Qy) o D ; X3[j'][i] = (Qx X2)^T ; U[i][j] = (Qx X2) Qy
-    const dim3 g1(H.Mj / 64, H.Mi / 64, pl.count), g2(H.Mi / 64, H.Mj / 64, pl.count);  // (n tiles, m tiles, items)
-    hipLaunchKernelGGL((h2d_gemm_kernel<false>), g1, dim3(256), 0, e->stream, h.Qx, H.Mi, h.W0, H.Mj, h.W1, nullptr, per);
-    hipLaunchKernelGGL((h2d_gemm_kernel<true>), g2, dim3(256), 0, e->stream, h.Qy, H.Mj, h.W1, H.Mi, h.W0, dinv, per);
-    hipLaunchKernelGGL((h2d_gemm_kernel<false>), g1, dim3(256), 0, e->stream, h.Qx, H.Mi, h.W0, H.Mj, h.W1, nullptr, per);
-    hipLaunchKernelGGL((h2d_gemm_kernel<false>), g2, dim3(256), 0, e->stream, h.Qy, H.Mj, h.W1, H.Mi, h.W0, nullptr, per);
+    // W1[j][i'] = x to spectral slots ; W0[i'][j'] = y to spectral slots, o D ; W1[j'][i] = x back ; W0[i][j] = y back = U
+    const dim3 fx(H.Mj / 64, H.Mi / 64, pl.count), fy(H.Mi / 64, H.Mj / 64, pl.count);        // (n tiles, slot tiles, items)
+    const dim3 ix(H.Mj / 64, h.HPx / 64, pl.count), iy(H.Mi / 64, h.HPy / 64, pl.count);      // (n tiles, i tiles, items)
+    hipLaunchKernelGGL((h2d_fwd_kernel<false>), fx, dim3(256), 0, e->stream, h.Fxe, h.Fxo, H.mi, h.HPx, h.W0, H.Mj, h.W1, nullptr, per);
+    hipLaunchKernelGGL((h2d_fwd_kernel<true>), fy, dim3(256), 0, e->stream, h.Fye, h.Fyo, H.mj, h.HPy, h.W1, H.Mi, h.W0, dinv, per);
+    hipLaunchKernelGGL(h2d_inv_kernel, ix, dim3(256), 0, e->stream, h.FxeT, h.FxoT, H.mi, h.HPx, h.W0, H.Mj, h.W1, per);
+    hipLaunchKernelGGL(h2d_inv_kernel, iy, dim3(256), 0, e->stream, h.FyeT, h.FyoT, H.mj, h.HPy, h.W1, H.Mi, h.W0, per);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1315,17 +1324,28 @@ int h2d_fas_rhs(mgrit_hip_engine *e, int lvl, PairList *pl) {
     return 0;
 }
 
-void h2d_sine_table(int m, int M, double *Q, std::vector<double> &lam, double f) {
+// folded sine tables of one axis (the oracle's h2d_axis_tables is the same text): Fe[k][e] = Q[k][2e],
+// Fo[k][o] = Q[k][2o+1] for k < ceil(m/2) resp. floor(m/2), their transposes, and the eigenvalues in spectral slot order
+void h2d_axis_tables(int m, int HP, double f, std::vector<double> &Fe, std::vector<double> &Fo, std::vector<double> &FeT,
+                     std::vector<double> &FoT, std::vector<double> &lam) {
+    const int hE = (m + 1) / 2, hO = m / 2;
     const double sc = std::sqrt(2.0 / (m + 1));
-    lam.assign(M, 0.0);
-    for (int i = 0; i < m; ++i) {
-        for (int k = 0; k < m; ++k) {
-            const long r = ((long)(i + 1) * (k + 1)) % (2L * (m + 1));
-            Q[(size_t)i * M + k] = sc * std::sin(M_PI * (double)r / (double)(m + 1));
+    Fe.assign((size_t)HP * HP, 0.0); Fo.assign((size_t)HP * HP, 0.0);
+    FeT.assign((size_t)HP * HP, 0.0); FoT.assign((size_t)HP * HP, 0.0);
+    lam.assign((size_t)2 * HP, 0.0);
+    for (int k = 0; k < hE; ++k) {
+        for (int e = 0; e < hE; ++e) {
+            const long r = ((long)(k + 1) * (2 * e + 1)) % (2L * (m + 1));
+            Fe[(size_t)k * HP + e] = FeT[(size_t)e * HP + k] = sc * std::sin(M_PI * (double)r / (double)(m + 1));
         }
-        const double hs = std::sin(M_PI * (double)(i + 1) / (2.0 * (m + 1)));
-        lam[i] = 4.0 * f * hs * hs;
+        if (k < hO)
+            for (int o = 0; o < hO; ++o) {
+                const long r = ((long)(k + 1) * (2 * o + 2)) % (2L * (m + 1));
+                Fo[(size_t)k * HP + o] = FoT[(size_t)o * HP + k] = sc * std::sin(M_PI * (double)r / (double)(m + 1));
+            }
     }
+    for (int e = 0; e < hE; ++e) { const double hs = std::sin(M_PI * (double)(2 * e + 1) / (2.0 * (m + 1))); lam[e] = 4.0 * f * hs * hs; }
+    for (int o = 0; o < hO; ++o) { const double hs = std::sin(M_PI * (double)(2 * o + 2) / (2.0 * (m + 1))); lam[HP + o] = 4.0 * f * hs * hs; }
 }
 
 int get_runs(mgrit_hip_engine *e, int lvl, int id, RunList **out) {
@@ -1493,14 +1513,15 @@ int mgrit_hip_level_heat2d(mgrit_hip_engine *e, int lvl, int n_pts_local, const 
     lv.h2d = h;
     H2DDev &H = h->dev;
     H.nx = nx; H.ny = ny; H.mi = nx - 2; H.mj = ny - 2;
-    H.Mi = ((H.mi + 63) / 64) * 64; H.Mj = ((H.mj + 63) / 64) * 64;
+    h->HPx = (((H.mi + 1) / 2 + 63) / 64) * 64; h->HPy = (((H.mj + 1) / 2 + 63) / 64) * 64;
+    H.Mi = 2 * h->HPx; H.Mj = 2 * h->HPy;   // one padded length per axis for the natural and the spectral layout
     H.K = K; H.n_pts = n_pts_local; H.ld = ld; H.fx = fx; H.fy = fy; H.theta = theta;
     h->dts.assign(n_pts_local > 0 ? n_pts_local : 0, 0.0);
     for (int i = 1; i < n_pts_local; ++i) h->dts[i] = t_local[i] - t_local[i - 1];
     // tables
-    std::vector<double> qx((size_t)H.Mi * H.Mi, 0.0), qy((size_t)H.Mj * H.Mj, 0.0);
-    h2d_sine_table(H.mi, H.Mi, qx.data(), h->lx, fx);
-    h2d_sine_table(H.mj, H.Mj, qy.data(), h->ly, fy);
+    std::vector<double> fxe, fxo, fxet, fxot, fye, fyo, fyet, fyot;
+    h2d_axis_tables(H.mi, h->HPx, fx, fxe, fxo, fxet, fxot, h->lx);
+    h2d_axis_tables(H.mj, h->HPy, fy, fye, fyo, fyet, fyot, h->ly);
     std::vector<double> W((size_t)H.Mi * H.Mj, 0.0), Sp((size_t)(K > 0 ? K : 0) * H.Mi * H.Mj, 0.0), bcv(bc, bc + (size_t)nx * ny);
     H.has_w = 0;
     for (int a = 0; a < H.mi; ++a)
@@ -1519,8 +1540,11 @@ int mgrit_hip_level_heat2d(mgrit_hip_engine *e, int lvl, int n_pts_local, const 
     std::vector<double> tauv;
     if (K > 0) tauv.assign(tau, tau + (size_t)K * n_pts_local);
     double *d_bc, *d_W, *d_S, *d_tau, *d_dt;
-    if ((rc = dev_upload(lv, e->stream, qx, &h->Qx))) return rc;
-    if ((rc = dev_upload(lv, e->stream, qy, &h->Qy))) return rc;
+    if ((rc = dev_upload(lv, e->stream, fxe, &h->Fxe)) || (rc = dev_upload(lv, e->stream, fxo, &h->Fxo)) ||
+        (rc = dev_upload(lv, e->stream, fxet, &h->FxeT)) || (rc = dev_upload(lv, e->stream, fxot, &h->FxoT)) ||
+        (rc = dev_upload(lv, e->stream, fye, &h->Fye)) || (rc = dev_upload(lv, e->stream, fyo, &h->Fyo)) ||
+        (rc = dev_upload(lv, e->stream, fyet, &h->FyeT)) || (rc = dev_upload(lv, e->stream, fyot, &h->FyoT)))
+        return rc;
     if ((rc = dev_upload(lv, e->stream, bcv, &d_bc))) return rc;
     if ((rc = dev_upload(lv, e->stream, W, &d_W))) return rc;
     if ((rc = dev_upload(lv, e->stream, Sp, &d_S))) return rc;
