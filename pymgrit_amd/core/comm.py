@@ -4,6 +4,7 @@
 CPU. Payloads are either device/CPU tensors (sent in place, no pickling) or small picklable Python objects.
 """
 import pickle
+import warnings
 
 import numpy as np
 import torch
@@ -101,7 +102,7 @@ class TorchTimeComm:
             for r in range(self.size - 1):   # every rank creates every group, in the same order (new_group is collective)
                 self._links[r] = dist.new_group([self._global(r), self._global(r + 1)], backend=self.backend)
         lo, hi = min(a, b), max(a, b)
-        return self._links[lo] if hi == lo + 1 else self.group
+        return self._links.get(lo, self.group) if hi == lo + 1 else self.group
 
     def _side_group(self):
         if self._side is None:
@@ -109,10 +110,22 @@ class TorchTimeComm:
         return self._side
 
     def prepare(self):
-        """create all communicators now (collective; call at the same program point on every rank)"""
-        if self.size > 1:
+        """create all communicators now (collective; call at the same program point on every rank). If any rank cannot
+        create them, every rank falls back to the main group alone: exchanges still work (one shared stream), the
+        asynchronous gather is switched off and with it the pipelined solve loop (Mgrit.pipeline_depth)."""
+        if self.size <= 1 or self._links is not None:
+            return
+        ok = True
+        try:
             self._link(0, 1)
             self._side_group()
+        except Exception as exc:   # noqa: BLE001 - any failure of the optional communicators is handled the same way
+            ok = False
+            warnings.warn(f"pymgrit_amd: extra communicators unavailable on rank {self.rank} ({exc!r}); using the main group only")
+        if not all(self.allgather_object(ok)):
+            self._links, self._side, self.async_gather = {}, None, False
+
+    async_gather = True
 
     # ---- convergence values -------------------------------------------------------------------------------------------
     def iallgather_floats(self, values, max_count):

@@ -486,7 +486,7 @@ class Mgrit:
         else:   # default 4 (the last of 8 ranks lags about two cycles, its values are posted one trip late); PYMGRIT_AMD_PIPELINE_DEPTH overrides it without touching the script
             want = int(os.environ.get("PYMGRIT_AMD_PIPELINE_DEPTH", "4"))
         usable = (self.comm_time_size > 1 and self.lvl_max > 1 and self.conv_crit == 0 and
-                  hasattr(self.comm_time, "iallgather_floats") and
+                  hasattr(self.comm_time, "iallgather_floats") and getattr(self.comm_time, "async_gather", True) and
                   not (self.output_fcn is not None and self.output_lvl == 2) and
                   type(self).convergence_criterion is Mgrit.convergence_criterion and
                   type(self).iteration is Mgrit.iteration)
