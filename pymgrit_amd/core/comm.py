@@ -3,6 +3,7 @@
 ``torch.distributed`` -- one process per GPU, backend "nccl" (= RCCL over xGMI on MI355X) for device rows, "gloo" on
 CPU. Payloads are either device/CPU tensors (sent in place, no pickling) or small picklable Python objects.
 """
+import os
 import pickle
 import warnings
 
@@ -110,13 +111,16 @@ class TorchTimeComm:
         return self._side
 
     def prepare(self):
-        """create all communicators now (collective; call at the same program point on every rank). If any rank cannot
-        create them, every rank falls back to the main group alone: exchanges still work (one shared stream), the
-        asynchronous gather is switched off and with it the pipelined solve loop (Mgrit.pipeline_depth)."""
+        """create all communicators now (collective; call at the same program point on every rank). If the creation is
+        refused (a backend without sub-groups, PYMGRIT_AMD_NO_EXTRA_GROUPS set) every rank falls back to the main group
+        alone: exchanges still work (one shared stream), the asynchronous gather is switched off and with it the
+        pipelined solve loop (Mgrit.pipeline_depth). (A rank that dies INSIDE a collective creation cannot be survived.)"""
         if self.size <= 1 or self._links is not None:
             return
         ok = True
         try:
+            if os.environ.get("PYMGRIT_AMD_NO_EXTRA_GROUPS"):   # switch (and test hook): main group only, on every rank
+                raise RuntimeError("extra communicators disabled by PYMGRIT_AMD_NO_EXTRA_GROUPS")
             self._link(0, 1)
             self._side_group()
         except Exception as exc:   # noqa: BLE001 - any failure of the optional communicators is handled the same way

@@ -22,7 +22,7 @@ def free_port():
     return port
 
 
-def launch(world, case, mode="plugin", backend="gloo", timeout=600, depth=None, slow_rank=None):
+def launch(world, case, mode="plugin", backend="gloo", timeout=600, depth=None, slow_rank=None, no_groups_rank=None):
     out = tempfile.mkdtemp(prefix=f"mgrit_{case}_{world}_")
     port = free_port()
     env = dict(os.environ)
@@ -32,6 +32,9 @@ def launch(world, case, mode="plugin", backend="gloo", timeout=600, depth=None, 
         env["MGRIT_TEST_PIPELINE_DEPTH"] = str(depth)
     if slow_rank is not None:
         env["MGRIT_TEST_SLOW_RANK"] = str(slow_rank)
+    env.pop("PYMGRIT_AMD_NO_EXTRA_GROUPS", None)
+    if no_groups_rank is not None:
+        env["PYMGRIT_AMD_NO_EXTRA_GROUPS"] = "1"
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), str(r), str(world), str(port), case,
                                mode, out, backend], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
              for r in range(world)]
@@ -104,4 +107,11 @@ def test_pipelined_solve_with_a_rank_far_behind(slow_rank):
     are in flight, stopping values arrive late -- same results as one rank"""
     conv1, u1 = launch(1, "heat_nx33_V_nested")
     conv, u = launch(3, "heat_nx33_V_nested", depth=3, slow_rank=slow_rank)
+    assert np.array_equal(conv, conv1) and np.array_equal(u, u1)
+
+
+def test_fallback_to_the_main_group_alone():
+    """no per-link / side groups (PYMGRIT_AMD_NO_EXTRA_GROUPS): every exchange on the main group, plain solve loop"""
+    conv1, u1 = launch(1, "heat_nx33_V_nested")
+    conv, u = launch(3, "heat_nx33_V_nested", no_groups_rank=1, timeout=120)
     assert np.array_equal(conv, conv1) and np.array_equal(u, u1)
