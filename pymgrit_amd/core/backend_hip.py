@@ -69,7 +69,8 @@ class HipBackend:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.current_stream(self.device)
         self.h = C.c_void_p()
-        check(self.lib.mgrit_hip_create(C.byref(self.h), mg.lvl_max, C.c_void_p(self.stream.cuda_stream)))
+        # one spare level index: the work level of AT-MGRIT on several ranks (at_forward_solve), described on first use
+        check(self.lib.mgrit_hip_create(C.byref(self.h), mg.lvl_max + 1, C.c_void_p(self.stream.cuda_stream)))
         self.desc = [p.device_stepper() for p in mg.problem]
         self.n = [int(d["n"]) for d in self.desc]
         # 1-D steppers: lane-blocked rows; Heat2D: the nx x ny grid in natural row-major order
@@ -101,20 +102,24 @@ class HipBackend:
             pass
 
     # -- state (mgrit.py:840-858) -------------------------------------------------------------------
+    def _describe_heat1d(self, engine_lvl, d, t_local, n, ld):
+        n_pts = t_local.size
+        s = np.ascontiguousarray(np.asarray(d.get("forcing_space", np.zeros((0, n))), dtype=np.float64).reshape(-1, n))
+        K = s.shape[0]
+        tau = np.zeros((K, n_pts))
+        for k in range(K):
+            tau[k] = [d["forcing_time"][k](tt) for tt in t_local]
+        tau = np.ascontiguousarray(tau)
+        check(self.lib.mgrit_hip_level_heat1d(self.h, engine_lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"]), K,
+                                              _ptr(s), _ptr(tau)))
+
     def create_u_v_g(self, lvl):
         mg = self.mg
         d, n, ld = self.desc[lvl], self.n[lvl], self.ld[lvl]
         t_local = np.ascontiguousarray(np.asarray(mg.t[lvl], dtype=np.float64))
         n_pts = t_local.size
         if d["kind"] == "heat1d":
-            s = np.ascontiguousarray(np.asarray(d.get("forcing_space", np.zeros((0, n))), dtype=np.float64).reshape(-1, n))
-            K = s.shape[0]
-            tau = np.zeros((K, n_pts))
-            for k in range(K):
-                tau[k] = [d["forcing_time"][k](tt) for tt in t_local]
-            tau = np.ascontiguousarray(tau)
-            check(self.lib.mgrit_hip_level_heat1d(self.h, lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"]), K,
-                                                  _ptr(s), _ptr(tau)))
+            self._describe_heat1d(lvl, d, t_local, n, ld)
         elif d["kind"] == "heat1d_2pts":
             s = np.ascontiguousarray(np.asarray(d.get("forcing_space", np.zeros((0, n))), dtype=np.float64).reshape(-1, n))
             K = s.shape[0]
@@ -343,10 +348,60 @@ class HipBackend:
             check(self.lib.mgrit_hip_copy_pairs_u_to_v(self.h, lvl, self._pair_id(lvl, pairs)))
 
     def at_forward_solve(self, lvl, k):
-        """AtMgrit.forward_solve (at_mgrit.py:79-87), one rank: truncated, mutually independent coarsest-level solves"""
-        if self.mg.comm_time_size > 1:
-            raise MgritHipError("AT-MGRIT on the HIP engine runs on one rank (several ranks: host applications only)")
-        check(self.lib.mgrit_hip_at_solve(self.h, lvl, int(k)))
+        """AtMgrit.forward_solve (at_mgrit.py:37-87): truncated, mutually independent coarsest-level solves. One rank: one
+        launch on the level itself. Several ranks: a point needs the old u and the g of the k-1 points before it, which
+        may live on the previous rank, and the steps in between: a private WORK level (the engine's spare level) is
+        described once on the time grid [halo | own points]; per solve the halo rows arrive from the previous rank (two
+        messages: u, g), the own rows are copied in, the same launch runs there and the own results are copied back. The
+        arithmetic of every point is that of the one-rank run (the reference instead gathers one point per rank over its
+        black / green communicators, at_mgrit.py:47-72)."""
+        mg, k = self.mg, int(k)
+        if mg.comm_time_size == 1:
+            check(self.lib.mgrit_hip_at_solve(self.h, lvl, k))
+            return
+        if self.desc[lvl]["kind"] not in ("heat1d", "advection1d"):
+            raise MgritHipError("AT-MGRIT on several ranks of the HIP engine: 1-D single-point steppers only")
+        own_g = [int(i) for i in mg.cpts[lvl]]                 # global indices of the owned points
+        counts = mg.comm_time.allgather_object(len(own_g)) if not hasattr(self, "_at") else None
+        if not hasattr(self, "_at"):
+            rank, size = mg.comm_time_rank, mg.comm_time_size
+            holders = [r for r in range(size) if counts[r] > 0]
+            prev = max([r for r in holders if r < rank], default=None) if own_g else None
+            nxt = min([r for r in holders if r > rank], default=None) if own_g else None
+            halo = min(k - 1, own_g[0]) if own_g else 0
+            for a, b in zip(holders[:-1], holders[1:]):            # the same verdict on every rank
+                if min(k - 1, sum(counts[:b])) > counts[a]:
+                    raise MgritHipError(f"AT-MGRIT distance k={k} reaches past the {counts[a]} coarsest points of rank {a}: "
+                                        f"use fewer ranks or a smaller k")
+            first_of_next = sum(counts[:nxt]) if nxt is not None else 0
+            give = min(k - 1, first_of_next) if nxt is not None else 0      # = the halo of the next holder
+            at = {"prev": prev, "next": nxt, "halo": halo, "give": give, "n_own": len(own_g)}
+            if own_g:
+                t_at = np.ascontiguousarray(mg.global_t[lvl][own_g[0] - halo:own_g[-1] + 1])
+                n, ld = self.n[lvl], self.ld[lvl]
+                at["u"] = torch.zeros((t_at.size, ld), dtype=torch.float64, device=self.device)
+                at["g"] = torch.zeros_like(at["u"])
+                work = mg.lvl_max
+                if self.desc[lvl]["kind"] == "heat1d":
+                    self._describe_heat1d(work, self.desc[lvl], t_at, n, ld)
+                else:
+                    check(self.lib.mgrit_hip_level_advection1d(self.h, work, t_at.size, _ptr(t_at), n, ld, float(self.desc[lvl]["fac"])))
+                check(self.lib.mgrit_hip_level_bind(self.h, work, C.c_void_p(at["u"].data_ptr()), C.c_void_p(at["u"].data_ptr()),
+                                                    C.c_void_p(at["g"].data_ptr())))
+            self._at = at
+        at = self._at
+        if not at["n_own"]:
+            return
+        own = slice(int(mg.index_local[lvl][0]), int(mg.index_local[lvl][-1]) + 1)   # rows of the owned points in the slab
+        U, G = self.U[lvl], self.G[lvl]
+        for slab, work in ((U, at["u"]), (G, at["g"])):        # old u, then g: last rows to the next holder, halo from the previous
+            send = (slab[own][at["n_own"] - at["give"]:], at["next"]) if at["give"] else None
+            recv = (work[:at["halo"]], at["prev"]) if at["halo"] else None
+            if send is not None or recv is not None:
+                mg.comm_time.exchange(send=send, recv=recv)
+            work[at["halo"]:].copy_(slab[own])
+        check(self.lib.mgrit_hip_at_solve(self.h, mg.lvl_max, k))
+        U[own].copy_(at["u"][at["halo"]:])
 
     def can_fuse_ec(self, lvl):
         tr = self.mg.transfer_objects[lvl]

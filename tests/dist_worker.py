@@ -16,6 +16,10 @@ def build_problem(case_name, mode):
     if case_name.startswith("h2d:"):
         prob, opts = cases.h2d_solve_problem(case_name[4:])
         return prob, None, opts
+    if case_name.startswith("at:"):      # AT-MGRIT: (problem, transfer, options incl. the distance k under "_at_k")
+        import test_at_mgrit as at
+        nx, nts, k, opts = at.CASES[case_name[3:]]
+        return at.heat(nx, nts, mode == "plugin"), None, dict(opts, _at_k=k)
     if case_name.startswith("bdf:"):
         c = cases.BDF_CASES[case_name[4:]]
         prob = cases.bdf_levels(c["nx"], c["n_pairs"], c["orders"], c["coarsening"], c["forcing"])
@@ -60,8 +64,11 @@ def run(rank, world, port, case_name, mode, out_dir, backend):
         dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     if mode == "hip":
         torch.cuda.set_device(rank % max(torch.cuda.device_count(), 1))
-    from pymgrit_amd import Mgrit
+    from pymgrit_amd import AtMgrit, Mgrit
     prob, tr, opts = build_problem(case_name, mode)
+    if "_at_k" in opts:
+        k = opts.pop("_at_k")
+        Mgrit = lambda *a, **kw: AtMgrit(k, 0 if "conv_crit" not in kw else kw.pop("conv_crit"), *a, **kw)  # noqa: E731
     if os.environ.get("MGRIT_TEST_PIPELINE_DEPTH") is not None:
         opts["pipeline_depth"] = int(os.environ["MGRIT_TEST_PIPELINE_DEPTH"])
     mg = Mgrit(prob, transfer=tr, logging_lvl=30, **opts)

@@ -154,3 +154,27 @@ def test_hip_truncated_solve_is_bit_exact_on_wide_states(oracle):
         mg.forward_solve(1)
         op.at_forward_solve(1, k)
         assert_state_equal(mg, op)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world", [("heat_nx33_k3_nonested_F", 2), ("heat_nx33_k3_nonested_F", 3), ("heat_nx33_k2", 2),
+                                        ("heat_nx33_2lvl_k4_w13", 3)])
+def test_hip_several_ranks_equal_one_rank(name, world):
+    """AT-MGRIT sharded over ranks on the HIP path (ranks share the one GPU of the test box; gloo transport): halo rows of
+    the previous rank through the private work level -- bit-identical to the one-rank run"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from test_distributed import launch
+    conv1, u1 = launch(1, "at:" + name, mode="hip")
+    conv, u = launch(world, "at:" + name, mode="hip", backend="gloo")
+    assert np.array_equal(conv, conv1), (conv, conv1)
+    assert np.array_equal(u, u1)
+
+
+@pytest.mark.parametrize("name,world", [("heat_nx33_k3", 3), ("heat_nx33_k2_jump", 2)])
+def test_several_processes_equal_one_on_the_host_path(name, world):
+    from test_distributed import launch
+    conv1, u1 = launch(1, "at:" + name)
+    conv, u = launch(world, "at:" + name)
+    assert np.array_equal(conv, conv1) and np.array_equal(u, u1)
