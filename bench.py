@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "smoke-test the N>1 path with several ranks on ONE GPU)")
     ap.add_argument("--nt-adv", dest="nt_adv", type=int, default=32769)
+    ap.add_argument("--at-k", dest="at_k", type=int, default=0,
+                    help="AT-MGRIT with local coarse grids of k points instead of MGRIT (not the headline algorithm)")
     ap.add_argument("--pipeline-depth", dest="pipeline_depth", type=int, default=None,
                     help="N>1: how many iterations the stopping value may lag (default: the solver's default, 4; 0 = check "
                          "after every cycle like the reference's loop)")
@@ -306,11 +308,18 @@ def main():
     grids = [t0, t0[::4], t0[::16]]
     problem = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=init_cond, rhs_separable=[(rhs_space, rhs_time)],
                       t_interval=g) for g in grids]
-    mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=False, max_iter=2 + args.warmup + args.steps, tol=0.0,
-               logging_lvl=30, pipeline_depth=args.pipeline_depth)
+    if args.at_k:   # AT-MGRIT variant of the same hierarchy (core/at_mgrit.py): truncated coarsest-level solves of distance k
+        from pymgrit_amd import AtMgrit
+        mg = AtMgrit(args.at_k, 0, problem, cf_iter=1, cycle_type='V', nested_iteration=False,
+                     max_iter=2 + args.warmup + args.steps, tol=0.0, logging_lvl=30)
+    else:
+        mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=False, max_iter=2 + args.warmup + args.steps, tol=0.0,
+                   logging_lvl=30, pipeline_depth=args.pipeline_depth)
     be = mg.backend
     dof = nx - 2
     counts = phi_counts(nts, [4, 4])
+    if args.at_k:   # coarsest level: point p is recomputed by min(p, k-1) steps instead of one step of the sequential solve
+        counts[-1] = counts[-1] - (nts[-1] - 1) + sum(min(p, args.at_k - 1) for p in range(1, nts[-1]))
     updates_per_cycle = float(sum(c * dof for c in counts))
 
     def cycle(it):
@@ -390,7 +399,8 @@ def main():
         "unit": "time-point-DOF updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle + residual check "
+        "config": {"workload": ("AT-MGRIT k=%d: " % args.at_k if args.at_k else "") +
+                               f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle + residual check "
                                f"(BASELINE configs[{2 if (nx, nt0) == (16384, 65537) else 1 if (nx, nt0) == (1024, 4097) else '-'}]; "
                                f"time points sharded over {world} GPU(s))",
                    "phi_per_cycle_by_level": counts, "dof": dof, "pipeline_depth": mg.pipeline_depth()},
