@@ -11,8 +11,8 @@ What stays on the host is control flow only: the cycle recursion (mgrit.py:261-2
 boundaries (mgrit.py:304-331,346-352,397-403,467-484,502-517 -- mpi4py pickled isend/recv replaced by
 torch.distributed point-to-point, RCCL over xGMI for device rows) and the stopping test.
 
-Local convergence criteria (conv_crit 2/3) are implemented for one rank; their multi-rank drain protocol is out of scope
-(SURVEY section 8f).
+Local convergence criteria (conv_crit 2/3) run on one or several ranks (the farewell messages of a rank that leaves the
+solve loop early: Mgrit._leave_local).
 """
 import logging
 import os
@@ -100,11 +100,11 @@ class Mgrit:
         self.conv_crit = conv_crit
         self.global_conv_crit = conv_crit in (0, 1)
         self.finished = [False, None]
-        self.pre_finished = [True, 0]   # rank 0 has no predecessor (mgrit.py:224-228)
-        if not self.global_conv_crit and self.comm_time_size > 1:
-            raise Exception('Local convergence criteria (conv_crit 2/3) run on one rank only: their multi-rank drain protocol '
-                            '(mgrit.py:434-455,648-691: ranks leave the solve loop in different iterations) is not '
-                            'implemented; choose 0 (global space-time residual) or 1 (global jump) on several ranks')
+        self.pre_finished = [True, 0] if self.comm_time_rank == 0 else [False, None]   # mgrit.py:224-228
+        self._dry = None            # 'send' / 'recv': farewell traffic of the local criteria (_drain_out / _drain_in)
+        self._pred_gone = None      # None / 'draining' / 'done': has the previous rank left the solve loop?
+        self._drain_seen = set()
+        self._real_backend = None
         self.save_values_last_iter = None
         self._pipeline_request = pipeline_depth
         self._pl = None
@@ -263,14 +263,38 @@ class Mgrit:
             return out
         return self._cached(('pair', lvl, bool(skip_first)), build)
 
-    def _exchange(self, lvl, send_idx=None, recv_idx=None, dest=None, src=None):
-        send = (self.backend.payload(lvl, send_idx), dest) if send_idx is not None else None
-        recv = (self.backend.recv_buffer(lvl, recv_idx), src) if recv_idx is not None else None
+    def _exchange(self, lvl, send_idx=None, recv_idx=None, dest=None, src=None, op=None):
+        """One exchange point of operation `op` (the reference's op ids 0-5, 7; mgrit.py:693-713). With a local stopping
+        criterion ranks leave the solve loop one after the other (see _drain_out): a receive from a predecessor that has
+        left is served once per (level, op) from its farewell messages and skipped afterwards."""
+        if self._dry == 'send':        # farewell of a finished rank: first occurrence of every send, frozen values, no receives
+            recv_idx = None
+            if send_idx is not None:
+                if (lvl, op) in self._drain_seen:
+                    return
+                self._drain_seen.add((lvl, op))
+                if op == 4:            # mgrit.py:663-665: the last C-point of the FINER level (identity transfer)
+                    send = (self._real_backend.payload(lvl - 1, int(self.index_local_c[lvl - 1][-1])), dest)
+                    self.comm_time.exchange(send=send)
+                    return
+        elif recv_idx is not None and not self.global_conv_crit:
+            if self._pred_gone == 'done':
+                recv_idx = None
+            elif self._pred_gone == 'draining' or self._dry == 'recv':
+                if (lvl, op) in self._drain_seen:
+                    recv_idx = None
+                else:
+                    self._drain_seen.add((lvl, op))
+        if self._dry == 'recv':
+            send_idx = None
+        backend = self._real_backend if self._dry else self.backend
+        send = (backend.payload(lvl, send_idx), dest) if send_idx is not None else None
+        recv = (backend.recv_buffer(lvl, recv_idx), src) if recv_idx is not None else None
         if send is None and recv is None:
             return
         got = self.comm_time.exchange(send=send, recv=recv)
         if recv is not None:
-            self.backend.commit(lvl, recv_idx, got)
+            backend.commit(lvl, recv_idx, got)
 
     def _last_slot(self, lvl):
         return len(self.t[lvl]) - 1
@@ -305,24 +329,24 @@ class Mgrit:
         each interval; the sweep order and the exchange points are those of the plain relaxation."""
         t0 = time.time()
         self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_c_point[lvl] else None,
-                       recv_idx=0 if self.first_is_f_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl])
+                       recv_idx=0 if self.first_is_f_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=0)
         runs = self._f_runs(lvl)
         if runs:
             front, back = self.comm_front[lvl], self.comm_back[lvl]
             if front and back and len(runs) == 1:
-                self._exchange(lvl, recv_idx=0, src=self.get_from[lvl])
+                self._exchange(lvl, recv_idx=0, src=self.get_from[lvl], op=1)
                 self._relax_f(lvl, 'f_all', runs, ec)
-                self._exchange(lvl, send_idx=self._last_slot(lvl), dest=self.send_to[lvl])
+                self._exchange(lvl, send_idx=self._last_slot(lvl), dest=self.send_to[lvl], op=1)
             elif not front and not back:
                 self._relax_f(lvl, 'f_all', runs, ec)
             else:
                 lo, hi = (1 if front else 0), (len(runs) - 1 if back else len(runs))
                 if back:  # the interval feeding the next rank goes first
                     self._relax_f(lvl, 'f_last', self._cached(('f_last', lvl), lambda: runs[-1:]), ec)
-                    self._exchange(lvl, send_idx=self._last_slot(lvl), dest=self.send_to[lvl])
+                    self._exchange(lvl, send_idx=self._last_slot(lvl), dest=self.send_to[lvl], op=1)
                 self._relax_f(lvl, 'f_mid', self._cached(('f_mid', lvl), lambda: runs[lo:hi]), ec)
                 if front:
-                    self._exchange(lvl, recv_idx=0, src=self.get_from[lvl])
+                    self._exchange(lvl, recv_idx=0, src=self.get_from[lvl], op=1)
                     self._relax_f(lvl, 'f_first', self._cached(('f_first', lvl), lambda: runs[:1]), ec)
         logging.debug(f"F-relax on {self.comm_time_rank} took {time.time() - t0} s")
 
@@ -353,7 +377,7 @@ class Mgrit:
         """C-relaxation (mgrit.py:335-370); op 2 = last local F-point to the next owner's ghost."""
         t0 = time.time()
         self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
-                       recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl])
+                       recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=2)
         self.backend.relax(lvl, self._c_runs(lvl), 'C')
         logging.debug(f"C-relax on {self.comm_time_rank} took {time.time() - t0} s")
 
@@ -364,7 +388,7 @@ class Mgrit:
     def compute_residual(self) -> list:
         """Per-C-point norms of r_i = Phi(u_{i-1}) - u_i on level 0 (mgrit.py:387-413); op 7 ghost refresh."""
         self._exchange(0, send_idx=self._last_slot(0) if self.last_is_f_point[0] else None,
-                       recv_idx=0 if self.first_is_c_point[0] else None, dest=self.send_to[0], src=self.get_from[0])
+                       recv_idx=0 if self.first_is_c_point[0] else None, dest=self.send_to[0], src=self.get_from[0], op=7)
         return self.backend.residual_norms(self._c_points(0))
 
     def convergence_criterion(self, iteration: int) -> None:
@@ -375,9 +399,17 @@ class Mgrit:
         if self.global_conv_crit:
             parts = self.comm_time.allgather_object([float(x) for x in val])
             self.conv[iteration] = time_norm(np.array([x for part in parts for x in part]), self.t_norm)
-        else:   # local criterion (mgrit.py:434-455), one rank: every point below the tolerance on its own
+        else:   # local criterion (mgrit.py:434-455): every local point below the tolerance AND the previous rank has finished
+            if self.comm_time_rank > 0 and not self.pre_finished[0]:            # op 6: the predecessor's verdict of this iteration
+                if bool(self.comm_time.exchange(recv=(None, self.comm_time_rank - 1))):
+                    self.pre_finished = [True, iteration]
+                    self._pred_gone, self._drain_seen = 'draining', set()
+            elif self._pred_gone == 'draining':
+                self._pred_gone = 'done'    # one iteration has consumed the predecessor's farewell messages
             self.finished = [bool(self.pre_finished[0] and (all(v < self.tol for v in val) or iteration == self.iter_max)),
                              iteration]
+            if self.comm_time_rank < self.comm_time_size - 1:
+                self.comm_time.exchange(send=(bool(self.finished[0]), self.comm_time_rank + 1))
             self.conv[iteration] = time_norm(np.array([float(x) for x in val]), self.t_norm)
         logging.debug(f"Convergence criterion on {self.comm_time_rank} took {time.time() - t0} s")
 
@@ -385,12 +417,12 @@ class Mgrit:
         """Sequential time stepping on level ``lvl`` (mgrit.py:459-486); op 5 = pipeline hand-off between owners."""
         t0 = time.time()
         if self.get_from[lvl] != -99:
-            self._exchange(lvl, recv_idx=0, src=self.get_from[lvl])
+            self._exchange(lvl, recv_idx=0, src=self.get_from[lvl], op=5)
         n = len(self.t[lvl])
         if n > 1:
             self.backend.relax(lvl, self._cached(('chain', lvl), lambda: [(1, n - 1)]), 'CHAIN')
         if self.send_to[lvl] != -99:
-            self._exchange(lvl, send_idx=int(self.index_local[lvl][-1]), dest=self.send_to[lvl])
+            self._exchange(lvl, send_idx=int(self.index_local[lvl][-1]), dest=self.send_to[lvl], op=5)
         logging.debug(f"Forward solve on {self.comm_time_rank} took {time.time() - t0} s")
 
     def fas_residual(self, lvl: int) -> None:
@@ -403,11 +435,11 @@ class Mgrit:
             return
         self.backend.restrict_u(lvl, self._pairs(lvl, skip_first=False))
         self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
-                       recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl])
+                       recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=3)
         self._exchange(lvl + 1,
                        send_idx=int(self.index_local[lvl + 1][-1]) if self.send_to[lvl + 1] >= 0 else None,
                        recv_idx=0 if self.get_from[lvl + 1] >= 0 else None,
-                       dest=self.send_to[lvl + 1], src=self.get_from[lvl + 1])
+                       dest=self.send_to[lvl + 1], src=self.get_from[lvl + 1], op=4)
         self.backend.copy_u_to_v(lvl + 1)
         self.backend.fas_rhs(lvl, self._pairs(lvl, skip_first=True))
         logging.debug(f"Fas residual on {self.comm_time_rank} took {time.time() - t0} s")
@@ -422,13 +454,13 @@ class Mgrit:
         triples = self._cached(('triples', lvl), lambda: [(all_pairs[k][0], all_pairs[k - 1][0], all_pairs[k][1])
                                                           for k in range(1, len(all_pairs))])
         self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
-                       recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl])
+                       recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=3)
         be.restrict_u(lvl, head)
         be.fas_fused(lvl, triples)
         self._exchange(lvl + 1,
                        send_idx=int(self.index_local[lvl + 1][-1]) if self.send_to[lvl + 1] >= 0 else None,
                        recv_idx=0 if self.get_from[lvl + 1] >= 0 else None,
-                       dest=self.send_to[lvl + 1], src=self.get_from[lvl + 1])
+                       dest=self.send_to[lvl + 1], src=self.get_from[lvl + 1], op=4)
         be.copy_pairs_u_to_v(lvl, head)
         if self._ghost[lvl + 1]:  # v ghost = clone of the received u ghost; then the first local pair, unfused
             be.copy_pairs_u_to_v(lvl, self._cached(('pair_ghost', lvl), lambda: [(all_pairs[0][0], 0)] if all_pairs else []))
@@ -533,7 +565,7 @@ class Mgrit:
             # residual of this iteration: launched now, read one trip later, so the host never waits for the device to
             # finish the iteration it has just queued (it stays one iteration ahead of it)
             self._exchange(0, send_idx=self._last_slot(0) if self.last_is_f_point[0] else None,
-                           recv_idx=0 if self.first_is_c_point[0] else None, dest=self.send_to[0], src=self.get_from[0])
+                           recv_idx=0 if self.first_is_c_point[0] else None, dest=self.send_to[0], src=self.get_from[0], op=7)
             handle = self.backend.residual_begin(self._c_points(0))
             pl["executed"] = it + 1
             self.backend.snapshot_cpoints((it + 1) % pl["slots"], pl["snap_points"])
@@ -588,6 +620,43 @@ class Mgrit:
         return {'conv': self.conv[np.where(self.conv != 0)], 'time_setup': self.runtime_setup,
                 'time_solve': self.runtime_solve}
 
+    # ------------------------------------------------------------------------------------------------
+    # Local stopping criteria on several ranks (mgrit.py:434-455,627-635,648-691). Ranks leave the solve loop one after
+    # the other, in rank order. The reference lets a leaving rank post one last message per (level, op) with its final
+    # boundary values (clean_up); its successor, still iterating, picks each of them up the first time it reaches that
+    # receive and skips the receive from then on -- the ghost values stay what they are. The messages of the reference are
+    # matched by tag; here a channel is first-in first-out, so the leaving rank posts them in the order in which its
+    # successor's next iteration reaches the receives: it walks once through its own iteration with every sweep switched
+    # off, sending at the first occurrence of each send point (_dry = 'send'). A rank that leaves in the same iteration as
+    # its predecessor has nothing left to iterate and takes the messages off the channel the same way (_dry = 'recv').
+    # ------------------------------------------------------------------------------------------------
+    class _NoSweeps:
+        """stands in for the backend during a dry walk: no sweep does anything"""
+
+        def __getattr__(self, name):
+            if name.startswith("can_"):
+                raise AttributeError(name)
+            return lambda *a, **k: None
+
+    def _dry_walk(self, mode, iteration):
+        self._real_backend, self.backend = self.backend, Mgrit._NoSweeps()
+        self._dry, self._drain_seen = mode, set()
+        try:
+            self.iteration(lvl=0, cycle_type=self.cycle_type, iteration=iteration, first_f=True)
+            if self.conv_crit == 2:     # op 7 belongs to the residual criterion; the jump criterion exchanges nothing
+                self._exchange(0, send_idx=self._last_slot(0) if self.last_is_f_point[0] else None,
+                               recv_idx=0 if self.first_is_c_point[0] else None, dest=self.send_to[0], src=self.get_from[0], op=7)
+        finally:
+            self.backend, self._real_backend, self._dry = self._real_backend, None, None
+
+    def _leave_local(self, iteration):
+        """clean_up (mgrit.py:648-691) of a rank that leaves the solve loop under a local criterion"""
+        if self.comm_time_rank < self.comm_time_size - 1:
+            self._dry_walk('send', iteration + 1)
+        if self.comm_time_rank > 0 and self._pred_gone == 'draining':   # the predecessor left in this very iteration
+            self._dry_walk('recv', iteration + 1)
+            self._pred_gone = 'done'
+
     def solve(self) -> dict:
         if self.pipeline_depth() > 0:
             return self._solve_pipelined()
@@ -610,6 +679,8 @@ class Mgrit:
                 self.output_fcn(self)
             if now < self.tol or iteration == self.iter_max - 1:
                 if self.global_conv_crit or (self.finished[0] and self.pre_finished[0]) or iteration == self.iter_max - 1:
+                    if not self.global_conv_crit and self.comm_time_size > 1:
+                        self._leave_local(iteration)
                     break
         self.backend.sync()
         getattr(self.comm_time, 'drain', lambda: None)()

@@ -20,6 +20,14 @@ def build_problem(case_name, mode):
         import test_at_mgrit as at
         nx, nts, k, opts = at.CASES[case_name[3:]]
         return at.heat(nx, nts, mode == "plugin"), None, dict(opts, _at_k=k)
+    if case_name.startswith("lc:"):      # local stopping criteria on several ranks (tests/test_local_conv.py)
+        import test_local_conv as lc
+        make, opts = lc._ranks_problem(case_name[3:])
+        prob = make()
+        if mode != "plugin":
+            for p in prob:
+                del p.device_stepper      # back to the class's declarative description: HIP path
+        return prob, None, dict(opts)
     if case_name.startswith("bdf:"):
         c = cases.BDF_CASES[case_name[4:]]
         prob = cases.bdf_levels(c["nx"], c["n_pairs"], c["orders"], c["coarsening"], c["forcing"])

@@ -511,6 +511,38 @@ def make_at_mgrit():
     print("wrote at_mgrit", {k: len(v["conv"]) for k, v in out.items()})
 
 
+# --------------------------------------------------------------------------------------------------
+# Local convergence criteria on SEVERAL ranks (the drain protocol, mgrit.py:434-455,648-691): the reference's true multi-rank
+# path on the thread-backed MPI stand-in (tests/golden/_mpi_stub: run_world)
+# --------------------------------------------------------------------------------------------------
+def make_local_conv_ranks():
+    from mpi4py import MPI
+    cases = {
+        "heat_crit2_V": (lambda: heat_levels(33, [65, 17, 5]), dict(tol=1e-7, max_iter=12, conv_crit=2)),
+        "heat_crit3_V": (lambda: heat_levels(33, [65, 17, 5]), dict(tol=1e-7, max_iter=12, conv_crit=3)),
+        "heat_crit2_F_nonested": (lambda: heat_levels(33, [65, 17, 5]), dict(tol=1e-7, max_iter=12, conv_crit=2, cycle_type='F',
+                                                                         nested_iteration=False)),
+        "heat_crit2_maxiter": (lambda: heat_levels(33, [65, 17, 5]), dict(tol=1e-14, max_iter=3, conv_crit=2)),
+        "heat_crit2_2lvl_cf2": (lambda: heat_levels(33, [65, 9]), dict(tol=1e-7, max_iter=12, conv_crit=2, cf_iter=2)),
+        "dahlquist_crit2": (lambda: simple_setup_problem(Dahlquist(t_start=0, t_stop=5, nt=101), level=3, coarsening=2),
+                            dict(tol=1e-10, conv_crit=2)),
+    }
+    out = {}
+    for name, (make, kw) in cases.items():
+        for size in (2, 3, 4):
+            def one(rank, make=make, kw=kw):
+                m = Mgrit(problem=make(), logging_lvl=QUIET, **kw)
+                info = m.solve()
+                own = [int(i) for i in m.index_local[0]]
+                pick = sorted({0, len(own) // 2, len(own) - 1})     # owned points sampled: first, middle, last
+                vals = {str(j): np.asarray(m.u[0][own[j]].get_values(), dtype=float).ravel().tolist() for j in pick}
+                return {"conv": [float(c) for c in info["conv"]], "n_owned": len(own), "u": vals}
+            out[f"{name}_P{size}"] = MPI.run_world(size, one)
+    with open(os.path.join(HERE, "local_conv_ranks.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("wrote local_conv_ranks", {k: [len(r["conv"]) for r in v] for k, v in out.items()})
+
+
 def ref_results():
     res = {}
     d = os.path.join(REF, "tests", "mpi", "results")
@@ -528,6 +560,9 @@ def main():
         return
     if "--only-advection-sc" in sys.argv:
         make_advection_sc()
+        return
+    if "--only-local-conv-ranks" in sys.argv:
+        make_local_conv_ranks()
         return
     if "--only-at-mgrit" in sys.argv:
         make_at_mgrit()
@@ -554,6 +589,7 @@ def main():
     make_bdf()
     make_local_conv()
     make_at_mgrit()
+    make_local_conv_ranks()
     res, kats = ref_results()
     with open(os.path.join(HERE, "ref_results.json"), "w") as f:
         json.dump({"tests_mpi_results": res}, f, indent=1)
