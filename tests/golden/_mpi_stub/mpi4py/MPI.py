@@ -96,7 +96,16 @@ class Comm:
         return self._collect(obj)[root]
 
     def Split(self, color=0, key=0):
-        return _Single()
+        """collective over the world: ranks with the same colour form a communicator (ordered by key); UNDEFINED -> COMM_NULL"""
+        w = self._w()
+        if not w:
+            return _Single()
+        _tls.splits = getattr(_tls, "splits", 0) + 1
+        table = self._collect((color, key, self.rank))
+        if color == UNDEFINED:
+            return COMM_NULL
+        members = [r for c, k, r in sorted((t for t in table if t[0] == color), key=lambda t: (t[1], t[2]))]
+        return _Sub(w, (_tls.splits, color), members)
 
 
 class _Single(Comm):
@@ -106,6 +115,40 @@ class _Single(Comm):
     @property
     def rank(self):
         return 0
+
+
+class _Sub:
+    """communicator over a subset of the world's ranks (result of Split): the collectives the reference uses on it"""
+
+    def __init__(self, world, ident, members):
+        self.world, self.ident, self.members = world, ident, members
+        self.seq = 0
+
+    def Get_rank(self):
+        return self.members.index(_tls.rank)
+
+    def Get_size(self):
+        return len(self.members)
+
+    def _collect(self, obj):
+        w = self.world
+        self.seq += 1
+        key = (self.ident, self.seq)
+        with w.cond:
+            slot = w.coll.setdefault(key, {})
+            slot[_tls.rank] = pickle.dumps(obj)
+            w.cond.notify_all()
+            w.cond.wait_for(lambda: len(slot) == len(self.members))
+            return [pickle.loads(slot[r]) for r in self.members]
+
+    def allgather(self, obj):
+        return self._collect(obj)
+
+    def bcast(self, obj, root=0):
+        return self._collect(obj)[root]
+
+    def barrier(self):
+        self._collect(None)
 
 
 COMM_WORLD = Comm()
