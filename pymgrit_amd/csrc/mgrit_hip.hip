@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *
 
 // error_correction + f_relax in one pass for the identity transfer (mgrit.py:715-726 followed by 292-333): a run whose
 // predecessor is a corrected C-point applies the correction itself -- u_c = u_c + (u^{l+1}_j - v^{l+1}_j), same operation
-// order as interp_rows_kernel -- writes the C-point back and goes on with the F-points, so the C-point travels through HBM
+// order as interp_rows_kernel, with v^{l+1}_j taken from u_c itself (see below) -- writes the C-point back and goes on with the F-points, so the C-point travels through HBM
 // once instead of twice. ec_coarse[r] = coarse slot j of run r's predecessor, or -1 (ghost / uncorrected predecessor).
 template <int KIND, int FORCE, bool USE_G>
 __global__ void __launch_bounds__(1024) ecf_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ run_start,
@@ -504,11 +504,12 @@ __global__ void __launch_bounds__(1024) ecf_kernel(LevelDev L, LevelDev Lc, cons
         double x[E], gi[E];
         load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
         if (j >= 0) {
+            // v^{l+1}_j is not read: fas_residual made it the clone of u^l at this very C-point (identity transfer) and nothing
+            // has touched level l since (iteration(): fas_residual(l), iteration(l+1), then this), so v_j == x bit for bit
             double uc[E];
             load_row(Lc.u + (size_t)j * Lc.ld, sl, uc);
-            load_row(Lc.v + (size_t)j * Lc.ld, sl, gi);
 #pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = x[k] + (uc[k] - gi[k]);
+            for (int k = 0; k < E; ++k) x[k] = x[k] + (uc[k] - x[k]);
             store_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
         }
         for (int i = start; i < start + len; ++i) {
