@@ -29,6 +29,9 @@ def main(tag):
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] == counter:
                     per[short(r["Kernel_Name"])][counter].append(float(r["Counter_Value"]))
+    if not per:
+        print("no counter passes found under gpurun_out/: profiles/ left untouched")
+        return
     summary = {}
     for k, d in per.items():
         if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
