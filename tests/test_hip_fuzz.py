@@ -1,0 +1,80 @@
+"""Seeded random configurations of the 1-D steppers on the HIP path against the oracle (bit-exact states and residual norms):
+sizes around the group boundaries, coarsening factors 2..8, two to four levels, V and F cycles, weights, cf_iter, forcing on /
+off, non-uniform time grids. A wider sweep of the same generator: `python tests/test_hip_fuzz.py 200`."""
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def random_case(seed):
+    rng = np.random.default_rng(seed)
+    kind = "heat" if rng.random() < 0.7 else "advection"
+    n_int = int(rng.choice([3, 17, 63, 64, 65, 1000, 1023, 1024, 1025, 2047, 2049, 3071, 4100, 8191, 16384]))
+    nx = n_int + 2 if kind == "heat" else n_int + 1
+    levels = int(rng.integers(2, 5))
+    m = int(rng.integers(2, 9)) if levels < 4 else int(rng.integers(2, 4))
+    nc = int(rng.integers(3, 6))
+    nt = (nc - 1) * m ** (levels - 1) + 1
+    while nt > 400 or (n_int > 4000 and nt > 80):
+        levels -= 1
+        nt = (nc - 1) * m ** (levels - 1) + 1
+    levels = max(levels, 2)
+    t0 = cases.lin(float(rng.uniform(0.01, 3.0)), nt)
+    if rng.random() < 0.3:   # non-uniform fine grid (several coefficient sets)
+        t0 = np.cumsum(np.concatenate(([0.0], rng.uniform(0.5, 1.5, nt - 1)))) * (t0[1] - t0[0])
+    grids = [t0[::m ** l] for l in range(levels)]
+    opts = dict(cycle_type='F' if rng.random() < 0.3 else 'V', cf_iter=int(rng.integers(0, 3)),
+                weight_c=float(rng.choice([1.0, 1.0, 1.3, 0.8])), nested_iteration=bool(rng.random() < 0.5),
+                max_iter=int(rng.integers(1, 4)), tol=0.0)
+    forcing = bool(rng.random() < 0.7)
+    return kind, nx, grids, forcing, opts
+
+
+def run_case(oracle, seed):
+    from test_hip_parity import make_pair
+    kind, nx, grids, forcing, opts = random_case(seed)
+    nested = opts.pop("nested_iteration")
+    mg, op = make_pair(oracle, kind, nx, grids, forcing=forcing, nested_iteration=False, **opts)
+    rng = np.random.default_rng(seed + 1)
+    ref = op.state("u", 0)
+    ref[1:] = rng.standard_normal(ref[1:].shape)       # random initial guess, the same on both sides
+    mg.backend.set_natural("u", 0, ref)
+    tag = (seed, kind, nx, [len(g) for g in grids], forcing, nested, opts)
+    if nested:
+        mg.nested_iteration(); op.nested_iteration()
+        for lvl in range(len(grids)):
+            assert np.array_equal(mg.backend.natural("u", lvl), op.state("u", lvl)), ("nested", lvl, tag)
+    for it in range(opts["max_iter"]):
+        mg.iteration(0, opts["cycle_type"], it, True); op.iteration(0, opts["cycle_type"], it, True)
+        got, want = np.array(mg.compute_residual()), op.residual_norms()
+        assert np.array_equal(got, want), ("residual", it, tag)
+    for lvl in range(len(grids)):
+        assert np.array_equal(mg.backend.natural("u", lvl), op.state("u", lvl)), ("u", lvl, tag)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations_bit_exact(oracle, seed):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    run_case(oracle, 1000 + seed)
+
+
+if __name__ == "__main__":
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle as orc
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    bad = 0
+    for s in range(n):
+        try:
+            run_case(orc, 5000 + s)
+        except AssertionError as exc:
+            bad += 1
+            print("FAIL", str(exc)[:300])
+    print(f"{n - bad} of {n} random configurations bit-exact")
