@@ -102,8 +102,11 @@ class Mgrit:
         self.finished = [False, None]
         self.pre_finished = [True, 0] if self.comm_time_rank == 0 else [False, None]   # mgrit.py:224-228
         self._dry = None            # 'send' / 'recv': farewell traffic of the local criteria (_drain_out / _drain_in)
-        self._pred_gone = None      # None / 'draining' / 'done': has the previous rank left the solve loop?
+        self._gone = {}             # rank -> 'draining' / 'done': lower ranks that have left the solve loop (local criteria)
+        self._gone_count = 0        # ranks 0 .. _gone_count-1 have left
         self._drain_seen = set()
+        self._announced_at = None   # criterion call in which this rank told its successor that it has finished
+        self._announce_seen = set()
         self._real_backend = None
         self.save_values_last_iter = None
         self._pipeline_request = pipeline_depth
@@ -277,10 +280,19 @@ class Mgrit:
                     send = (self._real_backend.payload(lvl - 1, int(self.index_local_c[lvl - 1][-1])), dest)
                     self.comm_time.exchange(send=send)
                     return
-        elif recv_idx is not None and not self.global_conv_crit:
-            if self._pred_gone == 'done':
+        if self._announced_at is not None and send_idx is not None and self._dry is None:
+            # finished by the point-wise test but still iterating (the norm of the local values is not below tol yet,
+            # mgrit.py:627-635): the successor takes the first message of every (level, op) of the NEXT iteration and
+            # nothing after that (sender_finished, mgrit.py:693-701)
+            if self.solve_iter != self._announced_at + 1 or (lvl, op) in self._announce_seen:
+                send_idx = None
+            else:
+                self._announce_seen.add((lvl, op))
+        if self._dry != 'send' and recv_idx is not None and not self.global_conv_crit:
+            state = self._gone.get(src)     # the sender of this level may be any lower rank (ranks without points are skipped)
+            if state == 'done' or (self._dry == 'recv' and state != 'draining'):
                 recv_idx = None
-            elif self._pred_gone == 'draining' or self._dry == 'recv':
+            elif state == 'draining':
                 if (lvl, op) in self._drain_seen:
                     recv_idx = None
                 else:
@@ -400,16 +412,26 @@ class Mgrit:
             parts = self.comm_time.allgather_object([float(x) for x in val])
             self.conv[iteration] = time_norm(np.array([x for part in parts for x in part]), self.t_norm)
         else:   # local criterion (mgrit.py:434-455): every local point below the tolerance AND the previous rank has finished
-            if self.comm_time_rank > 0 and not self.pre_finished[0]:            # op 6: the predecessor's verdict of this iteration
-                if bool(self.comm_time.exchange(recv=(None, self.comm_time_rank - 1))):
+            # op 6 carries HOW MANY leading ranks have left (the reference piggybacks a flag on every message instead): a
+            # coarse level's sender may be any lower rank, and its farewell messages must be recognised as such
+            rank = self.comm_time_rank
+            for q, st in list(self._gone.items()):
+                if st == 'draining':
+                    self._gone[q] = 'done'      # one iteration has consumed their farewell messages
+            if rank > 0 and not self.pre_finished[0]:
+                known = int(self.comm_time.exchange(recv=(None, rank - 1)))
+                for q in range(self._gone_count, known):
+                    self._gone[q] = 'draining'
+                if known > self._gone_count:
+                    self._gone_count, self._drain_seen = known, set()
+                if known >= rank:
                     self.pre_finished = [True, iteration]
-                    self._pred_gone, self._drain_seen = 'draining', set()
-            elif self._pred_gone == 'draining':
-                self._pred_gone = 'done'    # one iteration has consumed the predecessor's farewell messages
             self.finished = [bool(self.pre_finished[0] and (all(v < self.tol for v in val) or iteration == self.iter_max)),
                              iteration]
-            if self.comm_time_rank < self.comm_time_size - 1:
-                self.comm_time.exchange(send=(bool(self.finished[0]), self.comm_time_rank + 1))
+            if rank < self.comm_time_size - 1 and self._announced_at is None:   # the successor stops listening afterwards
+                self.comm_time.exchange(send=(rank + 1 if self.finished[0] else self._gone_count, rank + 1))
+                if self.finished[0]:
+                    self._announced_at = iteration
             self.conv[iteration] = time_norm(np.array([float(x) for x in val]), self.t_norm)
         logging.debug(f"Convergence criterion on {self.comm_time_rank} took {time.time() - t0} s")
 
@@ -651,11 +673,12 @@ class Mgrit:
 
     def _leave_local(self, iteration):
         """clean_up (mgrit.py:648-691) of a rank that leaves the solve loop under a local criterion"""
-        if self.comm_time_rank < self.comm_time_size - 1:
-            self._dry_walk('send', iteration + 1)
-        if self.comm_time_rank > 0 and self._pred_gone == 'draining':   # the predecessor left in this very iteration
+        if self.comm_time_rank < self.comm_time_size - 1 and self._announced_at == iteration + 1:
+            self._dry_walk('send', iteration + 1)   # announced earlier: the successor has already been served
+        if any(st == 'draining' for st in self._gone.values()):   # ranks that left in this very iteration: take their messages
             self._dry_walk('recv', iteration + 1)
-            self._pred_gone = 'done'
+            for q in self._gone:
+                self._gone[q] = 'done'
 
     def solve(self) -> dict:
         if self.pipeline_depth() > 0:
@@ -670,7 +693,8 @@ class Mgrit:
             it_stop = time.time()
             self.convergence_criterion(iteration=iteration + 1)
             now, before = self.conv[iteration + 1], self.conv[iteration]
-            factor = '-' if iteration == 0 else str(now / before)
+            with np.errstate(divide='ignore', invalid='ignore'):     # a rank whose residuals are exactly zero
+                factor = '-' if iteration == 0 else str(now / before)
             label = f" | conv: {now}" if self.global_conv_crit else f" | conv on process {self.comm_time_size - 1}: {now}"
             self.log_info('{0: <7}'.format(f"iter {iteration + 1}") + '{0: <32}'.format(label) +
                           '{0: <37}'.format(f" | conv factor: {factor}") +

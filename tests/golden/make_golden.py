@@ -543,6 +543,66 @@ def make_local_conv_ranks():
     print("wrote local_conv_ranks", {k: [len(r["conv"]) for r in v] for k, v in out.items()})
 
 
+class Labelled:
+    """a message of the reference together with the level it was sent for"""
+
+    def __init__(self, data, lvl):
+        self.data, self.lvl = data, lvl
+
+
+def make_exchange_fuzz():
+    """the reference on tests/fuzz_cases.py's random hierarchies at the SAME rank count (threads as ranks): with
+    non-uniform coarsening its results depend on the rank count, so the one-rank run is no yardstick there"""
+    from mpi4py import MPI
+    sys.path.insert(0, os.path.dirname(HERE))
+    from fuzz_cases import N_CASES, SEED0, random_case
+    # the reference's tags are base[op] + (messages so far on THAT level, op) (mgrit.py:192-195): two levels can hold the
+    # same tag at once, and the farewell messages of a finished rank (clean_up, mgrit.py:648-668) are then matched to the
+    # wrong level's receive. Label every message with its level to notice; such runs are recorded but are no yardstick.
+    crossed = []
+    ref_send, ref_receive = Mgrit.send, Mgrit.receive
+
+    def send(self, data, dest, lvl, op_id):
+        ref_send(self, Labelled(data, lvl), dest, lvl, op_id)
+
+    def receive(self, source, lvl, op_id):
+        got = ref_receive(self, source, lvl, op_id)
+        if got.lvl != lvl:
+            crossed.append((lvl, got.lvl, op_id))
+        return got.data
+    Mgrit.send, Mgrit.receive = send, receive
+    out = {}
+    for seed in range(SEED0, SEED0 + N_CASES):
+        grids, opts, size, _ = random_case(seed)
+        size = min(size, len(grids[0]))
+        del crossed[:]
+
+        def one(rank, grids=grids, opts=opts):
+            m = Mgrit(problem=[Dahlquist(t_interval=np.asarray(g)) for g in grids], logging_lvl=QUIET, **opts)
+            info = m.solve()
+            # the reference takes its F-point order from the iteration order of a Python set (mgrit.py:771-775); when the
+            # local index span exceeds the set's table the order is scrambled and an F-point can be updated BEFORE the
+            # F-point it depends on -- such runs of the reference are recorded but are no yardstick
+            scrambled = False
+            for order in m.index_local_f:
+                seen = set()
+                members = set(int(i) for i in order)
+                for i in (int(i) for i in order):
+                    scrambled |= (i - 1 in members and i - 1 not in seen)
+                    seen.add(i)
+            return {"conv": [float(c) for c in info["conv"]], "scrambled": bool(scrambled),
+                    "u": [float(np.asarray(m.u[0][int(i)].get_values()).ravel()[0]) for i in m.index_local[0]]}
+        ranks = MPI.run_world(size, one, timeout=120)
+        out[str(seed)] = {"size": size, "n": [len(g) for g in grids], "scrambled": any(r.pop("scrambled") for r in ranks),
+                          "crossed": bool(crossed), "ranks": ranks}
+    Mgrit.send, Mgrit.receive = ref_send, ref_receive
+    with open(os.path.join(HERE, "exchange_fuzz.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("wrote exchange_fuzz", os.path.getsize(os.path.join(HERE, "exchange_fuzz.json")),
+          "scrambled F order in", sum(v["scrambled"] for v in out.values()), "crossed messages in",
+          sum(v["crossed"] for v in out.values()), "of", len(out))
+
+
 def ref_results():
     res = {}
     d = os.path.join(REF, "tests", "mpi", "results")
@@ -563,6 +623,9 @@ def main():
         return
     if "--only-local-conv-ranks" in sys.argv:
         make_local_conv_ranks()
+        return
+    if "--only-exchange-fuzz" in sys.argv:
+        make_exchange_fuzz()
         return
     if "--only-at-mgrit" in sys.argv:
         make_at_mgrit()
@@ -590,6 +653,7 @@ def main():
     make_local_conv()
     make_at_mgrit()
     make_local_conv_ranks()
+    make_exchange_fuzz()
     res, kats = ref_results()
     with open(os.path.join(HERE, "ref_results.json"), "w") as f:
         json.dump({"tests_mpi_results": res}, f, indent=1)

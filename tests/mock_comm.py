@@ -159,8 +159,10 @@ def run_ranks(size, target, timeout=120, shared_stream=False):
     threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(size)]
     for t in threads:
         t.start()
+    import time
+    deadline = time.time() + timeout        # one deadline for the whole world, not one per rank
     for t in threads:
-        t.join(timeout)
+        t.join(max(0.0, deadline - time.time()))
     stuck = [r for r, t in enumerate(threads) if t.is_alive()]
     if any(e is not None for e in err):
         raise [e for e in err if e is not None][0]
