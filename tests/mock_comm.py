@@ -129,7 +129,7 @@ class MockComm:
             if recv is not None:
                 fut = queue.Queue(maxsize=1)
                 self._stream.put(("recv", recv[1], fut))
-                result = fut.get()
+                result = self._deliver(recv[0], fut.get())
             return result
         if send is not None:
             payload, dest = send
@@ -139,9 +139,17 @@ class MockComm:
             import copy
             self._outbox[dest].put(copy.deepcopy(payload))
         if recv is not None:
-            _, src = recv
-            result = self.world.channel(src, self.rank).get()
+            buf, src = recv
+            result = self._deliver(buf, self.world.channel(src, self.rank).get())
         return result
+
+    @staticmethod
+    def _deliver(buf, item):
+        """a tensor receive buffer is filled in place, as TorchTimeComm.exchange does (the HIP backend hands out slab rows)"""
+        if buf is not None and hasattr(buf, "copy_"):
+            buf.copy_(item)
+            return buf
+        return item
 
 
 def run_ranks(size, target, timeout=120, shared_stream=False):

@@ -1,0 +1,71 @@
+"""The random hierarchies of tests/fuzz_cases.py (uniform and arbitrary-subset coarsening, 2-8 ranks, ranks without coarse
+points, V/F cycles, cf_iter 0-2, every stopping criterion, pipelined depths 0-4) on the HIP engine: ranks are threads that
+share the one GPU and talk through the rendezvous communicator of tests/mock_comm.py. The yardstick is the SAME sharded run
+with host steppers (the plugin path, which tests/test_exchange_fuzz.py pins to the reference rank by rank): same number of
+iterations on every rank, stopping values and solution within the north-star tolerance (1e-10 relative); for uniform
+hierarchies under a global criterion the HIP run must also equal the one-rank HIP run bit for bit."""
+import numpy as np
+import pytest
+
+import cases
+from fuzz_cases import N_CASES, SEED0, random_case
+from mock_comm import run_ranks
+from test_exchange_fuzz import uniform
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+RTOL = 1e-10
+
+
+def heat(grids, nx, device):
+    from pymgrit_amd import Heat1D
+    prob = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=cases.init_cond, rhs_separable=[(cases.rhs_space, cases.rhs_time)],
+                   t_interval=np.asarray(g)) for g in grids]
+    if not device:
+        for p in prob:
+            p.device_stepper = lambda: None
+    return prob
+
+
+def sharded(grids, nx, opts, size, depth, device):
+    from pymgrit_amd import Mgrit
+
+    def target(comm):
+        mg = Mgrit(heat(grids, nx, device), comm_time=comm, logging_lvl=30, pipeline_depth=depth, **opts)
+        assert (type(mg.backend).__name__ == "HipBackend") == device
+        mg.solve()
+        # the unfiltered history (solve() drops exact zeros: a rank whose residual is 0 on one arithmetic and 1e-16 on the other)
+        return mg.conv.copy(), [np.asarray(mg.u[0][int(i)].pack(), dtype=np.float64).ravel() for i in mg.index_local[0]], mg.solve_iter
+    return run_ranks(size, target, timeout=120)
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
+def test_hip_ranks_equal_host_ranks(seed):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from pymgrit_amd import Mgrit
+    grids, opts, size, depth = random_case(SEED0 + seed)
+    size = min(size, len(grids[0]))
+    nx = int(np.random.default_rng(seed).choice([6, 17, 66, 1026]))
+    tag = (seed, [len(g) for g in grids], nx, opts, size, depth)
+    want = sharded(grids, nx, opts, size, depth, device=False)
+    got = sharded(grids, nx, opts, size, depth, device=True)
+    # values at rounding level carry no digits: eps * cond(I + dt L) ~ 1e-16 (nx-1)^2 for the implicit heat step
+    floor = max(RTOL * max([float(c) for conv, _, _ in want for c in conv] + [1e-4]), 1e-16 * (nx - 1) ** 2)
+    # a stopping value on the tolerance itself (or both in the rounding noise): the two arithmetics may stop an iteration apart
+    near_tol = any(abs(c - opts["tol"]) <= max(1e-6 * opts["tol"], floor) for conv, _, n in want for c in conv[1:n + 1])
+    for rank, ((conv, vals, iters), (conv_h, vals_h, iters_h)) in enumerate(zip(got, want)):
+        if near_tol:
+            continue
+        if opts["conv_crit"] in (2, 3):
+            assert iters == iters_h, (tag, rank, iters, iters_h)     # every rank leaves in the same iteration
+        assert np.allclose(conv, conv_h, rtol=RTOL, atol=floor), (tag, rank, conv, conv_h)
+        scale = max(float(np.max(np.abs(vals_h))) if len(vals_h) else 0.0, 1e-300)
+        assert len(vals) == len(vals_h) and all(np.max(np.abs(a - b)) <= RTOL * scale for a, b in zip(vals, vals_h)), (tag, rank)
+    if opts["conv_crit"] in (0, 1) and uniform(grids):
+        one = Mgrit(heat(grids, nx, True), logging_lvl=30, **opts)
+        one.solve()
+        assert np.array_equal(one.conv, got[0][0]), (tag, one.conv, got[0][0])
+        u1 = [np.asarray(one.u[0][i].pack(), dtype=np.float64).ravel() for i in range(len(grids[0]))]
+        assert all(np.array_equal(a, b) for a, b in zip([v for _, vals, _ in got for v in vals], u1)), tag
