@@ -178,6 +178,9 @@ typedef struct {
     double *tab;            /* heat: wg[j] (n) ; advection: rp[j] = r^(j+1) (n) */
     double pt_full[ORC_GROUP]; /* heat: local backward scan of rho^(j'+1) over a full group of 1024           */
     double pt_last[ORC_GROUP]; /* same for the last (possibly partial) group, zero beyond its length          */
+    /* tables of the overlapped chain, built on first use: [0] full group, [1] last group */
+    double *ch;                /* q1[2][GROUP], v1[2][GROUP], v2[2][GROUP], then v3[padded n] */
+    double ca1[2], cb1[2], ca2[2], cb2[2], ca3[16], cb3[16];
 } orc_cset;
 
 /* Pt_j' = sum_{i>=j'} rho^(i-j') * rho^(i+1) over a group of len elements: serial recurrences in double */
@@ -791,7 +794,7 @@ orc_problem *orc_problem_create(int n_levels) {
 }
 
 static void free_stepper(orc_stepper *st) {
-    for (int i = 0; i < st->n_csets; ++i) free(st->csets[i].tab);
+    for (int i = 0; i < st->n_csets; ++i) { free(st->csets[i].tab); free(st->csets[i].ch); }
     free(st->csets); free(st->s); free(st->tau); free(st->tau2); free(st->w1); free(st->w2);
     free(st->bc); free(st->W); free(st->Fxe); free(st->Fxo); free(st->Fye); free(st->Fyo); free(st->lx); free(st->ly); free(st->dinv); free(st->X0); free(st->X1);
 }
@@ -1172,8 +1175,129 @@ void orc_c_relax(orc_problem *p, int lvl) {
 }
 
 /* mgrit.py:459-486 */
+
+/* ================================================================================================
+ * Overlapped chain (spec): forward_solve on a Heat1D level whose steps all share one dt and whose vectors
+ * span several groups. The step is the same solve as 3.3, rearranged so that the group-local scans of step i+1 do not wait
+ * for the carries of step i: with the solve result of step i written as  w_i + cm*Q1 + cb*pw - z0*wg  (w_i = zh_i*ik + g_i,
+ * the part that needs no carries), the scans of step i+1 run on  fma(s, tau, w_i)  alone and the images of the three carry
+ * terms under the (linear) group-local scans are added afterwards from tables V1, V2, V3 and their totals.
+ * ============================================================================================== */
+/* group-local image of src (len valid entries, zero beyond): serial forward recurrence, zero padding, serial backward
+ * recurrence. a = forward total (last element), b = backward total (first element). */
+static void chain_local(const orc_cset *c, const double *src, int len, double *V, double *a, double *b) {
+    double y[ORC_GROUP];
+    y[0] = src[0];
+    for (int j = 1; j < ORC_GROUP; ++j) y[j] = fma(c->rho, y[j - 1], src[j]);
+    *a = y[ORC_GROUP - 1];
+    for (int j = len; j < ORC_GROUP; ++j) y[j] = 0.0;
+    double z = y[ORC_GROUP - 1];
+    V[ORC_GROUP - 1] = z;
+    for (int j = ORC_GROUP - 2; j >= 0; --j) { z = fma(c->rho, z, y[j]); V[j] = z; }
+    *b = V[0];
+}
+
+static void cset_chain_tables(orc_cset *c, int n) {
+    if (c->ch) return;
+    int NP = padded(n), G = NP / ORC_GROUP, last_len = n - (G - 1) * ORC_GROUP;
+    c->ch = (double *)calloc((size_t)6 * ORC_GROUP + (size_t)NP, sizeof(double));
+    double src[ORC_GROUP];
+    for (int var = 0; var < 2; ++var) {
+        int len = var ? last_len : ORC_GROUP;
+        const double *pt = var ? c->pt_last : c->pt_full;
+        double *q1 = c->ch + (size_t)var * ORC_GROUP, *v1 = c->ch + (size_t)(2 + var) * ORC_GROUP, *v2 = c->ch + (size_t)(4 + var) * ORC_GROUP;
+        for (int j = 0; j < ORC_GROUP; ++j) q1[j] = (j < len) ? c->ik * pt[j] : 0.0;
+        chain_local(c, q1, len, v1, &c->ca1[var], &c->cb1[var]);
+        for (int j = 0; j < ORC_GROUP; ++j) {
+            int l = j / ORC_E, k = j % ORC_E;
+            src[j] = (j < len) ? (c->lp[ORC_LANES - 1 - l] * c->ik) * c->pw[ORC_E - k] : 0.0;
+        }
+        chain_local(c, src, len, v2, &c->ca2[var], &c->cb2[var]);
+    }
+    double *v3 = c->ch + (size_t)6 * ORC_GROUP;
+    for (int g = 0; g < G; ++g) {
+        int len = (g == G - 1) ? last_len : ORC_GROUP;
+        for (int j = 0; j < ORC_GROUP; ++j) src[j] = (j < len) ? c->tab[(size_t)g * ORC_GROUP + j] : 0.0;
+        chain_local(c, src, len, v3 + (size_t)g * ORC_GROUP, &c->ca3[g], &c->cb3[g]);
+    }
+}
+
+/* does forward_solve on this level use the overlapped chain? (the HIP engine applies the same rule to its local points) */
+static int chain_overlapped(const orc_level *L) {
+    const orc_stepper *st = &L->st;
+    if (st->kind != ORC_HEAT1D || !st->variant || st->n <= ORC_GROUP || st->K > 1 || L->nt < 2) return 0;
+    double dt0 = L->t[1] - L->t[0];
+    for (int i = 2; i < L->nt; ++i) {
+        double dt = L->t[i] - L->t[i - 1];
+        if (memcmp(&dt, &dt0, sizeof(double)) != 0) return 0;
+    }
+    return 1;
+}
+
+static void heat1d_chain_spec(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl];
+    orc_stepper *st = &L->st;
+    int n = st->n, NP = padded(n), G = NP / ORC_GROUP, nt = L->nt, use_g = lvl > 0;
+    double dt = L->t[1] - L->t[0];
+    orc_cset *c = get_cset(st, dt);
+    cset_chain_tables(c, n);
+    const double *v3 = c->ch + (size_t)6 * ORC_GROUP;
+    double *w = (double *)calloc((size_t)NP, sizeof(double)), *zh = (double *)calloc((size_t)NP, sizeof(double));
+    double A[16] = {0}, B[16] = {0}, cm[16] = {0}, zin[17] = {0}, z0 = 0.0;
+    memcpy(w, ROW(L->u, L, 0), sizeof(double) * (size_t)n);
+    for (int i = 1; i < nt; ++i) {
+        p->phi_count[lvl]++;
+        /* group-local scans of step i on the carry-free part of the previous result */
+        for (int j = 0; j < n; ++j) zh[j] = st->K ? fma(st->s[j], st->tau[i] * dt, w[j]) : w[j];
+        for (int j = n; j < NP; ++j) zh[j] = 0.0;
+        for (int g = 0; g < G; ++g) {
+            double *dg = zh + (size_t)g * ORC_GROUP;
+            int var = (g == G - 1);
+            double a = group_scan_fwd(c, dg);
+            for (int j = 0; j < ORC_GROUP; ++j) if (g * ORC_GROUP + j >= n) dg[j] = 0.0;
+            double b = group_scan_bwd(c, dg);
+            /* images of the carry terms of step i-1 (all zero in front of the first step) */
+            const double *v1 = c->ch + (size_t)(2 + var) * ORC_GROUP, *v2 = c->ch + (size_t)(4 + var) * ORC_GROUP;
+            A[g] = fma(-z0, c->ca3[g], fma(zin[g + 1], c->ca2[var], fma(cm[g], c->ca1[var], a)));
+            B[g] = fma(-z0, c->cb3[g], fma(zin[g + 1], c->cb2[var], fma(cm[g], c->cb1[var], b)));
+            for (int j = 0; j < ORC_GROUP; ++j)
+                dg[j] = fma(-z0, v3[(size_t)g * ORC_GROUP + j], fma(zin[g + 1], v2[j], fma(cm[g], v1[j], dg[j])));
+        }
+        /* the one exchange of the step: carries from the totals of all groups (3.3 step 3) */
+        double I[16], Zf[17];
+        for (int g = 0; g < 16; ++g) I[g] = (g < G) ? A[g] : 0.0;
+        cross_scan(c, I, 0);
+        cm[0] = 0.0;
+        for (int g = 1; g < 16; ++g) cm[g] = I[g - 1];
+        for (int g = 0; g < 16; ++g)
+            Zf[g] = (g < G) ? fma(cm[g], (g == G - 1) ? c->pt_last[0] : c->pt_full[0], B[g]) : 0.0;
+        cross_scan(c, Zf, 1);
+        Zf[16] = 0.0;
+        z0 = Zf[0] * c->ik;
+        for (int g = 0; g < 16; ++g) zin[g + 1] = Zf[g + 1];
+        /* result of step i: carry-free part w, then the three carry terms (3.3 step 4 with ik folded into the tables) */
+        double *ui = ROW(L->u, L, i);
+        const double *gi = use_g ? ROW(L->g, L, i) : NULL;
+        for (int g = 0; g < G; ++g) {
+            const double *q1 = c->ch + (size_t)((g == G - 1) ? 1 : 0) * ORC_GROUP;
+            for (int l = 0; l < ORC_LANES; ++l) {
+                double cb = (c->lp[ORC_LANES - 1 - l] * c->ik) * zin[g + 1];
+                for (int k = 0; k < ORC_E; ++k) {
+                    int jj = l * ORC_E + k, j = g * ORC_GROUP + jj;
+                    if (j >= n) continue;
+                    double base = zh[j] * c->ik;
+                    w[j] = use_g ? gi[j] + base : base;
+                    ui[j] = fma(-z0, c->tab[j], fma(c->pw[ORC_E - k], cb, fma(cm[g], q1[jj], w[j])));
+                }
+            }
+        }
+    }
+    free(w); free(zh);
+}
+
 void orc_forward_solve(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl];
+    if (chain_overlapped(L)) { heat1d_chain_spec(p, lvl); return; }
     for (int i = 1; i < L->nt; ++i) {
         if (lvl == 0) phi(p, lvl, i, ROW(L->u, L, i - 1), ROW(L->u, L, i));
         else {

@@ -22,6 +22,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -81,6 +82,8 @@ struct LevelDev {
     const double2 *ptP;   // [n_csets][2][512] heat: group-local backward scan of rho^(j'+1) (full group, last group)
     const int32_t *cidx2; // two-point steppers: [n_pts][2] coefficient sets of the two half-solves (then tc is [K][n_pts][2])
     const double *hc;     // two-point BDF2: [n_pts][4] = (a, nb) of the first and of the second half-solve
+    const double *chT;    // overlapped chain, null when the level does not qualify: V3 row [ld], then
+                          // Q1, V1, V2 as [2][1024] each (full / last group), then a1 b1 a2 b2 [2] each, a3[16], b3[16]
     int n, ld, T, n_pts, K, kind;
 };
 
@@ -832,6 +835,54 @@ void build_pt(const CSet &c, int len, double *pt) {
     }
 }
 
+// group-local image of src (len valid entries, zero beyond) under forward scan, zero padding, backward scan;
+// serial recurrences. a = forward total, b = backward total. (The oracle's chain_local is the same text.)
+void chain_local(const CSet &c, const double *src, int len, double *V, double *a, double *b) {
+    std::vector<double> y(GROUP);
+    y[0] = src[0];
+    for (int j = 1; j < GROUP; ++j) y[j] = std::fma(c.rho, y[j - 1], src[j]);
+    *a = y[GROUP - 1];
+    for (int j = len; j < GROUP; ++j) y[j] = 0.0;
+    double z = y[GROUP - 1];
+    V[GROUP - 1] = z;
+    for (int j = GROUP - 2; j >= 0; --j) {
+        z = std::fma(c.rho, z, y[j]);
+        V[j] = z;
+    }
+    *b = V[0];
+}
+
+// tables of the overlapped chain for one coefficient set, in the layout LevelDev::chT describes
+void build_chain_tables(const CSet &c, const std::vector<double> &tab, const double *pt_full, const double *pt_last, int n,
+                        int ld, std::vector<double> &out) {
+    const int G = ld / GROUP, last_len = n - (G - 1) * GROUP;
+    out.assign((size_t)ld + 6 * GROUP + 8 + 2 * MAX_G, 0.0);
+    double *sc = out.data() + ld + 6 * GROUP;
+    std::vector<double> src(GROUP), q1(GROUP), V(GROUP);
+    for (int var = 0; var < 2; ++var) {
+        const int len = var ? last_len : GROUP;
+        const double *pt = var ? pt_last : pt_full;
+        for (int j = 0; j < GROUP; ++j) q1[j] = j < len ? c.ik * pt[j] : 0.0;
+        chain_local(c, q1.data(), len, V.data(), &sc[var], &sc[2 + var]);
+        for (int j = 0; j < GROUP; ++j) {
+            out[(size_t)ld + (size_t)var * GROUP + row_pos(j)] = q1[j];
+            out[(size_t)ld + (size_t)(2 + var) * GROUP + row_pos(j)] = V[j];
+        }
+        for (int j = 0; j < GROUP; ++j) {
+            const int l = j / E, k = j % E;
+            src[j] = j < len ? (c.lp[LANES - 1 - l] * c.ik) * c.pw[E - k] : 0.0;
+        }
+        chain_local(c, src.data(), len, V.data(), &sc[4 + var], &sc[6 + var]);
+        for (int j = 0; j < GROUP; ++j) out[(size_t)ld + (size_t)(4 + var) * GROUP + row_pos(j)] = V[j];
+    }
+    for (int g = 0; g < G; ++g) {
+        const int len = g == G - 1 ? last_len : GROUP;
+        for (int j = 0; j < GROUP; ++j) src[j] = j < len ? tab[(size_t)g * GROUP + j] : 0.0;
+        chain_local(c, src.data(), len, V.data(), &sc[8 + g], &sc[8 + MAX_G + g]);
+        for (int j = 0; j < GROUP; ++j) out[row_pos(g * GROUP + j)] = V[j];
+    }
+}
+
 void build_cset_heat1d(CSet &c, std::vector<double> &tab, int n, double fac, double dt) {
     const double beta = dt * fac;
     const double D = dt * (2.0 * fac) + 1.0;
@@ -885,6 +936,12 @@ int dev_upload(Level &lv, hipStream_t st, const std::vector<T> &h, T **out) {
     }
     *out = static_cast<T *>(d);
     return 0;
+}
+
+// MGRIT_HIP_CHAIN_PLAIN=1: forward_solve with the plain per-step arithmetic of 3.3 everywhere (measurement switch)
+bool plain_chain() {
+    static const bool v = [] { const char *s = std::getenv("MGRIT_HIP_CHAIN_PLAIN"); return s && s[0] == '1'; }();
+    return v;
 }
 
 size_t smem_bytes(int G) { return (size_t)(8 * G * LANES + 2 * 512) * sizeof(double2) + (5 * MAX_G + LANES) * sizeof(double); }
@@ -980,7 +1037,9 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     lv.n_csets = (int)uniq.size();
     std::vector<CSet> cs(uniq.size());
     std::vector<double> tabT(uniq.size() * (size_t)E * T, 0.0), tab;  // row storage order per coefficient set
-    std::vector<double> ptT(uniq.size() * (size_t)2 * GROUP, 0.0), pt(GROUP);
+    std::vector<double> ptT(uniq.size() * (size_t)2 * GROUP, 0.0), pt(GROUP), pt_last(GROUP), chT;
+    // the overlapped chain (the oracle's chain_overlapped is the same rule on its one rank)
+    const bool overlapped = kind == MGRIT_HIP_STEPPER_HEAT1D && G >= 2 && uniq.size() == 1 && K <= 1;
     for (size_t q = 0; q < uniq.size(); ++q) {
         std::memset(&cs[q], 0, sizeof(CSet));
         if (kind == MGRIT_HIP_STEPPER_HEAT1D) {
@@ -988,9 +1047,10 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
             build_pt(cs[q], GROUP, pt.data());
             cs[q].pi_full = pt[0];
             for (int j = 0; j < GROUP; ++j) ptT[q * (size_t)2 * GROUP + row_pos(j)] = pt[j];
-            build_pt(cs[q], n - ((n - 1) / GROUP) * GROUP, pt.data());
-            cs[q].pi_last = pt[0];
-            for (int j = 0; j < GROUP; ++j) ptT[q * (size_t)2 * GROUP + GROUP + row_pos(j)] = pt[j];
+            build_pt(cs[q], n - ((n - 1) / GROUP) * GROUP, pt_last.data());
+            cs[q].pi_last = pt_last[0];
+            for (int j = 0; j < GROUP; ++j) ptT[q * (size_t)2 * GROUP + GROUP + row_pos(j)] = pt_last[j];
+            if (overlapped) build_chain_tables(cs[q], tab, pt.data(), pt_last.data(), n, ld, chT);
         } else build_cset_advection1d(cs[q], tab, n, fac, uniq[q]);
         for (int j = 0; j < n; ++j) tabT[q * (size_t)E * T + row_pos(j)] = tab[j];
     }
@@ -1014,6 +1074,12 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     d.ptP = reinterpret_cast<const double2 *>(d_ptT);
     d.sP = reinterpret_cast<const double2 *>(d_sT);
     d.tabP = reinterpret_cast<const double2 *>(d_tabT);
+    d.chT = nullptr;
+    if (overlapped) {
+        double *d_chT;
+        if ((rc = dev_upload(lv, e->stream, chT, &d_chT))) return rc;
+        d.chT = d_chT;
+    }
     lv.set = true;
     return 0;
 }
@@ -1671,7 +1737,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
         // sequential chain: one two-wave workgroup (compute + streamer) per group, exchange through global granules
         if (!e->chain_gran) {
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->chain_gran), sizeof(u64) * 4 * MAX_G * 4));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->chain_err), 64, hipHostMallocMapped));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->chain_err), 256, hipHostMallocMapped));
             *e->chain_err = 0u;
         }
         const bool use_g = lvl > 0;
@@ -1680,6 +1746,20 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
             const dim3 grid(8 * lv.G), block(2 * LANES);
             const int st = rl->h_start[r], ln = rl->h_len[r];
+            if (lv.dev.chT && fm <= 1 && !plain_chain()) {   // one coefficient set, several groups: the overlapped chain
+                if (fm == 0 && !use_g) hipLaunchKernelGGL((chain2_kernel<0, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
+                if (fm == 0 && use_g) hipLaunchKernelGGL((chain2_kernel<0, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
+                if (fm == 1 && !use_g) hipLaunchKernelGGL((chain2_kernel<1, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
+                if (fm == 1 && use_g) hipLaunchKernelGGL((chain2_kernel<1, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
+                HIP_TRY(hipGetLastError());
+#ifdef MGRIT_EXPERIMENT_COUNT_SPINS
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                std::fprintf(stderr, "chain2 polls per step:");
+                for (int g = 0; g < lv.G; ++g) std::fprintf(stderr, " %.2f", (double)e->chain_err[1 + g] / ln);
+                std::fprintf(stderr, "\n");
+#endif
+                continue;
+            }
 #define CHAIN_CASE(K, F, G_, S_)                                                                              \
     if (lv.dev.kind == K && fm == F && use_g == G_ && (lv.G == 1) == S_)                                       \
         hipLaunchKernelGGL((chain_kernel<K, F, G_, S_>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);

@@ -293,6 +293,18 @@ def make_solve(big=True):
         c2 = heat_levels(1024, [4097, 1025, 257])
         rec = run(c2, cf_iter=1, nested_iteration=True, max_iter=4, tol=1e-30, sample_pts=(2048, 4096))
         out["heat_config2"] = rec
+    out.update(make_solve_wide())
+    return out
+
+
+def make_solve_wide():
+    """states wider than one group of 1024 values (several workgroups per state on the GPU): the coarsest
+    level runs through the overlapped chain of the spec; full and partial last group, V and F cycles, with / without forcing"""
+    out = {}
+    out["heat_nx2050_wide"] = run(heat_levels(2050, [65, 17, 5]), tol=1e-9, max_iter=6, sample_pts=(1, 33, 64))
+    out["heat_nx1500_wide_F"] = run(heat_levels(1500, [33, 9, 3], forcing=False), tol=1e-9, max_iter=6, cycle_type='F',
+                                    nested_iteration=False, sample_pts=(16, 32))
+    out["heat_nx3100_wide_2lvl"] = run(heat_levels(3100, [33, 9]), tol=1e-9, max_iter=2, cf_iter=2, sample_pts=(32,))
     return out
 
 
@@ -623,6 +635,13 @@ def main():
         return
     if "--only-local-conv-ranks" in sys.argv:
         make_local_conv_ranks()
+        return
+    if "--only-solve-wide" in sys.argv:
+        with open(os.path.join(HERE, "solve.json")) as f:
+            sol = json.load(f)
+        sol.update(make_solve_wide())
+        with open(os.path.join(HERE, "solve.json"), "w") as f:
+            json.dump(sol, f, separators=(",", ":"))
         return
     if "--only-exchange-fuzz" in sys.argv:
         make_exchange_fuzz()

@@ -169,6 +169,8 @@ def build_product(name):
         "heat_spatial_coarsening_F": ("heat", [129, 65, 33], 1.0, True),
         "advection_example": ("advection", 129, None, None), "advection_3lvl_F": ("advection", 257, None, None),
         "heat_config2": ("heat", 1024, 1.0, True),
+        "heat_nx2050_wide": ("heat", 2050, 1.0, True), "heat_nx1500_wide_F": ("heat", 1500, 1.0, False),
+        "heat_nx3100_wide_2lvl": ("heat", 3100, 1.0, True),
     }
     c = cases.solve_cases()[name]
     kind, nx, x_end, forcing = P.get(name, ("heat", 33, 1.0, True))
