@@ -331,6 +331,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # a GPU that has just been handed to the process is still ramping its clocks (first run on a fresh box: 20.6 ms per cycle,
+    # every later run 19.0-19.2): keep it busy for a second with level-0 F-relax launches -- idempotent on a relaxed state, no
+    # exchange, so every rank can do it on its own clock -- before the W warm-up steps
+    fence()
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 1.0:
+        for _ in range(20):
+            be.relax(0, mg._f_runs(0), 'F')
+        be.sync()
     pipelined = mg.pipeline_depth() > 0   # several ranks: the solver's own pipelined loop (Mgrit._solve_pipelined)
     if pipelined:
         # the same steps through the solver's pipelined loop: every step still is one cycle + its stopping value; the values
