@@ -685,6 +685,76 @@ __global__ void __launch_bounds__(1024) fas_fused_kernel(LevelDev L, LevelDev Lc
     }
 }
 
+// The same sweep in ONE pass per C-point for Heat1D (both levels of the pair): fine Phi with the fine level's tables in LDS
+// as everywhere else, then the coarse Phi with the coarse level's correction table, Pt and forcing factors read straight
+// from global memory -- 144 KB per level that every workgroup reads, so they stay in L2 and cost no HBM traffic -- and the
+// scalar coefficients of the level in use reloaded in front of each Phi (scalar loads; both sets at once would not fit the
+// SGPR file). The partial g of the two-phase form never leaves the registers: 3 vectors read (+g_i), 3 written per C-point
+// instead of 4-5 and 4. Arithmetic identical to fas_fused_kernel.
+template <int FORCE>
+__global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ fine_idx,
+                                                          const int32_t *__restrict__ prev_idx,
+                                                          const int32_t *__restrict__ coarse_idx, int n_items, int use_g) {
+    constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
+    WG_PROLOGUE;
+    Smem smc = sm;
+    for (int p = blockIdx.x; p < n_items; p += gridDim.x) {
+        const int i = fine_idx[p], j = coarse_idx[p], ip = prev_idx[p];
+        double x[E], w[E];
+        load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
+        load_row(L.u + (size_t)i * L.ld, sl, w);
+        store_row(Lc.u + (size_t)j * Lc.ld, sl, w);
+        store_row(Lc.v + (size_t)j * Lc.ld, sl, w);
+        if (use_g) {
+            double gi[E];
+            load_row(L.g + (size_t)i * L.ld, sl, gi);
+#pragma unroll
+            for (int k = 0; k < E; ++k) w[k] = gi[k] - w[k];
+        }
+        if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);   // not kept alive across the coarse Phi below
+        phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+        if (use_g) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = w[k] + x[k];
+            load_row(L.u + (size_t)i * L.ld, sl, w);   // u^l_i once more (one live vector less while Phi runs)
+        } else {
+            load_row(L.u + (size_t)i * L.ld, sl, w);   // likewise: re-read (an L2 hit) instead of held across Phi
+#pragma unroll
+            for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = x[k] + w[k];   // + v_j : the partial g of the coarse level
+        // ---- coarse Phi on v_{j-1} = u^l_{ip}
+        load_row(L.u + (size_t)ip * L.ld, sl, w);
+        const int cj = __builtin_amdgcn_readfirstlane(Lc.cidx[j]);
+        const CSet *gc = Lc.cs + cj;
+        smc.tab = const_cast<double2 *>(Lc.tabP) + (size_t)cj * 8 * Lc.T;
+        smc.pt = const_cast<double2 *>(Lc.ptP) + (size_t)cj * 1024;
+        if (FORCE != 0) {
+            for (int kk = 0; kk < Lc.K; ++kk) {
+                const double ck = Lc.tc[(size_t)kk * Lc.n_pts + j];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const double2 sv = Lc.sP[(size_t)kk * 8 * Lc.T + sl + q * 64];
+                    w[2 * q] = fma(sv.x, ck, w[2 * q]);
+                    w[2 * q + 1] = fma(sv.y, ck, w[2 * q + 1]);
+                }
+            }
+        }
+        {
+            Coef cc;
+            load_coef(cc, gc);
+            const LaneCoef lcc = lane_coef(gc->lp, lane);
+            const int par = ctx.parity;
+            ctx.parity ^= 1;
+            heat_solve(w, cc, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
+        store_row(Lc.g + (size_t)j * Lc.ld, sl, x);
+    }
+}
+
 // --- spatial transfer kernels (bandwidth-bound, elementwise over ROW POSITIONS of the destination) ---------------
 // restriction: dst row d_idx[p] <- R(src row s_idx[p]). kind 0 copy (same T: position-wise copy); kind 1 full
 // weighting (examples/example_spatial_coarsening.py:33-55: sol[2i]*1/4 + sol[2i+1]*1/2 + sol[2i+2]*1/4).
@@ -944,6 +1014,12 @@ bool plain_chain() {
     return v;
 }
 
+// MGRIT_HIP_FAS_TWO_PHASE=1: the two-phase fused FAS sweep for Heat1D as well (measurement switch)
+bool two_phase_fas() {
+    static const bool v = [] { const char *s = std::getenv("MGRIT_HIP_FAS_TWO_PHASE"); return s && s[0] == '1'; }();
+    return v;
+}
+
 size_t smem_bytes(int G) { return (size_t)(8 * G * LANES + 2 * 512) * sizeof(double2) + (5 * MAX_G + LANES) * sizeof(double); }
 
 constexpr int MAX_G2 = MGRIT_HIP_MAX_N_2PTS / GROUP;  // two-point steppers: waves per half
@@ -978,6 +1054,8 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(ecf_kernel<K, F, true>))) return rc;                                                     \
     if ((rc = allow_big_lds(at_kernel<K, F>))) return rc;
     FOR_EACH_STEPPER(ATTR_ALL)
+    if ((rc = allow_big_lds(fas_fused1_kernel<0>))) return rc;
+    if ((rc = allow_big_lds(fas_fused1_kernel<2>))) return rc;
     if ((rc = allow_big_lds(jump_kernel))) return rc;
 #define ATTR_2PTS(O, F)                                                                                              \
     if ((rc = allow_big_lds(relax2_kernel<O, F, false, false>, smem2_bytes(MAX_G2)))) return rc;                     \
@@ -1910,6 +1988,16 @@ int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id) {
         return fail(MGRIT_HIP_EUNSUPPORTED, "fused FAS residual needs the copy transfer and like steppers on both levels");
     if (pl->n == 0) return 0;
     const int use_g = lvl > 0 ? 1 : 0;
+    if (lf.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && !two_phase_fas()) {   // one pass per C-point, coarse tables from L2
+        const dim3 grid(persistent_grid(lf, pl->n)), block(lf.dev.T);
+        const int fm = force_mode(lf);
+        // forcing factors of both levels are streamed (FORCE 2, the same fma per term): one Phi per point does not pay for
+        // keeping them in registers, and the registers are needed for the partial g that stays live across the coarse Phi
+        if (fm == 0) hipLaunchKernelGGL((fas_fused1_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, lf.dev, lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);
+        else hipLaunchKernelGGL((fas_fused1_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, lf.dev, lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
 #define FUSED_CASE(K_, F_)                                                                                         \
     if (lf.dev.kind == K_ && force_mode(lf) == F_)                                                                  \
         hipLaunchKernelGGL((fas_fused_kernel<K_, F_>), dim3(persistent_grid(lf, pl->n)), dim3(lf.dev.T), smem_bytes(lf.G),  \
