@@ -265,6 +265,8 @@ def main():
     ap.add_argument("--nx", type=int, default=16384)
     ap.add_argument("--nt", type=int, default=65537)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ramp", action="store_true", help="skip the one-second clock ramp (profiling runs: it would "
+                    "fill the kernel summary with its own F-relax launches)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "smoke-test the N>1 path with several ranks on ONE GPU)")
     ap.add_argument("--nt-adv", dest="nt_adv", type=int, default=32769)
@@ -336,7 +338,7 @@ def main():
     # exchange, so every rank can do it on its own clock -- before the W warm-up steps
     fence()
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 1.0:
+    while not args.no_ramp and time.perf_counter() - t_ramp < 1.0:
         for _ in range(20):
             be.relax(0, mg._f_runs(0), 'F')
         be.sync()

@@ -44,7 +44,7 @@ def main(tag):
                       "hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0}
     with open(os.path.join(out, f"{tag}_traffic.json"), "w") as f:
         json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around "
-                           "`python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline`; KiB units; read side doubled "
+                           "`python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ramp`; KiB units; read side doubled "
                            "(gfx950 FETCH_SIZE tallies 128-B requests at 64 B). Averages mix levels for kernels that "
                            "are launched on several levels; relax_kernel<1, 1, false, 0> is level-0 F-relax only.",
                    "kernels": summary}, f, indent=1)
