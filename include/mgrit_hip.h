@@ -73,6 +73,15 @@ int mgrit_hip_level_heat2d(mgrit_hip_engine *e, int lvl, int n_pts_local, const 
                            double fx, double fy, double theta, const double *bc, int K, const double *S, const double *tau);
 /* Device slabs u, v, g of Mgrit.create_u_v_g (mgrit.py:840-858); v and g may be NULL on level 0. */
 int mgrit_hip_level_bind(mgrit_hip_engine *e, int lvl, double *u, double *v, double *g);
+/* Hand-over state of forward_solve (mgrit.py:459-486) between the owners of a level (op 5, mgrit.py:468-485): a level whose
+ * forward solve runs in the overlapped form continues on the next rank bit for bit only if that rank gets,
+ * besides the last point itself, the carry-free part of it and the carries of its step. *len_out = number of doubles of
+ * that state (0: the level hands over the last point alone). The caller owns the buffer (mgrit_hip_chain_bind), sends it
+ * behind the last point, and calls mgrit_hip_chain_resume(…, 1) after it has received one: the next CHAIN relax on the level
+ * then starts from the state instead of from the ghost point alone (the flag clears itself). */
+int mgrit_hip_chain_state_len(mgrit_hip_engine *e, int lvl, int *len_out);
+int mgrit_hip_chain_bind(mgrit_hip_engine *e, int lvl, double *state);
+int mgrit_hip_chain_resume(mgrit_hip_engine *e, int lvl, int on);
 /* Spatial transfer between lvl and lvl+1: GridTransferCopy (core/grid_transfer_copy.py:23-47) or the full-weighting
  * / linear-interpolation pair of examples/example_spatial_coarsening.py:33-82 (fine n = 2*coarse n + 1), or its periodic
  * analogue for Advection1D grids (fine n = 2*coarse n; no reference class exists, BASELINE config 5). */

@@ -90,6 +90,7 @@ class HipBackend:
         self.U, self.V, self.G = [], [], []
         self._runs, self._pairs = {}, {}
         self._described = [False] * mg.lvl_max
+        self.chain_state, self._handover = {}, {}
         self.prev = None
         self._sumsq = None
 
@@ -161,6 +162,13 @@ class HipBackend:
         check(self.lib.mgrit_hip_level_bind(self.h, lvl, C.c_void_p(u.data_ptr()),
                                             C.c_void_p(v.data_ptr() if v is not None else 0),
                                             C.c_void_p(g.data_ptr() if g is not None else 0)))
+        # hand-over state of the forward solve (op 5) for levels that run the overlapped chain: travels behind the last point
+        slen = C.c_int(0)
+        check(self.lib.mgrit_hip_chain_state_len(self.h, lvl, C.byref(slen)))
+        self.chain_state[lvl] = None
+        if slen.value:
+            self.chain_state[lvl] = torch.zeros(slen.value, dtype=torch.float64, device=self.device)
+            check(self.lib.mgrit_hip_chain_bind(self.h, lvl, C.c_void_p(self.chain_state[lvl].data_ptr())))
         mg.u.append(SlabVectorList(u, n, tmpl, self.perm[lvl]))
         mg.v.append(SlabVectorList(v, n, tmpl, self.perm[lvl]) if v is not None else None)
         mg.g.append(SlabVectorList(g, n, tmpl, self.perm[lvl]) if g is not None else None)
@@ -190,14 +198,25 @@ class HipBackend:
         slab[:, self.perm[lvl]] = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64)).to(slab.device)
 
     # -- exchange payloads: slab rows travel in place over RCCL ---------------------------------------
-    def payload(self, lvl, idx):
+    def payload(self, lvl, idx, op=None):
+        if op == 5 and self.chain_state.get(lvl) is not None:   # forward-solve hand-over: the point and the chain's state
+            return torch.cat((self.U[lvl][idx], self.chain_state[lvl]))
         return self.U[lvl][idx]
 
-    def recv_buffer(self, lvl, idx):
+    def recv_buffer(self, lvl, idx, op=None):
+        if op == 5 and self.chain_state.get(lvl) is not None:
+            if lvl not in self._handover:
+                self._handover[lvl] = torch.empty(self.U[lvl].shape[1] + self.chain_state[lvl].numel(), dtype=torch.float64,
+                                                  device=self.device)
+            return self._handover[lvl]
         return self.U[lvl][idx]
 
-    def commit(self, lvl, idx, got):
-        pass
+    def commit(self, lvl, idx, got, op=None):
+        if op == 5 and self.chain_state.get(lvl) is not None:
+            ld = self.U[lvl].shape[1]
+            self.U[lvl][idx].copy_(got[:ld])
+            self.chain_state[lvl].copy_(got[ld:])
+            check(self.lib.mgrit_hip_chain_resume(self.h, lvl, 1))   # the next forward solve continues the sender's chain
 
     # -- helpers ---------------------------------------------------------------------------------------
     def _handle(self, store, lvl, items, tag, create):

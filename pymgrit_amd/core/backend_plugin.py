@@ -36,13 +36,13 @@ class PluginBackend:
         pass
 
     # -- exchange payloads (mgrit.py:693-713: pack / unpack) ------------------------------------------
-    def payload(self, lvl, idx):
+    def payload(self, lvl, idx, op=None):
         return self.mg.u[lvl][idx].pack()
 
-    def recv_buffer(self, lvl, idx):
+    def recv_buffer(self, lvl, idx, op=None):
         return None
 
-    def commit(self, lvl, idx, got):
+    def commit(self, lvl, idx, got, op=None):
         self.mg.u[lvl][idx].unpack(got)
 
     # -- relaxation (mgrit.py:319-327, 358-368, 472-481) ----------------------------------------------

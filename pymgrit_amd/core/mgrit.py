@@ -300,13 +300,14 @@ class Mgrit:
         if self._dry == 'recv':
             send_idx = None
         backend = self._real_backend if self._dry else self.backend
-        send = (backend.payload(lvl, send_idx), dest) if send_idx is not None else None
-        recv = (backend.recv_buffer(lvl, recv_idx), src) if recv_idx is not None else None
+        kw = {'op': op} if op == 5 else {}     # op 5 (forward-solve hand-over): a backend may send more than the point itself
+        send = (backend.payload(lvl, send_idx, **kw), dest) if send_idx is not None else None
+        recv = (backend.recv_buffer(lvl, recv_idx, **kw), src) if recv_idx is not None else None
         if send is None and recv is None:
             return
         got = self.comm_time.exchange(send=send, recv=recv)
         if recv is not None:
-            backend.commit(lvl, recv_idx, got)
+            backend.commit(lvl, recv_idx, got, **kw)
 
     def _last_slot(self, lvl):
         return len(self.t[lvl]) - 1

@@ -856,6 +856,8 @@ struct Level {
     std::vector<PairList> pairs;
     double *scratch = nullptr;
     size_t scratch_rows = 0;
+    double *chain_state = nullptr;   // caller-owned [ld + CHAIN_STATE_TAIL]: carry-free part of the last point + carries
+    bool chain_resume = false;
 };
 
 }  // namespace
@@ -1711,6 +1713,29 @@ int mgrit_hip_level_bind(mgrit_hip_engine *e, int lvl, double *u, double *v, dou
     return 0;
 }
 
+int mgrit_hip_chain_state_len(mgrit_hip_engine *e, int lvl, int *len_out) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    if (!len_out) return fail(MGRIT_HIP_EINVAL, "null output");
+    *len_out = (e->L[lvl].dev.chT && !plain_chain()) ? e->L[lvl].dev.ld + CHAIN_STATE_TAIL : 0;
+    return 0;
+}
+
+int mgrit_hip_chain_bind(mgrit_hip_engine *e, int lvl, double *state) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    e->L[lvl].chain_state = state;
+    return 0;
+}
+
+int mgrit_hip_chain_resume(mgrit_hip_engine *e, int lvl, int on) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    if (on && !e->L[lvl].chain_state) return fail(MGRIT_HIP_EINVAL, "level %d has no chain state bound", lvl);
+    e->L[lvl].chain_resume = on != 0;
+    return 0;
+}
+
 int mgrit_hip_level_transfer(mgrit_hip_engine *e, int lvl, int kind) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
@@ -1825,10 +1850,13 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             const dim3 grid(8 * lv.G), block(2 * LANES);
             const int st = rl->h_start[r], ln = rl->h_len[r];
             if (lv.dev.chT && fm <= 1 && !plain_chain()) {   // one coefficient set, several groups: the overlapped chain
-                if (fm == 0 && !use_g) hipLaunchKernelGGL((chain2_kernel<0, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
-                if (fm == 0 && use_g) hipLaunchKernelGGL((chain2_kernel<0, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
-                if (fm == 1 && !use_g) hipLaunchKernelGGL((chain2_kernel<1, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
-                if (fm == 1 && use_g) hipLaunchKernelGGL((chain2_kernel<1, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
+                const int resume = (lv.chain_resume && r == 0) ? 1 : 0;
+                lv.chain_resume = false;
+                double *state = lv.chain_state;
+                if (fm == 0 && !use_g) hipLaunchKernelGGL((chain2_kernel<0, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume);
+                if (fm == 0 && use_g) hipLaunchKernelGGL((chain2_kernel<0, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume);
+                if (fm == 1 && !use_g) hipLaunchKernelGGL((chain2_kernel<1, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume);
+                if (fm == 1 && use_g) hipLaunchKernelGGL((chain2_kernel<1, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume);
                 HIP_TRY(hipGetLastError());
 #ifdef MGRIT_EXPERIMENT_COUNT_SPINS
                 HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1838,6 +1866,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
 #endif
                 continue;
             }
+            lv.chain_resume = false;
 #define CHAIN_CASE(K, F, G_, S_)                                                                              \
     if (lv.dev.kind == K && fm == F && use_g == G_ && (lv.G == 1) == S_)                                       \
         hipLaunchKernelGGL((chain_kernel<K, F, G_, S_>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
