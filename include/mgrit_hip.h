@@ -79,6 +79,10 @@ int mgrit_hip_level_bind(mgrit_hip_engine *e, int lvl, double *u, double *v, dou
  * that state (0: the level hands over the last point alone). The caller owns the buffer (mgrit_hip_chain_bind), sends it
  * behind the last point, and calls mgrit_hip_chain_resume(…, 1) after it has received one: the next CHAIN relax on the level
  * then starts from the state instead of from the ghost point alone (the flag clears itself). */
+/* mgrit_hip_chain_enable(…, 0) keeps the level on the plain per-step forward solve: the engine sees only this rank's points,
+ * but every owner of a level has to take the same form (and exchange the same hand-over), so the caller decides from the
+ * level's GLOBAL time grid (one step size everywhere) and tells every rank the same. Default: enabled. */
+int mgrit_hip_chain_enable(mgrit_hip_engine *e, int lvl, int on);
 int mgrit_hip_chain_state_len(mgrit_hip_engine *e, int lvl, int *len_out);
 int mgrit_hip_chain_bind(mgrit_hip_engine *e, int lvl, double *state);
 int mgrit_hip_chain_resume(mgrit_hip_engine *e, int lvl, int on);

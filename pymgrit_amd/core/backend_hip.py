@@ -8,6 +8,7 @@ is what output_fcn callbacks and subclasses of the reference read (SURVEY sectio
 No CPU fallback: constructing this backend without libmgrit_hip.so or without a GPU raises MgritHipError.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -90,7 +91,7 @@ class HipBackend:
         self.U, self.V, self.G = [], [], []
         self._runs, self._pairs = {}, {}
         self._described = [False] * mg.lvl_max
-        self.chain_state, self._handover = {}, {}
+        self.chain_state, self.chain_handover, self._handover = {}, {}, {}
         self.prev = None
         self._sumsq = None
 
@@ -162,11 +163,21 @@ class HipBackend:
         check(self.lib.mgrit_hip_level_bind(self.h, lvl, C.c_void_p(u.data_ptr()),
                                             C.c_void_p(v.data_ptr() if v is not None else 0),
                                             C.c_void_p(g.data_ptr() if g is not None else 0)))
-        # hand-over state of the forward solve (op 5) for levels that run the overlapped chain: travels behind the last point
+        # Overlapped chain: every owner of the level must take the same form of the forward solve and exchange
+        # the same hand-over (op 5: the last point + the chain's running state), so the decision comes from the level's GLOBAL
+        # time grid -- the engine only sees this rank's points
+        gt = np.asarray(mg.global_t[lvl], dtype=np.float64)
+        dts = np.diff(gt)
+        n_terms = np.asarray(d.get("forcing_space", np.zeros((0, n)))).reshape(-1, n).shape[0] if d["kind"] == "heat1d" else 0
+        wide = (d["kind"] == "heat1d" and n > 1024 and n_terms <= 1 and dts.size > 0
+                and bool(np.all(dts.view(np.int64) == dts.view(np.int64)[0])) and os.environ.get("MGRIT_HIP_CHAIN_PLAIN", "") != "1")
+        check(self.lib.mgrit_hip_chain_enable(self.h, lvl, int(wide)))
         slen = C.c_int(0)
         check(self.lib.mgrit_hip_chain_state_len(self.h, lvl, C.byref(slen)))
         self.chain_state[lvl] = None
+        self.chain_handover[lvl] = ld + 64 if wide else 0     # doubles behind the point in an op-5 message (0: the point alone)
         if slen.value:
+            assert slen.value == self.chain_handover[lvl]
             self.chain_state[lvl] = torch.zeros(slen.value, dtype=torch.float64, device=self.device)
             check(self.lib.mgrit_hip_chain_bind(self.h, lvl, C.c_void_p(self.chain_state[lvl].data_ptr())))
         mg.u.append(SlabVectorList(u, n, tmpl, self.perm[lvl]))
@@ -199,24 +210,28 @@ class HipBackend:
 
     # -- exchange payloads: slab rows travel in place over RCCL ---------------------------------------
     def payload(self, lvl, idx, op=None):
-        if op == 5 and self.chain_state.get(lvl) is not None:   # forward-solve hand-over: the point and the chain's state
-            return torch.cat((self.U[lvl][idx], self.chain_state[lvl]))
+        if op == 5 and self.chain_handover.get(lvl):   # forward-solve hand-over: the point and the chain's running state
+            state = self.chain_state[lvl]
+            if state is None:   # this rank has no step of its own on the level (it owns the first point only): a fresh start
+                state = torch.cat((self.U[lvl][idx], torch.zeros(64, dtype=torch.float64, device=self.device)))
+            return torch.cat((self.U[lvl][idx], state))
         return self.U[lvl][idx]
 
     def recv_buffer(self, lvl, idx, op=None):
-        if op == 5 and self.chain_state.get(lvl) is not None:
+        if op == 5 and self.chain_handover.get(lvl):
             if lvl not in self._handover:
-                self._handover[lvl] = torch.empty(self.U[lvl].shape[1] + self.chain_state[lvl].numel(), dtype=torch.float64,
+                self._handover[lvl] = torch.empty(self.U[lvl].shape[1] + self.chain_handover[lvl], dtype=torch.float64,
                                                   device=self.device)
             return self._handover[lvl]
         return self.U[lvl][idx]
 
     def commit(self, lvl, idx, got, op=None):
-        if op == 5 and self.chain_state.get(lvl) is not None:
+        if op == 5 and self.chain_handover.get(lvl):
             ld = self.U[lvl].shape[1]
             self.U[lvl][idx].copy_(got[:ld])
-            self.chain_state[lvl].copy_(got[ld:])
-            check(self.lib.mgrit_hip_chain_resume(self.h, lvl, 1))   # the next forward solve continues the sender's chain
+            if self.chain_state[lvl] is not None:
+                self.chain_state[lvl].copy_(got[ld:])
+                check(self.lib.mgrit_hip_chain_resume(self.h, lvl, 1))   # the next forward solve continues the sender's chain
 
     # -- helpers ---------------------------------------------------------------------------------------
     def _handle(self, store, lvl, items, tag, create):

@@ -858,6 +858,7 @@ struct Level {
     size_t scratch_rows = 0;
     double *chain_state = nullptr;   // caller-owned [ld + CHAIN_STATE_TAIL]: carry-free part of the last point + carries
     bool chain_resume = false;
+    bool chain_overlapped = true;    // mgrit_hip_chain_enable: the caller's (global) word on the overlapped chain
 };
 
 }  // namespace
@@ -1713,11 +1714,18 @@ int mgrit_hip_level_bind(mgrit_hip_engine *e, int lvl, double *u, double *v, dou
     return 0;
 }
 
+int mgrit_hip_chain_enable(mgrit_hip_engine *e, int lvl, int on) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    e->L[lvl].chain_overlapped = on != 0;
+    return 0;
+}
+
 int mgrit_hip_chain_state_len(mgrit_hip_engine *e, int lvl, int *len_out) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
     if (!len_out) return fail(MGRIT_HIP_EINVAL, "null output");
-    *len_out = (e->L[lvl].dev.chT && !plain_chain()) ? e->L[lvl].dev.ld + CHAIN_STATE_TAIL : 0;
+    *len_out = (e->L[lvl].dev.chT && e->L[lvl].chain_overlapped && !plain_chain()) ? e->L[lvl].dev.ld + CHAIN_STATE_TAIL : 0;
     return 0;
 }
 
@@ -1849,7 +1857,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
             const dim3 grid(8 * lv.G), block(2 * LANES);
             const int st = rl->h_start[r], ln = rl->h_len[r];
-            if (lv.dev.chT && fm <= 1 && !plain_chain()) {   // one coefficient set, several groups: the overlapped chain
+            if (lv.dev.chT && lv.chain_overlapped && fm <= 1 && !plain_chain()) {   // one coefficient set, several groups: the overlapped chain
                 const int resume = (lv.chain_resume && r == 0) ? 1 : 0;
                 lv.chain_resume = false;
                 double *state = lv.chain_state;
