@@ -1223,7 +1223,8 @@ static void cset_chain_tables(orc_cset *c, int n) {
 }
 
 /* does forward_solve on this level use the overlapped chain? (the HIP engine applies the same rule to its local points) */
-static int chain_overlapped(const orc_level *L) {
+static int chain_overlapped(const orc_level *L, int lvl) {
+    if (lvl == 0) return 0;   /* a one-level hierarchy is plain time stepping: its residual must vanish exactly */
     const orc_stepper *st = &L->st;
     if (st->kind != ORC_HEAT1D || !st->variant || st->n <= ORC_GROUP || st->K > 1 || L->nt < 2) return 0;
     double dt0 = L->t[1] - L->t[0];
@@ -1297,7 +1298,7 @@ static void heat1d_chain_spec(orc_problem *p, int lvl) {
 
 void orc_forward_solve(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl];
-    if (chain_overlapped(L)) { heat1d_chain_spec(p, lvl); return; }
+    if (chain_overlapped(L, lvl)) { heat1d_chain_spec(p, lvl); return; }
     for (int i = 1; i < L->nt; ++i) {
         if (lvl == 0) phi(p, lvl, i, ROW(L->u, L, i - 1), ROW(L->u, L, i));
         else {

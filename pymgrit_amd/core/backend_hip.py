@@ -169,7 +169,7 @@ class HipBackend:
         gt = np.asarray(mg.global_t[lvl], dtype=np.float64)
         dts = np.diff(gt)
         n_terms = np.asarray(d.get("forcing_space", np.zeros((0, n)))).reshape(-1, n).shape[0] if d["kind"] == "heat1d" else 0
-        wide = (d["kind"] == "heat1d" and n > 1024 and n_terms <= 1 and dts.size > 0
+        wide = (lvl > 0 and d["kind"] == "heat1d" and n > 1024 and n_terms <= 1 and dts.size > 0
                 and bool(np.all(dts.view(np.int64) == dts.view(np.int64)[0])) and os.environ.get("MGRIT_HIP_CHAIN_PLAIN", "") != "1")
         check(self.lib.mgrit_hip_chain_enable(self.h, lvl, int(wide)))
         slen = C.c_int(0)

@@ -1725,7 +1725,7 @@ int mgrit_hip_chain_state_len(mgrit_hip_engine *e, int lvl, int *len_out) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
     if (!len_out) return fail(MGRIT_HIP_EINVAL, "null output");
-    *len_out = (e->L[lvl].dev.chT && e->L[lvl].chain_overlapped && !plain_chain()) ? e->L[lvl].dev.ld + CHAIN_STATE_TAIL : 0;
+    *len_out = (lvl > 0 && e->L[lvl].dev.chT && e->L[lvl].chain_overlapped && !plain_chain()) ? e->L[lvl].dev.ld + CHAIN_STATE_TAIL : 0;
     return 0;
 }
 
@@ -1857,7 +1857,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
             const dim3 grid(8 * lv.G), block(2 * LANES);
             const int st = rl->h_start[r], ln = rl->h_len[r];
-            if (lv.dev.chT && lv.chain_overlapped && fm <= 1 && !plain_chain()) {   // one coefficient set, several groups: the overlapped chain
+            if (lv.dev.chT && lv.chain_overlapped && use_g && fm <= 1 && !plain_chain()) {   // (level 0 = a one-level hierarchy: plain)   // one coefficient set, several groups: the overlapped chain
                 const int resume = (lv.chain_resume && r == 0) ? 1 : 0;
                 lv.chain_resume = false;
                 double *state = lv.chain_state;
