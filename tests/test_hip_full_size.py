@@ -4,6 +4,7 @@ chain across the rank boundary) produces the residual history and the final time
 and converges like the bounded sample that is compared with the oracle elsewhere (three cycles to 1e-10)."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -16,8 +17,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def run(world):
     cmd = [sys.executable, os.path.join(HERE, "full_size_worker.py")]
     if world > 1:
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-               "--master-port", "29671", os.path.join(HERE, "full_size_worker.py")]
+               "--master-port", str(port), os.path.join(HERE, "full_size_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     res = [json.loads(line.split("RESULT", 1)[1]) for line in out.stdout.splitlines() if "RESULT" in line]
     assert len(res) == world, out.stdout[-2000:] + out.stderr[-2000:]
