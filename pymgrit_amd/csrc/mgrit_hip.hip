@@ -558,8 +558,10 @@ __global__ void __launch_bounds__(1024) residual_kernel(LevelDev L, const int32_
         const int i = run_start[r];
         double x[E], ui[E];
         load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
-        load_row(L.u + (size_t)i * L.ld, sl, ui);
         phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+        // u_i is loaded AFTER Phi: fetched ahead it is a second live vector in a 128-VGPR workgroup, the kernel spills
+        // (84 B per lane of scratch traffic) and runs 25 % longer than with the load latency exposed
+        load_row(L.u + (size_t)i * L.ld, sl, ui);
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] - ui[k];
         const double tot = block_sumsq(x, sm, t, lane, wave, G);
