@@ -18,3 +18,21 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+# Order of the suite (matters under `pytest -x`): the C ABI and the single-process oracle comparisons first, every test
+# that starts other processes or rank threads last, so a fault of the multi-process harness can never hide a parity test.
+_ORDER = ["test_hip_abi", "test_hip_parity", "test_hip_heat2d", "test_hip_fuzz", "test_hip_bdf", "test_advection_sc",
+          "test_hip_output", "test_hip_forcing", "test_hip_graph", "test_at_mgrit", "test_local_conv"]
+_LAST = ["test_hip_distributed", "test_hip_exchange_fuzz", "test_hip_bench_cli", "test_hip_full_size", "test_hip_rccl"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if name in _ORDER:
+            return (0, _ORDER.index(name))
+        if name in _LAST:
+            return (2, _LAST.index(name))
+        return (1, 0)
+    items.sort(key=key)         # stable: the order inside a file is kept

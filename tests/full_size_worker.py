@@ -1,6 +1,7 @@
 """Worker of tests/test_hip_full_size.py: Mgrit.solve() on BASELINE configs[2] at full size (heat_1d nx=16384, nt=65537, 3-level
-m=4) on one rank or sharded over the ranks of torch.distributed.run (gloo transport, all ranks on GPU 0). Prints the residual
-history and hashes of sampled level-0 states."""
+m=4) on one rank or sharded over the ranks of torch.distributed.run (gloo transport, all ranks on GPU 0). Each rank writes
+its residual history and hashes of sampled level-0 states to its OWN file <out_dir>/rank<r>.json (the ranks of
+torch.distributed.run share one stdout pipe: lines of two ranks can interleave there)."""
 import os, sys, hashlib, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
@@ -22,6 +23,10 @@ u = mg.backend.U[0]
 for i in own[:: max(1, len(own) // 64)]:
     h.update(u[i].cpu().numpy().tobytes())
 part = {"rank": rank, "conv": [float(c) for c in conv], "first": own[0], "n": len(own), "u_last": hashlib.sha256(u[own[-1]].cpu().numpy().tobytes()).hexdigest()}
-print("RESULT", json.dumps(part), flush=True)
+out_dir = sys.argv[1]
+tmp = os.path.join(out_dir, f"rank{rank}.json.tmp")
+with open(tmp, "w") as fh:
+    json.dump(part, fh)
+os.replace(tmp, os.path.join(out_dir, f"rank{rank}.json"))
 if world > 1:
     dist.barrier(); dist.destroy_process_group()
