@@ -257,6 +257,25 @@ def bench_advection(args):
     print(json.dumps(out), flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher environment: run the same command line under torch.distributed.run
+    (one rank per GPU, rendezvous on 127.0.0.1 at a free port) as a CHILD process and pass its output and exit code on."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    if proc.returncode != 0:
+        raise SystemExit(proc.returncode if proc.returncode > 0 else 1)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,6 +304,14 @@ def main():
     if args.workload == "advection":
         return bench_advection(args)
 
+    # ---- N > 1 without a launcher around us: start the ranks ourselves, BEFORE anything touches the GPU. The children are
+    # separate processes of `python -m torch.distributed.run` (never an exec of this one); rank 0's JSON line is relayed and
+    # any child failure is this process's exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+
     import torch
     import torch.distributed as dist
     from pymgrit_amd import Heat1D, Mgrit
@@ -302,7 +329,6 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     nx, nt0 = args.nx, args.nt
     nts = [nt0, (nt0 - 1) // 4 + 1, (nt0 - 1) // 16 + 1]

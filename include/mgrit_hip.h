@@ -148,10 +148,23 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id);
 int mgrit_hip_residual_host(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_host);
 int mgrit_hip_jump_host(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev, double *sumsq_host);
 
-/* Timing of the most recent mgrit_hip_relax launch on this engine, measured with HIP events on the engine's stream
- * (enable with mgrit_hip_set_timing(e, 1)); returns milliseconds in *ms. */
+/* Device time of the sweeps, measured with HIP events on the engine's stream around EVERY sweep entry point while timing is
+ * enabled (mgrit_hip_set_timing(e, 1)): what the reference reports per sweep through logging.debug (mgrit.py:301-302,333,
+ * 344,370,486,549). mgrit_hip_last_kernel_ms: the most recent timed call. mgrit_hip_timing_drain: all timed calls since the
+ * last drain, in call order, as (MGRIT_HIP_T_* kind, level, milliseconds); waits for them to finish; at most max_records
+ * are returned (the rest is dropped), *n_out = number returned. */
+enum { MGRIT_HIP_T_RELAX_F = 0, MGRIT_HIP_T_RELAX_C = 1, MGRIT_HIP_T_CHAIN = 2, MGRIT_HIP_T_RESIDUAL = 3, MGRIT_HIP_T_JUMP = 4,
+       MGRIT_HIP_T_RESTRICT = 5, MGRIT_HIP_T_COPY = 6, MGRIT_HIP_T_FAS_RHS = 7, MGRIT_HIP_T_FAS_FUSED = 8,
+       MGRIT_HIP_T_ERROR_CORRECTION = 9, MGRIT_HIP_T_INTERPOLATE = 10, MGRIT_HIP_T_EC_RELAX = 11, MGRIT_HIP_T_AT = 12,
+       MGRIT_HIP_T_KINDS = 13 };
 int mgrit_hip_set_timing(mgrit_hip_engine *e, int enabled);
 int mgrit_hip_last_kernel_ms(mgrit_hip_engine *e, float *ms);
+int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int *lvl, float *ms, int *n_out);
+
+/* All device work of later calls goes to this hipStream_t (the stream given at creation until then). The caller orders
+ * streams against each other (events): used to run the coarsest-level chain of one block of time points beside the
+ * bandwidth-bound sweeps of other blocks (pymgrit_amd/core/cycle_plan.py). */
+int mgrit_hip_set_stream(mgrit_hip_engine *e, void *stream);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,7 @@ class HipBackend:
         self.chain_state, self.chain_handover, self._handover = {}, {}, {}
         self.prev = None
         self._sumsq = None
+        self._cur_stream, self._chain_stream = self.stream, None
 
     def __del__(self):
         try:
@@ -287,6 +288,60 @@ class HipBackend:
             return
         code = {'F': hip_lib.RELAX_F, 'C': hip_lib.RELAX_C, 'CHAIN': hip_lib.RELAX_CHAIN}[mode]
         check(self.lib.mgrit_hip_relax(self.h, lvl, self._run_id(lvl, runs), code, float(self.mg.weight_c)))
+
+    def relax_chain_part(self, lvl, runs, resume):
+        """one block of the coarsest-level solve (cycle_plan.py); resume: it continues the chain of the block before it from
+        the running state that chain left in the hand-over buffer, exactly as a chain that continues on the
+        next rank does"""
+        if resume:
+            check(self.lib.mgrit_hip_chain_resume(self.h, lvl, 1))
+        self.relax(lvl, runs, 'CHAIN')
+
+    # -- planned cycle (cycle_plan.py): sweeps on the engine's stream, chain parts on a second stream -------------------
+    def plan_blocks(self):
+        """how many blocks of time points a planned cycle uses by default (1 = program order): the overlap pays when the
+        coarsest-level solve is long; Heat2D / two-point levels keep the program order"""
+        if any(d["kind"] not in ("heat1d", "advection1d") for d in self.desc) or self.mg.lvl_max < 2:
+            return 1
+        n_c = len(self.mg.t[-1])
+        return int(max(1, min(8, n_c // 512)))
+
+    def _use_stream(self, stream):
+        if stream is not self._cur_stream:
+            check(self.lib.mgrit_hip_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
+            self._cur_stream = stream
+
+    def plan_run(self, plan):
+        main = self.stream
+        if self._chain_stream is None:
+            self._chain_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            self._fork = torch.cuda.Event()
+        side = self._chain_stream
+        if plan.has_chain:
+            self._fork.record(main)
+            side.wait_event(self._fork)
+        last_side = None
+        try:
+            for node in plan.order:
+                st = side if node.stream == "chain" else main
+                for p in node.cross_preds:
+                    st.wait_event(p.event)
+                self._use_stream(st)
+                node.fn()
+                if node.needs_event:
+                    if node.event is None:
+                        node.event = torch.cuda.Event()
+                    node.event.record(st)
+                if st is side:
+                    last_side = node
+        finally:
+            self._use_stream(main)
+        if last_side is not None:      # whatever follows on the engine's stream sees the whole cycle
+            if last_side.event is None:
+                last_side.event = torch.cuda.Event()
+            if not last_side.needs_event:
+                last_side.event.record(side)
+            main.wait_event(last_side.event)
 
     def residual_norms(self, points):
         if not len(points):

@@ -73,6 +73,7 @@ class TorchTimeComm:
         self._inflight = []
         self._links = None
         self._side = None
+        self.stats = {"messages": 0, "bytes": 0, "device_messages": 0}   # sends posted by this rank (bench.py reports them)
 
     def Get_rank(self):
         return self.rank
@@ -170,10 +171,15 @@ class TorchTimeComm:
             g = self._link(self.rank, dest)
             if torch.is_tensor(payload):
                 staged = payload.detach().cpu() if (payload.is_cuda and self.backend != "nccl") else payload.detach().clone()
+                self.stats["messages"] += 1
+                self.stats["bytes"] += staged.numel() * staged.element_size()
+                self.stats["device_messages"] += int(staged.is_cuda)
                 self._inflight.append((dist.isend(staged, self._global(dest), group=g), staged))
             else:
                 raw = torch.frombuffer(bytearray(pickle.dumps(payload)), dtype=torch.uint8).to(self._device())
                 size = torch.tensor([raw.numel()], dtype=torch.int64, device=self._device())
+                self.stats["messages"] += 1
+                self.stats["bytes"] += raw.numel()
                 self._inflight.append((dist.isend(size, self._global(dest), group=g), size))
                 self._inflight.append((dist.isend(raw, self._global(dest), group=g), raw))
         if recv is not None:
@@ -194,10 +200,20 @@ class TorchTimeComm:
         return result
 
 
+_default_comm = {}   # process group -> its TorchTimeComm: the per-neighbour links and the side group are created once per
+                     # group and shared by every solver instance of the process (new_group is collective and never freed)
+
+
 def resolve_comm(comm_time):
     """``comm_time=None`` -> the default process group when torch.distributed is initialised, else serial."""
     if comm_time is None:
-        return TorchTimeComm() if dist.is_available() and dist.is_initialized() else SerialComm()
+        if not (dist.is_available() and dist.is_initialized()):
+            return SerialComm()
+        key = id(dist.group.WORLD)
+        comm = _default_comm.get(key)
+        if comm is None or comm.backend != dist.get_backend():
+            comm = _default_comm[key] = TorchTimeComm()
+        return comm
     if hasattr(comm_time, "exchange") and hasattr(comm_time, "Get_rank"):
         return comm_time
     raise Exception("comm_time must be None or a pymgrit_amd TimeComm (mpi4py communicators are not used on MI355X: "

@@ -7,6 +7,9 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libmgrit_hip.so")
 
 RELAX_F, RELAX_C, RELAX_CHAIN = 0, 1, 2
+# MGRIT_HIP_T_*: kinds of timed entry-point calls (mgrit_hip_timing_drain)
+TIMED_KINDS = ("relax_f", "relax_c", "chain", "residual", "jump", "restrict", "copy", "fas_rhs", "fas_fused",
+               "error_correction", "interpolate", "ec_relax", "at_solve")
 STEPPER_HEAT1D, STEPPER_ADVECTION1D = 1, 2
 TRANSFER_COPY, TRANSFER_HEAT1D = 0, 1
 MAX_N = 16384
@@ -55,6 +58,8 @@ EXPORTS = {
     "mgrit_hip_jump_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mgrit_hip_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "mgrit_hip_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "mgrit_hip_timing_drain": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "mgrit_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

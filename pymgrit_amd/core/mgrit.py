@@ -54,7 +54,7 @@ class Mgrit:
                  max_iter: int = 100, tol: float = 1e-7, nested_iteration: bool = True, cf_iter: int = 1,
                  cycle_type: str = 'V', comm_time=None, comm_space=None, logging_lvl: int = logging.INFO,
                  output_fcn=None, output_lvl=1, t_norm=2, random_init_guess: bool = False, conv_crit: int = 0,
-                 pipeline_depth: int = None) -> None:
+                 pipeline_depth: int = None, plan_blocks: int = None) -> None:
         logging.basicConfig(format='%(levelname)s - %(asctime)s - %(message)s', datefmt='%d-%m-%y %H:%M:%S',
                             level=logging_lvl, stream=sys.stdout)
         if transfer is None:
@@ -111,6 +111,7 @@ class Mgrit:
         self.save_values_last_iter = None
         self._pipeline_request = pipeline_depth
         self._pl = None
+        self._plan_request, self._plans, self._plan_recording = plan_blocks, {}, False
         self.output_lvl = output_lvl
         self.output_fcn = output_fcn if (output_fcn is not None and callable(output_fcn)) else None
         self._ghost, self._is_c_local = [], []
@@ -315,7 +316,46 @@ class Mgrit:
     # ------------------------------------------------------------------------------------------------
     # the MGRIT cycle (mgrit.py:261-290)
     # ------------------------------------------------------------------------------------------------
+    def plan_blocks(self) -> int:
+        """Blocks of time points of a planned cycle (core/cycle_plan.py); 1 = the cycle runs in program order. The plan
+        reorders the launches of ONE rank's cycle, so it needs a cycle without exchange points (one rank) whose sweeps are
+        the library's own (a subclass that overrides a sweep keeps the program order)."""
+        if self._plan_request is not None:
+            want = int(self._plan_request)
+        elif os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS"):
+            want = int(os.environ["PYMGRIT_AMD_PLAN_BLOCKS"])
+        else:
+            want = int(getattr(self.backend, "plan_blocks", lambda: 1)())
+        own = all(getattr(type(self), name) is getattr(Mgrit, name) for name in
+                  ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "forward_solve", "_exchange",
+                   "_ec_f_relax", "_fas_residual_fused", "_relax_f"))
+        usable = self.comm_time_size == 1 and self.lvl_max > 1 and own and self._dry is None
+        return max(want, 1) if usable else 1
+
+    def _planned(self, cycle_type, iteration, first_f):
+        """the cycle plan for this cycle shape (recorded on first use), or None"""
+        blocks = self.plan_blocks()
+        if blocks <= 1:
+            return None
+        from pymgrit_amd.core.cycle_plan import PlanUnsupported, record_cycle
+        key = (cycle_type, iteration == 0, bool(first_f), blocks, tuple(self.cf_iter), float(self.weight_c))
+        if key not in self._plans:
+            self._plan_recording = True
+            try:
+                self._plans[key] = record_cycle(self, self.backend, blocks, lambda: self.iteration(
+                    lvl=0, cycle_type=cycle_type, iteration=iteration, first_f=first_f))
+            except PlanUnsupported:
+                self._plans[key] = None
+            finally:
+                self._plan_recording = False
+        return self._plans[key]
+
     def iteration(self, lvl: int, cycle_type: str, iteration: int, first_f: bool) -> None:
+        if lvl == 0 and not self._plan_recording:
+            plan = self._planned(cycle_type, iteration, first_f)
+            if plan is not None:
+                plan.run(self.backend)
+                return
         if lvl == self.lvl_max - 1:
             self.forward_solve(lvl=lvl)
             return
@@ -374,7 +414,8 @@ class Mgrit:
 
     def _can_fuse_ec(self, lvl):
         return (getattr(self.backend, "can_fuse_ec", None) is not None and self.backend.can_fuse_ec(lvl) and
-                type(self).error_correction is Mgrit.error_correction and type(self).f_relax is Mgrit.f_relax)
+                type(self).error_correction is Mgrit.error_correction and type(self).f_relax is Mgrit.f_relax and
+                type(self).fas_residual is Mgrit.fas_residual)   # the kernel takes v_j from u_c: only the library's FAS sweep guarantees it
 
     def _ec_f_relax(self, lvl: int) -> None:
         """error_correction(lvl) then f_relax(lvl) (mgrit.py:283-284) with the correction of every C-point that is followed

@@ -870,8 +870,10 @@ struct mgrit_hip_engine {
     hipStream_t stream = nullptr;
     std::vector<Level> L;
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
+    struct TimeRec { int kind, lvl; hipEvent_t ev0, ev1; };
+    std::vector<TimeRec> trecs;              // one per timed entry-point call since the last drain
+    std::vector<hipEvent_t> ev_pool;         // events of drained records, reused
+    hipEvent_t last0 = nullptr, last1 = nullptr;   // events of the most recent timed call (mgrit_hip_last_kernel_ms)
     u64 *chain_gran = nullptr;    // [2][MAX_G][4] granules of the cross-workgroup chain
     unsigned *chain_err = nullptr;  // pinned, device-mapped: set by a worker whose bounded spin gave up
     double *pinned = nullptr;     // host staging buffer for small read-backs
@@ -880,6 +882,31 @@ struct mgrit_hip_engine {
 };
 
 namespace {
+
+// Brackets one entry-point call with a pair of HIP events on the engine's stream when timing is on (mgrit_hip_set_timing):
+// every sweep entry point carries one, so per-sweep device times can be read back with mgrit_hip_timing_drain.
+struct Timed {
+    mgrit_hip_engine *e;
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind, lvl;
+    static hipEvent_t get(mgrit_hip_engine *e) {
+        hipEvent_t ev = nullptr;
+        if (!e->ev_pool.empty()) { ev = e->ev_pool.back(); e->ev_pool.pop_back(); }
+        else if (hipEventCreate(&ev) != hipSuccess) ev = nullptr;
+        return ev;
+    }
+    Timed(mgrit_hip_engine *e_, int kind_, int lvl_) : e(e_), kind(kind_), lvl(lvl_) {
+        if (!e || !e->timing) return;
+        a = get(e); b = get(e);
+        if (a && b) (void)hipEventRecord(a, e->stream);
+    }
+    ~Timed() {
+        if (!a || !b) return;
+        (void)hipEventRecord(b, e->stream);
+        e->trecs.push_back({kind, lvl, a, b});
+        e->last0 = a; e->last1 = b;
+    }
+};
 
 void cset_powers(CSet &c, double rho) {
     c.rho = rho;
@@ -1612,8 +1639,8 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
     if (e->chain_err) (void)hipHostFree(e->chain_err);
     if (e->pinned) (void)hipHostFree(e->pinned);
     if (e->ev_read) (void)hipEventDestroy(e->ev_read);
-    if (e->ev0) (void)hipEventDestroy(e->ev0);
-    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    for (auto &r : e->trecs) { (void)hipEventDestroy(r.ev0); (void)hipEventDestroy(r.ev1); }
+    for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     delete e;
     return 0;
 }
@@ -1821,15 +1848,8 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     if (mode != MGRIT_HIP_RELAX_F && mode != MGRIT_HIP_RELAX_C && mode != MGRIT_HIP_RELAX_CHAIN) return fail(MGRIT_HIP_EINVAL, "bad relax mode %d", mode);
     if ((rc = check_bound(lv, lvl > 0))) return rc;
     if (rl->n == 0) return 0;
-    if (e->timing) {
-        if (!e->ev0) { HIP_TRY(hipEventCreate(&e->ev0)); HIP_TRY(hipEventCreate(&e->ev1)); }
-        HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    }
-    if (lv.h2d) {
-        if ((rc = h2d_relax(e, lvl, rl, mode, weight_c))) return rc;
-        if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
-        return 0;
-    }
+    Timed timed(e, mode == MGRIT_HIP_RELAX_F ? MGRIT_HIP_T_RELAX_F : mode == MGRIT_HIP_RELAX_C ? MGRIT_HIP_T_RELAX_C : MGRIT_HIP_T_CHAIN, lvl);
+    if (lv.h2d) return h2d_relax(e, lvl, rl, mode, weight_c);
     if (is_2pts(lv)) {
         const bool use_g = lvl > 0, weighted = mode == MGRIT_HIP_RELAX_C && weight_c != 1.0;
         const double w = weight_c, w1 = 1.0 - weight_c;
@@ -1843,7 +1863,6 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     RELAX2_CASE(O, F, true, true)
         FOR_EACH_2PTS(RELAX2_CASES)
         HIP_TRY(hipGetLastError());
-        if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
         return 0;
     }
     if (mode == MGRIT_HIP_RELAX_CHAIN) {
@@ -1885,7 +1904,6 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             FOR_EACH_STEPPER(CHAIN_CASES)
             HIP_TRY(hipGetLastError());
         }
-        if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
         return 0;
     }
     {
@@ -1906,7 +1924,6 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
         FOR_EACH_STEPPER(RELAX_CASES)
         HIP_TRY(hipGetLastError());
     }
-    if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
     return 0;
 }
 
@@ -1918,6 +1935,7 @@ int mgrit_hip_residual(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_
     if ((rc = check_bound(lv, false))) return rc;
     if (rl->n == 0) return 0;
     if (!sumsq_out) return fail(MGRIT_HIP_EINVAL, "null output");
+    Timed timed(e, MGRIT_HIP_T_RESIDUAL, lvl);
     if (lv.h2d) return h2d_points_sumsq(e, lvl, rl, nullptr, sumsq_out);
     if (is_2pts(lv)) LAUNCH2_BY_ORDER(residual2_kernel, lv, persistent_grid(lv, rl->n), lv.dev, rl->d_start, rl->n, sumsq_out);
     else LAUNCH_BY_KIND(residual_kernel, lv, persistent_grid(lv, rl->n), lv.dev, rl->d_start, rl->n, sumsq_out);
@@ -1932,6 +1950,7 @@ int mgrit_hip_jump(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev
     if ((rc = check_bound(lv, false))) return rc;
     if (rl->n == 0) return 0;
     if (!sumsq_out || !prev) return fail(MGRIT_HIP_EINVAL, "null argument");
+    Timed timed(e, MGRIT_HIP_T_JUMP, lvl);
     if (lv.h2d) return h2d_points_sumsq(e, lvl, rl, prev, sumsq_out);
     if (is_2pts(lv))
         hipLaunchKernelGGL(jump2_kernel, dim3(rl->n), dim3(lv.dev.T), smem2_bytes(lv.G), e->stream, lv.dev, rl->d_start, prev, sumsq_out);
@@ -1948,6 +1967,7 @@ int mgrit_hip_restrict_u(mgrit_hip_engine *e, int lvl, int pairs_id) {
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     if ((rc = check_bound(lf, false)) || (rc = check_bound(lc, false))) return rc;
     if (pl->n == 0) return 0;
+    Timed timed(e, MGRIT_HIP_T_RESTRICT, lvl);
     dim3 grid(pl->n, (lc.dev.ld + 255) / 256);
     hipLaunchKernelGGL(restrict_rows_kernel, grid, dim3(256), 0, e->stream, lf.dev.u, lf.dev.ld, lf.dev.T, pl->d_fine, lc.dev.u,
                        lc.dev.ld, lc.dev.T, pl->d_coarse, lc.dev.n, lf.transfer);
@@ -1961,6 +1981,7 @@ int mgrit_hip_copy_u_to_v(mgrit_hip_engine *e, int lvl_coarse) {
     Level &lc = e->L[lvl_coarse];
     if ((rc = check_bound(lc, true))) return rc;
     if (lc.dev.n_pts == 0) return 0;
+    Timed timed(e, MGRIT_HIP_T_COPY, lvl_coarse);
     HIP_TRY(hipMemcpyAsync(lc.dev.v, lc.dev.u, sizeof(double) * (size_t)lc.dev.n_pts * lc.dev.ld, hipMemcpyDeviceToDevice, e->stream));
     return 0;
 }
@@ -1972,6 +1993,7 @@ int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id) {
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
     if (pl->n == 0) return 0;
+    Timed timed(e, MGRIT_HIP_T_FAS_RHS, lvl);
     if (lf.h2d || lc.h2d) {
         if (!lf.h2d || !lc.h2d || lf.transfer != MGRIT_HIP_TRANSFER_COPY)
             return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D levels need Heat2D on both levels and the copy transfer");
@@ -2026,6 +2048,7 @@ int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id) {
         force_mode(lf) != force_mode(lc) || lf.dev.n != lc.dev.n)
         return fail(MGRIT_HIP_EUNSUPPORTED, "fused FAS residual needs the copy transfer and like steppers on both levels");
     if (pl->n == 0) return 0;
+    Timed timed(e, MGRIT_HIP_T_FAS_FUSED, lvl);
     const int use_g = lvl > 0 ? 1 : 0;
     if (lf.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && !two_phase_fas()) {   // one pass per C-point, coarse tables from L2
         const dim3 grid(persistent_grid(lf, pl->n)), block(lf.dev.T);
@@ -2053,6 +2076,7 @@ int mgrit_hip_copy_pairs_u_to_v(mgrit_hip_engine *e, int lvl, int pairs_id) {
     Level &lc = e->L[lvl + 1];
     if ((rc = check_bound(lc, true))) return rc;
     if (pl->n == 0) return 0;
+    Timed timed(e, MGRIT_HIP_T_COPY, lvl);
     dim3 grid(pl->n, (lc.dev.ld + 255) / 256);
     hipLaunchKernelGGL(restrict_rows_kernel, grid, dim3(256), 0, e->stream, lc.dev.u, lc.dev.ld, lc.dev.T, pl->d_coarse, lc.dev.v,
                        lc.dev.ld, lc.dev.T, pl->d_coarse, lc.dev.n, MGRIT_HIP_TRANSFER_COPY);
@@ -2067,6 +2091,7 @@ static int interp_common(mgrit_hip_engine *e, int lvl, int pairs_id, int mode) {
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     if ((rc = check_bound(lf, false)) || (rc = check_bound(lc, mode == 1))) return rc;
     if (pl->n == 0) return 0;
+    Timed timed(e, mode == 1 ? MGRIT_HIP_T_ERROR_CORRECTION : MGRIT_HIP_T_INTERPOLATE, lvl);
     dim3 grid(pl->n, (lf.dev.ld + 255) / 256);
     hipLaunchKernelGGL(interp_rows_kernel, grid, dim3(256), 0, e->stream, lf.dev.u, lf.dev.ld, lf.dev.T, pl->d_fine, lc.dev.u,
                        lc.dev.v, lc.dev.ld, lc.dev.T, pl->d_coarse, lf.dev.n, lc.dev.n, lf.transfer, mode);
@@ -2086,6 +2111,7 @@ int mgrit_hip_at_solve(mgrit_hip_engine *e, int lvl, int k) {
     if ((rc = check_bound(lv, true))) return rc;
     if (lv.h2d || is_2pts(lv)) return fail(MGRIT_HIP_EUNSUPPORTED, "AT-MGRIT coarsest solve: 1-D single-point steppers only");
     if (lv.dev.n_pts < 2) return 0;
+    Timed timed(e, MGRIT_HIP_T_AT, lvl);
     const size_t rows = (size_t)lv.dev.n_pts;
     if (lv.scratch_rows < rows) {
         if (lv.scratch) HIP_TRY(hipFree(lv.scratch));
@@ -2122,10 +2148,7 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id) {
     if (lf.h2d || lc.h2d || is_2pts(lf) || is_2pts(lc) || lf.transfer != MGRIT_HIP_TRANSFER_COPY || lf.dev.n != lc.dev.n)
         return fail(MGRIT_HIP_EUNSUPPORTED, "fused correction + F-relaxation needs 1-D steppers and the copy transfer");
     if (rl->n == 0) return 0;
-    if (e->timing) {
-        if (!e->ev0) { HIP_TRY(hipEventCreate(&e->ev0)); HIP_TRY(hipEventCreate(&e->ev1)); }
-        HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    }
+    Timed timed(e, MGRIT_HIP_T_EC_RELAX, lvl);
     const bool use_g = lvl > 0;
     const int fm = force_mode(lf);
     const dim3 grid(persistent_grid(lf, rl->n)), block(lf.dev.T);
@@ -2136,7 +2159,6 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id) {
 #define ECF_CASES(K, F) ECF_CASE(K, F, false) ECF_CASE(K, F, true)
     FOR_EACH_STEPPER(ECF_CASES)
     HIP_TRY(hipGetLastError());
-    if (e->timing) { HIP_TRY(hipEventRecord(e->ev1, e->stream)); e->ev_valid = true; }
     return 0;
 }
 
@@ -2190,15 +2212,38 @@ int mgrit_hip_jump_host(mgrit_hip_engine *e, int lvl, int runs_id, const double 
 int mgrit_hip_set_timing(mgrit_hip_engine *e, int enabled) {
     if (!e) return fail(MGRIT_HIP_EINVAL, "null engine");
     e->timing = enabled != 0;
-    e->ev_valid = false;
     return 0;
 }
 
 int mgrit_hip_last_kernel_ms(mgrit_hip_engine *e, float *ms) {
     if (!e || !ms) return fail(MGRIT_HIP_EINVAL, "null argument");
-    if (!e->ev_valid) return fail(MGRIT_HIP_EINVAL, "no timed launch recorded");
-    HIP_TRY(hipEventSynchronize(e->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, e->ev0, e->ev1));
+    if (!e->last0) return fail(MGRIT_HIP_EINVAL, "no timed launch recorded");
+    HIP_TRY(hipEventSynchronize(e->last1));
+    HIP_TRY(hipEventElapsedTime(ms, e->last0, e->last1));
+    return 0;
+}
+
+int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int *lvl, float *ms, int *n_out) {
+    if (!e || !n_out || max_records < 0 || (max_records > 0 && (!kind || !lvl || !ms))) return fail(MGRIT_HIP_EINVAL, "bad arguments");
+    int n = 0;
+    for (auto &r : e->trecs) {
+        if (n < max_records) {
+            HIP_TRY(hipEventSynchronize(r.ev1));
+            HIP_TRY(hipEventElapsedTime(&ms[n], r.ev0, r.ev1));
+            kind[n] = r.kind; lvl[n] = r.lvl;
+            ++n;
+        }
+        e->ev_pool.push_back(r.ev0); e->ev_pool.push_back(r.ev1);
+    }
+    e->trecs.clear();
+    e->last0 = e->last1 = nullptr;
+    *n_out = n;
+    return 0;
+}
+
+int mgrit_hip_set_stream(mgrit_hip_engine *e, void *stream) {
+    if (!e) return fail(MGRIT_HIP_EINVAL, "null engine");
+    e->stream = static_cast<hipStream_t>(stream);
     return 0;
 }
 
