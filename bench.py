@@ -294,6 +294,9 @@ def main():
     ap.add_argument("--pipeline-depth", dest="pipeline_depth", type=int, default=None,
                     help="N>1: how many iterations the stopping value may lag (default: the solver's default, 4; 0 = check "
                          "after every cycle like the reference's loop)")
+    ap.add_argument("--plan-blocks", dest="plan_blocks", type=int, default=None,
+                    help="blocks of time points of the planned cycle (core/cycle_plan.py); default: the backend's choice, "
+                         "1 = program order")
     ap.add_argument("--workload", default="heat1d", choices=["heat1d", "heat2d", "advection"],
                     help="heat1d = BASELINE configs[2] (default, the driver's run); heat2d = configs[3] on one GPU")
     ap.add_argument("--nx2d", type=int, default=512)
@@ -342,7 +345,7 @@ def main():
                      max_iter=2 + args.warmup + args.steps, tol=0.0, logging_lvl=30)
     else:
         mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=False, max_iter=2 + args.warmup + args.steps, tol=0.0,
-                   logging_lvl=30, pipeline_depth=args.pipeline_depth)
+                   logging_lvl=30, pipeline_depth=args.pipeline_depth, plan_blocks=args.plan_blocks)
     be = mg.backend
     dof = nx - 2
     counts = phi_counts(nts, [4, 4])
@@ -440,7 +443,8 @@ def main():
                                f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle + residual check "
                                f"(BASELINE configs[{2 if (nx, nt0) == (16384, 65537) else 1 if (nx, nt0) == (1024, 4097) else '-'}]; "
                                f"time points sharded over {world} GPU(s))",
-                   "phi_per_cycle_by_level": counts, "dof": dof, "pipeline_depth": mg.pipeline_depth()},
+                   "phi_per_cycle_by_level": counts, "dof": dof, "pipeline_depth": mg.pipeline_depth(),
+                   "plan_blocks": mg.plan_blocks()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "relax_kernel<HEAT1D,false,ROLE_F> (level-0 F-relax)", "launch_ms": f_ms,

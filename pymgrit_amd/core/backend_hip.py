@@ -317,11 +317,17 @@ class HipBackend:
             self._chain_stream = torch.cuda.Stream(device=self.device, priority=-1)
             self._fork = torch.cuda.Event()
         side = self._chain_stream
+        reserve = 0
         if plan.has_chain:
             self._fork.record(main)
             side.wait_event(self._fork)
+            # the sweeps leave one CU of XCD 0 per chain worker (one worker per group of 1024 values) to the chain
+            groups = max(self.ld[lvl] // 1024 for lvl in {n.lvl for n in plan.order if n.stream == "chain"})
+            reserve = int(os.environ.get("PYMGRIT_AMD_PLAN_RESERVE", min(24, max(1, groups))))
         last_side = None
         try:
+            if reserve:
+                check(self.lib.mgrit_hip_set_reserve(self.h, reserve))
             for node in plan.order:
                 st = side if node.stream == "chain" else main
                 for p in node.cross_preds:
@@ -336,6 +342,8 @@ class HipBackend:
                     last_side = node
         finally:
             self._use_stream(main)
+            if reserve:
+                check(self.lib.mgrit_hip_set_reserve(self.h, 0))
         if last_side is not None:      # whatever follows on the engine's stream sees the whole cycle
             if last_side.event is None:
                 last_side.event = torch.cuda.Event()
@@ -348,7 +356,7 @@ class HipBackend:
             return []
         host = np.empty(len(points), dtype=np.float64)
         check(self.lib.mgrit_hip_residual_host(self.h, 0, self._point_run_id(0, points), _ptr(host)))
-        return np.sqrt(host).tolist()
+        return np.sqrt(host)
 
     def residual_begin(self, points):
         """launch the residual kernel and return at once; the per-point sums of squares land in pinned host memory that the
@@ -371,7 +379,7 @@ class HipBackend:
             return []
         buf, ev = handle
         ev.synchronize()
-        return np.sqrt(buf.numpy()).tolist()
+        return np.sqrt(buf.numpy())
 
     def save_last(self):
         self.prev = self.U[0].clone()
@@ -397,7 +405,7 @@ class HipBackend:
             host = np.empty(len(points), dtype=np.float64)
             check(self.lib.mgrit_hip_jump_host(self.h, 0, self._point_run_id(0, points),
                                                C.c_void_p(self.prev.data_ptr()), _ptr(host)))
-            out = np.sqrt(host).tolist()
+            out = np.sqrt(host)
         self.prev.copy_(self.U[0])
         return out
 

@@ -60,6 +60,7 @@ EXPORTS = {
     "mgrit_hip_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "mgrit_hip_timing_drain": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mgrit_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mgrit_hip_set_reserve": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib = None

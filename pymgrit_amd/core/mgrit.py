@@ -451,8 +451,12 @@ class Mgrit:
         t0 = time.time()
         val = self.compute_residual() if self.conv_crit in (0, 2) else self.compute_jump()
         if self.global_conv_crit:
-            parts = self.comm_time.allgather_object([float(x) for x in val])
-            self.conv[iteration] = time_norm(np.array([x for part in parts for x in part]), self.t_norm)
+            if self.comm_time_size == 1:     # no Python loop over the (tens of thousands of) per-point values on the critical path
+                allv = np.asarray(val, dtype=np.float64).ravel()
+            else:
+                parts = self.comm_time.allgather_object(np.asarray(val, dtype=np.float64).ravel().tolist())
+                allv = np.array([x for part in parts for x in part])
+            self.conv[iteration] = time_norm(allv, self.t_norm)
         else:   # local criterion (mgrit.py:434-455): every local point below the tolerance AND the previous rank has finished
             # op 6 carries HOW MANY leading ranks have left (the reference piggybacks a flag on every message instead): a
             # coarse level's sender may be any lower rank, and its farewell messages must be recognised as such
@@ -474,7 +478,7 @@ class Mgrit:
                 self.comm_time.exchange(send=(rank + 1 if self.finished[0] else self._gone_count, rank + 1))
                 if self.finished[0]:
                     self._announced_at = iteration
-            self.conv[iteration] = time_norm(np.array([float(x) for x in val]), self.t_norm)
+            self.conv[iteration] = time_norm(np.asarray(val, dtype=np.float64).ravel(), self.t_norm)
         logging.debug(f"Convergence criterion on {self.comm_time_rank} took {time.time() - t0} s")
 
     def forward_solve(self, lvl: int) -> None:

@@ -85,6 +85,11 @@ struct LevelDev {
     const double *chT;    // overlapped chain, null when the level does not qualify: V3 row [ld], then
                           // Q1, V1, V2 as [2][1024] each (full / last group), then a1 b1 a2 b2 [2] each, a3[16], b3[16]
     int n, ld, T, n_pts, K, kind;
+    // launch-time fields (set per launch by the host, not part of the level description):
+    int *sched;           // null: persistent workgroups walk their items with stride gridDim.x. Else {next, xcc0, done}: items
+                          // are drawn from a device-wide queue head (see WgQueue)
+    int xcc0_limit;       // with sched: how many workgroups may stay on XCD 0 (the others there leave at once, so that the
+                          // chain workers of a planned cycle find free CUs on that XCD); <= 0: no limit
 };
 
 __host__ __device__ __forceinline__ int row_pos(int j) {
@@ -110,6 +115,81 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0), vmcnt / expcnt untouched (gfx9 encoding)
     __builtin_amdgcn_s_barrier();
 }
+
+__device__ __forceinline__ int xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return (int)(x & 0xfu);
+}
+
+// One device-scope add by ONE lane of the calling wave, without a divergent branch: every lane of the wave issues the
+// atomic, lane 0 adds `inc` to *word, lanes 1..63 add 0 to a word of their own in the 256-byte dummy row behind the counters
+// (one fully coalesced atomic wave-instruction). Returns the value lane 0 got back, wave-uniform. Call it from code that the
+// whole wave executes (branch on wave-uniform scalars only). Why not `if (t == 0) atomicAdd(...)`: with that branch at the top
+// of the item loop of the 128-VGPR sweep kernels the compiler (ROCm 7.2) placed a live-range copy of a loop-invariant VGPR in
+// front of the `s_or_b64 exec` that re-joins the branch, i.e. executed it for lane 0 only -- every other lane lost the value.
+constexpr int SCHED_DUMMY = 16;   // ints from the counter block to the dummy row (64 ints)
+__device__ __forceinline__ int lane0_add(int *base, int word, int inc, int lane) {
+    int *p = lane == 0 ? base + word : base + SCHED_DUMMY + lane;
+    const int old = __hip_atomic_fetch_add(p, lane == 0 ? inc : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(old);
+}
+// issue only (the returned per-lane value is made uniform later, after the loads that were issued behind it)
+__device__ __forceinline__ int lane0_add_issue(int *base, int word, int inc, int lane) {
+    int *p = lane == 0 ? base + word : base + SCHED_DUMMY + lane;
+    return __hip_atomic_fetch_add(p, lane == 0 ? inc : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Item scheduling of the persistent sweep kernels. Program order (sched == null): workgroup b takes items b, b + gridDim.x, ...
+// Planned cycle (sched != null): the sweeps share the chip with the coarsest-level chain, whose 16 single-group workers want
+// 16 CUs of ONE XCD (their exchange stays inside that XCD's L2). The dispatcher hands workgroups to XCDs round-robin, so a
+// chip-filling sweep would leave no room anywhere: instead, of the sweep workgroups that find themselves on XCD 0 (hardware
+// id) only `xcc0_limit` stay, the others return at once, and -- the number of active workgroups no longer being known in
+// advance -- every workgroup draws its items from a queue head with one device-scope atomic add per item, issued ahead of
+// the item's row loads so that its latency is hidden behind them. Which workgroup processes which item has no effect on the
+// results (items are independent). The last workgroup to leave resets the three counters for the next launch on the stream.
+// sched = {next, xcc0, done, -, (chain: tickets, done), ..., dummy row at SCHED_DUMMY}
+struct WgQueue {
+    int *ctr;       // counter block or null
+    int cur, par, pending;
+    int *slot;      // LDS: two ints
+    bool w0;        // this wave is wave 0 of the workgroup (wave-uniform)
+    __device__ __forceinline__ void begin(int *ctr_, int xcc0_limit, int *lds2, int t) {
+        ctr = ctr_; slot = lds2; par = 0; pending = 0;
+        w0 = __builtin_amdgcn_readfirstlane(t >> 6) == 0;
+        if (!ctr) { cur = (int)blockIdx.x; return; }
+        if (w0) {
+            const int lane = t & 63;
+            bool stay = true;
+            if (xcc0_limit > 0 && xcc_id() == 0) stay = lane0_add(ctr, 1, 1, lane) < xcc0_limit;
+            int first = 0x7fffffff;
+            if (stay) first = lane0_add(ctr, 0, 1, lane);
+            slot[0] = first;      // every lane of wave 0 stores the same value
+        }
+        __syncthreads();
+        cur = slot[0];
+    }
+    // call at the top of an item, BEFORE its loads: draws the next item, the value is consumed in advance()
+    __device__ __forceinline__ void prefetch(int t) {
+        if (ctr && w0) pending = lane0_add_issue(ctr, 0, 1, t & 63);
+    }
+    __device__ __forceinline__ void advance(int t) {
+        if (!ctr) { cur += (int)gridDim.x; return; }
+        par ^= 1;
+        if (w0) slot[par] = __builtin_amdgcn_readfirstlane(pending);
+        __syncthreads();
+        cur = slot[par];
+    }
+    __device__ __forceinline__ void end(int t) {
+        if (ctr && w0) {
+            const int lane = t & 63;
+            if (lane0_add(ctr, 2, 1, lane) == (int)gridDim.x - 1) {   // the last workgroup to leave: clear {next, xcc0, done}
+                int *p = lane < 3 ? ctr + lane : ctr + SCHED_DUMMY + lane;
+                __hip_atomic_store(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+};
 
 __device__ __forceinline__ void load_row(const double *__restrict__ row, unsigned s0, double (&x)[E]) {
     const double2 *r2 = reinterpret_cast<const double2 *>(row) + s0;
@@ -459,6 +539,9 @@ extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const Smem sm = carve_smem(smem_raw, L.T);                                             \
     const unsigned sl = slot0(t);                                                          \
     StepCtx ctx;                                                                           \
+    __shared__ int wgq_slot[2];                                                            \
+    WgQueue wq;                                                                            \
+    (void)wgq_slot; (void)wq;                                                              \
     ctx_init<KIND, FORCE>(ctx, L, t)
 
 // f_relax / c_relax / forward_solve (mgrit.py:292-370,459-486). ROLE only separates the launches by purpose (distinct
@@ -471,7 +554,9 @@ __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *
     WG_PROLOGUE;
     // persistent workgroups: the grid is sized to the chip (not to the run list), each workgroup walks the runs with
     // stride gridDim.x and keeps the coefficient tables of its current time-step size in LDS / SGPRs across runs
-    for (int r = blockIdx.x; r < n_runs; r += gridDim.x) {
+    for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < n_runs; wq.advance(t)) {
+        const int r = wq.cur;
+        wq.prefetch(t);
         const int start = run_start[r], len = run_len[r];
         double x[E], gi[E];
         load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
@@ -491,6 +576,7 @@ __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *
             store_row(L.u + (size_t)i * L.ld, sl, x);
         }
     }
+    wq.end(t);
 }
 
 // error_correction + f_relax in one pass for the identity transfer (mgrit.py:715-726 followed by 292-333): a run whose
@@ -502,7 +588,9 @@ __global__ void __launch_bounds__(1024) ecf_kernel(LevelDev L, LevelDev Lc, cons
                                                    const int32_t *__restrict__ run_len, const int32_t *__restrict__ ec_coarse,
                                                    int n_runs) {
     WG_PROLOGUE;
-    for (int r = blockIdx.x; r < n_runs; r += gridDim.x) {
+    for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < n_runs; wq.advance(t)) {
+        const int r = wq.cur;
+        wq.prefetch(t);
         const int start = run_start[r], len = run_len[r], j = ec_coarse[r];
         double x[E], gi[E];
         load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
@@ -525,6 +613,7 @@ __global__ void __launch_bounds__(1024) ecf_kernel(LevelDev L, LevelDev Lc, cons
             store_row(L.u + (size_t)i * L.ld, sl, x);
         }
     }
+    wq.end(t);
 }
 
 // AtMgrit.forward_solve (core/at_mgrit.py:79-87): point p of the coarsest level is recomputed from the OLD value k-1
@@ -554,7 +643,9 @@ template <int KIND, int FORCE>
 __global__ void __launch_bounds__(1024) residual_kernel(LevelDev L, const int32_t *__restrict__ run_start, int n_runs,
                                                         double *__restrict__ out) {
     WG_PROLOGUE;
-    for (int r = blockIdx.x; r < n_runs; r += gridDim.x) {  // persistent workgroups, tables stay resident
+    for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < n_runs; wq.advance(t)) {  // persistent workgroups, tables stay resident
+        const int r = wq.cur;
+        wq.prefetch(t);
         const int i = run_start[r];
         double x[E], ui[E];
         load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
@@ -567,6 +658,7 @@ __global__ void __launch_bounds__(1024) residual_kernel(LevelDev L, const int32_
         const double tot = block_sumsq(x, sm, t, lane, wave, G);
         if (t == 0) out[r] = tot;
     }
+    wq.end(t);
 }
 
 // compute_jump (mgrit.py:372-385): out[run] = || u_i - prev_i ||^2
@@ -700,7 +792,9 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
     WG_PROLOGUE;
     Smem smc = sm;
-    for (int p = blockIdx.x; p < n_items; p += gridDim.x) {
+    for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < n_items; wq.advance(t)) {
+        const int p = wq.cur;
+        wq.prefetch(t);
         const int i = fine_idx[p], j = coarse_idx[p], ip = prev_idx[p];
         double x[E], w[E];
         load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
@@ -755,6 +849,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
         store_row(Lc.g + (size_t)j * Lc.ld, sl, x);
     }
+    wq.end(t);
 }
 
 // --- spatial transfer kernels (bandwidth-bound, elementwise over ROW POSITIONS of the destination) ---------------
@@ -874,6 +969,10 @@ struct mgrit_hip_engine {
     std::vector<TimeRec> trecs;              // one per timed entry-point call since the last drain
     std::vector<hipEvent_t> ev_pool;         // events of drained records, reused
     hipEvent_t last0 = nullptr, last1 = nullptr;   // events of the most recent timed call (mgrit_hip_last_kernel_ms)
+    int reserve = 0;              // mgrit_hip_set_reserve: CUs of XCD 0 the sweeps leave to the chain workers (0: program order)
+    int *sched = nullptr;         // device: {next, xcc0, done} of the sweeps' item queue, then {tickets, done} of the chain's
+                                  // worker selection (both reset themselves at the end of every launch)
+    unsigned chain_epoch = 0;     // granule epochs run on across chain launches (no reset of the granules between launches)
     u64 *chain_gran = nullptr;    // [2][MAX_G][4] granules of the cross-workgroup chain
     unsigned *chain_err = nullptr;  // pinned, device-mapped: set by a worker whose bounded spin gave up
     double *pinned = nullptr;     // host staging buffer for small read-backs
@@ -1553,11 +1652,12 @@ int check_bound(const Level &lv, bool need_vg) {
 // grid of persistent workgroups: as many as stay resident on the chip (LDS- and thread-limited), at most one per item
 bool is_2pts(const Level &lv) { return lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D_2PTS; }
 
-int persistent_grid(const Level &lv, int n_items) {
+int wgs_per_cu(const Level &lv) {
     const size_t lds = is_2pts(lv) ? smem2_bytes(lv.G) : smem_bytes(lv.G);
-    const int per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / lv.dev.T));
-    return std::min(n_items, 256 * per_cu);
+    return std::max(1, std::min((int)(160 * 1024 / lds), 2048 / lv.dev.T));
 }
+
+int persistent_grid(const Level &lv, int n_items) { return std::min(n_items, 256 * wgs_per_cu(lv)); }
 
 int force_mode(const Level &lv) {
     if (lv.dev.kind != MGRIT_HIP_STEPPER_HEAT1D && lv.dev.kind != MGRIT_HIP_STEPPER_HEAT1D_2PTS) return 0;
@@ -1587,6 +1687,15 @@ int force_mode(const Level &lv) {
         LAUNCH_CASE(kernel, MGRIT_HIP_STEPPER_ADVECTION1D, 0, lv, grid, __VA_ARGS__)                              \
         HIP_TRY(hipGetLastError());                                                                              \
     } while (0)
+
+// level description as a kernel argument, with the launch-time scheduling fields filled in (see WgQueue): only the kernels
+// that walk their items through a WgQueue look at them
+LevelDev sched_dev(const mgrit_hip_engine *e, const Level &lv) {
+    LevelDev d = lv.dev;
+    d.sched = e->reserve > 0 ? e->sched : nullptr;
+    d.xcc0_limit = e->reserve > 0 ? (32 - e->reserve) * wgs_per_cu(lv) : 0;
+    return d;
+}
 
 }  // namespace
 
@@ -1636,6 +1745,7 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
         if (lv.scratch) (void)hipFree(lv.scratch);
     }
     if (e->chain_gran) (void)hipFree(e->chain_gran);
+    if (e->sched) (void)hipFree(e->sched);
     if (e->chain_err) (void)hipHostFree(e->chain_err);
     if (e->pinned) (void)hipHostFree(e->pinned);
     if (e->ev_read) (void)hipEventDestroy(e->ev_read);
@@ -1871,21 +1981,32 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->chain_gran), sizeof(u64) * 4 * MAX_G * 4));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->chain_err), 256, hipHostMallocMapped));
             *e->chain_err = 0u;
+            HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
+            e->chain_epoch = 0;
         }
         const bool use_g = lvl > 0;
         const int fm = force_mode(lv);
         for (int r = 0; r < rl->n; ++r) {
-            HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
-            const dim3 grid(8 * lv.G), block(2 * LANES);
             const int st = rl->h_start[r], ln = rl->h_len[r];
+            // granule tags are epochs that run on from launch to launch: a stale granule always carries an older epoch, so the
+            // granules are never cleared between launches (a clear is a dispatch of its own, and in a planned cycle it would
+            // queue behind the sweeps that fill the chip)
+            if (e->chain_epoch > 0xE0000000u || (unsigned)ln > 0x10000000u) {
+                HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
+                e->chain_epoch = 0;
+            }
+            const unsigned ebase = e->chain_epoch;
+            e->chain_epoch += (unsigned)ln + 2u;
+            int *sel = e->reserve > 0 ? e->sched : nullptr;   // chain_worker uses the words 4, 5 of the block
+            const dim3 grid(sel ? 256 : 8 * lv.G), block(2 * LANES);
             if (lv.dev.chT && lv.chain_overlapped && use_g && fm <= 1 && !plain_chain()) {   // (level 0 = a one-level hierarchy: plain)   // one coefficient set, several groups: the overlapped chain
                 const int resume = (lv.chain_resume && r == 0) ? 1 : 0;
                 lv.chain_resume = false;
                 double *state = lv.chain_state;
-                if (fm == 0 && !use_g) hipLaunchKernelGGL((chain2_kernel<0, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume);
-                if (fm == 0 && use_g) hipLaunchKernelGGL((chain2_kernel<0, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume);
-                if (fm == 1 && !use_g) hipLaunchKernelGGL((chain2_kernel<1, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume);
-                if (fm == 1 && use_g) hipLaunchKernelGGL((chain2_kernel<1, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume);
+                if (fm == 0 && !use_g) hipLaunchKernelGGL((chain2_kernel<0, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, ebase, sel);
+                if (fm == 0 && use_g) hipLaunchKernelGGL((chain2_kernel<0, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, ebase, sel);
+                if (fm == 1 && !use_g) hipLaunchKernelGGL((chain2_kernel<1, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, ebase, sel);
+                if (fm == 1 && use_g) hipLaunchKernelGGL((chain2_kernel<1, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, ebase, sel);
                 HIP_TRY(hipGetLastError());
 #ifdef MGRIT_EXPERIMENT_COUNT_SPINS
                 HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1898,7 +2019,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             lv.chain_resume = false;
 #define CHAIN_CASE(K, F, G_, S_)                                                                              \
     if (lv.dev.kind == K && fm == F && use_g == G_ && (lv.G == 1) == S_)                                       \
-        hipLaunchKernelGGL((chain_kernel<K, F, G_, S_>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err);
+        hipLaunchKernelGGL((chain_kernel<K, F, G_, S_>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, ebase, sel);
 #define CHAIN_CASES(K, F) CHAIN_CASE(K, F, false, false) CHAIN_CASE(K, F, true, false) CHAIN_CASE(K, F, false, true) \
     CHAIN_CASE(K, F, true, true)
             FOR_EACH_STEPPER(CHAIN_CASES)
@@ -1916,7 +2037,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
         const int fm = force_mode(lv);
 #define RELAX_CASE(K, F, G_, R)                                                                                    \
     if (lv.dev.kind == K && fm == F && use_g == G_ && role == R)                                                    \
-        hipLaunchKernelGGL((relax_kernel<K, F, G_, R>), grid, block, lds, e->stream, lv.dev, rl->d_start, rl->d_len, rl->n, \
+        hipLaunchKernelGGL((relax_kernel<K, F, G_, R>), grid, block, lds, e->stream, sched_dev(e, lv), rl->d_start, rl->d_len, rl->n, \
                            w, w1);
 #define RELAX_CASES(K, F)                                                                                          \
     RELAX_CASE(K, F, false, ROLE_F) RELAX_CASE(K, F, true, ROLE_F) RELAX_CASE(K, F, false, ROLE_C)                  \
@@ -1938,7 +2059,7 @@ int mgrit_hip_residual(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_
     Timed timed(e, MGRIT_HIP_T_RESIDUAL, lvl);
     if (lv.h2d) return h2d_points_sumsq(e, lvl, rl, nullptr, sumsq_out);
     if (is_2pts(lv)) LAUNCH2_BY_ORDER(residual2_kernel, lv, persistent_grid(lv, rl->n), lv.dev, rl->d_start, rl->n, sumsq_out);
-    else LAUNCH_BY_KIND(residual_kernel, lv, persistent_grid(lv, rl->n), lv.dev, rl->d_start, rl->n, sumsq_out);
+    else LAUNCH_BY_KIND(residual_kernel, lv, persistent_grid(lv, rl->n), sched_dev(e, lv), rl->d_start, rl->n, sumsq_out);
     return 0;
 }
 
@@ -2055,8 +2176,8 @@ int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id) {
         const int fm = force_mode(lf);
         // forcing factors of both levels are streamed (FORCE 2, the same fma per term): one Phi per point does not pay for
         // keeping them in registers, and the registers are needed for the partial g that stays live across the coarse Phi
-        if (fm == 0) hipLaunchKernelGGL((fas_fused1_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, lf.dev, lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);
-        else hipLaunchKernelGGL((fas_fused1_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, lf.dev, lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);
+        if (fm == 0) hipLaunchKernelGGL((fas_fused1_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);
+        else hipLaunchKernelGGL((fas_fused1_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -2154,7 +2275,7 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id) {
     const dim3 grid(persistent_grid(lf, rl->n)), block(lf.dev.T);
 #define ECF_CASE(K, F, G_)                                                                                          \
     if (lf.dev.kind == K && fm == F && use_g == G_)                                                                 \
-        hipLaunchKernelGGL((ecf_kernel<K, F, G_>), grid, block, smem_bytes(lf.G), e->stream, lf.dev, lc.dev, rl->d_start,  \
+        hipLaunchKernelGGL((ecf_kernel<K, F, G_>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, rl->d_start,  \
                            rl->d_len, rl->d_ec, rl->n);
 #define ECF_CASES(K, F) ECF_CASE(K, F, false) ECF_CASE(K, F, true)
     FOR_EACH_STEPPER(ECF_CASES)
@@ -2238,6 +2359,18 @@ int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int 
     e->trecs.clear();
     e->last0 = e->last1 = nullptr;
     *n_out = n;
+    return 0;
+}
+
+int mgrit_hip_set_reserve(mgrit_hip_engine *e, int n_cus) {
+    if (!e) return fail(MGRIT_HIP_EINVAL, "null engine");
+    if (n_cus < 0 || n_cus > 24) return fail(MGRIT_HIP_EINVAL, "reserve %d outside [0,24]", n_cus);
+    if (n_cus > 0 && !e->sched) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->sched), 512));
+        HIP_TRY(hipMemsetAsync(e->sched, 0, 512, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    e->reserve = n_cus;
     return 0;
 }
 
