@@ -323,7 +323,7 @@ class HipBackend:
             side.wait_event(self._fork)
             # the sweeps leave one CU of XCD 0 per chain worker (one worker per group of 1024 values) to the chain
             groups = max(self.ld[lvl] // 1024 for lvl in {n.lvl for n in plan.order if n.stream == "chain"})
-            reserve = int(os.environ.get("PYMGRIT_AMD_PLAN_RESERVE", min(24, max(1, groups))))
+            reserve = int(os.environ.get("PYMGRIT_AMD_PLAN_RESERVE", min(32, max(1, groups))))
         last_side = None
         try:
             if reserve:

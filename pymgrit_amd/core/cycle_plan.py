@@ -17,6 +17,8 @@ The recorder works at the backend interface (``relax``, ``fas_fused``, ``ec_rela
 engine and for the plugin backend (on the CPU the plan is executed serially in its scheduled order: that is how the
 dependency rules are tested without a GPU, tests/test_cycle_plan.py).
 """
+import os
+
 import numpy as np
 
 
@@ -151,7 +153,7 @@ class Recorder:
                     (lambda p=part: real.relax(lvl, p, 'CHAIN'))
                 # ("chain", lvl): the parts of one forward solve share the engine's granules and hand-over state
                 self._add("chain", lvl, b, fn, reads, {("u", lvl, b), ("chain", lvl, 0)}, n_pts, stream="chain",
-                          cost=5e-6 + n_pts * 1.4e-6)
+                          cost=5e-6 + n_pts * float(os.environ.get('PYMGRIT_AMD_PLAN_CHAIN_US', '2.0')) * 1e-6)
             else:
                 rows = len(part) + n_pts * (2 if lvl > 0 else 1)
                 self._add("relax_" + mode, lvl, b, lambda p=part: real.relax(lvl, p, mode), reads, {("u", lvl, b)}, rows)

@@ -89,7 +89,7 @@ struct LevelDev {
     int *sched;           // null: persistent workgroups walk their items with stride gridDim.x. Else {next, xcc0, done}: items
                           // are drawn from a device-wide queue head (see WgQueue)
     int xcc0_limit;       // with sched: how many workgroups may stay on XCD 0 (the others there leave at once, so that the
-                          // chain workers of a planned cycle find free CUs on that XCD); <= 0: no limit
+                          // chain workers of a planned cycle find free CUs on that XCD); < 0: no limit
 };
 
 __host__ __device__ __forceinline__ int row_pos(int j) {
@@ -161,7 +161,7 @@ struct WgQueue {
         if (w0) {
             const int lane = t & 63;
             bool stay = true;
-            if (xcc0_limit > 0 && xcc_id() == 0) stay = lane0_add(ctr, 1, 1, lane) < xcc0_limit;
+            if (xcc0_limit >= 0 && xcc_id() == 0) stay = lane0_add(ctr, 1, 1, lane) < xcc0_limit;
             int first = 0x7fffffff;
             if (stay) first = lane0_add(ctr, 0, 1, lane);
             slot[0] = first;      // every lane of wave 0 stores the same value
@@ -1693,7 +1693,7 @@ int force_mode(const Level &lv) {
 LevelDev sched_dev(const mgrit_hip_engine *e, const Level &lv) {
     LevelDev d = lv.dev;
     d.sched = e->reserve > 0 ? e->sched : nullptr;
-    d.xcc0_limit = e->reserve > 0 ? (32 - e->reserve) * wgs_per_cu(lv) : 0;
+    d.xcc0_limit = e->reserve > 0 ? (32 - e->reserve) * wgs_per_cu(lv) : -1;
     return d;
 }
 
@@ -2364,7 +2364,7 @@ int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int 
 
 int mgrit_hip_set_reserve(mgrit_hip_engine *e, int n_cus) {
     if (!e) return fail(MGRIT_HIP_EINVAL, "null engine");
-    if (n_cus < 0 || n_cus > 24) return fail(MGRIT_HIP_EINVAL, "reserve %d outside [0,24]", n_cus);
+    if (n_cus < 0 || n_cus > 32) return fail(MGRIT_HIP_EINVAL, "reserve %d outside [0,32]", n_cus);
     if (n_cus > 0 && !e->sched) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->sched), 512));
         HIP_TRY(hipMemsetAsync(e->sched, 0, 512, e->stream));
