@@ -8,8 +8,9 @@ over the ranks by time blocks (strong scaling) and ghost time points travel over
 One "step" = one steady-state MGRIT V-cycle on level 0 (C-relax, F-relax, FAS residual, recursion, error correction,
 F-relax) + the residual-norm convergence check -- exactly what Mgrit.solve() does per iteration after the first.
 value = time-point-DOF updates per second = (Phi applications of the cycle, SURVEY 3.5 work model) x DOFs / wall time,
-inputs resident in HBM. "roofline" is measured live with HIP events on the engine's stream around the level-0 F-relax
-launch (the dominant kernel): algorithmic bytes = F_0 x 16 B x nx.
+inputs resident in HBM. "sweeps" lists every sweep of the cycle with its device time (HIP events around every entry point on
+the engine's stream, three extra cycles in program order) and SURVEY 8d's algorithmic bytes; "roofline" is the row with the
+largest share of the cycle.
 """
 import argparse
 import json
@@ -83,18 +84,20 @@ def cycle_phi_counts(nts, m_list, cycle_type='V'):
     return counts
 
 
-def cpu_baseline(nx, seconds_target=12.0):
-    """The parity oracle ("port", variant 0 = plain Thomas) timed on this host on a bounded sample of the same workload:
-    nx as given, nt=1025, 3-level m=4. Twice: single-threaded, and with the independent F-intervals / C-points of every
-    sweep spread over all host cores (OpenMP) -- the parallelism the reference's mpi4py path has across ranks; the
-    coarsest-level solve stays serial there as well. `value` is the all-cores figure, `cores` the threads used."""
+def cpu_baseline(nx, nt=16385):
+    """The parity oracle ("port" of the reference's algorithm: variant 0 = plain Thomas solves) timed on this host on a bounded
+    sample of the same workload: nx as given, nt = 16385 (a quarter of the time grid: 4096 F-intervals / C-points per level-0
+    sweep, enough independent work for every core), 3-level m=4, steady-state V-cycles incl. the residual check. Single-threaded,
+    and with the independent F-intervals / C-points of every sweep spread over OpenMP threads (the parallelism the reference's
+    mpi4py path has across ranks; the coarsest-level solve stays serial there as well) for several thread counts up to all
+    cores. `value` is the best of them, `cores` the threads that gave it."""
     import cases
     from oracle import oracle as orc
-    nts = (1025, 257, 65)
+    nts = (nt, (nt - 1) // 4 + 1, (nt - 1) // 16 + 1)
     upd_per_cycle = sum(c * (nx - 2) for c in phi_counts(nts, [4, 4]))
 
-    def run(threads, budget):
-        levels = [cases.heat_level_spec(nx, cases.lin(2.0 * (nts[0] - 1) / 65536, nt)) for nt in nts]
+    def run(threads, min_cycles, budget):
+        levels = [cases.heat_level_spec(nx, cases.lin(2.0 * (nts[0] - 1) / 65536, n)) for n in nts]
         p = orc.OracleProblem(levels, variant=0, nested_iteration=False, max_iter=1, tol=0.0, norm_spec=False)
         used = p.set_threads(threads)
         p.iteration(0, 'V', 0, True)  # warm-up cycle (first iteration does one more F-relax)
@@ -104,23 +107,25 @@ def cpu_baseline(nx, seconds_target=12.0):
             p.residual_norms()
             cycles += 1
             el = time.perf_counter() - t0
-            if el > budget or cycles >= 256:
+            if (cycles >= min_cycles and el > budget) or cycles >= 64:
                 break
         return upd_per_cycle * cycles / el, used, cycles, el
-    v1, _, c1, e1 = run(1, seconds_target / 3)
+    v1, _, c1, e1 = run(1, 1, 0.0)
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     tried = {}
-    for threads in sorted({min(avail, t) for t in (16, 32, 64, avail)}):   # more threads is not always faster (wake-up cost)
-        tried[threads] = run(threads, seconds_target / 6)
-    best = max(tried, key=lambda t: tried[t][0])
-    vn, used, cn, en = tried[best]
+    for threads in sorted({min(avail, t) for t in (8, 16, 32, 64, 128, avail)}):
+        if threads > 1:
+            tried[threads] = run(threads, 2, 1.5)
+    best = max(tried, key=lambda t: tried[t][0]) if tried else 1
+    vn, used, cn, en = tried[best] if tried else (v1, 1, c1, e1)
     if v1 > vn:
         vn, used, cn, en = v1, 1, c1, e1
     return {"value": vn, "unit": "time-point-DOF updates/s", "cores": used, "kind": "port", "value_1core": v1,
-            "by_threads": {str(t): r[0] for t, r in tried.items()},
-            "sample": f"oracle variant 0 (Thomas), heat_1d nx={nx} nt={nts[0]} 3-level m=4, V-cycles incl. residual check: "
-                      f"{c1} cycles in {e1:.1f} s on 1 core, {cn} cycles in {en:.1f} s on {used} OpenMP threads (best of "
-                      f"{sorted(tried)} threads; host has {os.cpu_count()} cores, {avail} usable)"}
+            "host_cores": os.cpu_count(), "by_threads": {str(t): r[0] for t, r in tried.items()},
+            "sample": f"port = parity oracle variant 0 (Thomas solves, reference operation order), {used} of {os.cpu_count()} "
+                      f"cores: heat_1d nx={nx} nt={nts[0]} 3-level m=4 ({(nts[0] - 1) // 4} F-intervals per level-0 sweep), "
+                      f"V-cycles incl. residual check: {c1} cycle(s) in {e1:.1f} s on 1 core, {cn} cycles in {en:.1f} s on "
+                      f"{used} OpenMP threads (tried {sorted(tried)}; {avail} usable cores)"}
 
 
 def iters_to_tol(problem, nx, tol=1e-10):
@@ -255,6 +260,62 @@ def bench_advection(args):
     out["config"]["phi_per_cycle_by_level"] = counts
     out["value"] = sum(c * d for c, d in zip(counts, out["config"]["dof_by_level"])) * args.steps / elapsed
     print(json.dumps(out), flush=True)
+
+
+KERNEL_OF = {"relax_f": "relax_kernel<1, 1, {g}, 0>", "relax_c": "relax_kernel<1, 1, {g}, 1>", "fas_fused": "fas_fused1_kernel<2>",
+             "ec_relax": "ecf_kernel<1, 1, {g}>", "residual": "residual_kernel<1, 1>", "chain": "chain2_kernel<1, true>"}
+LIMITED_BY = {"chain": "latency: the coarsest-level solve is sequential, one cross-workgroup exchange per step (measured floor "
+                       "0.98 us/step = one store -> L2 -> load round trip); bytes are not what bounds it",
+              "default": "HBM bandwidth (one 1024-thread workgroup per CU streaming rows; 6.29 TB/s copy ceiling of the guide)"}
+
+
+def sweep_bytes(nts, m_list, dof):
+    """SURVEY 8d algorithmic bytes per steady-state V-cycle + residual check, by (sweep, level): Phi = 16*n B on level 0, 24*n
+    on coarser levels; fas_residual per C-point (16|24)*n + 24*n + 8*n; error_correction per C-point 32*n; residual 16*n."""
+    L = len(nts)
+    out = {}
+    for lvl in range(L - 1):
+        N, m = nts[lvl] - 1, m_list[lvl]
+        F, C = N * (m - 1) // m, N // m
+        phi = 16.0 if lvl == 0 else 24.0
+        out[f"relax_c L{lvl}"] = C * phi * dof
+        out[f"relax_f L{lvl}"] = (1 if lvl == 0 else 2) * F * phi * dof
+        out[f"fas_fused L{lvl}"] = C * (phi + 32.0) * dof
+        out[f"ec_relax L{lvl}"] = (C * 32.0 + F * phi) * dof
+    out["residual L0"] = ((nts[0] - 1) // m_list[0]) * 16.0 * dof
+    out[f"chain L{L - 1}"] = (nts[-1] - 1) * 24.0 * dof
+    return out
+
+
+def sweep_table(mg, be, nts, m_list, dof, cycle, cycles=3):
+    from pymgrit_amd.core import hip_lib
+    keep = mg._plan_request
+    mg._plan_request = 1          # program order: one full-width launch per sweep and level
+    try:
+        cycle(1)
+        be.sync()
+        be.set_timing(True)
+        be.timing_drain()
+        for _ in range(cycles):
+            cycle(1)
+        recs = be.timing_drain()
+        be.set_timing(False)
+    finally:
+        mg._plan_request = keep
+    agg = {}
+    for kind, lvl, ms in recs:
+        a = agg.setdefault(f"{kind} L{lvl}", [0, 0.0])
+        a[0] += 1
+        a[1] += ms
+    alg = sweep_bytes(nts, m_list, dof)
+    table = {}
+    for key, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        kind = key.split()[0]
+        sym = KERNEL_OF.get(kind, kind).format(g="true" if not key.endswith("L0") else "false")
+        table[key] = {"kernel_symbol": sym, "launches_per_cycle": n / cycles, "ms_per_launch": tot / n, "ms_per_cycle": tot / cycles,
+                      "algorithmic_bytes_per_cycle": alg.get(key, 0.0),
+                      "limited_by": LIMITED_BY.get(kind, LIMITED_BY["default"])}
+    return table
 
 
 def self_launch(n):
@@ -397,47 +458,43 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # --- roofline of the dominant kernel: level-0 F-relax launch, HIP events on the engine's stream -----------
-    f_runs = mg._f_runs(0)
-    n_f_local = sum(r[1] for r in f_runs)
-    be.set_timing(True)
-    ms = []
-    for _ in range(5):
-        be.relax(0, f_runs, 'F')
-        ms.append(be.last_kernel_ms())
-    c_runs = mg._c_runs(0)
-    ms_c = []
-    for _ in range(5):
-        be.relax(0, c_runs, 'C')
-        ms_c.append(be.last_kernel_ms())
-    be.set_timing(False)
-    f_ms, c_ms = float(np.mean(ms[1:])), float(np.mean(ms_c[1:]))
-    alg_bytes_f = n_f_local * 16.0 * dof
-    achieved = alg_bytes_f / (f_ms * 1e-3) / 1e9          # this rank's launch (rank 0 is reported)
-    # level-0 FCF sweep of the whole job: all F/C points of the global grid, slowest rank's F + C + F kernel time
+    # --- per-sweep device times: HIP events around EVERY sweep entry point (mgrit_hip_set_timing), measured live on the
+    # engine's stream over three more cycles in PROGRAM order (one full-width launch per sweep and level, nothing beside it:
+    # these are the kernel times a rocprofv3 --kernel-trace --stats run of `bench.py --plan-blocks 1` shows per kernel)
+    table = sweep_table(mg, be, nts, [4, 4], dof, cycle)
+    local_share = 1.0 / world      # the table holds THIS rank's launches: its share of the job's bytes
+    for row in table.values():
+        row["algorithmic_bytes_per_cycle"] *= local_share
+        row["algorithmic_GBps"] = row["algorithmic_bytes_per_cycle"] / (row["ms_per_cycle"] * 1e-3) / 1e9 if row["ms_per_cycle"] else None
+        row["frac_of_hbm_peak"] = row["algorithmic_GBps"] / HBM_PEAK_GBS if row["algorithmic_GBps"] else None
+    f_ms = table["relax_f L0"]["ms_per_launch"]
+    c_ms = table["relax_c L0"]["ms_per_launch"]
     fcf_ms = 2 * f_ms + c_ms
-    n_f_all, n_c_all = n_f_local, len(c_runs)
     if world > 1:
         red = torch.tensor([fcf_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
         fcf_ms = float(red.item())
-        cnt = torch.tensor([float(n_f_local), float(len(c_runs))], dtype=torch.float64,
-                           device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        n_f_all, n_c_all = int(cnt[0].item()), int(cnt[1].item())
-    fcf_bytes = (2 * n_f_all + n_c_all) * 16.0 * dof
+    N0 = nts[0] - 1
+    fcf_bytes = (2 * (N0 * 3 // 4) + N0 // 4) * 16.0 * dof          # whole job: (2 F_0 + C_0) x 16 B x DOF  
     fcf_gbs = fcf_bytes / (fcf_ms * 1e-3) / 1e9
+    dominant = max(table, key=lambda k: table[k]["ms_per_cycle"])
+    dom = table[dominant]
+    cycle_bytes = sum(r["algorithmic_bytes_per_cycle"] for r in table.values()) / local_share
+    ms_step = 1e3 * elapsed / args.steps
 
-    traffic = None  # HBM bytes per level-0 F-relax launch from the committed PMC passes (same workload, N=1 only)
-    tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if world == 1 and nx == 16384 and nt0 == 65537 and os.path.exists(tfile):
-        k = json.load(open(tfile))["kernels"].get("relax_kernel<1, 1, false, 0>")
-        traffic = k["hbm_bytes_per_launch"] if k else None
+    traffic, traffic_src = None, None  # HBM bytes per launch of the dominant kernel from the committed PMC passes (N=1, same workload)
+    for tag in ("r02", "r01"):
+        tfile = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
+        if world == 1 and nx == 16384 and nt0 == 65537 and os.path.exists(tfile):
+            k = json.load(open(tfile))["kernels"].get(dom["kernel_symbol"])
+            if k:
+                traffic, traffic_src = k["hbm_bytes_per_launch"], f"profiles/{tag}_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run)"
+                break
 
     out = {
         "metric": "time-point-DOF updates/sec per MGRIT V-cycle", "value": updates_per_cycle * args.steps / elapsed,
         "unit": "time-point-DOF updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": ("AT-MGRIT k=%d: " % args.at_k if args.at_k else "") +
                                f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle + residual check "
@@ -445,17 +502,41 @@ def main():
                                f"time points sharded over {world} GPU(s))",
                    "phi_per_cycle_by_level": counts, "dof": dof, "pipeline_depth": mg.pipeline_depth(),
                    "plan_blocks": mg.plan_blocks()},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "relax_kernel<HEAT1D,false,ROLE_F> (level-0 F-relax)", "launch_ms": f_ms,
-                     "algorithmic_bytes_per_launch": alg_bytes_f},
+        # the kernel that takes the largest share of the cycle's device time (this rank), priced against the HBM roofline with
+        # SURVEY 8d's algorithmic bytes; `limited_by` says what really bounds it
+        "roofline": {"bound": "hbm", "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dom["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": f"{dom['kernel_symbol']} ({dominant})", "launch_ms": dom["ms_per_launch"],
+                     "launches_per_cycle": dom["launches_per_cycle"], "ms_per_cycle": dom["ms_per_cycle"],
+                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_cycle"] / max(dom["launches_per_cycle"], 1),
+                     "limited_by": dom["limited_by"]},
+        "sweeps": table,
+        "cycle": {"algorithmic_bytes": cycle_bytes, "algorithmic_GBps": cycle_bytes / (ms_step * 1e-3) / 1e9,
+                  "frac_of_hbm_peak": cycle_bytes / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+                  "sum_of_sweep_ms_in_program_order": sum(r["ms_per_cycle"] for r in table.values()),
+                  "note": "whole V-cycle + residual check: SURVEY 8d bytes of all sweeps / wall time of a step; in a planned "
+                          "cycle the chain runs beside the sweeps, so a step is shorter than the sum of its sweeps"},
         "fcf_relax_level0": {"ms": fcf_ms, "algorithmic_GBps": fcf_gbs,
                              "frac_of_hbm_peak": fcf_gbs / (HBM_PEAK_GBS * world),
-                             "updates_per_s": (2 * n_f_all + n_c_all) * dof / (fcf_ms * 1e-3),
+                             "updates_per_s": (2 * (N0 * 3 // 4) + N0 // 4) * dof / (fcf_ms * 1e-3),
                              "c_relax_ms": c_ms, "f_relax_ms": f_ms,
                              "note": "kernel time of the level-0 F-relax + C-relax + F-relax launches (max over ranks), "
-                                     "whole-job bytes; the sweep-only scaling figure of the north_star"},
+                                     "whole-job bytes; the sweep-only figure of the north_star (bar: 0.60)"},
     }
+    if world > 1:
+        comm = mg.comm_time
+        st = getattr(comm, "stats", None)
+        if st is not None:
+            per = torch.tensor([float(st["messages"]), float(st["bytes"]), float(st["device_messages"])], dtype=torch.float64,
+                               device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(per, op=dist.ReduceOp.SUM)
+            cycles_run = max(mg.solve_iter, 1) + 3
+            out["exchange"] = {"backend": args.backend, "messages_total": int(per[0].item()), "bytes_total": int(per[1].item()),
+                               "device_resident_messages": int(per[2].item()),
+                               "messages_per_cycle": per[0].item() / cycles_run, "bytes_per_cycle": per[1].item() / cycles_run,
+                               "note": "point-to-point ghost rows of all ranks (ops 0-5, 7 of reference mgrit.py:693-713); "
+                                       "SURVEY 2b counts 24-27 per V-cycle at P=4"}
+        out["nccl_ranks"] = dist.get_world_size() if args.backend == "nccl" else 0
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx)

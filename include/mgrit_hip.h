@@ -53,6 +53,11 @@ int mgrit_hip_sync(mgrit_hip_engine *e);
  */
 int mgrit_hip_level_heat1d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int n, int ld,
                            double fac, int K, const double *s, const double *tau);
+/* General (non-separable) forcing of a Heat1D level described with K = 0: rows = DEVICE slab [n_pts_local][ld] (row storage
+ * order, caller-owned like the state slabs) with rows[i] = rhs(x, t_i) * (t_i - t_{i-1}), the product Heat1D.step adds to
+ * u_start (heat/heat_1d.py:213: u_start + rhs(x, t_stop) * (t_stop - t_start)); Phi then computes (I + dt L)^-1 (u + rows[i]).
+ * +8 B per DOF and Phi of HBM traffic. NULL switches it off again. */
+int mgrit_hip_level_forcing_rows(mgrit_hip_engine *e, int lvl, const double *rows);
 /* Replaces Heat1DBDF1.step / Heat1DBDF2.step (heat/heat_1d_2pts_bdf1.py:84-117, heat/heat_1d_2pts_bdf2.py:82-138): a state
  * is the pair (u(t), u(t + dtau)) of VectorHeat1D2Pts (heat/vector_heat_1d_2pts.py:9-140) stored as one slab row
  * [first | second], each half laid out like a Heat1D row of n values: ld = 2 * mgrit_hip_row_stride(n). One Phi = two

@@ -352,6 +352,8 @@ typedef struct {
     double *s;             /* [K][n] */
     double *tau;           /* [K][nt] */
     double *tau2;          /* two-point steppers: [K][nt] tau_k(t_i + dtau) */
+    double *frows;         /* heat1d, general (non-separable) forcing: [nt][n] rows rhs(x, t_i) * (t_i - t_{i-1}), the very
+                              product heat_1d.py:213 adds to u_start (row 0 unused); NULL: forcing given by s / tau */
     double dtau;           /* two-point steppers: spacing inside a pair; method = BDF order (1 or 2) */
     orc_cset *csets; int n_csets, cap_csets;
     double *w1, *w2;       /* work (padded) */
@@ -383,6 +385,7 @@ static int padded(int n) { return ((n + ORC_GROUP - 1) / ORC_GROUP) * ORC_GROUP;
 /* heat_1d.py:198-217:  spsolve(dt*L + I, u + rhs(x, t_stop)*dt) */
 static void heat1d_rhs(const orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *d) {
     int n = st->n;
+    if (st->frows) { for (int j = 0; j < n; ++j) d[j] = u[j] + st->frows[(size_t)i_stop * n + j]; return; }
     if (st->K == 0) { memcpy(d, u, sizeof(double) * (size_t)n); return; }
     for (int j = 0; j < n; ++j) {
         double f = st->s[j] * st->tau[i_stop];
@@ -470,9 +473,10 @@ static void heat1d_step_spec(orc_stepper *st, int nt, int i_stop, double dt, con
     int n = st->n;
     orc_cset *c = get_cset(st, dt);
     double *d = st->w1;
-    /* d = u + dt*b(x, t_i) with the forcing folded as fma(s_k, tau_k*dt, .) */
+    /* d = u + dt*b(x, t_i) with the forcing folded as fma(s_k, tau_k*dt, .); a general forcing: d = u + (rhs*dt) row */
     for (int j = 0; j < n; ++j) {
         double v = u[j];
+        if (st->frows) v = v + st->frows[(size_t)i_stop * n + j];
         for (int k = 0; k < st->K; ++k) v = fma(st->s[(size_t)k * n + j], st->tau[(size_t)k * nt + i_stop] * dt, v);
         d[j] = v;
     }
@@ -795,7 +799,7 @@ orc_problem *orc_problem_create(int n_levels) {
 
 static void free_stepper(orc_stepper *st) {
     for (int i = 0; i < st->n_csets; ++i) { free(st->csets[i].tab); free(st->csets[i].ch); }
-    free(st->csets); free(st->s); free(st->tau); free(st->tau2); free(st->w1); free(st->w2);
+    free(st->csets); free(st->s); free(st->tau); free(st->tau2); free(st->w1); free(st->w2); free(st->frows);
     free(st->bc); free(st->W); free(st->Fxe); free(st->Fxo); free(st->Fye); free(st->Fyo); free(st->lx); free(st->ly); free(st->dinv); free(st->X0); free(st->X1);
 }
 
@@ -834,6 +838,15 @@ void orc_problem_set_level_heat1d(orc_problem *p, int lvl, int nt, const double 
         memcpy(st->s, s, sizeof(double) * (size_t)K * n);
         memcpy(st->tau, tau, sizeof(double) * (size_t)K * nt);
     }
+}
+
+/* general forcing of a heat1d level (after orc_problem_set_level_heat1d with K = 0): rows[i][j] = rhs(x_j, t_i) * (t_i - t_{i-1}) */
+void orc_problem_set_forcing_rows(orc_problem *p, int lvl, const double *rows) {
+    orc_level *L = &p->L[lvl];
+    orc_stepper *st = &L->st;
+    free(st->frows);
+    st->frows = (double *)malloc(sizeof(double) * (size_t)L->nt * st->n);
+    memcpy(st->frows, rows, sizeof(double) * (size_t)L->nt * st->n);
 }
 
 /* two-point heat stepper: n values per time point of the pair (state = 2n), order = 1 (BDF1) or 2 (BDF2);
@@ -1226,7 +1239,7 @@ static void cset_chain_tables(orc_cset *c, int n) {
 static int chain_overlapped(const orc_level *L, int lvl) {
     if (lvl == 0) return 0;   /* a one-level hierarchy is plain time stepping: its residual must vanish exactly */
     const orc_stepper *st = &L->st;
-    if (st->kind != ORC_HEAT1D || !st->variant || st->n <= ORC_GROUP || st->K > 1 || L->nt < 2) return 0;
+    if (st->kind != ORC_HEAT1D || !st->variant || st->n <= ORC_GROUP || st->K > 1 || st->frows || L->nt < 2) return 0;
     double dt0 = L->t[1] - L->t[0];
     for (int i = 2; i < L->nt; ++i) {
         double dt = L->t[i] - L->t[i - 1];

@@ -42,6 +42,7 @@ def lib():
         L.orc_problem_destroy.argtypes = [C.c_void_p]
         L.orc_problem_set_level_heat1d.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_int,
                                                    dp, dp, dp, C.c_int]
+        L.orc_problem_set_forcing_rows.argtypes = [C.c_void_p, C.c_int, dp]
         L.orc_problem_set_level_heat1d_2pts.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_double,
                                                         C.c_int, C.c_int, dp, dp, dp, dp, C.c_int]
         L.orc_sumsq_spec_2pts.restype = C.c_double
@@ -181,6 +182,9 @@ class OracleProblem:
                 u0 = _f64(s["u0"])
                 L.orc_problem_set_level_heat1d(self.h, lvl, t.size, _dp(t), n, float(s["fac"]), K, _dp(sa), _dp(ta),
                                                _dp(u0), int(variant))
+                if s.get("b_rows") is not None:   # general forcing: [nt][n] rows rhs(x, t_i) * dt_i
+                    rows = _f64(np.asarray(s["b_rows"]).reshape(t.size, n))
+                    L.orc_problem_set_forcing_rows(self.h, lvl, _dp(rows))
             elif s["kind"] == "heat1d_2pts":
                 m = int(s["n"])
                 n = 2 * m

@@ -88,7 +88,7 @@ class HipBackend:
             else:
                 perm = hip_lib.row_permutation(n)
             self.perm.append(torch.from_numpy(np.asarray(perm, dtype=np.int64)).to(self.device))
-        self.U, self.V, self.G = [], [], []
+        self.U, self.V, self.G, self.FB = [], [], [], {}
         self._runs, self._pairs = {}, {}
         self._described = [False] * mg.lvl_max
         self.chain_state, self.chain_handover, self._handover = {}, {}, {}
@@ -115,6 +115,19 @@ class HipBackend:
         tau = np.ascontiguousarray(tau)
         check(self.lib.mgrit_hip_level_heat1d(self.h, engine_lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"]), K,
                                               _ptr(s), _ptr(tau)))
+        if d.get("forcing_rows") is not None:
+            # general forcing: rows rhs(x, t_i)*dt_i for the local points, uploaded in blocks (a level of BASELINE config 3
+            # is 8.6 GB of them), in the engine's row storage order
+            rows = torch.zeros((max(n_pts, 1), ld), dtype=torch.float64, device=self.device)
+            perm = hip_lib.row_permutation(n)
+            for a in range(1, n_pts, 1024):
+                z = min(n_pts, a + 1024)
+                host = np.zeros((z - a, ld))
+                for i in range(a, z):
+                    host[i - a, perm] = d["forcing_rows"](float(t_local[i - 1]), float(t_local[i]))
+                rows[a:z].copy_(torch.from_numpy(host))
+            self.FB[engine_lvl] = rows
+            check(self.lib.mgrit_hip_level_forcing_rows(self.h, engine_lvl, C.c_void_p(rows.data_ptr())))
 
     def create_u_v_g(self, lvl):
         mg = self.mg
@@ -170,7 +183,7 @@ class HipBackend:
         gt = np.asarray(mg.global_t[lvl], dtype=np.float64)
         dts = np.diff(gt)
         n_terms = np.asarray(d.get("forcing_space", np.zeros((0, n)))).reshape(-1, n).shape[0] if d["kind"] == "heat1d" else 0
-        wide = (lvl > 0 and d["kind"] == "heat1d" and n > 1024 and n_terms <= 1 and dts.size > 0
+        wide = (lvl > 0 and d["kind"] == "heat1d" and n > 1024 and n_terms <= 1 and d.get("forcing_rows") is None and dts.size > 0
                 and bool(np.all(dts.view(np.int64) == dts.view(np.int64)[0])) and os.environ.get("MGRIT_HIP_CHAIN_PLAIN", "") != "1")
         check(self.lib.mgrit_hip_chain_enable(self.h, lvl, int(wide)))
         slen = C.c_int(0)
@@ -532,6 +545,15 @@ class HipBackend:
     # -- measurement hooks (bench.py) ------------------------------------------------------------------
     def set_timing(self, on):
         check(self.lib.mgrit_hip_set_timing(self.h, int(bool(on))))
+
+    def timing_drain(self, max_records=4096):
+        """[(sweep kind, level, milliseconds)] of every timed entry-point call since the last drain (waits for them)"""
+        kinds = np.zeros(max_records, dtype=np.int32)
+        lvls = np.zeros(max_records, dtype=np.int32)
+        ms = np.zeros(max_records, dtype=np.float32)
+        n = C.c_int(0)
+        check(self.lib.mgrit_hip_timing_drain(self.h, max_records, _ptr(kinds), _ptr(lvls), _ptr(ms), C.byref(n)))
+        return [(hip_lib.TIMED_KINDS[int(kinds[i])], int(lvls[i]), float(ms[i])) for i in range(n.value)]
 
     def last_kernel_ms(self):
         ms = C.c_float(0.0)

@@ -28,6 +28,7 @@ EXPORTS = {
                                          C.c_int, C.c_void_p, C.c_void_p]),
     "mgrit_hip_level_heat1d_2pts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double,
                                               C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgrit_hip_level_forcing_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mgrit_hip_ec_runs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mgrit_hip_ec_relax": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_at_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

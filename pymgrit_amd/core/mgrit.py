@@ -67,6 +67,11 @@ class Mgrit:
         self.comm_time_size = self.comm_time.Get_size()
         if self.comm_time_size > len(problem[0].t):
             raise Exception('More processors than time points. Not useful and not implemented yet')
+        if conv_crit in (2, 3) and self.comm_time_size > 1 and any(not isinstance(t, GridTransferCopy) for t in transfer):
+            # the farewell message of op 4 (reference mgrit.py:663-665) carries a row of the FINER level into a buffer of the
+            # coarser one: with a transfer that changes the number of values that is a size-mismatched point-to-point message
+            raise Exception('Local convergence criteria on several ranks need the identity transfer (GridTransferCopy) on '
+                            'every level')
         self.spatial_parallel = comm_space is not None
         self.comm_space_rank = comm_space.Get_rank() if self.spatial_parallel else -99
         self.comm_space_size = comm_space.Get_size() if self.spatial_parallel else 1
@@ -116,6 +121,7 @@ class Mgrit:
         self.output_fcn = output_fcn if (output_fcn is not None and callable(output_fcn)) else None
         self._ghost, self._is_c_local = [], []
 
+        self._transfer_for_selection = transfer
         self.backend = self._select_backend(problem)
 
         for lvl in range(self.lvl_max):
@@ -135,6 +141,11 @@ class Mgrit:
             self.step.append(problem[lvl].step)
             self.create_u_v_g(lvl=lvl)
         self.backend.finalize()
+        # logging.DEBUG: the reference reports the time of every sweep (mgrit.py:333,370,486,549); on the device path the lines
+        # also carry the DEVICE time of the sweep's kernels (HIP events around every entry point, mgrit_hip_set_timing)
+        self._sweep_timing = logging_lvl <= logging.DEBUG and hasattr(self.backend, "timing_drain")
+        if self._sweep_timing:
+            self.backend.set_timing(True)
 
         if nested_iteration:
             self.nested_iteration()
@@ -181,16 +192,50 @@ class Mgrit:
         raise Exception('Incorrect datatype cf_iter. Specify a list of values for all but the coarsest level or an '
                         'integer ( used for all levels).')
 
+    @staticmethod
+    def _library_method(obj, name):
+        """True when obj.<name> is the library's own implementation: the class that provides it lives in pymgrit_amd and
+        the instance does not shadow it. A user subclass that overrides ``step`` (or a transfer's ``restriction`` /
+        ``interpolation``) wants ITS code to run -- the device kernels would silently ignore it."""
+        if name in getattr(obj, "__dict__", {}):
+            return False
+        for klass in type(obj).__mro__:
+            if name in klass.__dict__:
+                return klass.__module__.split(".")[0] == "pymgrit_amd"
+        return False
+
     def _select_backend(self, problem):
-        """Backend by application TYPE (never by hardware availability)."""
+        """Backend by application TYPE (never by hardware availability): the HIP engine for hierarchies whose levels all
+        describe their time stepper declaratively (``device_stepper()``) AND whose ``step`` / transfer methods are the
+        library's own; everything else -- user plugins, Dahlquist, user subclasses that override ``step`` or a transfer --
+        runs through the plugin path, i.e. through the user's Python code, like in the reference."""
         has_desc = [hasattr(p, "device_stepper") and p.device_stepper() is not None for p in problem]
+        custom = [type(p).__name__ for p, d in zip(problem, has_desc) if d and not self._library_method(p, "step")]
+        custom += [type(t).__name__ for t in self.__dict__.get("_transfer_for_selection", ())
+                   if hasattr(t, "device_transfer") and not (self._library_method(t, "restriction") and
+                                                             self._library_method(t, "interpolation"))]
+        if all(has_desc) and custom:
+            logging.warning('pymgrit_amd: %s override step() / restriction() / interpolation(): the hierarchy runs through '
+                            'these Python methods (plugin path), not through the MI355X kernels', sorted(set(custom)))
+            has_desc = [False] * len(problem)
         if all(has_desc):
             from pymgrit_amd.core.backend_hip import HipBackend
             return HipBackend(self)
-        if any(has_desc):
+        if any(has_desc) and not custom:
             raise Exception('Mixed hierarchy: every level must be a device application (device_stepper()) or none')
         from pymgrit_amd.core.backend_plugin import PluginBackend
         return PluginBackend(self)
+
+    def _log_sweep(self, what: str, t0: float) -> None:
+        """the reference's per-sweep debug line (same wording), plus the device time of the sweep's kernels"""
+        if not logging.getLogger().isEnabledFor(logging.DEBUG):
+            return
+        line = f"{what} on {self.comm_time_rank} took {time.time() - t0} s"
+        if getattr(self, "_sweep_timing", False) and not self._plan_recording:
+            recs = self.backend.timing_drain()
+            if recs:
+                line += " | device: " + ", ".join(f"{k} L{lv} {ms:.3f} ms" for k, lv, ms in recs)
+        logging.debug(line)
 
     def log_info(self, message: str) -> None:
         """Only the last time rank (and space rank 0) logs (mgrit.py:247-259)."""
@@ -329,7 +374,8 @@ class Mgrit:
         own = all(getattr(type(self), name) is getattr(Mgrit, name) for name in
                   ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "forward_solve", "_exchange",
                    "_ec_f_relax", "_fas_residual_fused", "_relax_f"))
-        usable = self.comm_time_size == 1 and self.lvl_max > 1 and own and self._dry is None
+        usable = (self.comm_time_size == 1 and self.lvl_max > 1 and own and self._dry is None and
+                  not getattr(self, "_sweep_timing", False))     # per-sweep debug timing reports the sweeps in program order
         return max(want, 1) if usable else 1
 
     def _planned(self, cycle_type, iteration, first_f):
@@ -401,7 +447,7 @@ class Mgrit:
                 if front:
                     self._exchange(lvl, recv_idx=0, src=self.get_from[lvl], op=1)
                     self._relax_f(lvl, 'f_first', self._cached(('f_first', lvl), lambda: runs[:1]), ec)
-        logging.debug(f"F-relax on {self.comm_time_rank} took {time.time() - t0} s")
+        self._log_sweep("F-relax", t0)
 
     def _relax_f(self, lvl, tag, runs, ec):
         if not ec:
@@ -433,7 +479,7 @@ class Mgrit:
         self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
                        recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=2)
         self.backend.relax(lvl, self._c_runs(lvl), 'C')
-        logging.debug(f"C-relax on {self.comm_time_rank} took {time.time() - t0} s")
+        self._log_sweep("C-relax", t0)
 
     def compute_jump(self) -> list:
         """||u_i - u_i(previous iteration)|| at the local C-points (mgrit.py:372-385)."""
@@ -479,7 +525,7 @@ class Mgrit:
                 if self.finished[0]:
                     self._announced_at = iteration
             self.conv[iteration] = time_norm(np.asarray(val, dtype=np.float64).ravel(), self.t_norm)
-        logging.debug(f"Convergence criterion on {self.comm_time_rank} took {time.time() - t0} s")
+        self._log_sweep("Convergence criterion", t0)
 
     def forward_solve(self, lvl: int) -> None:
         """Sequential time stepping on level ``lvl`` (mgrit.py:459-486); op 5 = pipeline hand-off between owners."""
@@ -491,7 +537,7 @@ class Mgrit:
             self.backend.relax(lvl, self._cached(('chain', lvl), lambda: [(1, n - 1)]), 'CHAIN')
         if self.send_to[lvl] != -99:
             self._exchange(lvl, send_idx=int(self.index_local[lvl][-1]), dest=self.send_to[lvl], op=5)
-        logging.debug(f"Forward solve on {self.comm_time_rank} took {time.time() - t0} s")
+        self._log_sweep("Forward solve", t0)
 
     def fas_residual(self, lvl: int) -> None:
         """Inject the C-points and the FAS right-hand side into level lvl+1 (mgrit.py:488-549). op 3 = ghost refresh on
@@ -499,7 +545,7 @@ class Mgrit:
         t0 = time.time()
         if getattr(self.backend, "can_fuse_fas", None) is not None and self.backend.can_fuse_fas(lvl):
             self._fas_residual_fused(lvl)
-            logging.debug(f"Fas residual on {self.comm_time_rank} took {time.time() - t0} s")
+            self._log_sweep("Fas residual", t0)
             return
         self.backend.restrict_u(lvl, self._pairs(lvl, skip_first=False))
         self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
@@ -510,7 +556,7 @@ class Mgrit:
                        dest=self.send_to[lvl + 1], src=self.get_from[lvl + 1], op=4)
         self.backend.copy_u_to_v(lvl + 1)
         self.backend.fas_rhs(lvl, self._pairs(lvl, skip_first=True))
-        logging.debug(f"Fas residual on {self.comm_time_rank} took {time.time() - t0} s")
+        self._log_sweep("Fas residual", t0)
 
     def _fas_residual_fused(self, lvl: int) -> None:
         """Same sweep as fas_residual with the device backend's fused kernel: every local C-point whose previous

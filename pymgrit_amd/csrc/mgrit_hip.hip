@@ -82,6 +82,8 @@ struct LevelDev {
     const double2 *ptP;   // [n_csets][2][512] heat: group-local backward scan of rho^(j'+1) (full group, last group)
     const int32_t *cidx2; // two-point steppers: [n_pts][2] coefficient sets of the two half-solves (then tc is [K][n_pts][2])
     const double *hc;     // two-point BDF2: [n_pts][4] = (a, nb) of the first and of the second half-solve
+    const double *fb;     // general (non-separable) forcing, FORCE == 3: [n_pts][ld] rows rhs(x, t_i)*dt_i in row storage
+                          // order (the product heat_1d.py:213 adds to u_start), caller-owned like the state slabs; else null
     const double *chT;    // overlapped chain, null when the level does not qualify: V3 row [ld], then
                           // Q1, V1, V2 as [2][1024] each (full / last group), then a1 b1 a2 b2 [2] each, a3[16], b3[16]
     int n, ld, T, n_pts, K, kind;
@@ -332,7 +334,8 @@ struct StepCtx {
     int parity;     // double-buffer index of the LDS gather slots
 };
 
-// FORCE: 0 = no forcing term, 1 = one separable term (space factor held in registers), 2 = K >= 2 terms (streamed)
+// FORCE: 0 = no forcing term, 1 = one separable term (space factor held in registers), 2 = K >= 2 terms (streamed),
+// 3 = general forcing: one precomputed row rhs(x, t_i)*dt_i per time point, streamed from HBM (+8 B per DOF and Phi)
 template <int KIND, int FORCE>
 __device__ __forceinline__ void ctx_init(StepCtx &ctx, const LevelDev &L, int t) {
     ctx.cur = -1;
@@ -381,6 +384,14 @@ __device__ __forceinline__ void add_forcing(double (&x)[E], const StepCtx &ctx, 
                 x[2 * q] = fma(sv.x, ck, x[2 * q]);
                 x[2 * q + 1] = fma(sv.y, ck, x[2 * q + 1]);
             }
+        }
+    } else if (FORCE == 3) {   // u + rhs(x, t_i)*dt_i: the reference's own operation order (heat_1d.py:213)
+        const double2 *b2 = reinterpret_cast<const double2 *>(L.fb + (size_t)i * L.ld) + slot0(t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double2 bv = b2[q * 64];
+            x[2 * q] = x[2 * q] + bv.x;
+            x[2 * q + 1] = x[2 * q + 1] + bv.y;
         }
     }
 }
@@ -1164,7 +1175,7 @@ int allow_big_lds(K kernel, size_t bytes = smem_bytes(MAX_G)) {
 
 // Dispatch tables over the template space: kind (heat1d, advection1d) x forcing mode (0, 1, 2; advection has none).
 #define FOR_EACH_STEPPER(X) X(MGRIT_HIP_STEPPER_HEAT1D, 0) X(MGRIT_HIP_STEPPER_HEAT1D, 1) X(MGRIT_HIP_STEPPER_HEAT1D, 2) \
-    X(MGRIT_HIP_STEPPER_ADVECTION1D, 0)
+    X(MGRIT_HIP_STEPPER_HEAT1D, 3) X(MGRIT_HIP_STEPPER_ADVECTION1D, 0)
 
 // two-point steppers: BDF order (1, 2) x forcing mode (0, 1, 2)
 #define FOR_EACH_2PTS(X) X(1, 0) X(1, 1) X(1, 2) X(2, 0) X(2, 1) X(2, 2)
@@ -1229,18 +1240,22 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     // coefficient sets keyed by the bit pattern of dt = t[i] - t[i-1] (the reference uses each step's own dt)
     std::vector<double> dts(n_pts > 0 ? n_pts : 0, 0.0), uniq;
     std::vector<int32_t> cidx(n_pts > 0 ? n_pts : 0, 0);
+    std::map<uint64_t, int> seen;   // bit pattern of dt -> coefficient set
     for (int i = 1; i < n_pts; ++i) {
         const double dt = t_local[i] - t_local[i - 1];
         dts[i] = dt;
-        int found = -1;
-        for (size_t q = 0; q < uniq.size(); ++q)
-            if (std::memcmp(&uniq[q], &dt, sizeof(double)) == 0) { found = (int)q; break; }
-        if (found < 0) {
-            if (uniq.size() >= 4096) return fail(MGRIT_HIP_EUNSUPPORTED, "more than 4096 distinct time-step sizes on level %d", lvl);
-            found = (int)uniq.size();
+        uint64_t bits;
+        std::memcpy(&bits, &dt, sizeof(double));
+        auto it = seen.find(bits);
+        if (it == seen.end()) {
+            // every distinct step size costs one set of tables (8*ld bytes each, resident in HBM): a grid with a different step
+            // at every point (random or graded grids with tens of thousands of points) is refused, not silently slow
+            if (uniq.size() >= 4096)
+                return fail(MGRIT_HIP_EUNSUPPORTED, "more than 4096 distinct time-step sizes on level %d (one coefficient table per size)", lvl);
+            it = seen.emplace(bits, (int)uniq.size()).first;
             uniq.push_back(dt);
         }
-        cidx[i] = found;
+        cidx[i] = it->second;
     }
     if (n_pts > 0) cidx[0] = 0;
     lv.n_csets = (int)uniq.size();
@@ -1661,6 +1676,7 @@ int persistent_grid(const Level &lv, int n_items) { return std::min(n_items, 256
 
 int force_mode(const Level &lv) {
     if (lv.dev.kind != MGRIT_HIP_STEPPER_HEAT1D && lv.dev.kind != MGRIT_HIP_STEPPER_HEAT1D_2PTS) return 0;
+    if (lv.dev.fb) return 3;
     return lv.dev.K == 0 ? 0 : lv.dev.K == 1 ? 1 : 2;
 }
 
@@ -1684,6 +1700,7 @@ int force_mode(const Level &lv) {
         LAUNCH_CASE(kernel, MGRIT_HIP_STEPPER_HEAT1D, 0, lv, grid, __VA_ARGS__)                                   \
         LAUNCH_CASE(kernel, MGRIT_HIP_STEPPER_HEAT1D, 1, lv, grid, __VA_ARGS__)                                   \
         LAUNCH_CASE(kernel, MGRIT_HIP_STEPPER_HEAT1D, 2, lv, grid, __VA_ARGS__)                                   \
+        LAUNCH_CASE(kernel, MGRIT_HIP_STEPPER_HEAT1D, 3, lv, grid, __VA_ARGS__)                                   \
         LAUNCH_CASE(kernel, MGRIT_HIP_STEPPER_ADVECTION1D, 0, lv, grid, __VA_ARGS__)                              \
         HIP_TRY(hipGetLastError());                                                                              \
     } while (0)
@@ -1853,6 +1870,16 @@ int mgrit_hip_level_bind(mgrit_hip_engine *e, int lvl, double *u, double *v, dou
     return 0;
 }
 
+int mgrit_hip_level_forcing_rows(mgrit_hip_engine *e, int lvl, const double *rows) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    Level &lv = e->L[lvl];
+    if (lv.dev.kind != MGRIT_HIP_STEPPER_HEAT1D) return fail(MGRIT_HIP_EUNSUPPORTED, "forcing rows: Heat1D levels only");
+    if (rows && lv.dev.K != 0) return fail(MGRIT_HIP_EINVAL, "level %d already has %d separable forcing terms", lvl, lv.dev.K);
+    lv.dev.fb = rows;
+    return 0;
+}
+
 int mgrit_hip_chain_enable(mgrit_hip_engine *e, int lvl, int on) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
@@ -1864,7 +1891,7 @@ int mgrit_hip_chain_state_len(mgrit_hip_engine *e, int lvl, int *len_out) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
     if (!len_out) return fail(MGRIT_HIP_EINVAL, "null output");
-    *len_out = (lvl > 0 && e->L[lvl].dev.chT && e->L[lvl].chain_overlapped && !plain_chain()) ? e->L[lvl].dev.ld + CHAIN_STATE_TAIL : 0;
+    *len_out = (lvl > 0 && e->L[lvl].dev.chT && e->L[lvl].chain_overlapped && !plain_chain() && !e->L[lvl].dev.fb) ? e->L[lvl].dev.ld + CHAIN_STATE_TAIL : 0;
     return 0;
 }
 
@@ -2171,7 +2198,7 @@ int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id) {
     if (pl->n == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_FAS_FUSED, lvl);
     const int use_g = lvl > 0 ? 1 : 0;
-    if (lf.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && !two_phase_fas()) {   // one pass per C-point, coarse tables from L2
+    if (lf.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && !two_phase_fas() && force_mode(lf) != 3) {   // one pass per C-point, coarse tables from L2
         const dim3 grid(persistent_grid(lf, pl->n)), block(lf.dev.T);
         const int fm = force_mode(lf);
         // forcing factors of both levels are streamed (FORCE 2, the same fma per term): one Phi per point does not pay for

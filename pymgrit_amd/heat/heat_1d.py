@@ -6,7 +6,8 @@ same grid (``nx-2`` interior points, ``dx = x[1]-x[0]``), same backward-Euler st
 
 On MI355X the step runs as a HIP kernel described by ``device_stepper()``. The kernel needs the forcing in
 declarative form ``b(x,t) = sum_k s_k(x) tau_k(t)``: pass ``rhs_separable=[(s_fn, tau_fn), ...]`` (exact), or let the
-constructor detect a rank-one ``rhs`` numerically. A forcing that is not separable is rejected for the device path.
+constructor detect a rank-one ``rhs`` numerically. Any other forcing -- the reference accepts every callable ``rhs(x, t)`` --
+runs on the device from precomputed rows ``rhs(x, t_i)*dt_i`` (one per time point, streamed from HBM).
 """
 import numpy as np
 
@@ -86,10 +87,16 @@ def thomas_toeplitz(beta, diag, d):
     return out
 
 
+class NotSeparable(Exception):
+    """rhs(x, t) is not of the rank-one form s(x)*tau(t)"""
+
+
 def detect_separable(rhs, x, t, who='Heat1D'):
-    """Find (s, tau) with rhs(x,t) = s(x)*tau(t) to rounding, or K=0 for a zero forcing."""
+    """Find (s, tau) with rhs(x,t) = s(x)*tau(t) to rounding, or K=0 for a zero forcing; raises NotSeparable otherwise.
+    The shape of the forcing is compared at 16 times spread over the grid (tau itself is evaluated from rhs at a pivot
+    point for every time point, so its time dependence is exact whatever it is)."""
     nx = x.shape[0]
-    probes = np.unique(np.concatenate((t[:1], t[len(t) // 3:len(t) // 3 + 1], t[len(t) // 2:len(t) // 2 + 1], t[-1:])))
+    probes = np.unique(t[np.unique(np.linspace(0, len(t) - 1, 16).astype(int))])
     samples = [np.asarray(rhs(x, float(tp)), dtype=np.float64) * np.ones(nx) for tp in probes]
     norms = [np.max(np.abs(s)) for s in samples]
     if max(norms) == 0.0:
@@ -102,8 +109,8 @@ def detect_separable(rhs, x, t, who='Heat1D'):
         return float(np.asarray(rhs(_xp, tt), dtype=np.float64).ravel()[0]) / _den
     for tp, smp in zip(probes, samples):
         if np.max(np.abs(smp - s_vec * tau_fn(float(tp)))) > 1e-12 * max(norms):
-            raise Exception(f'{who}: rhs(x,t) is not of the separable form s(x)*tau(t); pass rhs_separable=[(s_fn, '
-                            'tau_fn), ...] to run on the MI355X engine')
+            raise NotSeparable(f'{who}: rhs(x,t) is not of the separable form s(x)*tau(t); pass rhs_separable=[(s_fn, '
+                               'tau_fn), ...] to run on the MI355X engine')
     return [s_vec], [tau_fn]
 
 
@@ -138,6 +145,7 @@ class Heat1D(Application):
         if self._separable is not None:
             rhs = separable_rhs(self._separable)
         self.rhs = rhs
+        self._rhs_declared = rhs      # a caller that replaces .rhs afterwards gets the replaced forcing on the device too
         self.init_cond = init_cond
         self.vector_template = VectorHeat1D(self.nx)
         self.vector_t_start = VectorHeat1D(self.nx)
@@ -158,13 +166,23 @@ class Heat1D(Application):
 
     def device_stepper(self):
         """Declarative Phi for libmgrit_hip (include/mgrit_hip.h: mgrit_hip_level_heat1d)."""
-        if self._device_desc is None:
-            if self._separable is not None:
+        if self._device_desc is None or self._device_desc.get("_rhs") is not self.rhs:
+            rows = None
+            if self._separable is not None and self.rhs is self._rhs_declared:
                 space = [np.asarray(s_fn(self.x), dtype=np.float64) * np.ones(self.nx) for s_fn, _ in self._separable]
                 time_fns = [tau_fn for _, tau_fn in self._separable]
             else:
-                space, time_fns = self._detect_separable()
+                try:
+                    space, time_fns = self._detect_separable()
+                except NotSeparable:
+                    # any rhs(x, t) of the reference (heat/heat_1d.py:138,213): the engine streams one precomputed row
+                    # rhs(x, t_i)*dt_i per time point from HBM instead of evaluating s(x)*tau(t) in registers
+                    space, time_fns, rows = [], [], self.forcing_row
             self._device_desc = {"kind": "heat1d", "n": self.nx, "fac": self.fac,
                                  "forcing_space": np.array(space, dtype=np.float64).reshape(len(space), self.nx),
-                                 "forcing_time": time_fns}
+                                 "forcing_time": time_fns, "forcing_rows": rows, "_rhs": self.rhs}
         return self._device_desc
+
+    def forcing_row(self, t_start, t_stop):
+        """rhs(x, t_stop) * (t_stop - t_start): the term ``step`` adds to u_start (reference heat_1d.py:213), as one row"""
+        return np.asarray(self.rhs(self.x, t_stop) * (t_stop - t_start), dtype=np.float64) * np.ones(self.nx)

@@ -202,9 +202,20 @@ class Heat2D(Application):
             return []
         s1 = (f[2] - f[0]) / (ts[2] - ts[0])
         s0 = f[0] - s1 * ts[0]
+        msg = ('Heat2D: rhs(x,y,t) is not of the form S0(x,y) + S1(x,y)*t; pass rhs_separable=[(S_fn, tau_fn), ...] to run on '
+               'the MI355X engine')
         if np.max(np.abs(s0 + s1 * ts[1] - f[1])) > 1e-12 * scale:
-            raise Exception('Heat2D: rhs(x,y,t) is not of the form S0(x,y) + S1(x,y)*t; pass rhs_separable=[(S_fn, tau_fn), '
-                            '...] to run on the MI355X engine')
+            raise Exception(msg)
+        # the fit must hold at EVERY time point, not only at the three it was made from (a forcing like cos(2t)*x*y on
+        # [0, 2 pi] agrees with a constant there): checked on a 6 x 6 sub-grid of probe points for all t
+        pi = np.unique(np.linspace(0, shape[0] - 1, 6).astype(int))
+        pj = np.unique(np.linspace(0, shape[1] - 1, 6).astype(int))
+        xp, yp = xi[pi, :], yi[:, pj]
+        p0, p1 = s0[np.ix_(pi, pj)], s1[np.ix_(pi, pj)]
+        for tt in self.t:
+            got = np.asarray(self.rhs(x=xp, y=yp, t=float(tt)), dtype=np.float64) * np.ones((pi.size, pj.size))
+            if np.max(np.abs(p0 + p1 * float(tt) - got)) > 1e-11 * scale:
+                raise Exception(msg)
         terms = [(s0, lambda t: 1.0)]
         if np.max(np.abs(s1)) > 0:
             terms.append((s1, lambda t: t))

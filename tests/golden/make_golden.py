@@ -8,6 +8,8 @@ size-1 ``mpi4py`` stand-in in ``tests/golden/_mpi_stub``) and writes small data-
                                 trick of reference tests/core/test_mgrit.py:86-218
   tests/golden/phi.npz/.json    known-answer Application.step outputs (Heat1D, Advection1D, Dahlquist)
   tests/golden/solve.json       residual histories (full precision) + selected solution vectors
+  tests/golden/solve_restated.json  the reference's Mgrit driven by a numpy restatement of the oracle's Thomas step (pins
+                                the solver logic at 1e-10), and a general (non-separable) forcing
   tests/golden/ref_results.json the reference's own tests/mpi/results/* files (data) + literal KATs cited
 
 Usage:  python tests/golden/make_golden.py            (needs /root/reference; ~2 min)
@@ -615,6 +617,76 @@ def make_exchange_fuzz():
           sum(v["crossed"] for v in out.values()), "of", len(out))
 
 
+# --------------------------------------------------------------------------------------------------
+# SURVEY stage (B): the reference's OWN Mgrit (cycle logic, FAS operand order, transfers, stopping test) driven by a
+# Heat1D whose step is the plain-numpy restatement of the oracle's variant-0 Phi (Thomas algorithm, same operation order as
+# oracle/mgrit_oracle.c heat1d_rhs + thomas_toeplitz). With the SuperLU rounding out of the way, the oracle has to
+# reproduce these residual histories to the north-star tolerance (1e-10 relative per iteration; in practice ~1e-15).
+# Also: a general (non-separable) forcing, through the reference's SuperLU step and through the restated step.
+# --------------------------------------------------------------------------------------------------
+def general_rhs(x, t):      # not of the form s(x)*tau(t)
+    return np.exp(-x * t) * np.cos(3.0 * x + t) + x * x * t
+
+
+class RestatedHeat1D(Heat1D):
+    """reference Heat1D with step = Thomas algorithm in the oracle's operation order (no SuperLU)"""
+
+    def step(self, u_start, t_start, t_stop):
+        dt = t_stop - t_start
+        beta, diag = dt * self.fac_, dt * (2.0 * self.fac_) + 1.0
+        d = u_start.get_values() + self.rhs(self.x, t_stop) * dt
+        n = d.shape[0]
+        cp = np.empty(n)
+        piv = diag
+        cp[0] = -beta / piv
+        d[0] = d[0] / piv
+        for j in range(1, n):
+            piv = diag + beta * cp[j - 1]
+            cp[j] = -beta / piv
+            d[j] = (d[j] + beta * d[j - 1]) / piv
+        out = np.empty(n)
+        out[n - 1] = d[n - 1]
+        for j in range(n - 2, -1, -1):
+            out[j] = d[j] - cp[j] * out[j + 1]
+        ret = VectorHeat1D(n)
+        ret.set_values(out)
+        return ret
+
+
+def restated_levels(nxs, ts, x_end=1.0, forcing=rhs, cls=RestatedHeat1D):
+    out = []
+    for nx, t in zip(nxs, ts):
+        app = cls(x_start=0, x_end=x_end, nx=nx, a=1.0, init_cond=init_cond, rhs=forcing, t_interval=t)
+        app.fac_ = 1.0 / (app.x[1] - app.x[0]) ** 2      # a / dx^2 exactly as cases.heat_level_spec computes it
+        out.append(app)
+    return out
+
+
+def make_restated():
+    out = {}
+    t0 = np.linspace(0, 2, 129)
+    ts3 = [t0, t0[::4], t0[::16]]
+
+    def rec(problem, sample_pts, **kw):
+        r = run(problem, sample_pts=sample_pts, **kw)
+        return r
+    out["restated_V"] = rec(restated_levels([65] * 3, ts3), (1, 64, 128), tol=1e-13, max_iter=10)
+    out["restated_F_w13"] = rec(restated_levels([65] * 3, ts3), (128,), tol=1e-13, max_iter=10, cycle_type='F', weight_c=1.3,
+                                nested_iteration=False)
+    out["restated_cf2_nonested"] = rec(restated_levels([33] * 3, ts3), (128,), tol=1e-13, max_iter=10, cf_iter=2,
+                                       nested_iteration=False)
+    tsc = [t0, t0[::2], t0[::4], t0[::8]]
+    out["restated_spatial_coarsening"] = rec(restated_levels([17, 9, 5, 5], tsc, x_end=2.0), (128,),
+                                             transfer=[GridTransferHeat(), GridTransferHeat(), GridTransferCopy()],
+                                             tol=1e-13, max_iter=10)
+    out["restated_general_forcing"] = rec(restated_levels([65] * 3, ts3, forcing=general_rhs), (1, 128), tol=1e-13, max_iter=10)
+    out["superlu_general_forcing"] = rec(restated_levels([65] * 3, ts3, forcing=general_rhs, cls=Heat1D), (1, 128),
+                                         tol=1e-9, max_iter=10)
+    with open(os.path.join(HERE, "solve_restated.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("solve_restated.json:", {k: len(v["conv"]) for k, v in out.items()})
+
+
 def ref_results():
     res = {}
     d = os.path.join(REF, "tests", "mpi", "results")
@@ -655,6 +727,9 @@ def main():
     if "--only-bdf" in sys.argv:
         make_bdf()
         return
+    if "--only-restated" in sys.argv:
+        make_restated()
+        return
     big = "--small" not in sys.argv
     lay = make_layout()
     with open(os.path.join(HERE, "layout.json"), "w") as f:
@@ -673,6 +748,7 @@ def main():
     make_at_mgrit()
     make_local_conv_ranks()
     make_exchange_fuzz()
+    make_restated()
     res, kats = ref_results()
     with open(os.path.join(HERE, "ref_results.json"), "w") as f:
         json.dump({"tests_mpi_results": res}, f, indent=1)

@@ -57,3 +57,22 @@ def test_planned_wide_chain_against_oracle(oracle):
     ref = op.solve()
     assert np.max(np.abs(conv - ref) / ref) <= 1e-10, (conv, ref)
     assert np.array_equal(mg.backend.natural("u", 0), op.state("u", 0))
+
+
+def test_debug_lines_carry_device_times(caplog):
+    """logging.DEBUG: the reference's per-sweep lines (mgrit.py:333,370,486,549), here with the device time of the kernels"""
+    import logging
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from pymgrit_amd import Mgrit
+    prob, tr, opts = dist_worker.build_problem("heat_nx257_nt257", "hip")
+    opts.update(max_iter=1)
+    with caplog.at_level(logging.DEBUG):
+        Mgrit(prob, transfer=tr, logging_lvl=logging.DEBUG, **opts).solve()
+    lines = [r.getMessage() for r in caplog.records]
+    for what, kind in (("F-relax", "relax_f"), ("C-relax", "relax_c"), ("Fas residual", "fas_fused"), ("Forward solve", "chain"),
+                       ("Convergence criterion", "residual")):
+        hit = [ln for ln in lines if ln.startswith(what) and "| device:" in ln and kind in ln]
+        assert hit, (what, lines[:20])
+        ms = float(hit[0].split(kind)[1].split()[1])
+        assert 0.0 < ms < 100.0

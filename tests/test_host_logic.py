@@ -273,3 +273,52 @@ def test_device_application_without_gpu_fails_loudly():
     prob = [Heat1D(x_start=0, x_end=1, nx=17, a=1, t_start=0, t_stop=1, nt=n) for n in (17, 5)]
     with pytest.raises(MgritHipError):
         Mgrit(prob, logging_lvl=30)
+
+
+def test_user_subclass_overriding_step_runs_its_own_step():
+    """backend by type: a subclass of a device application that overrides step() (or a transfer that overrides restriction /
+    interpolation) runs through ITS methods on the plugin path -- the kernels would silently ignore the override"""
+    from pymgrit_amd import GridTransferCopy, Heat1D, Mgrit
+    calls = []
+
+    class MyHeat(Heat1D):
+        def step(self, u_start, t_start, t_stop):
+            calls.append(t_stop)
+            return super().step(u_start, t_start, t_stop)
+
+    class MyCopy(GridTransferCopy):
+        def restriction(self, u):
+            calls.append("R")
+            return super().restriction(u)
+    grids = [np.linspace(0, 1, 17), np.linspace(0, 1, 5)]
+    prob = [MyHeat(x_start=0, x_end=1, nx=9, a=1, t_interval=t) for t in grids]
+    mg = Mgrit(prob, logging_lvl=30, max_iter=1)
+    assert mg.backend.name == "plugin"
+    mg.solve()
+    assert calls
+    del calls[:]
+    prob = [Heat1D(x_start=0, x_end=1, nx=9, a=1, t_interval=t) for t in grids]
+    for p in prob:
+        p.device_stepper = lambda: None      # (no GPU here: keep the library applications on the host path too)
+    mg = Mgrit(prob, transfer=[MyCopy()], logging_lvl=30, max_iter=1)
+    mg.solve()
+    assert "R" in calls
+
+
+def test_library_method_detection():
+    from pymgrit_amd import GridTransferCopy, Heat1D, Mgrit
+
+    class Sub(Heat1D):
+        pass
+
+    class Over(Heat1D):
+        def step(self, u_start, t_start, t_stop):
+            return super().step(u_start, t_start, t_stop)
+    t = np.linspace(0, 1, 5)
+    assert Mgrit._library_method(Sub(x_start=0, x_end=1, nx=9, a=1, t_interval=t), "step")
+    assert not Mgrit._library_method(Over(x_start=0, x_end=1, nx=9, a=1, t_interval=t), "step")
+    plain = Heat1D(x_start=0, x_end=1, nx=9, a=1, t_interval=t)
+    assert Mgrit._library_method(plain, "step")
+    plain.step = lambda *a: None
+    assert not Mgrit._library_method(plain, "step")
+    assert Mgrit._library_method(GridTransferCopy(), "restriction")

@@ -236,3 +236,33 @@ def test_threaded_sweeps_equal_serial_sweeps(oracle):
             assert np.array_equal(a.state(which, lvl), b.state(which, lvl))
     spec = oracle.OracleProblem([cases.heat_level_spec(259, cases.lin(0.01, nt)) for nt in nts], variant=1)
     assert spec.set_threads(4) == 1   # only the natural variant is threaded
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SURVEY stage (B): the solver logic pinned at the north-star tolerance. solve_restated.json holds residual histories of the
+# REFERENCE's Mgrit (its cycle recursion, FAS operand order, transfers, norms) driven by a numpy restatement of the oracle's
+# variant-0 Phi (Thomas algorithm, same operation order): nothing but the solver logic can differ.
+# ------------------------------------------------------------------------------------------------------------------
+RESTATED = cases.load_json("solve_restated.json")
+
+
+@pytest.mark.parametrize("name", [k for k in cases.restated_cases() if k.startswith("restated_")])
+def test_solver_logic_matches_reference_at_1e10(oracle, name):
+    c = cases.restated_cases()[name]
+    conv = oracle.OracleProblem(c["levels"], transfer=c.get("transfer"), variant=0, **c["opts"]).solve()
+    ref = np.array(RESTATED[name]["conv"])
+    assert len(conv) == len(ref)
+    assert np.max(np.abs(conv - ref) / ref) <= 1e-10, (conv, ref)      # measured: <= 3e-16 over ten iterations
+    # the arithmetic spec (variant 1) solves the same systems in another association: same histories down to the
+    # rounding floor eps * ||u|| of a residual (conv falls to 1e-13 here)
+    conv1 = oracle.OracleProblem(c["levels"], transfer=c.get("transfer"), variant=1, **c["opts"]).solve()
+    assert len(conv1) == len(ref) and np.all(np.abs(conv1 - ref) <= 1e-10 * ref + 2e-14), (conv1, ref)
+
+
+def test_general_forcing_matches_reference(oracle):
+    """a forcing that is not separable (rows rhs(x, t_i)*dt_i): the reference's own SuperLU step, fixture tolerance"""
+    c = cases.restated_cases()["superlu_general_forcing"]
+    ref = np.array(RESTATED["superlu_general_forcing"]["conv"])
+    for variant in (0, 1):
+        conv = oracle.OracleProblem(c["levels"], variant=variant, **c["opts"]).solve()
+        assert len(conv) == len(ref) and np.all(np.abs(conv - ref) <= 1e-9 * ref + 2e-11), (variant, conv, ref)
