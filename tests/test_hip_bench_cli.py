@@ -27,7 +27,8 @@ def test_bench_single_gpu_line():
     b = _last_json(r.stdout)
     assert b["metric"].startswith("time-point-DOF updates/sec") and b["n_gpus"] == 1 and b["steps"] == 3 and b["dtype"] == "f64"
     assert b["value"] > 0 and b["higher_is_better"] is True and b["vs_baseline"] is None and b["data"] == "synthetic"
-    assert set(b["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and b["roofline"]["bound"] == "hbm"
+    assert set(b["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"} and b["roofline"]["bound"] == "hbm"
+    assert b["sweeps"] and all(r["ms_per_cycle"] > 0 for r in b["sweeps"].values()) and b["cycle"]["algorithmic_bytes"] > 0
     assert set(b["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and b["cpu_baseline"]["kind"] == "port"
     assert b["iters_to_tol"]["sample_nt1025"]["gpu_iters"] == b["iters_to_tol"]["sample_nt1025"]["cpu_iters"]
     assert "workload" in b["config"]
@@ -37,11 +38,35 @@ def test_bench_two_ranks_line():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU visible")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "1024",
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    # no launcher around it: `python bench.py --gpus 2` starts its own ranks (torch.distributed.run as a child process, before
+    # anything touches the GPU) and relays rank 0's line
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "1024",
                         "--nt", "2049", "--steps", "3", "--warmup", "1", "--backend", "gloo"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     b = _last_json(r.stdout)
     assert b["n_gpus"] == 2 and b["config"]["pipeline_depth"] == 4 and b["value"] > 0 and b["scaling"] == "strong"
     assert b["fcf_relax_level0"]["ms"] > 0
+    assert b["exchange"]["messages_per_cycle"] > 0 and b["exchange"]["backend"] == "gloo" and b["nccl_ranks"] == 0
+
+
+def test_bench_refuses_a_mismatched_launcher():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120,
+                       cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stdout + r.stderr)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL transport cannot share one device")
+def test_bench_two_gpus_over_rccl():
+    """the N > 1 line the driver's scaling run produces: ghost rows travel device to device over RCCL (nccl backend)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "4096", "--nt", "4097", "--steps", "3",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    b = _last_json(r.stdout)
+    assert b["n_gpus"] == 2 and b["nccl_ranks"] == 2 and b["exchange"]["device_resident_messages"] == b["exchange"]["messages_total"]
