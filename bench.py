@@ -358,6 +358,10 @@ def main():
     ap.add_argument("--plan-blocks", dest="plan_blocks", type=int, default=None,
                     help="blocks of time points of the planned cycle (core/cycle_plan.py); default: the backend's choice, "
                          "1 = program order")
+    ap.add_argument("--all-configs", dest="all_configs", action="store_true",
+                    help="after the headline line (BASELINE configs[2]) print one more JSON line per other GPU configuration: "
+                         "configs[1] heat_1d 1024 x 4097, configs[3] heat_2d 512^2, configs[4] advection_1d (each in a child "
+                         "process of its own)")
     ap.add_argument("--workload", default="heat1d", choices=["heat1d", "heat2d", "advection"],
                     help="heat1d = BASELINE configs[2] (default, the driver's run); heat2d = configs[3] on one GPU")
     ap.add_argument("--nx2d", type=int, default=512)
@@ -501,7 +505,8 @@ def main():
                                f"(BASELINE configs[{2 if (nx, nt0) == (16384, 65537) else 1 if (nx, nt0) == (1024, 4097) else '-'}]; "
                                f"time points sharded over {world} GPU(s))",
                    "phi_per_cycle_by_level": counts, "dof": dof, "pipeline_depth": mg.pipeline_depth(),
-                   "plan_blocks": mg.plan_blocks()},
+                   "plan_blocks": mg.plan_blocks(),
+                   "cycle_graph": any(p is not None and getattr(p, "_hip", {}).get("graph") is not None for p in mg._plans.values())},
         # the kernel that takes the largest share of the cycle's device time (this rank), priced against the HBM roofline with
         # SURVEY 8d's algorithmic bytes; `limited_by` says what really bounds it
         "roofline": {"bound": "hbm", "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -545,6 +550,18 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if args.all_configs and world == 1:
+        import subprocess
+        del mg, be, problem
+        torch.cuda.empty_cache()
+        me = os.path.abspath(__file__)
+        for extra in (["--nx", "1024", "--nt", "4097", "--steps", "200", "--warmup", "20", "--no-cpu-baseline"],
+                      ["--workload", "heat2d", "--steps", "3", "--warmup", "1"],
+                      ["--workload", "advection", "--steps", "10", "--warmup", "3"]):
+            r = subprocess.run([sys.executable, me] + extra, capture_output=True, text=True)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            print(lines[-1] if lines and r.returncode == 0 else json.dumps({"config": {"workload": " ".join(extra)}, "error": r.stderr[-400:]}),
+                  flush=True)
 
 
 if __name__ == "__main__":

@@ -319,42 +319,79 @@ class HipBackend:
         n_c = len(self.mg.t[-1])
         return int(max(1, min(8, n_c // 512)))
 
+    def plan_single_block(self):
+        """a cycle too small to be cut into blocks is still planned (as one block, program order): what pays there is the
+        replay of the whole cycle as one hipGraph (plan_run)"""
+        return all(d["kind"] in ("heat1d", "advection1d") for d in self.desc) and self.mg.lvl_max >= 2
+
     def _use_stream(self, stream):
         if stream is not self._cur_stream:
             check(self.lib.mgrit_hip_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
             self._cur_stream = stream
 
     def plan_run(self, plan):
-        main = self.stream
+        """Replay a planned cycle. The first two executions issue the launches one by one (they also create the device-side
+        index lists); from the third on the whole cycle -- both streams, with the events between them -- is ONE hipGraph
+        captured from exactly those launches and replayed with a single call: a cycle of a small hierarchy is a dozen kernels
+        of 5-20 us each, and without the graph their launch cost, not their run time, is what a cycle takes.
+        PYMGRIT_AMD_PLAN_GRAPH=0 keeps the launch-by-launch form."""
+        graph_ok = os.environ.get("PYMGRIT_AMD_PLAN_GRAPH", "1") != "0" and not getattr(self, "_timing_on", False)
+        state = plan.__dict__.setdefault("_hip", {"runs": 0, "graph": None, "failed": False})
+        if state["graph"] is not None and graph_ok:
+            state["graph"].replay()
+            return
+        if graph_ok and state["runs"] >= 2 and not state["failed"]:
+            try:
+                self.sync()
+                graph = torch.cuda.CUDAGraph()
+                cap = self._capture_stream = getattr(self, "_capture_stream", None) or torch.cuda.Stream(device=self.device)
+                with torch.cuda.graph(graph, stream=cap):
+                    self._plan_issue(plan, cap)
+                state["graph"] = graph
+                graph.replay()
+                return
+            except Exception as exc:   # noqa: BLE001 - capture is an optimisation: any refusal falls back to plain launches
+                state["failed"] = True
+                self._use_stream(self.stream)
+                if os.environ.get("PYMGRIT_AMD_PLAN_GRAPH") == "require":
+                    raise
+                import warnings
+                warnings.warn(f"pymgrit_amd: cycle graph capture failed ({exc!r}); launching the cycle kernel by kernel")
+        state["runs"] += 1
+        self._plan_issue(plan, self.stream)
+
+    def _plan_issue(self, plan, main):
         if self._chain_stream is None:
             self._chain_stream = torch.cuda.Stream(device=self.device, priority=-1)
             self._fork = torch.cuda.Event()
         side = self._chain_stream
         reserve = 0
-        if plan.has_chain:
+        if plan.has_chain and plan.n_blocks > 1:
             self._fork.record(main)
             side.wait_event(self._fork)
             # the sweeps leave one CU of XCD 0 per chain worker (one worker per group of 1024 values) to the chain
             groups = max(self.ld[lvl] // 1024 for lvl in {n.lvl for n in plan.order if n.stream == "chain"})
             reserve = int(os.environ.get("PYMGRIT_AMD_PLAN_RESERVE", min(32, max(1, groups))))
+        two = plan.has_chain and plan.n_blocks > 1
         last_side = None
         try:
             if reserve:
                 check(self.lib.mgrit_hip_set_reserve(self.h, reserve))
             for node in plan.order:
-                st = side if node.stream == "chain" else main
-                for p in node.cross_preds:
-                    st.wait_event(p.event)
+                st = side if (two and node.stream == "chain") else main
+                if two:
+                    for p in node.cross_preds:
+                        st.wait_event(p.event)
                 self._use_stream(st)
                 node.fn()
-                if node.needs_event:
+                if two and node.needs_event:
                     if node.event is None:
                         node.event = torch.cuda.Event()
                     node.event.record(st)
                 if st is side:
                     last_side = node
         finally:
-            self._use_stream(main)
+            self._use_stream(self.stream)
             if reserve:
                 check(self.lib.mgrit_hip_set_reserve(self.h, 0))
         if last_side is not None:      # whatever follows on the engine's stream sees the whole cycle
@@ -544,6 +581,7 @@ class HipBackend:
 
     # -- measurement hooks (bench.py) ------------------------------------------------------------------
     def set_timing(self, on):
+        self._timing_on = bool(on)
         check(self.lib.mgrit_hip_set_timing(self.h, int(bool(on))))
 
     def timing_drain(self, max_records=4096):

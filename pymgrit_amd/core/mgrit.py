@@ -361,7 +361,7 @@ class Mgrit:
     # ------------------------------------------------------------------------------------------------
     # the MGRIT cycle (mgrit.py:261-290)
     # ------------------------------------------------------------------------------------------------
-    def plan_blocks(self) -> int:
+    def plan_blocks(self, probe_usable: bool = False) -> int:
         """Blocks of time points of a planned cycle (core/cycle_plan.py); 1 = the cycle runs in program order. The plan
         reorders the launches of ONE rank's cycle, so it needs a cycle without exchange points (one rank) whose sweeps are
         the library's own (a subclass that overrides a sweep keeps the program order)."""
@@ -376,13 +376,20 @@ class Mgrit:
                    "_ec_f_relax", "_fas_residual_fused", "_relax_f"))
         usable = (self.comm_time_size == 1 and self.lvl_max > 1 and own and self._dry is None and
                   not getattr(self, "_sweep_timing", False))     # per-sweep debug timing reports the sweeps in program order
+        if probe_usable:
+            return int(usable)
         return max(want, 1) if usable else 1
 
     def _planned(self, cycle_type, iteration, first_f):
         """the cycle plan for this cycle shape (recorded on first use), or None"""
         blocks = self.plan_blocks()
         if blocks <= 1:
-            return None
+            # one block = program order; the device backend still replays it as one graph launch (small hierarchies)
+            single = (self._plan_request is None and not os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS") and self.comm_time_size == 1
+                      and self.plan_blocks(probe_usable=True) and getattr(self.backend, "plan_single_block", lambda: False)())
+            if not single:
+                return None
+            blocks = 1
         from pymgrit_amd.core.cycle_plan import PlanUnsupported, record_cycle
         key = (cycle_type, iteration == 0, bool(first_f), blocks, tuple(self.cf_iter), float(self.weight_c))
         if key not in self._plans:

@@ -981,9 +981,10 @@ struct mgrit_hip_engine {
     std::vector<hipEvent_t> ev_pool;         // events of drained records, reused
     hipEvent_t last0 = nullptr, last1 = nullptr;   // events of the most recent timed call (mgrit_hip_last_kernel_ms)
     int reserve = 0;              // mgrit_hip_set_reserve: CUs of XCD 0 the sweeps leave to the chain workers (0: program order)
-    int *sched = nullptr;         // device: {next, xcc0, done} of the sweeps' item queue, then {tickets, done} of the chain's
-                                  // worker selection (both reset themselves at the end of every launch)
-    unsigned chain_epoch = 0;     // granule epochs run on across chain launches (no reset of the granules between launches)
+    int *sched = nullptr;         // device counter block (512 B, allocated with the first chain / planned launch): [0..2] {next, xcc0,
+                                  // done} of the sweeps' item queue, [4..5] {tickets, done} of the chain's worker selection (both
+                                  // reset themselves at the end of every launch), [8..9] {granule epoch base, workers done} of the
+                                  // chain, [16..79] the dummy row of lane0_add
     u64 *chain_gran = nullptr;    // [2][MAX_G][4] granules of the cross-workgroup chain
     unsigned *chain_err = nullptr;  // pinned, device-mapped: set by a worker whose bounded spin gave up
     double *pinned = nullptr;     // host staging buffer for small read-backs
@@ -1705,6 +1706,17 @@ int force_mode(const Level &lv) {
         HIP_TRY(hipGetLastError());                                                                              \
     } while (0)
 
+int ensure_sched(mgrit_hip_engine *e) {
+    if (e->sched) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(e->stream, &cs);
+    if (cs != hipStreamCaptureStatusNone) return fail(MGRIT_HIP_EINVAL, "first chain / planned launch inside a stream capture");
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->sched), 512));
+    HIP_TRY(hipMemsetAsync(e->sched, 0, 512, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 // level description as a kernel argument, with the launch-time scheduling fields filled in (see WgQueue): only the kernels
 // that walk their items through a WgQueue look at them
 LevelDev sched_dev(const mgrit_hip_engine *e, const Level &lv) {
@@ -1775,6 +1787,8 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
 static int chain_status(mgrit_hip_engine *e) {
     if (e->chain_err && *e->chain_err != 0u) {
         *e->chain_err = 0u;
+        if (e->sched) (void)hipMemset(e->sched, 0, 512);       // the workers left their counters behind
+        if (e->chain_gran) (void)hipMemset(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4);
         return fail(MGRIT_HIP_EHIP, "cross-workgroup chain kernel timed out waiting for a peer workgroup (results invalid)");
     }
     return 0;
@@ -2009,31 +2023,23 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->chain_err), 256, hipHostMallocMapped));
             *e->chain_err = 0u;
             HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
-            e->chain_epoch = 0;
         }
+        if ((rc = ensure_sched(e))) return rc;
         const bool use_g = lvl > 0;
         const int fm = force_mode(lv);
         for (int r = 0; r < rl->n; ++r) {
             const int st = rl->h_start[r], ln = rl->h_len[r];
-            // granule tags are epochs that run on from launch to launch: a stale granule always carries an older epoch, so the
-            // granules are never cleared between launches (a clear is a dispatch of its own, and in a planned cycle it would
-            // queue behind the sweeps that fill the chip)
-            if (e->chain_epoch > 0xE0000000u || (unsigned)ln > 0x10000000u) {
-                HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
-                e->chain_epoch = 0;
-            }
-            const unsigned ebase = e->chain_epoch;
-            e->chain_epoch += (unsigned)ln + 2u;
+            if ((unsigned)ln > 0x10000000u) return fail(MGRIT_HIP_EUNSUPPORTED, "chain of %d steps", ln);
             int *sel = e->reserve > 0 ? e->sched : nullptr;   // chain_worker uses the words 4, 5 of the block
             const dim3 grid(sel ? 256 : 8 * lv.G), block(2 * LANES);
             if (lv.dev.chT && lv.chain_overlapped && use_g && fm <= 1 && !plain_chain()) {   // (level 0 = a one-level hierarchy: plain)   // one coefficient set, several groups: the overlapped chain
                 const int resume = (lv.chain_resume && r == 0) ? 1 : 0;
                 lv.chain_resume = false;
                 double *state = lv.chain_state;
-                if (fm == 0 && !use_g) hipLaunchKernelGGL((chain2_kernel<0, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, ebase, sel);
-                if (fm == 0 && use_g) hipLaunchKernelGGL((chain2_kernel<0, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, ebase, sel);
-                if (fm == 1 && !use_g) hipLaunchKernelGGL((chain2_kernel<1, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, ebase, sel);
-                if (fm == 1 && use_g) hipLaunchKernelGGL((chain2_kernel<1, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, ebase, sel);
+                if (fm == 0 && !use_g) hipLaunchKernelGGL((chain2_kernel<0, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, e->sched, sel);
+                if (fm == 0 && use_g) hipLaunchKernelGGL((chain2_kernel<0, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, e->sched, sel);
+                if (fm == 1 && !use_g) hipLaunchKernelGGL((chain2_kernel<1, false>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, e->sched, sel);
+                if (fm == 1 && use_g) hipLaunchKernelGGL((chain2_kernel<1, true>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, state, resume, e->sched, sel);
                 HIP_TRY(hipGetLastError());
 #ifdef MGRIT_EXPERIMENT_COUNT_SPINS
                 HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2046,7 +2052,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             lv.chain_resume = false;
 #define CHAIN_CASE(K, F, G_, S_)                                                                              \
     if (lv.dev.kind == K && fm == F && use_g == G_ && (lv.G == 1) == S_)                                       \
-        hipLaunchKernelGGL((chain_kernel<K, F, G_, S_>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, ebase, sel);
+        hipLaunchKernelGGL((chain_kernel<K, F, G_, S_>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, e->sched, sel);
 #define CHAIN_CASES(K, F) CHAIN_CASE(K, F, false, false) CHAIN_CASE(K, F, true, false) CHAIN_CASE(K, F, false, true) \
     CHAIN_CASE(K, F, true, true)
             FOR_EACH_STEPPER(CHAIN_CASES)
@@ -2392,11 +2398,8 @@ int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int 
 int mgrit_hip_set_reserve(mgrit_hip_engine *e, int n_cus) {
     if (!e) return fail(MGRIT_HIP_EINVAL, "null engine");
     if (n_cus < 0 || n_cus > 32) return fail(MGRIT_HIP_EINVAL, "reserve %d outside [0,32]", n_cus);
-    if (n_cus > 0 && !e->sched) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->sched), 512));
-        HIP_TRY(hipMemsetAsync(e->sched, 0, 512, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-    }
+    int rc;
+    if (n_cus > 0 && (rc = ensure_sched(e))) return rc;
     e->reserve = n_cus;
     return 0;
 }
