@@ -148,6 +148,28 @@ int mgrit_hip_ec_runs_create(mgrit_hip_engine *e, int lvl, int n_runs, const int
                              const int32_t *coarse_idx, int *id_out);
 int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id);
 
+/* Whole-level sweeps in one pass for Heat1D with separable forcing on lvl and lvl+1, the identity transfer and lvl = 0.
+ * Interval list: interval i runs from the C-point at fine slot cstart[i] to the next C-point at cend[i] (>= 1 F-point between
+ * them); cend_coarse[i] / cstart_coarse[i] = their coarse slots, cstart_coarse[i] = -1 when the starting C-point takes no part
+ * in the sweep (the first point of the time grid: neither relaxed nor corrected); res_pos[i] = position of the closing
+ * C-point in the residual output of res_len values (a list may hold only some of the
+ * level's intervals: one block of a planned cycle). Workgroups walk chunks of at most `chunk` consecutive intervals in time order.
+ *   mgrit_hip_cf_fas:        Mgrit.c_relax, then Mgrit.f_relax, then Mgrit.fas_residual (mgrit.py:335-370, 292-333, 488-549 in
+ *                            the order of Mgrit.iteration, mgrit.py:277-281; weight_c = 1) for the C-points the intervals end
+ *                            on: they receive u_i = Phi(u_{i-1}), and u, v, g of lvl+1 the injected value and the FAS
+ *                            right-hand side. The F-points of lvl are NOT written (nothing reads them before the next
+ *                            error correction + F-relaxation rewrites them).
+ *   mgrit_hip_ec_relax_res:  Mgrit.error_correction, then Mgrit.f_relax (mgrit.py:715-726, 292-333 as in mgrit.py:283-284), then
+ *                            Mgrit.compute_residual (mgrit.py:387-413): ||Phi(u_{i-1}) - u_i||^2 of every closing C-point is
+ *                            kept in pinned host memory; mgrit_hip_residual_fetch(e, n, out) waits for the sweep and copies
+ *                            the n values (order res_pos) out. */
+int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_t *cstart, const int32_t *cend,
+                               const int32_t *cstart_coarse, const int32_t *cend_coarse, const int32_t *res_pos, int res_len,
+                               int chunk, int *id_out);
+int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int intervals_id);
+int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int intervals_id);
+int mgrit_hip_residual_fetch(mgrit_hip_engine *e, int n, double *sumsq_host);
+
 /* Same two reductions with the result delivered to HOST memory (sumsq_host[r], r < n_runs) when the call returns: the
  * device->host leg of Mgrit.convergence_criterion (mgrit.py:425-432). */
 int mgrit_hip_residual_host(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_host);
@@ -161,7 +183,7 @@ int mgrit_hip_jump_host(mgrit_hip_engine *e, int lvl, int runs_id, const double 
 enum { MGRIT_HIP_T_RELAX_F = 0, MGRIT_HIP_T_RELAX_C = 1, MGRIT_HIP_T_CHAIN = 2, MGRIT_HIP_T_RESIDUAL = 3, MGRIT_HIP_T_JUMP = 4,
        MGRIT_HIP_T_RESTRICT = 5, MGRIT_HIP_T_COPY = 6, MGRIT_HIP_T_FAS_RHS = 7, MGRIT_HIP_T_FAS_FUSED = 8,
        MGRIT_HIP_T_ERROR_CORRECTION = 9, MGRIT_HIP_T_INTERPOLATE = 10, MGRIT_HIP_T_EC_RELAX = 11, MGRIT_HIP_T_AT = 12,
-       MGRIT_HIP_T_KINDS = 13 };
+       MGRIT_HIP_T_CF_FAS = 13, MGRIT_HIP_T_EC_RELAX_RES = 14, MGRIT_HIP_T_KINDS = 15 };
 int mgrit_hip_set_timing(mgrit_hip_engine *e, int enabled);
 int mgrit_hip_last_kernel_ms(mgrit_hip_engine *e, float *ms);
 int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int *lvl, float *ms, int *n_out);

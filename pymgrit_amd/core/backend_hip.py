@@ -30,8 +30,8 @@ class SlabVectorList:
     lane-blocked storage order, include/mgrit_hip.h) and wraps it in the application's Vector type; assignment
     uploads a Vector."""
 
-    def __init__(self, slab, n, template, perm):
-        self.slab, self.n, self.template, self.perm = slab, n, template, perm
+    def __init__(self, slab, n, template, perm, on_write=None):
+        self.slab, self.n, self.template, self.perm, self.on_write = slab, n, template, perm, on_write
 
     def __len__(self):
         return self.slab.shape[0]
@@ -52,6 +52,8 @@ class SlabVectorList:
         return vec
 
     def __setitem__(self, i, vec):
+        if self.on_write is not None:
+            self.on_write()
         vals = np.ascontiguousarray(np.asarray(vec.pack(), dtype=np.float64)).ravel()
         self.slab[self._row(int(i))][self.perm] = torch.from_numpy(vals).to(self.slab.device)
 
@@ -194,7 +196,7 @@ class HipBackend:
             assert slen.value == self.chain_handover[lvl]
             self.chain_state[lvl] = torch.zeros(slen.value, dtype=torch.float64, device=self.device)
             check(self.lib.mgrit_hip_chain_bind(self.h, lvl, C.c_void_p(self.chain_state[lvl].data_ptr())))
-        mg.u.append(SlabVectorList(u, n, tmpl, self.perm[lvl]))
+        mg.u.append(SlabVectorList(u, n, tmpl, self.perm[lvl], on_write=self._forget_residual))
         mg.v.append(SlabVectorList(v, n, tmpl, self.perm[lvl]) if v is not None else None)
         mg.g.append(SlabVectorList(g, n, tmpl, self.perm[lvl]) if g is not None else None)
         if mg.comm_time_rank == 0 and n_pts:
@@ -211,12 +213,16 @@ class HipBackend:
                                     f"device-capable GridTransfer (GridTransferCopy, GridTransferHeat)")
             check(self.lib.mgrit_hip_level_transfer(self.h, lvl, int(tr.device_transfer())))
 
+    def _forget_residual(self):
+        self._residual_cache = None
+
     def natural(self, which, lvl):
         """host copy of a whole slab in natural x order, shape [n_local_points][n] (tests / post-processing)"""
         slab = {"u": self.U, "v": self.V, "g": self.G}[which][lvl]
         return slab[:, self.perm[lvl]].cpu().numpy()
 
     def set_natural(self, which, lvl, values):
+        self._residual_cache = None
         """upload a [n_local_points][n] host array given in natural x order"""
         slab = {"u": self.U, "v": self.V, "g": self.G}[which][lvl]
         slab.zero_()
@@ -240,6 +246,7 @@ class HipBackend:
         return self.U[lvl][idx]
 
     def commit(self, lvl, idx, got, op=None):
+        self._residual_cache = None
         if op == 5 and self.chain_handover.get(lvl):
             ld = self.U[lvl].shape[1]
             self.U[lvl][idx].copy_(got[:ld])
@@ -297,6 +304,8 @@ class HipBackend:
 
     # -- sweeps ----------------------------------------------------------------------------------------
     def relax(self, lvl, runs, mode):
+        if lvl == 0:
+            self._residual_cache = None
         if not runs:
             return
         code = {'F': hip_lib.RELAX_F, 'C': hip_lib.RELAX_C, 'CHAIN': hip_lib.RELAX_CHAIN}[mode]
@@ -341,18 +350,31 @@ class HipBackend:
             state["graph"].replay()
             return
         if graph_ok and state["runs"] >= 2 and not state["failed"]:
+            import gc
+            gc_was_on = gc.isenabled()
             try:
                 self.sync()
                 graph = torch.cuda.CUDAGraph()
                 cap = self._capture_stream = getattr(self, "_capture_stream", None) or torch.cuda.Stream(device=self.device)
-                with torch.cuda.graph(graph, stream=cap):
-                    self._plan_issue(plan, cap)
+                gc.collect()
+                gc.disable()     # a collection inside the capture could run the destructor of an old engine (hipFree,
+                                 # hipStreamSynchronize): calls that invalidate a capture in progress
+                try:
+                    with torch.cuda.graph(graph, stream=cap, capture_error_mode="thread_local"):
+                        self._plan_issue(plan, cap)
+                finally:
+                    if gc_was_on:
+                        gc.enable()
                 state["graph"] = graph
                 graph.replay()
                 return
             except Exception as exc:   # noqa: BLE001 - capture is an optimisation: any refusal falls back to plain launches
                 state["failed"] = True
                 self._use_stream(self.stream)
+                try:
+                    torch.cuda.synchronize(self.device)   # surfaces (and clears) what the broken capture left behind
+                except Exception:   # noqa: BLE001
+                    pass
                 if os.environ.get("PYMGRIT_AMD_PLAN_GRAPH") == "require":
                     raise
                 import warnings
@@ -405,6 +427,10 @@ class HipBackend:
         if not len(points):
             return []
         host = np.empty(len(points), dtype=np.float64)
+        cache = getattr(self, "_residual_cache", None)
+        if cache is not None and len(cache) == len(points) and (cache is points or cache == tuple(points)):
+            check(self.lib.mgrit_hip_residual_fetch(self.h, len(points), _ptr(host)))
+            return np.sqrt(host)
         check(self.lib.mgrit_hip_residual_host(self.h, 0, self._point_run_id(0, points), _ptr(host)))
         return np.sqrt(host)
 
@@ -446,6 +472,7 @@ class HipBackend:
             torch.index_select(self.U[0], 0, self._snap_idx, out=self._snap[slot])
 
     def restore_cpoints(self, slot, points):
+        self._residual_cache = None
         if len(points):
             self.U[0].index_copy_(0, self._snap_idx, self._snap[slot])
 
@@ -558,6 +585,8 @@ class HipBackend:
 
     def ec_relax(self, lvl, triples):
         """error correction of the C-point in front of each run + the run's F-relaxation in one launch"""
+        if lvl == 0:
+            self._residual_cache = None
         if not triples:
             return
 
@@ -568,11 +597,53 @@ class HipBackend:
             return rid.value
         check(self.lib.mgrit_hip_ec_relax(self.h, lvl, self._handle(self._runs, lvl, triples, "ecruns", create)))
 
+    # -- whole-level sweeps in one pass (include/mgrit_hip.h: mgrit_hip_cf_fas / mgrit_hip_ec_relax_res) -------------------
+    def can_fuse_level(self, lvl):
+        """level 0, Heat1D with a separable forcing on both levels, identity transfer (weight and layout: the caller)"""
+        tr = self.mg.transfer_objects[lvl]
+        da, db = self.desc[lvl], self.desc[lvl + 1]
+        return (lvl == 0 and os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and hasattr(tr, "device_transfer") and
+                int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and da["kind"] == db["kind"] == "heat1d" and
+                self.n[lvl] == self.n[lvl + 1] and da.get("forcing_rows") is None and db.get("forcing_rows") is None and
+                len(da.get("forcing_time", [])) == len(db.get("forcing_time", [])))
+
+    def _intervals_id(self, lvl, intervals):
+        def create():
+            iid = C.c_int(-1)
+            cols = [_i32([iv[k] for iv in intervals]) for k in range(5)]
+            chunk = int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK", "4"))
+            res_len = len(self.mg._c_points(lvl))
+            check(self.lib.mgrit_hip_intervals_create(self.h, lvl, len(intervals), _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]),
+                                                      _ptr(cols[3]), _ptr(cols[4]), res_len, chunk, C.byref(iid)))
+            return iid.value
+        return self._handle(self._runs, lvl, intervals, "ivals", create)
+
+    def cf_fas(self, lvl, intervals):
+        """c_relax + f_relax + fas_residual of level lvl for the intervals (cstart, cend, cstart_coarse, cend_coarse, res_pos)"""
+        if intervals:
+            self._residual_cache = None
+            check(self.lib.mgrit_hip_cf_fas(self.h, lvl, self._intervals_id(lvl, intervals)))
+
+    def ec_relax_res(self, lvl, intervals, base=0):
+        """error_correction + f_relax + compute_residual; the per-point sums of squares stay in pinned host memory until
+        residual_norms() asks for exactly these points"""
+        if intervals:
+            check(self.lib.mgrit_hip_ec_relax_res(self.h, lvl, self._intervals_id(lvl, intervals)))
+
+    def residual_ready(self, points):
+        """the residual of exactly these level-0 points has been produced by the last ec_relax_res sweep(s) and level 0 has not
+        been touched since (Mgrit._ec_f_relax sets it, every other sweep on level 0 clears it)"""
+        self._residual_cache = tuple(points) if not isinstance(points, tuple) else points
+
     def error_correction(self, lvl, pairs):
+        if lvl == 0:
+            self._residual_cache = None
         if pairs:
             check(self.lib.mgrit_hip_error_correction(self.h, lvl, self._pair_id(lvl, pairs)))
 
     def interpolate(self, lvl, pairs):
+        if lvl == 0:
+            self._residual_cache = None
         if pairs:
             check(self.lib.mgrit_hip_interpolate(self.h, lvl, self._pair_id(lvl, pairs)))
 

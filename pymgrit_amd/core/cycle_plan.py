@@ -67,6 +67,7 @@ class Recorder:
         self.mg, self.real = mg, backend
         self.K, self.block_of = block_maps(mg.t, n_blocks)
         self.nodes = []
+        self.host_after = []        # host-only bookkeeping calls of the cycle: run after every execution of the plan
         self._last_write, self._readers = {}, {}
         self.row_bytes = [8.0 * getattr(backend, "ld", [1] * mg.lvl_max)[lvl] if hasattr(backend, "ld") else 8.0
                           for lvl in range(mg.lvl_max)]
@@ -217,6 +218,31 @@ class Recorder:
                 reads |= {("g", lvl, b)}
             self._add("fas_rhs", lvl, b, lambda p=part: real.fas_rhs(lvl, p), reads, self._cells("g", lvl + 1, co), 8 * len(part))
 
+    # whole-level passes of the device backend (backend_hip.cf_fas / ec_relax_res): items are intervals
+    # (cstart, cend, cstart_coarse, cend_coarse, res_pos); an interval belongs to the block of the C-point it ends on
+    def cf_fas(self, lvl, intervals):
+        real = self.real
+        for b, part in self._by_block(lvl, intervals, 1):
+            cs, ce, jcs, jce = _interval_cells(self, lvl, part)
+            # reads: the old last F-point of every interval (its own block), and for the first interval of a chunk the F-point
+            # in front of its starting C-point or that C-point itself (possibly the block before)
+            reads = {("u", lvl, b)} | self._cells("u", lvl, cs) | self._cells("u", lvl, np.maximum(cs - 1, 0))
+            writes = {("u", lvl, b)} | self._cells("u", lvl + 1, jce) | self._cells("v", lvl + 1, jce) | self._cells("g", lvl + 1, jce)
+            self._add("cf_fas", lvl, b, lambda p=part: real.cf_fas(lvl, p), reads, writes, 7 * len(part))
+
+    def ec_relax_res(self, lvl, intervals):
+        real = self.real
+        for b, part in self._by_block(lvl, intervals, 1):
+            cs, ce, jcs, jce = _interval_cells(self, lvl, part)
+            reads = self._cells("u", lvl + 1, jce) | self._cells("v", lvl + 1, jce) | self._cells("u", lvl + 1, jcs[jcs >= 0]) | \
+                self._cells("v", lvl + 1, jcs[jcs >= 0]) | self._cells("u", lvl, cs[jcs < 0])
+            n_f = int(np.sum(ce - cs - 1))
+            self._add("ec_relax_res", lvl, b, lambda p=part: real.ec_relax_res(lvl, p), reads, {("u", lvl, b), ("res", lvl, b)},
+                      3 * len(part) + n_f)
+
+    def residual_ready(self, points):
+        self.host_after.append(lambda: self.real.residual_ready(points))
+
     def fas_fused(self, lvl, triples):
         real = self.real
         for b, part in self._by_block(lvl, triples, 0):
@@ -228,12 +254,17 @@ class Recorder:
             self._add("fas_fused", lvl, b, lambda p=part: real.fas_fused(lvl, p), reads, writes, (7 if lvl > 0 else 6) * len(part))
 
 
+def _interval_cells(rec, lvl, part):
+    cs, ce, jcs, jce = [np.asarray([iv[k] for iv in part], dtype=np.int64) for k in range(4)]
+    return cs, ce, jcs, jce
+
+
 class Plan:
     """the scheduled cycle: `order` = nodes in issue order (a topological order of the graph); per node the stream it runs on
     and the nodes of the OTHER stream it has to wait for"""
 
-    def __init__(self, nodes, n_blocks):
-        self.nodes, self.n_blocks = nodes, n_blocks
+    def __init__(self, nodes, n_blocks, host_after=()):
+        self.nodes, self.n_blocks, self.host_after = nodes, n_blocks, list(host_after)
         self.order = schedule(nodes)
         self.makespan = max((n.finish for n in nodes), default=0.0)
         self.has_chain = any(n.stream == "chain" for n in nodes)
@@ -241,9 +272,12 @@ class Plan:
     def run(self, backend):
         runner = getattr(backend, "plan_run", None)
         if runner is not None:
-            return runner(self)
-        for node in self.order:      # host backends: the scheduled order, serially
-            node.fn()
+            runner(self)
+        else:
+            for node in self.order:      # host backends: the scheduled order, serially
+                node.fn()
+        for fn in self.host_after:
+            fn()
 
     def describe(self):
         return [f"{n.start * 1e3:8.3f} ms  {n.stream:5s}  {n.name:18s} L{n.lvl} block {n.chunk}" for n in self.order]
@@ -302,4 +336,4 @@ def record_cycle(mg, backend, n_blocks, walk):
         walk()
     finally:
         mg.backend = backend
-    return Plan(rec.nodes, rec.K)
+    return Plan(rec.nodes, rec.K, rec.host_after)

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libmgrit_hip.so")
 RELAX_F, RELAX_C, RELAX_CHAIN = 0, 1, 2
 # MGRIT_HIP_T_*: kinds of timed entry-point calls (mgrit_hip_timing_drain)
 TIMED_KINDS = ("relax_f", "relax_c", "chain", "residual", "jump", "restrict", "copy", "fas_rhs", "fas_fused",
-               "error_correction", "interpolate", "ec_relax", "at_solve")
+               "error_correction", "interpolate", "ec_relax", "at_solve", "cf_fas", "ec_relax_res")
 STEPPER_HEAT1D, STEPPER_ADVECTION1D = 1, 2
 TRANSFER_COPY, TRANSFER_HEAT1D = 0, 1
 MAX_N = 16384
@@ -62,6 +62,11 @@ EXPORTS = {
     "mgrit_hip_timing_drain": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mgrit_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgrit_hip_set_reserve": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgrit_hip_intervals_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "mgrit_hip_cf_fas": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_ec_relax_res": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_residual_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -365,12 +365,14 @@ class Mgrit:
         """Blocks of time points of a planned cycle (core/cycle_plan.py); 1 = the cycle runs in program order. The plan
         reorders the launches of ONE rank's cycle, so it needs a cycle without exchange points (one rank) whose sweeps are
         the library's own (a subclass that overrides a sweep keeps the program order)."""
+        if self._dry is not None or self.comm_time_size != 1:
+            return 0 if probe_usable else 1
         if self._plan_request is not None:
             want = int(self._plan_request)
         elif os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS"):
             want = int(os.environ["PYMGRIT_AMD_PLAN_BLOCKS"])
         else:
-            want = int(getattr(self.backend, "plan_blocks", lambda: 1)())
+            want = int(getattr(self.backend, "plan_blocks", lambda: 1)() or 1)
         own = all(getattr(type(self), name) is getattr(Mgrit, name) for name in
                   ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "forward_solve", "_exchange",
                    "_ec_f_relax", "_fas_residual_fused", "_relax_f"))
@@ -414,12 +416,23 @@ class Mgrit:
             return
         if first_f and (lvl > 0 or iteration == 0):
             self.f_relax(lvl=lvl)
-        for _ in range(self.cf_iter[lvl]):
+        fused = self._level_intervals(lvl)     # whole-level sweeps in one pass (device backend, one rank), or None
+        down = fused is not None and self.cf_iter[lvl] >= 1
+        for _ in range(self.cf_iter[lvl] - (1 if down else 0)):
             self.c_relax(lvl=lvl)
             self.f_relax(lvl=lvl)
-        self.fas_residual(lvl=lvl)
+        if down:      # the last C-relaxation + F-relaxation + the FAS residual: one pass
+            head = self._cached(('pair_head', lvl), lambda: self._pairs(lvl, skip_first=False)[:1])
+            self.backend.restrict_u(lvl, head)
+            self.backend.cf_fas(lvl, fused)
+            self.backend.copy_pairs_u_to_v(lvl, head)
+        else:
+            self.fas_residual(lvl=lvl)
         self.iteration(lvl=lvl + 1, cycle_type=cycle_type, iteration=iteration, first_f=True)
-        if self._can_fuse_ec(lvl):
+        if fused is not None and lvl == 0 and self.conv_crit in (0, 2):   # correction + F-relaxation + the residual check's sums
+            self.backend.ec_relax_res(lvl, fused)
+            self.backend.residual_ready(self._c_points(0))
+        elif self._can_fuse_ec(lvl):
             self._ec_f_relax(lvl)
         else:
             self.error_correction(lvl=lvl)
@@ -464,6 +477,32 @@ class Mgrit:
             coarse_of = dict(self._pairs(lvl, skip_first=True))
             return [(st, ln, coarse_of.get(st - 1, -1)) for st, ln in runs]
         self.backend.ec_relax(lvl, self._cached(('ec_' + tag, lvl), build))
+
+    def _level_intervals(self, lvl):
+        """[(cstart, cend, cstart_coarse, cend_coarse, res_pos)] of level lvl when its sweeps can run as whole-level passes
+        (mgrit_hip_cf_fas / mgrit_hip_ec_relax_res), else None: one rank (no exchange point inside the pass), the library's own
+        sweeps, weight 1, and a level whose F-points all lie between two local C-points."""
+        def build():
+            be = self.backend
+            own = all(getattr(type(self), name) is getattr(Mgrit, name) for name in
+                      ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "compute_residual", "_exchange",
+                       "_ec_f_relax"))
+            if not (own and self.comm_time_size == 1 and self.weight_c == 1.0 and lvl < self.lvl_max - 1 and
+                    not getattr(self, "_sweep_timing", False) and     # per-sweep debug lines: sweep by sweep
+                    getattr(be, "can_fuse_level", None) is not None and be.can_fuse_level(lvl)):
+                return [None]
+            pairs = self._pairs(lvl, skip_first=False)
+            if len(pairs) < 2 or pairs[0][0] != 0 or self._c_points(lvl) != [p[0] for p in pairs[1:]]:
+                return [None]
+            runs = self._f_runs(lvl)
+            want = [(pairs[k][0] + 1, pairs[k + 1][0] - pairs[k][0] - 1) for k in range(len(pairs) - 1)]
+            if [tuple(r) for r in runs] != want or any(ln < 1 for _, ln in want):
+                return [None]
+            return [[(pairs[k][0], pairs[k + 1][0], pairs[k][1] if k >= 1 else -1, pairs[k + 1][1], k) for k in range(len(pairs) - 1)]]
+        got = self._cached(('intervals', lvl), build)[0]
+        if got is None:
+            return None
+        return self._cached(('intervals_list', lvl), lambda: got)
 
     def _can_fuse_ec(self, lvl):
         return (getattr(self.backend, "can_fuse_ec", None) is not None and self.backend.can_fuse_ec(lvl) and

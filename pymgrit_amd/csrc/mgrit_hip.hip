@@ -790,6 +790,169 @@ __global__ void __launch_bounds__(1024) fas_fused_kernel(LevelDev L, LevelDev Lc
     }
 }
 
+// Phi of ANOTHER Heat1D level (Lc, step j) applied to w while the calling kernel's own level keeps its tables in LDS: the
+// correction table, Pt and the forcing factors of Lc are read straight from global memory -- 144 KB per level that every
+// workgroup reads, so they stay in L2 and cost no HBM traffic -- and its scalar coefficients live only for this call (the
+// caller reloads its own set afterwards: both at once do not fit the SGPR file). Arithmetic identical to phi_apply on Lc.
+template <int FORCE>
+__device__ __forceinline__ void phi_other_level(double (&w)[E], StepCtx &ctx, const LevelDev &Lc, int j, const Smem &sm, unsigned sl,
+                                                int t, int lane, int wave, int G) {
+    const int cj = __builtin_amdgcn_readfirstlane(Lc.cidx[j]);
+    const CSet *gc = Lc.cs + cj;
+    Smem smc = sm;
+    smc.tab = const_cast<double2 *>(Lc.tabP) + (size_t)cj * 8 * Lc.T;
+    smc.pt = const_cast<double2 *>(Lc.ptP) + (size_t)cj * 1024;
+    if (FORCE != 0) {
+        for (int kk = 0; kk < Lc.K; ++kk) {
+            const double ck = Lc.tc[(size_t)kk * Lc.n_pts + j];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double2 sv = Lc.sP[(size_t)kk * 8 * Lc.T + sl + q * 64];
+                w[2 * q] = fma(sv.x, ck, w[2 * q]);
+                w[2 * q + 1] = fma(sv.y, ck, w[2 * q + 1]);
+            }
+        }
+    }
+    Coef cc;
+    load_coef(cc, gc);
+    const LaneCoef lcc = lane_coef(gc->lp, lane);
+    const int par = ctx.parity;
+    ctx.parity ^= 1;
+    heat_solve(w, cc, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
+}
+
+// Interval list of the fused level sweeps below: item = the interval from one C-point to the next,
+//   cstart / cend = fine slots of the two C-points (at least one F-point between them), cend_coarse = coarse slot of the
+//   closing C-point, res_pos = position of the closing C-point in the residual output.
+// Workgroups take CHUNKS of consecutive intervals (chunk_first, chunk_len) and walk them in time order, so the C-point an
+// interval ends on is the one the next interval starts from and stays in registers; chunk_start_coarse = coarse slot of the
+// chunk's first C-point when that point takes part in the sweep (it is C-relaxed / corrected), -1 when it is not (the first
+// point of the time grid).
+struct IntervalsDev {
+    const int32_t *cstart, *cend, *cend_coarse, *res_pos, *chunk_first, *chunk_len, *chunk_start_coarse;
+    int n_chunks;
+};
+
+// c_relax + f_relax + fas_residual of one level in ONE pass (mgrit.py:335-370, 292-333, 488-549 as Mgrit.iteration calls them
+// one after the other, mgrit.py:277-281), Heat1D on both levels, identity transfer, weight 1. Per interval (C_j, C_{j+1}]:
+//   q        = Phi_{l+1}(C'_j)                      parked in the row of g^{l+1}_{j+1}
+//   F'_last  = Phi_l^{m-1}(C'_j)                    the F-relaxation; its points are NOT stored: nothing reads a level's F-points
+//                                                   before the error correction + F-relaxation on the way up rewrites them
+//   C'_{j+1} = Phi_l(u_old[c_{j+1} - 1])            the C-relaxation, from the OLD last F-point of the interval (F rows are
+//                                                   never written here, so no other workgroup can have touched it)
+//   u^{l+1}_{j+1} = v^{l+1}_{j+1} = C'_{j+1},   g^{l+1}_{j+1} = ((Phi_l(F'_last) - C'_{j+1}) + C'_{j+1}) - q
+// Rows through HBM per interval: 1 read + 5 written + the parked q (written and read back) instead of 12 (C-relax 2, F-relax
+// m, fused FAS 6). A chunk's first C-point is recomputed from its old F-point (one more Phi per chunk), not waited for.
+template <int FORCE>
+__global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, IntervalsDev I) {
+    constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
+    WG_PROLOGUE;
+    for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < I.n_chunks; wq.advance(t)) {
+        const int k = wq.cur;
+        wq.prefetch(t);
+        const int i0 = I.chunk_first[k], cnt = I.chunk_len[k];
+        double x[E];
+        {
+            const int cs = I.cstart[i0];
+            if (I.chunk_start_coarse[k] >= 0) {   // C'_j of the chunk's first C-point, recomputed
+                load_row(L.u + (size_t)(cs - 1) * L.ld, sl, x);
+                if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);
+                phi_apply<KIND, FORCE>(x, ctx, L, cs, sm, t, lane, wave, G);
+            } else {
+                load_row(L.u + (size_t)cs * L.ld, sl, x);
+            }
+        }
+        for (int it = i0; it < i0 + cnt; ++it) {
+            const int cs = I.cstart[it], ce = I.cend[it], jc = I.cend_coarse[it];
+            {   // q = Phi_{l+1}(v_j), v_j = C'_j
+                double w[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) w[e] = x[e];
+                phi_other_level<FORCE>(w, ctx, Lc, jc, sm, sl, t, lane, wave, G);
+                store_row(Lc.g + (size_t)jc * Lc.ld, sl, w);
+            }
+            if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);   // not kept alive across the coarse Phi
+            for (int i = cs + 1; i < ce; ++i) phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+            double b[E];
+            load_row(L.u + (size_t)(ce - 1) * L.ld, sl, b);
+            phi_apply<KIND, FORCE>(b, ctx, L, ce, sm, t, lane, wave, G);
+            store_row(L.u + (size_t)ce * L.ld, sl, b);
+            store_row(Lc.u + (size_t)jc * Lc.ld, sl, b);
+            store_row(Lc.v + (size_t)jc * Lc.ld, sl, b);
+            phi_apply<KIND, FORCE>(x, ctx, L, ce, sm, t, lane, wave, G);
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = x[e] + b[e];
+            {
+                double w[E];
+                load_row(Lc.g + (size_t)jc * Lc.ld, sl, w);   // q, written above by this very lane
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[e] = x[e] - w[e];
+            }
+            store_row(Lc.g + (size_t)jc * Lc.ld, sl, x);
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = b[e];
+        }
+    }
+    wq.end(t);
+}
+
+// error_correction + f_relax + compute_residual of level 0 in ONE pass (mgrit.py:715-726, 292-333 as Mgrit.iteration calls
+// them, mgrit.py:283-284, then 387-413 from convergence_criterion), identity transfer. Per interval (C_j, C_{j+1}]:
+//   F''      = Phi-propagation from the corrected C''_j, stored
+//   C''_{j+1} = v^{l+1}_{j+1} + (u^{l+1}_{j+1} - v^{l+1}_{j+1})   (v^{l+1}_{j+1} IS u^l at that C-point, bit for bit; read from v,
+//                                                                 which nobody writes on the way up), stored
+//   out[res_pos] = || Phi_l(F''_last) - C''_{j+1} ||^2
+// 2 rows read + m written per interval instead of 2 + m (correction + F-relaxation) and 2 more for the residual.
+template <int FORCE>
+__global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, double *__restrict__ out) {
+    constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
+    WG_PROLOGUE;
+    for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < I.n_chunks; wq.advance(t)) {
+        const int k = wq.cur;
+        wq.prefetch(t);
+        const int i0 = I.chunk_first[k], cnt = I.chunk_len[k];
+        double x[E];
+        {
+            const int cs = I.cstart[i0], js = I.chunk_start_coarse[k];
+            if (js >= 0) {   // the corrected value of the chunk's first C-point (stored by the chunk that ends on it)
+                double w[E];
+                load_row(Lc.v + (size_t)js * Lc.ld, sl, x);
+                load_row(Lc.u + (size_t)js * Lc.ld, sl, w);
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[e] = x[e] + (w[e] - x[e]);
+            } else {
+                load_row(L.u + (size_t)cs * L.ld, sl, x);
+            }
+        }
+        for (int it = i0; it < i0 + cnt; ++it) {
+            const int cs = I.cstart[it], ce = I.cend[it], jc = I.cend_coarse[it];
+            for (int i = cs + 1; i < ce; ++i) {
+                phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+                store_row(L.u + (size_t)i * L.ld, sl, x);
+            }
+            double b[E];
+            {
+                double w[E];
+                load_row(Lc.v + (size_t)jc * Lc.ld, sl, b);
+                load_row(Lc.u + (size_t)jc * Lc.ld, sl, w);
+#pragma unroll
+                for (int e = 0; e < E; ++e) b[e] = b[e] + (w[e] - b[e]);
+            }
+            store_row(L.u + (size_t)ce * L.ld, sl, b);
+            phi_apply<KIND, FORCE>(x, ctx, L, ce, sm, t, lane, wave, G);
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
+            const double tot = block_sumsq(x, sm, t, lane, wave, G);
+            if (t == 0) out[I.res_pos[it]] = tot;
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = b[e];
+        }
+    }
+    wq.end(t);
+}
+
 // The same sweep in ONE pass per C-point for Heat1D (both levels of the pair): fine Phi with the fine level's tables in LDS
 // as everywhere else, then the coarse Phi with the coarse level's correction table, Pt and forcing factors read straight
 // from global memory -- 144 KB per level that every workgroup reads, so they stay in L2 and cost no HBM traffic -- and the
@@ -962,6 +1125,8 @@ struct Level {
     std::vector<void *> allocs;
     std::vector<RunList> runs;
     std::vector<PairList> pairs;
+    std::vector<IntervalsDev> ivals;   // mgrit_hip_intervals_create (device arrays live in allocs)
+    std::vector<int> ivals_n;          // intervals per list
     double *scratch = nullptr;
     size_t scratch_rows = 0;
     double *chain_state = nullptr;   // caller-owned [ld + CHAIN_STATE_TAIL]: carry-free part of the last point + carries
@@ -1197,6 +1362,10 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(ecf_kernel<K, F, true>))) return rc;                                                     \
     if ((rc = allow_big_lds(at_kernel<K, F>))) return rc;
     FOR_EACH_STEPPER(ATTR_ALL)
+    if ((rc = allow_big_lds(cfas_kernel<0>))) return rc;
+    if ((rc = allow_big_lds(cfas_kernel<2>))) return rc;
+    if ((rc = allow_big_lds(ecfr_kernel<0>))) return rc;
+    if ((rc = allow_big_lds(ecfr_kernel<2>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<0>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<2>))) return rc;
     if ((rc = allow_big_lds(jump_kernel))) return rc;
@@ -2393,6 +2562,95 @@ int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int 
     e->last0 = e->last1 = nullptr;
     *n_out = n;
     return 0;
+}
+
+int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_t *cstart, const int32_t *cend,
+                               const int32_t *cstart_coarse, const int32_t *cend_coarse, const int32_t *res_pos, int res_len,
+                               int chunk, int *id_out) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    if (lvl + 1 >= e->n_levels || !e->L[lvl + 1].set) return fail(MGRIT_HIP_EINVAL, "level %d has no described coarser level", lvl);
+    if (n < 0 || chunk < 1 || res_len < n || !id_out || (n > 0 && (!cstart || !cend || !cstart_coarse || !cend_coarse || !res_pos)))
+        return fail(MGRIT_HIP_EINVAL, "bad interval list");
+    Level &lv = e->L[lvl];
+    const Level &lc = e->L[lvl + 1];
+    for (int i = 0; i < n; ++i) {
+        if (cstart[i] < 0 || cend[i] >= lv.dev.n_pts || cend[i] - cstart[i] < 2)
+            return fail(MGRIT_HIP_EINVAL, "interval %d = (%d,%d]: two C-points of the local grid with an F-point between them", i, cstart[i], cend[i]);
+        if (cstart_coarse[i] < -1 || cstart_coarse[i] >= lc.dev.n_pts || cend_coarse[i] < 0 || cend_coarse[i] >= lc.dev.n_pts ||
+            (cstart_coarse[i] >= 0 && cstart[i] < 1) || res_pos[i] < 0 || res_pos[i] >= res_len)
+            return fail(MGRIT_HIP_EINVAL, "interval %d: coarse slot or residual position out of range", i);
+    }
+    std::vector<int32_t> cf, cl, cc;
+    for (int i = 0; i < n;) {   // chunks: runs of consecutive intervals, at most `chunk` long
+        int len = 1;
+        while (i + len < n && len < chunk && cstart[i + len] == cend[i + len - 1]) ++len;
+        cf.push_back(i); cl.push_back(len); cc.push_back(cstart_coarse[i]);
+        i += len;
+    }
+    IntervalsDev d{};
+    int32_t *p[7];
+    const std::vector<int32_t> hs[7] = {std::vector<int32_t>(cstart, cstart + n), std::vector<int32_t>(cend, cend + n),
+                                        std::vector<int32_t>(cend_coarse, cend_coarse + n), std::vector<int32_t>(res_pos, res_pos + n),
+                                        cf, cl, cc};
+    for (int k = 0; k < 7; ++k)
+        if ((rc = dev_upload(lv, e->stream, hs[k], &p[k]))) return rc;
+    d.cstart = p[0]; d.cend = p[1]; d.cend_coarse = p[2]; d.res_pos = p[3]; d.chunk_first = p[4]; d.chunk_len = p[5];
+    d.chunk_start_coarse = p[6]; d.n_chunks = (int)cf.size();
+    lv.ivals.push_back(d);
+    lv.ivals_n.push_back(res_len);
+    *id_out = (int)lv.ivals.size() - 1;
+    return 0;
+}
+
+static int fused_level_check(mgrit_hip_engine *e, int lvl, int ivals_id, const char *what) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    if (lvl != 0) return fail(MGRIT_HIP_EUNSUPPORTED, "%s: level 0 only", what);
+    if (lvl + 1 >= e->n_levels || !e->L[lvl + 1].set) return fail(MGRIT_HIP_EINVAL, "level %d has no coarser level", lvl);
+    Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    if (ivals_id < 0 || ivals_id >= (int)lf.ivals.size()) return fail(MGRIT_HIP_EINVAL, "bad interval-list id %d on level %d", ivals_id, lvl);
+    if ((rc = check_bound(lf, false)) || (rc = check_bound(lc, true))) return rc;
+    if (lf.dev.kind != MGRIT_HIP_STEPPER_HEAT1D || lc.dev.kind != MGRIT_HIP_STEPPER_HEAT1D || lf.transfer != MGRIT_HIP_TRANSFER_COPY ||
+        lf.dev.n != lc.dev.n || force_mode(lf) != force_mode(lc) || force_mode(lf) == 3)
+        return fail(MGRIT_HIP_EUNSUPPORTED, "%s needs Heat1D with separable forcing on both levels and the copy transfer", what);
+    return 0;
+}
+
+int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id) {
+    int rc = fused_level_check(e, lvl, ivals_id, "fused C-F-relaxation + FAS residual");
+    if (rc) return rc;
+    Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    const IntervalsDev &I = lf.ivals[ivals_id];
+    if (I.n_chunks == 0) return 0;
+    Timed timed(e, MGRIT_HIP_T_CF_FAS, lvl);
+    const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
+    if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I);
+    else hipLaunchKernelGGL((cfas_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int ivals_id) {
+    int rc = fused_level_check(e, lvl, ivals_id, "fused correction + F-relaxation + residual");
+    if (rc) return rc;
+    Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    const IntervalsDev &I = lf.ivals[ivals_id];
+    if (I.n_chunks == 0) return 0;
+    if ((rc = ensure_pinned(e, lf.ivals_n[ivals_id]))) return rc;
+    Timed timed(e, MGRIT_HIP_T_EC_RELAX_RES, lvl);
+    const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
+    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned);
+    else hipLaunchKernelGGL((ecfr_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mgrit_hip_residual_fetch(mgrit_hip_engine *e, int n, double *sumsq_host) {
+    if (!e || n < 0 || (n > 0 && !sumsq_host)) return fail(MGRIT_HIP_EINVAL, "bad arguments");
+    if ((size_t)n > e->pinned_len) return fail(MGRIT_HIP_EINVAL, "no %d residual values have been produced", n);
+    if (n == 0) return 0;
+    return wait_pinned(e, n, sumsq_host);
 }
 
 int mgrit_hip_set_reserve(mgrit_hip_engine *e, int n_cus) {

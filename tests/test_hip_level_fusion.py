@@ -1,0 +1,67 @@
+"""GPU: the whole-level passes of level 0 (mgrit_hip_cf_fas = C-relaxation + F-relaxation + FAS residual, mgrit_hip_ec_relax_res =
+error correction + F-relaxation + residual sums) against the sweep-by-sweep form (PYMGRIT_AMD_NO_LEVEL_FUSION=1) and the oracle:
+same Phi applications on the same values, so everything an iteration leaves behind is bit-identical."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import dist_worker
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+CASES = ["heat_nx33_V_nested", "heat_nx33_V_nonested", "heat_nx33_F_nested", "heat_nx33_V_cf2", "heat_nx33_V_cflist", "heat_nx33_2lvl_m8",
+         "heat_nx257_nt257", "heat_nx2050_wide", "heat_nx3100_wide_2lvl", "heat_nx33_noforcing", "heat_config2"]
+
+
+def solve(case, fused, blocks=None):
+    from pymgrit_amd import Mgrit
+    prob, tr, opts = dist_worker.build_problem(case, "hip")
+    old = os.environ.pop("PYMGRIT_AMD_NO_LEVEL_FUSION", None)
+    if not fused:
+        os.environ["PYMGRIT_AMD_NO_LEVEL_FUSION"] = "1"
+    try:
+        mg = Mgrit(prob, transfer=tr, logging_lvl=30, plan_blocks=blocks, **opts)
+        assert (mg._level_intervals(0) is not None) == fused
+        conv = mg.solve()["conv"]
+    finally:
+        os.environ.pop("PYMGRIT_AMD_NO_LEVEL_FUSION", None)
+        if old is not None:
+            os.environ["PYMGRIT_AMD_NO_LEVEL_FUSION"] = old
+    return conv, [mg.backend.natural("u", lvl) for lvl in range(mg.lvl_max)], mg
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_level_passes_bit_identical(case):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    conv0, u0, _ = solve(case, False, blocks=1)
+    for blocks in (1, None, 4):
+        conv, u, mg = solve(case, True, blocks=blocks)
+        assert np.array_equal(conv, conv0), (case, blocks, conv, conv0)
+        for a, b in zip(u, u0):
+            assert np.array_equal(a, b), (case, blocks)
+
+
+def test_level_passes_against_oracle(oracle):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from pymgrit_amd import Heat1D, Mgrit
+    nx, nts = 3100, (257, 65, 17)
+    grids = [cases.lin(2, nt) for nt in nts]
+    prob = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=cases.init_cond, rhs_separable=[(cases.rhs_space, cases.rhs_time)],
+                   t_interval=g) for g in grids]
+    mg = Mgrit(prob, logging_lvl=30, max_iter=3, tol=0.0)
+    assert mg._level_intervals(0) is not None
+    conv = mg.solve()["conv"]
+    op = oracle.OracleProblem([cases.heat_level_spec(nx, g) for g in grids], variant=1, max_iter=3, tol=0.0)
+    ref = op.solve()
+    assert np.max(np.abs(conv - ref) / ref) <= 1e-10, (conv, ref)
+    for lvl in range(3):
+        assert np.array_equal(mg.backend.natural("u", lvl), op.state("u", lvl)), lvl
+    # the per-point residual sums the fused pass delivers are those of the residual kernel
+    got = np.asarray(mg.compute_residual())
+    mg.backend._residual_cache = None
+    assert np.array_equal(got, np.asarray(mg.compute_residual()))
