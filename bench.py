@@ -461,6 +461,7 @@ def main():
             cycle(1)
         fence()
     elapsed = time.perf_counter() - t_start
+    chain_clock = be.chain_clock() if hasattr(be, "chain_clock") else (0.0, 0.0)   # last chain launch of the timed region
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -519,7 +520,7 @@ def main():
                                f"(BASELINE configs[{2 if (nx, nt0) == (16384, 65537) else 1 if (nx, nt0) == (1024, 4097) else '-'}]; "
                                f"time points sharded over {world} GPU(s))",
                    "phi_per_cycle_by_level": counts, "dof": dof, "pipeline_depth": mg.pipeline_depth(),
-                   "plan_blocks": mg.plan_blocks(),
+                   "plan_blocks": mg.plan_blocks(), "chain_shader_mhz": chain_clock[0], "chain_us_per_step": chain_clock[1],
                    "cycle_graph": any(p is not None and getattr(p, "_hip", {}).get("graph") is not None for p in mg._plans.values())},
         # the kernel that takes the largest share of the cycle's device time (this rank), priced against the HBM roofline with
         # SURVEY 8d's algorithmic bytes; `limited_by` says what really bounds it

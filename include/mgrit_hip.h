@@ -192,6 +192,9 @@ int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int 
  * streams against each other (events): used to run the coarsest-level chain of one block of time points beside the
  * bandwidth-bound sweeps of other blocks (pymgrit_amd/core/cycle_plan.py). */
 int mgrit_hip_set_stream(mgrit_hip_engine *e, void *stream);
+/* Diagnostics of the most recent overlapped chain launch that has finished: shader clock (MHz, cycle counter against the
+ * constant 100 MHz counter) and microseconds per step as seen by worker 0. Zeros when there is none. */
+int mgrit_hip_chain_clock(mgrit_hip_engine *e, double *mhz, double *us_per_step);
 /* n_cus > 0: the sweeps of later calls leave n_cus CUs of XCD 0 free (their workgroups draw items from a queue; of those that
  * land on XCD 0 only 32 - n_cus per CU-slot stay) and the chain launches take their workers from XCD 0: the two run side by
  * side on two streams. 0 (default): every sweep fills the chip, the chain's workers are the blocks with blockIdx % 8 == 0. */

@@ -55,6 +55,11 @@ def block_maps(t_levels, n_blocks):
         return 1, [np.zeros(len(t), dtype=np.int64) for t in t_levels]
     stride = max(1, -(-(n_c - 1) // n_blocks))
     cuts = tc[stride:n_c - 1:stride]
+    shape = os.environ.get("PYMGRIT_AMD_PLAN_SHAPE")   # relative block sizes, e.g. "1,1,2,4,4,2,1,1" (experiments)
+    if shape:
+        w = np.cumsum([float(x) for x in shape.split(",")])
+        idx = np.unique(np.clip(np.round(w[:-1] / w[-1] * (n_c - 1)).astype(int), 1, n_c - 2))
+        cuts = tc[idx]
     return len(cuts) + 1, [np.searchsorted(cuts, np.asarray(t, dtype=np.float64), side='left').astype(np.int64) for t in t_levels]
 
 

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libmgrit_hip.so")
+LIB_PATH = os.environ.get("PYMGRIT_AMD_LIB") or os.path.join(_PKG, "lib", "libmgrit_hip.so")   # (override: experiment builds)
 
 RELAX_F, RELAX_C, RELAX_CHAIN = 0, 1, 2
 # MGRIT_HIP_T_*: kinds of timed entry-point calls (mgrit_hip_timing_drain)
@@ -62,6 +62,7 @@ EXPORTS = {
     "mgrit_hip_timing_drain": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mgrit_hip_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgrit_hip_set_reserve": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgrit_hip_chain_clock": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mgrit_hip_intervals_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "mgrit_hip_cf_fas": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

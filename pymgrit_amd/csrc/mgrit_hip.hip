@@ -1146,10 +1146,10 @@ struct mgrit_hip_engine {
     std::vector<hipEvent_t> ev_pool;         // events of drained records, reused
     hipEvent_t last0 = nullptr, last1 = nullptr;   // events of the most recent timed call (mgrit_hip_last_kernel_ms)
     int reserve = 0;              // mgrit_hip_set_reserve: CUs of XCD 0 the sweeps leave to the chain workers (0: program order)
-    int *sched = nullptr;         // device counter block (512 B, allocated with the first chain / planned launch): [0..2] {next, xcc0,
+    int *sched = nullptr;         // device counter block (1 KB, allocated with the first chain / planned launch): [0..2] {next, xcc0,
                                   // done} of the sweeps' item queue, [4..5] {tickets, done} of the chain's worker selection (both
                                   // reset themselves at the end of every launch), [8..9] {granule epoch base, workers done} of the
-                                  // chain, [16..79] the dummy row of lane0_add
+                                  // chain, [16..79] the dummy row of lane0_add, [96..159] per-CU claims of the chain's worker selection
     u64 *chain_gran = nullptr;    // [2][MAX_G][4] granules of the cross-workgroup chain
     unsigned *chain_err = nullptr;  // pinned, device-mapped: set by a worker whose bounded spin gave up
     double *pinned = nullptr;     // host staging buffer for small read-backs
@@ -1880,8 +1880,8 @@ int ensure_sched(mgrit_hip_engine *e) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(e->stream, &cs);
     if (cs != hipStreamCaptureStatusNone) return fail(MGRIT_HIP_EINVAL, "first chain / planned launch inside a stream capture");
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->sched), 512));
-    HIP_TRY(hipMemsetAsync(e->sched, 0, 512, e->stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->sched), 1024));
+    HIP_TRY(hipMemsetAsync(e->sched, 0, 1024, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
 }
@@ -1956,7 +1956,7 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
 static int chain_status(mgrit_hip_engine *e) {
     if (e->chain_err && *e->chain_err != 0u) {
         *e->chain_err = 0u;
-        if (e->sched) (void)hipMemset(e->sched, 0, 512);       // the workers left their counters behind
+        if (e->sched) (void)hipMemset(e->sched, 0, 1024);      // the workers left their counters behind
         if (e->chain_gran) (void)hipMemset(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4);
         return fail(MGRIT_HIP_EHIP, "cross-workgroup chain kernel timed out waiting for a peer workgroup (results invalid)");
     }
@@ -2190,7 +2190,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
         if (!e->chain_gran) {
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->chain_gran), sizeof(u64) * 4 * MAX_G * 4));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->chain_err), 256, hipHostMallocMapped));
-            *e->chain_err = 0u;
+            std::memset(e->chain_err, 0, 256);
             HIP_TRY(hipMemsetAsync(e->chain_gran, 0, sizeof(u64) * 4 * MAX_G * 4, e->stream));
         }
         if ((rc = ensure_sched(e))) return rc;
@@ -2659,6 +2659,31 @@ int mgrit_hip_set_reserve(mgrit_hip_engine *e, int n_cus) {
     int rc;
     if (n_cus > 0 && (rc = ensure_sched(e))) return rc;
     e->reserve = n_cus;
+    return 0;
+}
+
+int mgrit_hip_chain_clock(mgrit_hip_engine *e, double *mhz, double *us_per_step) {
+    if (!e || !mhz || !us_per_step) return fail(MGRIT_HIP_EINVAL, "null argument");
+    *mhz = *us_per_step = 0.0;
+    if (!e->chain_err) return 0;
+    const volatile unsigned long long *w = reinterpret_cast<const volatile unsigned long long *>(e->chain_err);
+    if (w[2] == 0 || w[3] == 0) return 0;
+    *mhz = 100.0 * (double)w[1] / (double)w[2];
+    *us_per_step = (double)w[2] / 100.0 / (double)w[3];
+    if (std::getenv("MGRIT_HIP_CHAIN_DEBUG") && e->sched) {
+        int h[16];
+        if (hipMemcpy(h, e->sched + 160, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            std::fprintf(stderr, "chain workers (xcd.cu flags):");
+            for (int k = 0; k < 16; ++k) std::fprintf(stderr, " %d.%02x%s%s(%d)", h[k] & 15, (h[k] >> 4) & 0xff, (h[k] & 0x1000) ? "s" : "", (h[k] & 0x2000) ? "X" : "", h[k] >> 16);
+            std::fprintf(stderr, "\n");
+        }
+        int c[2];
+        if (hipMemcpy(c, e->sched + 10, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
+            std::fprintf(stderr, "chain workers drawn on another XCD so far: %d, second on a CU: %d\n", c[0], c[1]);
+        std::fprintf(stderr, "chain launches by us/step (<1.0, 1.0, 1.1, ...):");
+        for (int b = 0; b < 32; ++b) std::fprintf(stderr, " %u", e->chain_err[32 + b]);
+        std::fprintf(stderr, "\n");
+    }
     return 0;
 }
 
