@@ -169,8 +169,9 @@ def test_heat_1d_forcing_forms():
         fa = da["forcing_space"][0] * da["forcing_time"][0](t)
         fb = db["forcing_space"][0] * db["forcing_time"][0](t)
         assert np.abs(fa - rhs(a.x, t)).max() <= 1e-13 * 10 and np.array_equal(fb, rhs(b.x, t))
-    with pytest.raises(Exception):
-        Heat1D(a=1, x_start=0, x_end=1, nx=17, rhs=lambda x, t: np.sin(x * t), t_start=0, t_stop=2, nt=9).device_stepper()
+    # a forcing that is not of the form s(x)*tau(t) is streamed as rows rhs(x, t_i)*dt_i (general forcing)
+    g = Heat1D(a=1, x_start=0, x_end=1, nx=17, rhs=lambda x, t: np.sin(x * t), t_start=0, t_stop=2, nt=9).device_stepper()
+    assert len(g["forcing_space"]) == 0 and g.get("forcing_rows") is not None
 
 
 def test_advection_1d_constructor_and_host_step():
