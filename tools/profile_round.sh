@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): the profiles a round commits under profiles/ (tools/summarize_profiles.py <tag> copies them).
+#   <tag>_stats          rocprofv3 --kernel-trace --stats, cycle in program order (one launch per sweep and level)
+#   <tag>_stats_planned  the same for the default planned cycle (blocks of time points on two streams, graph replay)
+#   <tag>_fetch/_write   separate --pmc FETCH_SIZE / WRITE_SIZE passes (program order)
+#   <tag>_bench*.log     plain bench lines (default run with the CPU baseline; --all-configs)
+set -o pipefail
+tag=${1:-r02}
+out=$PWD/gpurun_out
+mkdir -p "$out"
+export TMPDIR=/tmp
+B="$PWD/bench.py"
+cd /tmp
+timeout -k 10 300 python3 "$B" --all-configs > "$out/${tag}_bench_all.log" 2> "$out/${tag}_bench_all.err" || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_bench_program_order.log" 2>&1 || exit 2
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_planned" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-ramp > "$out/${tag}_bench_planned.log" 2>&1 || exit 3
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_fetch" -- python3 "$B" --steps 4 --warmup 2 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_fetch.log" 2>&1 || exit 4
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$out/${tag}_write" -- python3 "$B" --steps 4 --warmup 2 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_write.log" 2>&1 || exit 5
+# keep only the summaries (the traces are large)
+find "$out" -name '*kernel_trace.csv' -size +20M -delete
+ls -R "$out" | head -50

@@ -18,13 +18,47 @@ def short(name):
     return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 
 
+def stats_from_db(db, dest):
+    """rocprofv3 of ROCm 7.2 writes a rocpd SQLite database instead of CSV files: rebuild the --stats kernel table
+    (same columns as <pid>_kernel_stats.csv) from its `kernels` view."""
+    import sqlite3
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                       "group by name order by 3 desc").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    with open(dest, "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_ALL)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for name, calls, tot, avg, mn, mx in rows:
+            w.writerow([name, calls, int(tot), f"{avg:.3f}", f"{100.0 * tot / total:.6f}", int(mn), int(mx)])
+
+
+def counters_from_db(db, counter):
+    import sqlite3
+    con = sqlite3.connect(db)
+    return con.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
+
+
 def main(tag):
     out = os.path.join(ROOT, "profiles")
-    stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_stats", "*", "*kernel_stats.csv"))
-    if stats:
-        shutil.copy(stats[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+    for sub in ("stats", "stats_planned"):
+        dest = os.path.join(out, f"{tag}_kernel_{sub}.csv")
+        stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*kernel_stats.csv"))
+        dbs = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*.db"))
+        if stats:
+            shutil.copy(stats[0], dest)
+        elif dbs:
+            stats_from_db(dbs[0], dest)
+    for log in glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_bench*.log")):
+        lines = [ln for ln in open(log) if ln.startswith("{")]
+        if lines:
+            with open(os.path.join(out, os.path.basename(log).replace(".log", ".json")), "w") as f:
+                f.writelines(lines)
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        for db in glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{which}", "*", "*.db")):
+            for name, value in counters_from_db(db, counter):
+                per[short(name)][counter].append(float(value))
         for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{which}", "*", "*counter_collection.csv")):
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] == counter:
@@ -44,9 +78,8 @@ def main(tag):
                       "hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0}
     with open(os.path.join(out, f"{tag}_traffic.json"), "w") as f:
         json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around "
-                           "`python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ramp`; KiB units; read side doubled "
-                           "(gfx950 FETCH_SIZE tallies 128-B requests at 64 B). Averages mix levels for kernels that "
-                           "are launched on several levels; relax_kernel<1, 1, false, 0> is level-0 F-relax only.",
+                           "`python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ramp --plan-blocks 1` (tools/profile_round.sh); KiB units; read side doubled "
+                           "(gfx950 FETCH_SIZE tallies 128-B requests at 64 B). Every kernel name of the headline cycle belongs to one (sweep, level): cfas/ecfr = level 0, the <.., true, ..> kernels and fas_fused1 = level 1, chain2 = level 2; relax_kernel<1, 1, false, 0|1> = the stand-alone level-0 F-/C-relax launches of the fcf_relax_level0 figure.",
                    "kernels": summary}, f, indent=1)
     print("wrote", os.listdir(out))
 
