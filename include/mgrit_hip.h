@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MGRIT_HIP_ABI_VERSION 1
+#define MGRIT_HIP_ABI_VERSION 2
 #define MGRIT_HIP_E 16            /* elements per lane (arithmetic spec) */
 #define MGRIT_HIP_MAX_N 16384     /* max DOFs per time point for the register-resident steppers */
 #define MGRIT_HIP_MAX_N_2PTS 4096 /* two-point steppers: max DOFs per time point of a pair (two coefficient sets in LDS) */
@@ -162,10 +162,16 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id);
  *   mgrit_hip_ec_relax_res:  Mgrit.error_correction, then Mgrit.f_relax (mgrit.py:715-726, 292-333 as in mgrit.py:283-284), then
  *                            Mgrit.compute_residual (mgrit.py:387-413): ||Phi(u_{i-1}) - u_i||^2 of every closing C-point is
  *                            kept in pinned host memory; mgrit_hip_residual_fetch(e, n, out) waits for the sweep and copies
- *                            the n values (order res_pos) out. */
+ *                            the n values (order res_pos) out.
+ * keep[i] (null: 3 everywhere) names the rows of lvl+1 that the closing C-point of interval i must receive from mgrit_hip_cf_fas:
+ * bit 0 = u^{l+1} (not needed where the first sweep of lvl+1 overwrites it unread: its F-points when the level starts with an
+ * F-relaxation, mgrit.py:270-271; every point but the first of a coarsest level solved by forward_solve, mgrit.py:459-486),
+ * bit 1 = v^{l+1} (not needed when mgrit_hip_ec_relax_res performs the error correction: it takes the same bits from the fine
+ * C-point; the library adds the bit where a chunk ends). Chunks are cut where res_pos is a multiple of `chunk`, so all lists
+ * of a level are cut alike; the lists given to mgrit_hip_cf_fas and mgrit_hip_ec_relax_res within one cycle must be the same. */
 int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_t *cstart, const int32_t *cend,
                                const int32_t *cstart_coarse, const int32_t *cend_coarse, const int32_t *res_pos, int res_len,
-                               int chunk, int *id_out);
+                               int chunk, const int32_t *keep, int *id_out);
 int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int intervals_id);
 int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int intervals_id);
 int mgrit_hip_residual_fetch(mgrit_hip_engine *e, int n, double *sumsq_host);

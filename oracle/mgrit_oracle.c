@@ -206,6 +206,16 @@ static void cset_powers(orc_cset *c, double rho) {
     for (int l = 1; l < ORC_LANES; ++l) c->lp[l] = c->lp[l - 1] * c->pw[ORC_E];
 }
 
+/* r^e, e >= 0: binary powering, bits of e from the lowest up */
+static double ipow(double r, int e) {
+    double acc = 1.0, sq = r;
+    for (; e > 0; e >>= 1) {
+        if (e & 1) acc = acc * sq;
+        if (e > 1) sq = sq * sq;
+    }
+    return acc;
+}
+
 /* Heat1D: T = tridiag(-beta, D, -beta) = kappa (I - rho S)(I - rho S^T) + kappa rho^2 e0 e0^T */
 static void cset_heat1d(orc_cset *c, int n, double fac, double dt) {
     double beta = dt * fac;
@@ -215,18 +225,34 @@ static void cset_heat1d(orc_cset *c, int n, double fac, double dt) {
     double rho = beta / kappa;
     c->dt = dt; c->ik = 1.0 / kappa; c->scal = 0.0;
     cset_powers(c, rho);
+    /* rank-one correction table, closed form: wg_j = gamma * (A^{-1} e0)_j with
+       (A^{-1} e0)_j = (rho^j - rho^(2n-j)) / (kappa (1 - rho^2)); rho^j and rho^(2n-j) are assembled from the group, lane and
+       element powers so that every entry is  fma(-Q_t, rho^(15-k), P_t * rho^k)  for element k of thread t = j / 16 */
     c->tab = (double *)malloc(sizeof(double) * (size_t)n);
-    double *y = (double *)malloc(sizeof(double) * (size_t)n);
-    y[0] = 1.0;
-    for (int j = 1; j < n; ++j) y[j] = rho * y[j - 1];
-    double zn = y[n - 1];
-    c->tab[n - 1] = zn;
-    for (int j = n - 2; j >= 0; --j) { zn = fma(rho, zn, y[j]); c->tab[j] = zn; }
+    double one_minus_r2 = (1.0 - rho) * (1.0 + rho);
     double kr2 = beta * rho;
-    double w0 = c->tab[0] * c->ik;
+    double w0 = ((1.0 - ipow(rho, 2 * n)) * c->ik) / one_minus_r2;
     double gamma = kr2 / (1.0 + kr2 * w0);
-    for (int j = 0; j < n; ++j) c->tab[j] = gamma * (c->tab[j] * c->ik);
-    free(y);
+    double gprime = (gamma * c->ik) / one_minus_r2;
+    double grp[16];                                  /* gc^g, sequential products */
+    grp[0] = 1.0;
+    for (int g = 1; g < 16; ++g) grp[g] = grp[g - 1] * c->gc;
+    int last_thread = (n - 1) / ORC_E;               /* thread that holds element n-1 */
+    int g_last = last_thread / ORC_LANES, l_last = last_thread % ORC_LANES;
+    int e_base = 2 * n - ORC_E * last_thread - (ORC_E - 1);   /* exponent of rho^(2n-j) at the last thread's element 15 */
+    double r_base;
+    if (e_base >= 0) r_base = ipow(rho, e_base);
+    else r_base = (rho >= 1e-12) ? 1.0 / ipow(rho, -e_base) : 0.0;
+    double q_base = gprime * r_base;
+    for (int j = 0; j < n; ++j) {
+        int thread = j / ORC_E, k = j % ORC_E, g = thread / ORC_LANES, l = thread % ORC_LANES;
+        double pfac = (gprime * grp[g]) * c->lp[l];
+        double qgrp;
+        if (l <= l_last) qgrp = (g <= g_last) ? q_base * grp[g_last - g] : 0.0;
+        else qgrp = (g < g_last) ? q_base * grp[g_last - g - 1] : 0.0;
+        double qfac = qgrp * c->lp[(l_last - l) & (ORC_LANES - 1)];
+        c->tab[j] = fma(-qfac, c->pw[ORC_E - 1 - k], pfac * c->pw[k]);
+    }
     cset_pt(c, ORC_GROUP, c->pt_full);
     cset_pt(c, n - ((n - 1) / ORC_GROUP) * ORC_GROUP, c->pt_last);
 }

@@ -610,16 +610,17 @@ class HipBackend:
     def _intervals_id(self, lvl, intervals):
         def create():
             iid = C.c_int(-1)
-            cols = [_i32([iv[k] for iv in intervals]) for k in range(5)]
+            cols = [_i32([iv[k] for iv in intervals]) for k in range(6)]
             chunk = int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK", "4"))
             res_len = len(self.mg._c_points(lvl))
             check(self.lib.mgrit_hip_intervals_create(self.h, lvl, len(intervals), _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]),
-                                                      _ptr(cols[3]), _ptr(cols[4]), res_len, chunk, C.byref(iid)))
+                                                      _ptr(cols[3]), _ptr(cols[4]), res_len, chunk, _ptr(cols[5]), C.byref(iid)))
             return iid.value
         return self._handle(self._runs, lvl, intervals, "ivals", create)
 
     def cf_fas(self, lvl, intervals):
-        """c_relax + f_relax + fas_residual of level lvl for the intervals (cstart, cend, cstart_coarse, cend_coarse, res_pos)"""
+        """c_relax + f_relax + fas_residual of level lvl for the intervals (cstart, cend, cstart_coarse, cend_coarse, res_pos,
+        keep): keep = which rows of lvl+1 the closing C-point needs (bit 0: u, bit 1: v; include/mgrit_hip.h)"""
         if intervals:
             self._residual_cache = None
             check(self.lib.mgrit_hip_cf_fas(self.h, lvl, self._intervals_id(lvl, intervals)))

@@ -64,7 +64,7 @@ EXPORTS = {
     "mgrit_hip_set_reserve": (C.c_int, [C.c_void_p, C.c_int]),
     "mgrit_hip_chain_clock": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mgrit_hip_intervals_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                             C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+                                             C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "mgrit_hip_cf_fas": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_ec_relax_res": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_residual_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -88,7 +88,7 @@ def load():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.mgrit_hip_abi_version() != 1:
+        if lib.mgrit_hip_abi_version() != 2:
             raise MgritHipError("libmgrit_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -479,7 +479,7 @@ class Mgrit:
         self.backend.ec_relax(lvl, self._cached(('ec_' + tag, lvl), build))
 
     def _level_intervals(self, lvl):
-        """[(cstart, cend, cstart_coarse, cend_coarse, res_pos)] of level lvl when its sweeps can run as whole-level passes
+        """[(cstart, cend, cstart_coarse, cend_coarse, res_pos, keep)] of level lvl when its sweeps can run as whole-level passes
         (mgrit_hip_cf_fas / mgrit_hip_ec_relax_res), else None: one rank (no exchange point inside the pass), the library's own
         sweeps, weight 1, and a level whose F-points all lie between two local C-points."""
         def build():
@@ -498,7 +498,19 @@ class Mgrit:
             want = [(pairs[k][0] + 1, pairs[k + 1][0] - pairs[k][0] - 1) for k in range(len(pairs) - 1)]
             if [tuple(r) for r in runs] != want or any(ln < 1 for _, ln in want):
                 return [None]
-            return [[(pairs[k][0], pairs[k + 1][0], pairs[k][1] if k >= 1 else -1, pairs[k + 1][1], k) for k in range(len(pairs) - 1)]]
+            # rows of lvl+1 that the down pass must really store for the closing C-point (include/mgrit_hip.h, keep): u only
+            # where the coarse level reads it before writing it -- its C-points when it starts with an F-relaxation (always,
+            # mgrit.py:270-271), nothing on a coarsest level that forward_solve overwrites from its first point on --, v only
+            # when the correction on the way up is not the pass that takes v from the fine C-point
+            coarsest = lvl + 1 == self.lvl_max - 1
+            if coarsest:
+                need_u = (lambda j: False) if type(self).forward_solve is Mgrit.forward_solve else (lambda j: True)
+            else:
+                c_next = {int(i) for i in self.index_local_c[lvl + 1]}
+                need_u = lambda j: j in c_next
+            need_v = 0 if (lvl == 0 and self.conv_crit in (0, 2)) else 2
+            return [[(pairs[k][0], pairs[k + 1][0], pairs[k][1] if k >= 1 else -1, pairs[k + 1][1], k,
+                      (1 if need_u(pairs[k + 1][1]) else 0) | need_v) for k in range(len(pairs) - 1)]]
         got = self._cached(('intervals', lvl), build)[0]
         if got is None:
             return None

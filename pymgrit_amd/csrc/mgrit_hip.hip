@@ -61,6 +61,7 @@ int fail(int code, const char *fmt, ...) {
 struct CSet {
     double rho, ik, scal, gc;
     double pi_full, pi_last;  // heat: Pt[0] of a full / of the last group
+    double pg[MAX_G], qg[MAX_G], qg2[MAX_G];  // heat: per-group factors of the rank-one correction (build_cset_heat1d)
     double pw[E + 1];   // rho^k
     double sc[6];       // rho^(E*2^s)
     double lp[LANES];   // rho^(E*l)
@@ -227,12 +228,14 @@ __device__ __forceinline__ double read_lane(double v, int src) {
 }
 
 struct Smem {
-    double2 *tab;   // [8*T] correction table of the current coefficient set (heat: w-gamma, advection: r^(j+1)), row order
+    double2 *tab;   // [8*T] correction table of the current coefficient set (heat: w-gamma, advection: r^(j+1)), row order;
+                    // free for the kernel's own use where every Heat1D step is taken with heat_solve<CLOSED> (cfas_kernel)
     double2 *pt;    // [2][512] heat: group-local backward scan of rho^(j'+1): [0] full group, [1] last group
     double *ga;     // [2][MAX_G] forward group totals A_g, double-buffered by step parity
     double *gb;     // [2][MAX_G] backward group totals B_g (advection: slot [p][0] carries y-hat of the last real element)
     double *lp;     // [LANES] rho^(E*l) of the current coefficient set
     double *red;    // [MAX_G] per-wave partial sums of block_sumsq (own slots: persistent kernels reuse the others)
+    double *wf;     // [3][MAX_G] heat: per-group factors pg | qg | qg2 of the rank-one correction (CSet, build_cset_heat1d)
 };
 
 // wave-uniform scalar coefficients of the current coefficient set, forced into SGPRs (readfirstlane)
@@ -269,6 +272,22 @@ __device__ __forceinline__ double to_sgpr(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// Wave-uniform loads of the read-only per-step data of a level (coefficient-set index, forcing coefficient) through the
+// scalar cache. Written as plain loads they become VECTOR loads (the kernels store to global memory, so the compiler cannot
+// prove the arrays unchanged and refuses s_load), and a vector load's result can only be waited for with s_waitcnt vmcnt,
+// which retires in order: the load issued at the top of a step then also waits for the row STORES of the step before it --
+// one exposed store round trip per Phi. Scalar loads count on lgkmcnt and leave the stores in flight.
+__device__ __forceinline__ int ld_uniform(const int32_t *p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+}
+__device__ __forceinline__ double ld_uniform(const double *p) {
+    double v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    return v;
+}
+
 __device__ __forceinline__ Smem carve_smem(char *base, int T) {
     Smem s;
     s.tab = reinterpret_cast<double2 *>(base);
@@ -278,6 +297,7 @@ __device__ __forceinline__ Smem carve_smem(char *base, int T) {
     s.gb = tail + 2 * MAX_G;
     s.lp = tail + 4 * MAX_G;
     s.red = tail + 4 * MAX_G + LANES;
+    s.wf = tail + 5 * MAX_G + LANES;
     return s;
 }
 
@@ -372,12 +392,12 @@ __device__ __forceinline__ void load_coef(Coef &c, const CSet *g) {
 template <int FORCE>
 __device__ __forceinline__ void add_forcing(double (&x)[E], const StepCtx &ctx, const LevelDev &L, int i, int t) {
     if (FORCE == 1) {
-        const double c0 = L.tc[i];
+        const double c0 = ld_uniform(L.tc + i);
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = fma(ctx.s0[k], c0, x[k]);
     } else if (FORCE == 2) {
         for (int kk = 0; kk < L.K; ++kk) {
-            const double ck = L.tc[(size_t)kk * L.n_pts + i];
+            const double ck = ld_uniform(L.tc + (size_t)kk * L.n_pts + i);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const double2 sv = L.sP[(size_t)kk * 8 * L.T + slot0(t) + q * 64];
@@ -436,6 +456,15 @@ __device__ __forceinline__ double fwd_chain(const Coef &c, double A, int G, int 
     return read_lane(C, __builtin_amdgcn_readfirstlane(wave));
 }
 
+// v if a > b else 0.0, compare and selects back to back on vcc: written as `a > b ? v : 0.0` the compiler hoists the sixteen
+// compares of a finishing pass in front of the workgroup barrier and keeps their lane masks in 32 SGPRs (which it then spills)
+__device__ __forceinline__ double zero_unless_gt(double v, int a, int b) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    asm volatile("v_cmp_gt_i32 vcc, %2, %3\n\tv_cndmask_b32 %0, 0, %0, vcc\n\tv_cndmask_b32 %1, 0, %1, vcc"
+                 : "+v"(lo), "+v"(hi) : "v"(a), "v"(b) : "vcc");
+    return __hiloint2double(hi, lo);
+}
+
 // final pass of the heat step for one lane: carries + rank-one correction
 __device__ __forceinline__ void heat_finish(double (&x)[E], const Coef &c, double cm, double cb, double z0, int q, double2 w,
                                             double2 p) {
@@ -446,7 +475,15 @@ __device__ __forceinline__ void heat_finish(double (&x)[E], const Coef &c, doubl
 }
 
 // x <- (I + dt L)^{-1} x for the coefficient set resident in c / lc / sm: group-local scans,
-// one exchange of the group totals through the LDS slots ga/gb (one barrier), carries + rank-one correction
+// one exchange of the group totals through the LDS slots ga/gb (one barrier), carries + rank-one correction. The correction
+// entries w-gamma_j of this lane come from the table in LDS (sm.tab) or, CLOSED, from the closed form
+// fma(-Q, rho^(15-k), P * rho^k) with the per-thread factors P = pg[wave] * lp[lane], Q = (qg | qg2)[wave] *
+// lp[(l_last - lane) mod 64] -- the very bits build_cset_heat1d puts into the table, at two more instructions per element but
+// without 8 B per DOF of LDS (the fused level passes use that space; a coarse-level Phi inside a fine-level kernel needs no
+// table traffic at all). With CLOSED the padding positions j >= n of the result are NOT zero (the table's entries there are,
+// the expression's are not): padding of a Heat1D row holds unspecified finite values, which the next step's zeroing between
+// its two scans, the masked norms (block_sumsq) and the host views ignore.
+template <bool CLOSED = false>
 __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const LaneCoef &lc, const Smem &sm, double *ga,
                                            double *gb, int n, int t, int lane, int wave, int G) {
     const int j0 = t * E, li = lane & 15;
@@ -456,6 +493,12 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
         if (j0 + k >= n) x[k] = 0.0;
     const double b = scan_bwd(x, c, lc, lane);
     if (lane == 0) { ga[wave] = a; gb[wave] = b; }
+    double P = 0.0, Q = 0.0;
+    if (CLOSED) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave), l_last = ((n - 1) / E) & (LANES - 1);
+        P = sm.wf[wv] * lc.f_in;
+        Q = (lane <= l_last ? sm.wf[MAX_G + wv] : sm.wf[2 * MAX_G + wv]) * sm.lp[(l_last - lane) & (LANES - 1)];
+    }
     __syncthreads();
     double cm, zin, zf0;
     heat_chains(c, li < G ? ga[li] : 0.0, li < G ? gb[li] : 0.0, G, wave, lane, cm, zin, zf0);
@@ -463,21 +506,34 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
     const double cb = lc.b_in * zin;
     const double2 *pt = sm.pt + (wave == G - 1 ? 512 : 0) + lane;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) heat_finish(x, c, cm, cb, z0, q, sm.tab[slot0(t) + q * 64], pt[q * 64]);
+    for (int q = 0; q < 8; ++q) {
+        double2 w;
+        if (CLOSED) {
+            w.x = fma(-Q, c.pw[E - 1 - 2 * q], P * c.pw[2 * q]);
+            w.y = fma(-Q, c.pw[E - 2 - 2 * q], P * c.pw[2 * q + 1]);
+        } else {
+            w = sm.tab[slot0(t) + q * 64];
+        }
+        heat_finish(x, c, cm, cb, z0, q, w, pt[q * 64]);
+    }
 }
 
 // x <- Phi(x) for the step (i-1 -> i) of level L, one workgroup holding the whole vector (heat_1d.py:198-217 /
 // advection_1d.py:129-143; arithmetic: DESIGN.md section 3). One workgroup barrier per application.
-template <int KIND, int FORCE>
+template <int KIND, int FORCE, bool CLOSED = false>
 __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const LevelDev &L, int i, const Smem &sm, int t,
                                           int lane, int wave, int G) {
-    const int ci = __builtin_amdgcn_readfirstlane(L.cidx[i]);
+    const int ci = ld_uniform(L.cidx + i);
     if (ci != ctx.cur) {  // (re)load this coefficient set: tables + lane powers -> LDS, scalars -> SGPRs; uniform branch
         __syncthreads();
-        const double2 *src = L.tabP + (size_t)ci * 8 * L.T + slot0(t);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) sm.tab[slot0(t) + q * 64] = src[q * 64];
         const CSet *g = L.cs + ci;
+        if (KIND == MGRIT_HIP_STEPPER_HEAT1D && CLOSED) {
+            if (t < 3 * MAX_G) sm.wf[t] = (&g->pg[0])[t];   // pg | qg | qg2 are consecutive members
+        } else {
+            const double2 *src = L.tabP + (size_t)ci * 8 * L.T + slot0(t);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sm.tab[slot0(t) + q * 64] = src[q * 64];
+        }
         if (t < LANES) sm.lp[t] = g->lp[t];
         if (KIND == MGRIT_HIP_STEPPER_HEAT1D && t < 2 * 512) sm.pt[t] = L.ptP[(size_t)ci * 1024 + t];
         if (KIND == MGRIT_HIP_STEPPER_HEAT1D && L.T < 1024)
@@ -493,7 +549,7 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const Le
     double *ga = sm.ga + par * MAX_G, *gb = sm.gb + par * MAX_G;
     if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
         add_forcing<FORCE>(x, ctx, L, i, t);
-        heat_solve(x, c, lc, sm, ga, gb, L.n, t, lane, wave, G);
+        heat_solve<CLOSED>(x, c, lc, sm, ga, gb, L.n, t, lane, wave, G);
     } else {
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] * c.ik;
@@ -525,10 +581,11 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const Le
 }
 
 // sum of squares of the lane-blocked vector r with the spec's reduction tree; result valid in thread 0
-__device__ __forceinline__ double block_sumsq(const double (&r)[E], const Smem &sm, int t, int lane, int wave, int G) {
+__device__ __forceinline__ double block_sumsq(const double (&r)[E], const Smem &sm, int n, int t, int lane, int wave, int G) {
     double acc = 0.0;
+    const int kv = n - t * E;   // padding positions (unspecified values, heat_solve) do not count
 #pragma unroll
-    for (int k = 0; k < E; ++k) acc = fma(r[k], r[k], acc);
+    for (int k = 0; k < E; ++k) acc = fma(zero_unless_gt(r[k], kv, k), r[k], acc);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
     __syncthreads();
@@ -666,7 +723,7 @@ __global__ void __launch_bounds__(1024) residual_kernel(LevelDev L, const int32_
         load_row(L.u + (size_t)i * L.ld, sl, ui);
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] - ui[k];
-        const double tot = block_sumsq(x, sm, t, lane, wave, G);
+        const double tot = block_sumsq(x, sm, L.n, t, lane, wave, G);
         if (t == 0) out[r] = tot;
     }
     wq.end(t);
@@ -684,7 +741,7 @@ __global__ void __launch_bounds__(1024) jump_kernel(LevelDev L, const int32_t *_
     load_row(prev + (size_t)i * L.ld, sl, p);
 #pragma unroll
     for (int k = 0; k < E; ++k) x[k] = x[k] - p[k];
-    const double tot = block_sumsq(x, sm, t, lane, wave, G);
+    const double tot = block_sumsq(x, sm, L.n, t, lane, wave, G);
     if (t == 0) out[blockIdx.x] = tot;
 }
 
@@ -797,14 +854,15 @@ __global__ void __launch_bounds__(1024) fas_fused_kernel(LevelDev L, LevelDev Lc
 template <int FORCE>
 __device__ __forceinline__ void phi_other_level(double (&w)[E], StepCtx &ctx, const LevelDev &Lc, int j, const Smem &sm, unsigned sl,
                                                 int t, int lane, int wave, int G) {
-    const int cj = __builtin_amdgcn_readfirstlane(Lc.cidx[j]);
+    const int cj = ld_uniform(Lc.cidx + j);
     const CSet *gc = Lc.cs + cj;
     Smem smc = sm;
-    smc.tab = const_cast<double2 *>(Lc.tabP) + (size_t)cj * 8 * Lc.T;
+    smc.wf = const_cast<double *>(gc->pg);
+    smc.lp = const_cast<double *>(gc->lp);
     smc.pt = const_cast<double2 *>(Lc.ptP) + (size_t)cj * 1024;
     if (FORCE != 0) {
         for (int kk = 0; kk < Lc.K; ++kk) {
-            const double ck = Lc.tc[(size_t)kk * Lc.n_pts + j];
+            const double ck = ld_uniform(Lc.tc + (size_t)kk * Lc.n_pts + j);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const double2 sv = Lc.sP[(size_t)kk * 8 * Lc.T + sl + q * 64];
@@ -818,7 +876,7 @@ __device__ __forceinline__ void phi_other_level(double (&w)[E], StepCtx &ctx, co
     const LaneCoef lcc = lane_coef(gc->lp, lane);
     const int par = ctx.parity;
     ctx.parity ^= 1;
-    heat_solve(w, cc, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
+    heat_solve<true>(w, cc, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
 }
 
 // Interval list of the fused level sweeps below: item = the interval from one C-point to the next,
@@ -828,21 +886,26 @@ __device__ __forceinline__ void phi_other_level(double (&w)[E], StepCtx &ctx, co
 // interval ends on is the one the next interval starts from and stays in registers; chunk_start_coarse = coarse slot of the
 // chunk's first C-point when that point takes part in the sweep (it is C-relaxed / corrected), -1 when it is not (the first
 // point of the time grid).
+// keep[i] says which rows of the coarse level the closing C-point of interval i really needs (mgrit_hip_intervals_create):
+//   bit 0: u^{l+1} -- not needed at a coarse F-point (the coarse level's first sweep, an F-relaxation, writes it before anything
+//          reads it) nor anywhere on a coarsest level that is solved by forward_solve;
+//   bit 1: v^{l+1} -- its only reader is the error correction, which may take the same bits from the fine C-point (identity
+//          transfer); needed where a chunk of the way up starts (that row is being overwritten by the chunk in front of it).
 struct IntervalsDev {
-    const int32_t *cstart, *cend, *cend_coarse, *res_pos, *chunk_first, *chunk_len, *chunk_start_coarse;
+    const int32_t *cstart, *cend, *cend_coarse, *res_pos, *chunk_first, *chunk_len, *chunk_start_coarse, *keep;
     int n_chunks;
 };
 
 // c_relax + f_relax + fas_residual of one level in ONE pass (mgrit.py:335-370, 292-333, 488-549 as Mgrit.iteration calls them
 // one after the other, mgrit.py:277-281), Heat1D on both levels, identity transfer, weight 1. Per interval (C_j, C_{j+1}]:
-//   q        = Phi_{l+1}(C'_j)                      parked in the row of g^{l+1}_{j+1}
+//   q        = Phi_{l+1}(C'_j)                      parked in LDS: every Phi of this kernel evaluates its rank-one correction in
+//                                                   closed form (heat_solve<CLOSED>), so the table's 8 B per DOF of LDS are free
 //   F'_last  = Phi_l^{m-1}(C'_j)                    the F-relaxation; its points are NOT stored: nothing reads a level's F-points
 //                                                   before the error correction + F-relaxation on the way up rewrites them
 //   C'_{j+1} = Phi_l(u_old[c_{j+1} - 1])            the C-relaxation, from the OLD last F-point of the interval (F rows are
 //                                                   never written here, so no other workgroup can have touched it)
 //   u^{l+1}_{j+1} = v^{l+1}_{j+1} = C'_{j+1},   g^{l+1}_{j+1} = ((Phi_l(F'_last) - C'_{j+1}) + C'_{j+1}) - q
-// Rows through HBM per interval: 1 read + 5 written + the parked q (written and read back) instead of 12 (C-relax 2, F-relax
-// m, fused FAS 6). A chunk's first C-point is recomputed from its old F-point (one more Phi per chunk), not waited for.
+// Rows through HBM per interval: 1 read + 3..5 written (IntervalsDev::keep) instead of 12 (C-relax 2, F-relax m, fused FAS 6). A chunk's first C-point is recomputed from its old F-point (one more Phi per chunk), not waited for.
 template <int FORCE>
 __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, IntervalsDev I) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
@@ -857,7 +920,7 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
             if (I.chunk_start_coarse[k] >= 0) {   // C'_j of the chunk's first C-point, recomputed
                 load_row(L.u + (size_t)(cs - 1) * L.ld, sl, x);
                 if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);
-                phi_apply<KIND, FORCE>(x, ctx, L, cs, sm, t, lane, wave, G);
+                phi_apply<KIND, FORCE, true>(x, ctx, L, cs, sm, t, lane, wave, G);
             } else {
                 load_row(L.u + (size_t)cs * L.ld, sl, x);
             }
@@ -869,26 +932,28 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
 #pragma unroll
                 for (int e = 0; e < E; ++e) w[e] = x[e];
                 phi_other_level<FORCE>(w, ctx, Lc, jc, sm, sl, t, lane, wave, G);
-                store_row(Lc.g + (size_t)jc * Lc.ld, sl, w);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sm.tab[sl + q * 64] = make_double2(w[2 * q], w[2 * q + 1]);   // parked in LDS
             }
             if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);   // not kept alive across the coarse Phi
-            for (int i = cs + 1; i < ce; ++i) phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+            for (int i = cs + 1; i < ce; ++i) phi_apply<KIND, FORCE, true>(x, ctx, L, i, sm, t, lane, wave, G);
             double b[E];
-            load_row(L.u + (size_t)(ce - 1) * L.ld, sl, b);
-            phi_apply<KIND, FORCE>(b, ctx, L, ce, sm, t, lane, wave, G);
+            load_row(L.u + (size_t)(ce - 1) * L.ld, sl, b);   // (requested one Phi earlier it costs more in spills than it hides)
+            phi_apply<KIND, FORCE, true>(b, ctx, L, ce, sm, t, lane, wave, G);
             store_row(L.u + (size_t)ce * L.ld, sl, b);
-            store_row(Lc.u + (size_t)jc * Lc.ld, sl, b);
-            store_row(Lc.v + (size_t)jc * Lc.ld, sl, b);
-            phi_apply<KIND, FORCE>(x, ctx, L, ce, sm, t, lane, wave, G);
+            const int keep = __builtin_amdgcn_readfirstlane(I.keep[it]);
+            if (keep & 1) store_row(Lc.u + (size_t)jc * Lc.ld, sl, b);
+            if (keep & 2) store_row(Lc.v + (size_t)jc * Lc.ld, sl, b);
+            phi_apply<KIND, FORCE, true>(x, ctx, L, ce, sm, t, lane, wave, G);
 #pragma unroll
             for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
 #pragma unroll
             for (int e = 0; e < E; ++e) x[e] = x[e] + b[e];
-            {
-                double w[E];
-                load_row(Lc.g + (size_t)jc * Lc.ld, sl, w);   // q, written above by this very lane
 #pragma unroll
-                for (int e = 0; e < E; ++e) x[e] = x[e] - w[e];
+            for (int q = 0; q < 8; ++q) {   // q, parked above by this very lane
+                const double2 w = sm.tab[sl + q * 64];
+                x[2 * q] = x[2 * q] - w.x;
+                x[2 * q + 1] = x[2 * q + 1] - w.y;
             }
             store_row(Lc.g + (size_t)jc * Lc.ld, sl, x);
 #pragma unroll
@@ -901,8 +966,9 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
 // error_correction + f_relax + compute_residual of level 0 in ONE pass (mgrit.py:715-726, 292-333 as Mgrit.iteration calls
 // them, mgrit.py:283-284, then 387-413 from convergence_criterion), identity transfer. Per interval (C_j, C_{j+1}]:
 //   F''      = Phi-propagation from the corrected C''_j, stored
-//   C''_{j+1} = v^{l+1}_{j+1} + (u^{l+1}_{j+1} - v^{l+1}_{j+1})   (v^{l+1}_{j+1} IS u^l at that C-point, bit for bit; read from v,
-//                                                                 which nobody writes on the way up), stored
+//   C''_{j+1} = v^{l+1}_{j+1} + (u^{l+1}_{j+1} - v^{l+1}_{j+1})   (v^{l+1}_{j+1} IS u^l at that C-point, bit for bit: read from the
+//                                                                 fine row inside a chunk, from v -- which nobody writes on the
+//                                                                 way up -- for the C-point a chunk starts from), stored
 //   out[res_pos] = || Phi_l(F''_last) - C''_{j+1} ||^2
 // 2 rows read + m written per interval instead of 2 + m (correction + F-relaxation) and 2 more for the residual.
 template <int FORCE>
@@ -933,9 +999,9 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
                 store_row(L.u + (size_t)i * L.ld, sl, x);
             }
             double b[E];
-            {
+            {   // v^{l+1}_{j+1} from the fine row itself (the same bits; only this chunk writes that row), see IntervalsDev::keep
                 double w[E];
-                load_row(Lc.v + (size_t)jc * Lc.ld, sl, b);
+                load_row(L.u + (size_t)ce * L.ld, sl, b);
                 load_row(Lc.u + (size_t)jc * Lc.ld, sl, w);
 #pragma unroll
                 for (int e = 0; e < E; ++e) b[e] = b[e] + (w[e] - b[e]);
@@ -944,7 +1010,7 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
             phi_apply<KIND, FORCE>(x, ctx, L, ce, sm, t, lane, wave, G);
 #pragma unroll
             for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
-            const double tot = block_sumsq(x, sm, t, lane, wave, G);
+            const double tot = block_sumsq(x, sm, L.n, t, lane, wave, G);
             if (t == 0) out[I.res_pos[it]] = tot;
 #pragma unroll
             for (int e = 0; e < E; ++e) x[e] = b[e];
@@ -996,13 +1062,14 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         for (int k = 0; k < E; ++k) x[k] = x[k] + w[k];   // + v_j : the partial g of the coarse level
         // ---- coarse Phi on v_{j-1} = u^l_{ip}
         load_row(L.u + (size_t)ip * L.ld, sl, w);
-        const int cj = __builtin_amdgcn_readfirstlane(Lc.cidx[j]);
+        const int cj = ld_uniform(Lc.cidx + j);
         const CSet *gc = Lc.cs + cj;
-        smc.tab = const_cast<double2 *>(Lc.tabP) + (size_t)cj * 8 * Lc.T;
+        smc.wf = const_cast<double *>(gc->pg);
+        smc.lp = const_cast<double *>(gc->lp);
         smc.pt = const_cast<double2 *>(Lc.ptP) + (size_t)cj * 1024;
         if (FORCE != 0) {
             for (int kk = 0; kk < Lc.K; ++kk) {
-                const double ck = Lc.tc[(size_t)kk * Lc.n_pts + j];
+                const double ck = ld_uniform(Lc.tc + (size_t)kk * Lc.n_pts + j);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const double2 sv = Lc.sP[(size_t)kk * 8 * Lc.T + sl + q * 64];
@@ -1017,7 +1084,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
             const LaneCoef lcc = lane_coef(gc->lp, lane);
             const int par = ctx.parity;
             ctx.parity ^= 1;
-            heat_solve(w, cc, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
+            heat_solve<true>(w, cc, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
         }
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
@@ -1261,6 +1328,21 @@ void build_chain_tables(const CSet &c, const std::vector<double> &tab, const dou
     }
 }
 
+// rho^e by square-and-multiply, lowest bit first
+double pow_int(double r, int e) {
+    double res = 1.0, b = r;
+    while (e > 0) {
+        if (e & 1) res = res * b;
+        e >>= 1;
+        if (e) b = b * b;
+    }
+    return res;
+}
+
+// Rank-one correction table in closed form: w = A^{-1} e0 has the entries (rho^j - rho^(2n-j)) / (kappa (1 - rho^2)),
+// so w-gamma_j = P_t * rho^k - Q_t * rho^(15-k) for element k of thread t = j / 16, with per-thread factors that are products of
+// one per-group and one per-lane power. The sweep kernels evaluate exactly this expression (heat_w) instead of holding the
+// n-entry table in LDS; kernels that keep a table (chain workers, two-point steppers) read the same bits from tabP.
 void build_cset_heat1d(CSet &c, std::vector<double> &tab, int n, double fac, double dt) {
     const double beta = dt * fac;
     const double D = dt * (2.0 * fac) + 1.0;
@@ -1270,20 +1352,28 @@ void build_cset_heat1d(CSet &c, std::vector<double> &tab, int n, double fac, dou
     c.ik = 1.0 / kappa;
     c.scal = 0.0;
     cset_powers(c, rho);
-    tab.assign(n, 0.0);
-    std::vector<double> y(n);
-    y[0] = 1.0;
-    for (int j = 1; j < n; ++j) y[j] = rho * y[j - 1];
-    double z = y[n - 1];
-    tab[n - 1] = z;
-    for (int j = n - 2; j >= 0; --j) {
-        z = std::fma(rho, z, y[j]);
-        tab[j] = z;
-    }
+    const double om = (1.0 - rho) * (1.0 + rho);
+    const double w0 = ((1.0 - pow_int(rho, 2 * n)) * c.ik) / om;
     const double kr2 = beta * rho;
-    const double w0 = tab[0] * c.ik;
     const double gamma = kr2 / (1.0 + kr2 * w0);
-    for (int j = 0; j < n; ++j) tab[j] = gamma * (tab[j] * c.ik);
+    const double gp = (gamma * c.ik) / om;
+    double Gp[MAX_G];
+    Gp[0] = 1.0;
+    for (int g = 1; g < MAX_G; ++g) Gp[g] = Gp[g - 1] * c.gc;
+    const int t_last = (n - 1) / E, gL = t_last / LANES, lL = t_last % LANES, e0 = 2 * n - E * t_last - (E - 1);
+    const double qb = gp * (e0 >= 0 ? pow_int(rho, e0) : (rho >= 1e-12 ? 1.0 / pow_int(rho, -e0) : 0.0));
+    for (int g = 0; g < MAX_G; ++g) {
+        c.pg[g] = gp * Gp[g];
+        c.qg[g] = g <= gL ? qb * Gp[gL - g] : 0.0;
+        c.qg2[g] = g < gL ? qb * Gp[gL - g - 1] : 0.0;
+    }
+    tab.assign(n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        const int t = j / E, k = j % E, g = t / LANES, l = t % LANES;
+        const double P = c.pg[g] * c.lp[l];
+        const double Q = (l <= lL ? c.qg[g] : c.qg2[g]) * c.lp[(lL - l) & (LANES - 1)];
+        tab[j] = std::fma(-Q, c.pw[E - 1 - k], P * c.pw[k]);
+    }
 }
 
 // (1+alpha) x_j - alpha x_{j-1 mod n} = u_j ; r = alpha/D ; x_j = y_j + r^(j+1) x_{n-1}, x_{n-1} = y_{n-1}/(1 - r^n)
@@ -1328,10 +1418,10 @@ bool two_phase_fas() {
     return v;
 }
 
-size_t smem_bytes(int G) { return (size_t)(8 * G * LANES + 2 * 512) * sizeof(double2) + (5 * MAX_G + LANES) * sizeof(double); }
+size_t smem_bytes(int G) { return (size_t)(8 * G * LANES + 2 * 512) * sizeof(double2) + (8 * MAX_G + LANES) * sizeof(double); }
 
 constexpr int MAX_G2 = MGRIT_HIP_MAX_N_2PTS / GROUP;  // two-point steppers: waves per half
-size_t smem2_bytes(int G) { return (size_t)2 * (8 * G * LANES + 2 * 512) * sizeof(double2) + (6 * MAX_G + 2 * LANES) * sizeof(double); }
+size_t smem2_bytes(int G) { return (size_t)2 * (8 * G * LANES + 2 * 512) * sizeof(double2) + (12 * MAX_G + 2 * LANES) * sizeof(double); }
 
 template <typename K>
 int allow_big_lds(K kernel, size_t bytes = smem_bytes(MAX_G)) {
@@ -2566,7 +2656,7 @@ int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int 
 
 int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_t *cstart, const int32_t *cend,
                                const int32_t *cstart_coarse, const int32_t *cend_coarse, const int32_t *res_pos, int res_len,
-                               int chunk, int *id_out) {
+                               int chunk, const int32_t *keep, int *id_out) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
     if (lvl + 1 >= e->n_levels || !e->L[lvl + 1].set) return fail(MGRIT_HIP_EINVAL, "level %d has no described coarser level", lvl);
@@ -2582,21 +2672,30 @@ int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_
             return fail(MGRIT_HIP_EINVAL, "interval %d: coarse slot or residual position out of range", i);
     }
     std::vector<int32_t> cf, cl, cc;
-    for (int i = 0; i < n;) {   // chunks: runs of consecutive intervals, at most `chunk` long
+    for (int i = 0; i < n;) {   // chunks: runs of consecutive intervals, cut where res_pos is a multiple of `chunk` -- a position
+                                // of the LEVEL, so every list of the level (one block of a planned cycle, all intervals) is cut at
+                                // the same C-points and at its own ends
         int len = 1;
-        while (i + len < n && len < chunk && cstart[i + len] == cend[i + len - 1]) ++len;
+        while (i + len < n && cstart[i + len] == cend[i + len - 1] && res_pos[i + len] % chunk != 0) ++len;
         cf.push_back(i); cl.push_back(len); cc.push_back(cstart_coarse[i]);
         i += len;
     }
+    // what the closing C-point of every interval needs on the coarse level: the caller's word (null: everything), plus v where
+    // a chunk ends: the next chunk -- of this list or of the list that continues it -- starts from that C-point, and
+    // ecfr_kernel reads the old value of a chunk's first C-point from v (its fine row is being overwritten)
+    std::vector<int32_t> kp(n, 3);
+    if (keep)
+        for (int i = 0; i < n; ++i) kp[i] = keep[i] & 3;
+    for (size_t k = 0; k < cf.size(); ++k) kp[cf[k] + cl[k] - 1] |= 2;   // a chunk (of this or of the next list) starts from its end
     IntervalsDev d{};
-    int32_t *p[7];
-    const std::vector<int32_t> hs[7] = {std::vector<int32_t>(cstart, cstart + n), std::vector<int32_t>(cend, cend + n),
+    int32_t *p[8];
+    const std::vector<int32_t> hs[8] = {std::vector<int32_t>(cstart, cstart + n), std::vector<int32_t>(cend, cend + n),
                                         std::vector<int32_t>(cend_coarse, cend_coarse + n), std::vector<int32_t>(res_pos, res_pos + n),
-                                        cf, cl, cc};
-    for (int k = 0; k < 7; ++k)
+                                        cf, cl, cc, kp};
+    for (int k = 0; k < 8; ++k)
         if ((rc = dev_upload(lv, e->stream, hs[k], &p[k]))) return rc;
     d.cstart = p[0]; d.cend = p[1]; d.cend_coarse = p[2]; d.res_pos = p[3]; d.chunk_first = p[4]; d.chunk_len = p[5];
-    d.chunk_start_coarse = p[6]; d.n_chunks = (int)cf.size();
+    d.chunk_start_coarse = p[6]; d.keep = p[7]; d.n_chunks = (int)cf.size();
     lv.ivals.push_back(d);
     lv.ivals_n.push_back(res_len);
     *id_out = (int)lv.ivals.size() - 1;

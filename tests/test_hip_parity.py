@@ -74,7 +74,9 @@ def assert_state_equal(mg, op, what=("u", "v", "g")):
             assert np.array_equal(got, ref), (name, lvl, np.abs(got - ref).max())
             pad = torch.ones(slabs[lvl].shape[1], dtype=torch.bool, device=slabs[lvl].device)
             pad[mg.backend.perm[lvl]] = False
-            assert not slabs[lvl][:, pad].any().item(), ("padding positions must stay zero", name, lvl)
+            # padding positions of a row: unspecified FINITE values (a Phi whose rank-one correction is evaluated in closed form
+            # leaves -z0 * w there instead of 0; the kernels zero them between their scans and mask them in the norms)
+            assert torch.isfinite(slabs[lvl][:, pad]).all().item(), ("padding positions must stay finite", name, lvl)
 
 
 GRIDS3 = [cases.lin(2, 65), cases.lin(2, 17), cases.lin(2, 5)]
