@@ -162,7 +162,11 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id);
  *   mgrit_hip_ec_relax_res:  Mgrit.error_correction, then Mgrit.f_relax (mgrit.py:715-726, 292-333 as in mgrit.py:283-284), then
  *                            Mgrit.compute_residual (mgrit.py:387-413): ||Phi(u_{i-1}) - u_i||^2 of every closing C-point is
  *                            kept in pinned host memory; mgrit_hip_residual_fetch(e, n, out) waits for the sweep and copies
- *                            the n values (order res_pos) out.
+ *                            the n values (order res_pos) out. store_all_f = 0 writes, of every interval's F-points, only
+ *                            the last one (which the next C-relaxation reads): nothing else of an MGRIT cycle reads an
+ *                            F-point before the next F-relaxation rewrites it, and mgrit_hip_relax(mode F) over the level's
+ *                            F-runs restores all of them bit for bit when the caller wants to look at the solution
+ *                            (C-point storage, as in XBraid's default storage mode).
  * keep[i] (null: 3 everywhere) names the rows of lvl+1 that the closing C-point of interval i must receive from mgrit_hip_cf_fas:
  * bit 0 = u^{l+1} (not needed where the first sweep of lvl+1 overwrites it unread: its F-points when the level starts with an
  * F-relaxation, mgrit.py:270-271; every point but the first of a coarsest level solved by forward_solve, mgrit.py:459-486),
@@ -173,7 +177,7 @@ int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_
                                const int32_t *cstart_coarse, const int32_t *cend_coarse, const int32_t *res_pos, int res_len,
                                int chunk, const int32_t *keep, int *id_out);
 int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int intervals_id);
-int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int intervals_id);
+int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int intervals_id, int store_all_f);
 int mgrit_hip_residual_fetch(mgrit_hip_engine *e, int n, double *sumsq_host);
 
 /* Same two reductions with the result delivered to HOST memory (sumsq_host[r], r < n_runs) when the call returns: the

@@ -30,8 +30,8 @@ class SlabVectorList:
     lane-blocked storage order, include/mgrit_hip.h) and wraps it in the application's Vector type; assignment
     uploads a Vector."""
 
-    def __init__(self, slab, n, template, perm, on_write=None):
-        self.slab, self.n, self.template, self.perm, self.on_write = slab, n, template, perm, on_write
+    def __init__(self, slab, n, template, perm, on_write=None, on_read=None):
+        self.slab, self.n, self.template, self.perm, self.on_write, self.on_read = slab, n, template, perm, on_write, on_read
 
     def __len__(self):
         return self.slab.shape[0]
@@ -46,6 +46,8 @@ class SlabVectorList:
     def __getitem__(self, i):
         if isinstance(i, slice):
             return [self[k] for k in range(*i.indices(len(self)))]
+        if self.on_read is not None:
+            self.on_read()
         vec = self.template.clone_zero()
         host = self.slab[self._row(int(i))][self.perm].cpu().numpy()
         vec.unpack(host.reshape(np.shape(vec.pack())).copy())   # pack()/unpack(): the Vector's own flat payload form
@@ -90,7 +92,8 @@ class HipBackend:
             else:
                 perm = hip_lib.row_permutation(n)
             self.perm.append(torch.from_numpy(np.asarray(perm, dtype=np.int64)).to(self.device))
-        self.U, self.V, self.G, self.FB = [], [], [], {}
+        self._U, self.V, self.G, self.FB = [], [], [], {}
+        self._f_stale = False     # level-0 F-points (all but the last of every interval) await materialise()
         self._runs, self._pairs = {}, {}
         self._described = [False] * mg.lvl_max
         self.chain_state, self.chain_handover, self._handover = {}, {}, {}
@@ -175,7 +178,7 @@ class HipBackend:
         if lvl > 0:
             v = torch.zeros_like(u)
             g = torch.zeros_like(u)
-        self.U.append(u), self.V.append(v), self.G.append(g)
+        self._U.append(u), self.V.append(v), self.G.append(g)
         check(self.lib.mgrit_hip_level_bind(self.h, lvl, C.c_void_p(u.data_ptr()),
                                             C.c_void_p(v.data_ptr() if v is not None else 0),
                                             C.c_void_p(g.data_ptr() if g is not None else 0)))
@@ -196,7 +199,8 @@ class HipBackend:
             assert slen.value == self.chain_handover[lvl]
             self.chain_state[lvl] = torch.zeros(slen.value, dtype=torch.float64, device=self.device)
             check(self.lib.mgrit_hip_chain_bind(self.h, lvl, C.c_void_p(self.chain_state[lvl].data_ptr())))
-        mg.u.append(SlabVectorList(u, n, tmpl, self.perm[lvl], on_write=self._forget_residual))
+        mg.u.append(SlabVectorList(u, n, tmpl, self.perm[lvl], on_write=self._forget_residual,
+                                   on_read=self.materialise if lvl == 0 else None))
         mg.v.append(SlabVectorList(v, n, tmpl, self.perm[lvl]) if v is not None else None)
         mg.g.append(SlabVectorList(g, n, tmpl, self.perm[lvl]) if g is not None else None)
         if mg.comm_time_rank == 0 and n_pts:
@@ -216,15 +220,34 @@ class HipBackend:
     def _forget_residual(self):
         self._residual_cache = None
 
+    @property
+    def U(self):
+        """the state slabs, level 0 with every F-point in place (tests, post-processing)"""
+        self.materialise()
+        return self._U
+
+    def materialise(self):
+        """C-point storage (include/mgrit_hip.h, mgrit_hip_ec_relax_res): in the steady state of a solve the way up stores, of
+        every level-0 interval's F-points, only the last one. Whoever wants to SEE the solution -- the end of Mgrit.solve(),
+        output_fcn, mgrit.u[0][i], natural(), the U slabs -- gets the others rebuilt here by one F-relaxation from the
+        C-points: the same Phi on the same values, so bit for bit what an every-point store would have left."""
+        if self._f_stale:
+            self._f_stale = False
+            cache = self._residual_cache          # an F-relaxation that rewrites identical values leaves the residual valid
+            self.relax(0, self.mg._f_runs(0), 'F')
+            self._residual_cache = cache
+
     def natural(self, which, lvl):
         """host copy of a whole slab in natural x order, shape [n_local_points][n] (tests / post-processing)"""
-        slab = {"u": self.U, "v": self.V, "g": self.G}[which][lvl]
+        if which == "u" and lvl == 0:
+            self.materialise()
+        slab = {"u": self._U, "v": self.V, "g": self.G}[which][lvl]
         return slab[:, self.perm[lvl]].cpu().numpy()
 
     def set_natural(self, which, lvl, values):
         self._residual_cache = None
         """upload a [n_local_points][n] host array given in natural x order"""
-        slab = {"u": self.U, "v": self.V, "g": self.G}[which][lvl]
+        slab = {"u": self._U, "v": self.V, "g": self.G}[which][lvl]
         slab.zero_()
         slab[:, self.perm[lvl]] = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64)).to(slab.device)
 
@@ -233,23 +256,23 @@ class HipBackend:
         if op == 5 and self.chain_handover.get(lvl):   # forward-solve hand-over: the point and the chain's running state
             state = self.chain_state[lvl]
             if state is None:   # this rank has no step of its own on the level (it owns the first point only): a fresh start
-                state = torch.cat((self.U[lvl][idx], torch.zeros(64, dtype=torch.float64, device=self.device)))
-            return torch.cat((self.U[lvl][idx], state))
-        return self.U[lvl][idx]
+                state = torch.cat((self._U[lvl][idx], torch.zeros(64, dtype=torch.float64, device=self.device)))
+            return torch.cat((self._U[lvl][idx], state))
+        return self._U[lvl][idx]
 
     def recv_buffer(self, lvl, idx, op=None):
         if op == 5 and self.chain_handover.get(lvl):
             if lvl not in self._handover:
-                self._handover[lvl] = torch.empty(self.U[lvl].shape[1] + self.chain_handover[lvl], dtype=torch.float64,
+                self._handover[lvl] = torch.empty(self._U[lvl].shape[1] + self.chain_handover[lvl], dtype=torch.float64,
                                                   device=self.device)
             return self._handover[lvl]
-        return self.U[lvl][idx]
+        return self._U[lvl][idx]
 
     def commit(self, lvl, idx, got, op=None):
         self._residual_cache = None
         if op == 5 and self.chain_handover.get(lvl):
-            ld = self.U[lvl].shape[1]
-            self.U[lvl][idx].copy_(got[:ld])
+            ld = self._U[lvl].shape[1]
+            self._U[lvl][idx].copy_(got[:ld])
             if self.chain_state[lvl] is not None:
                 self.chain_state[lvl].copy_(got[ld:])
                 check(self.lib.mgrit_hip_chain_resume(self.h, lvl, 1))   # the next forward solve continues the sender's chain
@@ -326,7 +349,10 @@ class HipBackend:
         if any(d["kind"] not in ("heat1d", "advection1d") for d in self.desc) or self.mg.lvl_max < 2:
             return 1
         n_c = len(self.mg.t[-1])
-        return int(max(1, min(8, n_c // 1024)))   # measured on config 3 (4097 coarsest points): 4 blocks 13.0 ms, 8 blocks 14.5, 2 blocks 15.4
+        # measured on config 3 (4097 coarsest points, round 2): 4 blocks 12.2 ms, 5 11.3, 6 10.8, 7 11.9, 8 13.3 -- more blocks
+        # shorten the fill and drain of the block pipeline, fewer keep the launches large (a level-0 pass of one block is
+        # 16384 / blocks / 4 chunks for 240 workgroups: with 6 blocks 2.8 rounds, with 8 blocks 2.1)
+        return int(max(1, min(8, n_c // 680)))
 
     def plan_single_block(self):
         """a cycle too small to be cut into blocks is still planned (as one block, program order): what pays there is the
@@ -348,6 +374,7 @@ class HipBackend:
         state = plan.__dict__.setdefault("_hip", {"runs": 0, "graph": None, "failed": False})
         if state["graph"] is not None and graph_ok:
             state["graph"].replay()
+            self._f_stale = self._f_stale or state.get("f_stale", False)   # what the replayed launches did to the F-points
             return
         if graph_ok and state["runs"] >= 2 and not state["failed"]:
             import gc
@@ -367,6 +394,7 @@ class HipBackend:
                         gc.enable()
                 state["graph"] = graph
                 graph.replay()
+                self._f_stale = self._f_stale or state.get("f_stale", False)
                 return
             except Exception as exc:   # noqa: BLE001 - capture is an optimisation: any refusal falls back to plain launches
                 state["failed"] = True
@@ -380,7 +408,10 @@ class HipBackend:
                 import warnings
                 warnings.warn(f"pymgrit_amd: cycle graph capture failed ({exc!r}); launching the cycle kernel by kernel")
         state["runs"] += 1
+        was, self._f_stale = self._f_stale, False
         self._plan_issue(plan, self.stream)
+        state["f_stale"] = self._f_stale          # does this cycle leave level-0 F-points to materialise()?
+        self._f_stale = self._f_stale or was
 
     def _plan_issue(self, plan, main):
         if self._chain_stream is None:
@@ -458,7 +489,7 @@ class HipBackend:
         return np.sqrt(buf.numpy())
 
     def save_last(self):
-        self.prev = self.U[0].clone()
+        self.prev = self._U[0].clone()
         self.mg.save_values_last_iter = SlabVectorList(self.prev, self.n[0], self.mg.problem[0].vector_template,
                                                        self.perm[0])
 
@@ -469,12 +500,12 @@ class HipBackend:
         if slot not in self._snap:
             self._snap[slot] = torch.empty((len(points), self.ld[0]), dtype=torch.float64, device=self.device)
         if len(points):
-            torch.index_select(self.U[0], 0, self._snap_idx, out=self._snap[slot])
+            torch.index_select(self._U[0], 0, self._snap_idx, out=self._snap[slot])
 
     def restore_cpoints(self, slot, points):
         self._residual_cache = None
         if len(points):
-            self.U[0].index_copy_(0, self._snap_idx, self._snap[slot])
+            self._U[0].index_copy_(0, self._snap_idx, self._snap[slot])
 
     def jump_norms(self, points):
         out = []
@@ -483,7 +514,7 @@ class HipBackend:
             check(self.lib.mgrit_hip_jump_host(self.h, 0, self._point_run_id(0, points),
                                                C.c_void_p(self.prev.data_ptr()), _ptr(host)))
             out = np.sqrt(host)
-        self.prev.copy_(self.U[0])
+        self.prev.copy_(self._U[0])
         return out
 
     def restrict_u(self, lvl, pairs):
@@ -567,7 +598,7 @@ class HipBackend:
         if not at["n_own"]:
             return
         own = slice(int(mg.index_local[lvl][0]), int(mg.index_local[lvl][-1]) + 1)   # rows of the owned points in the slab
-        U, G = self.U[lvl], self.G[lvl]
+        U, G = self._U[lvl], self.G[lvl]
         for slab, work in ((U, at["u"]), (G, at["g"])):        # old u, then g: last rows to the next holder, halo from the previous
             send = (slab[own][at["n_own"] - at["give"]:], at["next"]) if at["give"] else None
             recv = (work[:at["halo"]], at["prev"]) if at["halo"] else None
@@ -627,9 +658,13 @@ class HipBackend:
 
     def ec_relax_res(self, lvl, intervals, base=0):
         """error_correction + f_relax + compute_residual; the per-point sums of squares stay in pinned host memory until
-        residual_norms() asks for exactly these points"""
+        residual_norms() asks for exactly these points. F-points: C-point storage (materialise()) unless
+        PYMGRIT_AMD_STORE_ALL_F=1"""
         if intervals:
-            check(self.lib.mgrit_hip_ec_relax_res(self.h, lvl, self._intervals_id(lvl, intervals)))
+            lazy = lvl == 0 and os.environ.get("PYMGRIT_AMD_STORE_ALL_F", "") != "1"
+            check(self.lib.mgrit_hip_ec_relax_res(self.h, lvl, self._intervals_id(lvl, intervals), 0 if lazy else 1))
+            if lazy:
+                self._f_stale = True
 
     def residual_ready(self, points):
         """the residual of exactly these level-0 points has been produced by the last ec_relax_res sweep(s) and level 0 has not

@@ -781,6 +781,7 @@ class Mgrit:
         self._pl = None
         self._pl_advance(self.iter_max)
         self._pl_finish()
+        getattr(self.backend, 'materialise', lambda: None)()   # C-point storage on the way up: every F-point in place again
         self.backend.sync()
         getattr(self.comm_time, 'drain', lambda: None)()
         self.comm_time.barrier()
@@ -856,6 +857,7 @@ class Mgrit:
                     if not self.global_conv_crit and self.comm_time_size > 1:
                         self._leave_local(iteration)
                     break
+        getattr(self.backend, 'materialise', lambda: None)()   # C-point storage on the way up: every F-point in place again
         self.backend.sync()
         getattr(self.comm_time, 'drain', lambda: None)()
         self.comm_time.barrier()

@@ -965,14 +965,16 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
 
 // error_correction + f_relax + compute_residual of level 0 in ONE pass (mgrit.py:715-726, 292-333 as Mgrit.iteration calls
 // them, mgrit.py:283-284, then 387-413 from convergence_criterion), identity transfer. Per interval (C_j, C_{j+1}]:
-//   F''      = Phi-propagation from the corrected C''_j, stored
+//   F''      = Phi-propagation from the corrected C''_j, stored -- all of them, or with store_f = 0 only the last one (the
+//              point the next C-relaxation starts from): F-points are a function of the C-points, and an F-relaxation
+//              (mgrit_hip_relax mode F) rebuilds them bit for bit whenever somebody wants to see them
 //   C''_{j+1} = v^{l+1}_{j+1} + (u^{l+1}_{j+1} - v^{l+1}_{j+1})   (v^{l+1}_{j+1} IS u^l at that C-point, bit for bit: read from the
 //                                                                 fine row inside a chunk, from v -- which nobody writes on the
 //                                                                 way up -- for the C-point a chunk starts from), stored
 //   out[res_pos] = || Phi_l(F''_last) - C''_{j+1} ||^2
 // 2 rows read + m written per interval instead of 2 + m (correction + F-relaxation) and 2 more for the residual.
 template <int FORCE>
-__global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, double *__restrict__ out) {
+__global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, double *__restrict__ out, int store_f) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
     WG_PROLOGUE;
     for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < I.n_chunks; wq.advance(t)) {
@@ -996,7 +998,7 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
             const int cs = I.cstart[it], ce = I.cend[it], jc = I.cend_coarse[it];
             for (int i = cs + 1; i < ce; ++i) {
                 phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
-                store_row(L.u + (size_t)i * L.ld, sl, x);
+                if (store_f || i == ce - 1) store_row(L.u + (size_t)i * L.ld, sl, x);
             }
             double b[E];
             {   // v^{l+1}_{j+1} from the fine row itself (the same bits; only this chunk writes that row), see IntervalsDev::keep
@@ -2730,7 +2732,7 @@ int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id) {
     return 0;
 }
 
-int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int ivals_id) {
+int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int ivals_id, int store_all_f) {
     int rc = fused_level_check(e, lvl, ivals_id, "fused correction + F-relaxation + residual");
     if (rc) return rc;
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
@@ -2739,8 +2741,8 @@ int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int ivals_id) {
     if ((rc = ensure_pinned(e, lf.ivals_n[ivals_id]))) return rc;
     Timed timed(e, MGRIT_HIP_T_EC_RELAX_RES, lvl);
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
-    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned);
-    else hipLaunchKernelGGL((ecfr_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned);
+    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
+    else hipLaunchKernelGGL((ecfr_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
     HIP_TRY(hipGetLastError());
     return 0;
 }

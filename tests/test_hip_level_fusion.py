@@ -65,3 +65,35 @@ def test_level_passes_against_oracle(oracle):
     got = np.asarray(mg.compute_residual())
     mg.backend._residual_cache = None
     assert np.array_equal(got, np.asarray(mg.compute_residual()))
+
+
+def test_c_point_storage_rebuilds_every_f_point(monkeypatch):
+    """the way up stores only the last F-point of every level-0 interval (mgrit_hip_ec_relax_res, store_all_f = 0); whoever
+    looks at the solution -- mgrit.u[0][i], natural(), the U slabs, the end of solve() -- sees what an every-point store leaves"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from pymgrit_amd import Mgrit
+
+    def run(store_all, blocks):
+        if store_all:
+            monkeypatch.setenv("PYMGRIT_AMD_STORE_ALL_F", "1")
+        else:
+            monkeypatch.delenv("PYMGRIT_AMD_STORE_ALL_F", raising=False)
+        prob, tr, opts = dist_worker.build_problem("heat_nx257_nt257", "hip")
+        mg = Mgrit(prob, transfer=tr, logging_lvl=30, plan_blocks=blocks, **opts)
+        assert mg._level_intervals(0) is not None
+        for it in range(4):       # iterations by hand (no solve()): the fourth replays the captured graph when planned
+            mg.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True)
+            mg.convergence_criterion(iteration=it + 1)
+        return mg
+    eager = run(True, 1)
+    assert not eager.backend._f_stale
+    want = eager.backend.natural("u", 0)
+    for blocks in (1, 2, None):
+        mg = run(False, blocks)
+        assert mg.backend._f_stale                       # F-points pending ...
+        row = mg.u[0][2].get_values()                    # ... until somebody looks (an F-point that was not stored)
+        assert not mg.backend._f_stale and np.array_equal(row, want[2])
+        assert np.array_equal(mg.backend.natural("u", 0), want) and np.array_equal(mg.conv[1:5], eager.conv[1:5])
+        mg.iteration(lvl=0, cycle_type='V', iteration=4, first_f=True)
+        assert mg.backend._f_stale and mg.backend.U[0] is mg.backend._U[0] and not mg.backend._f_stale
