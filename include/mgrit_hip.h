@@ -29,7 +29,11 @@ typedef struct mgrit_hip_engine mgrit_hip_engine;
 enum { MGRIT_HIP_OK = 0, MGRIT_HIP_EINVAL = -1, MGRIT_HIP_EHIP = -2, MGRIT_HIP_ENODEV = -3, MGRIT_HIP_EUNSUPPORTED = -4 };
 enum { MGRIT_HIP_STEPPER_HEAT1D = 1, MGRIT_HIP_STEPPER_ADVECTION1D = 2, MGRIT_HIP_STEPPER_HEAT2D = 3,
        MGRIT_HIP_STEPPER_HEAT1D_2PTS = 4 };
-enum { MGRIT_HIP_TRANSFER_COPY = 0, MGRIT_HIP_TRANSFER_HEAT1D = 1, MGRIT_HIP_TRANSFER_PERIODIC1D = 2 };
+enum { MGRIT_HIP_TRANSFER_COPY = 0, MGRIT_HIP_TRANSFER_HEAT1D = 1, MGRIT_HIP_TRANSFER_PERIODIC1D = 2,
+       /* the caller applies restriction / interpolation itself (a user's GridTransfer, reference core/grid_transfer.py:31-55:
+          any Python code): mgrit_hip_restrict_u / _fas_rhs / _error_correction / _interpolate refuse the level pair, the FAS
+          right-hand side is taken in two halves around the caller's restriction (mgrit_hip_fas_fine_rows / _fas_coarse) */
+       MGRIT_HIP_TRANSFER_CALLER = 3 };
 enum { MGRIT_HIP_RELAX_F = 0, MGRIT_HIP_RELAX_C = 1, MGRIT_HIP_RELAX_CHAIN = 2 };
 
 int mgrit_hip_abi_version(void);
@@ -123,6 +127,13 @@ int mgrit_hip_jump(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev
 int mgrit_hip_restrict_u(mgrit_hip_engine *e, int lvl, int pairs_id);
 int mgrit_hip_copy_u_to_v(mgrit_hip_engine *e, int lvl_coarse);
 int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id);
+/* The two halves of mgrit_hip_fas_rhs for a transfer the caller applies (MGRIT_HIP_TRANSFER_CALLER; 1-D steppers):
+ *   mgrit_hip_fas_fine_rows: rows[p] (device, row stride ld_rows >= the level's row stride, engine row order) =
+ *       Phi_l(u_{i-1}) - u_i  (lvl 0)  or  (g_i - u_i) + Phi_l(u_{i-1})  for the p-th pair's fine point i   (mgrit.py:528-532, 538-543)
+ *   the caller restricts every row and stores the result in g^{l+1}_j of the pair's coarse point
+ *   mgrit_hip_fas_coarse:    g^{l+1}_j = (g^{l+1}_j + v^{l+1}_j) - Phi_{l+1}(v^{l+1}_{j-1})                        (mgrit.py:533-536, 544-547) */
+int mgrit_hip_fas_fine_rows(mgrit_hip_engine *e, int lvl, int pairs_id, double *rows, int ld_rows);
+int mgrit_hip_fas_coarse(mgrit_hip_engine *e, int lvl, int pairs_id);
 /* The same sweep fused into one pass for the identity transfer (GridTransferCopy) and like steppers on both levels:
  * triple = (fine slot i of a C-point, fine slot of the PREVIOUS C-point (must be local), coarse slot j). For every triple:
  * u^{l+1}_j = v^{l+1}_j = u^l_i and g^{l+1}_j as above with v_{j-1} read as u^l at the previous C-point. Pairs whose

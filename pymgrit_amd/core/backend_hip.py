@@ -212,10 +212,22 @@ class HipBackend:
         mg = self.mg
         for lvl in range(mg.lvl_max - 1):
             tr = mg.transfer_objects[lvl]
-            if not hasattr(tr, "device_transfer"):
-                raise MgritHipError(f"transfer {type(tr).__name__} has no device_transfer(): device applications need a "
-                                    f"device-capable GridTransfer (GridTransferCopy, GridTransferHeat)")
-            check(self.lib.mgrit_hip_level_transfer(self.h, lvl, int(tr.device_transfer())))
+            kind = int(tr.device_transfer()) if self._device_transfer(lvl) else hip_lib.TRANSFER_CALLER
+            if kind == hip_lib.TRANSFER_CALLER and self.desc[lvl]["kind"] not in ("heat1d", "advection1d"):
+                raise MgritHipError(f"transfer {type(tr).__name__} is applied through its Python methods, which the "
+                                    f"{self.desc[lvl]['kind']} levels do not support (they take GridTransferCopy)")
+            check(self.lib.mgrit_hip_level_transfer(self.h, lvl, kind))
+
+    def _host_transfers(self):
+        return any(not self._device_transfer(lvl) for lvl in range(self.mg.lvl_max - 1))
+
+    def _device_transfer(self, lvl):
+        """True when the transfer between lvl and lvl+1 is one of the library's own (its kernels apply it); False for a user's
+        GridTransfer (reference core/grid_transfer.py:31-55) or a subclass that overrides restriction / interpolation: those
+        run through their Python methods, row by row on the host, while every Phi stays on the device"""
+        tr = self.mg.transfer_objects[lvl]
+        lib_method = type(self.mg)._library_method
+        return hasattr(tr, "device_transfer") and lib_method(tr, "restriction") and lib_method(tr, "interpolation")
 
     def _forget_residual(self):
         self._residual_cache = None
@@ -346,7 +358,7 @@ class HipBackend:
     def plan_blocks(self):
         """how many blocks of time points a planned cycle uses by default (1 = program order): the overlap pays when the
         coarsest-level solve is long; Heat2D / two-point levels keep the program order"""
-        if any(d["kind"] not in ("heat1d", "advection1d") for d in self.desc) or self.mg.lvl_max < 2:
+        if any(d["kind"] not in ("heat1d", "advection1d") for d in self.desc) or self.mg.lvl_max < 2 or self._host_transfers():
             return 1
         n_c = len(self.mg.t[-1])
         # measured on config 3 (4097 coarsest points, round 2): 4 blocks 12.2 ms, 5 11.3, 6 10.8, 7 11.9, 8 13.3 -- more blocks
@@ -357,7 +369,8 @@ class HipBackend:
     def plan_single_block(self):
         """a cycle too small to be cut into blocks is still planned (as one block, program order): what pays there is the
         replay of the whole cycle as one hipGraph (plan_run)"""
-        return all(d["kind"] in ("heat1d", "advection1d") for d in self.desc) and self.mg.lvl_max >= 2
+        return (all(d["kind"] in ("heat1d", "advection1d") for d in self.desc) and self.mg.lvl_max >= 2 and
+                not self._host_transfers())      # host round trips cannot be part of a captured graph
 
     def _use_stream(self, stream):
         if stream is not self._cur_stream:
@@ -518,22 +531,41 @@ class HipBackend:
         return out
 
     def restrict_u(self, lvl, pairs):
-        if pairs:
-            check(self.lib.mgrit_hip_restrict_u(self.h, lvl, self._pair_id(lvl, pairs)))
+        if not pairs:
+            return
+        if not self._device_transfer(lvl):     # the user's restriction (mgrit.py:498-500), row by row
+            mg = self.mg
+            for i, j in pairs:
+                mg.u[lvl + 1][j] = mg.restriction[lvl](mg.u[lvl][i])
+            return
+        check(self.lib.mgrit_hip_restrict_u(self.h, lvl, self._pair_id(lvl, pairs)))
 
     def copy_u_to_v(self, lvl):
         check(self.lib.mgrit_hip_copy_u_to_v(self.h, lvl))
 
     def fas_rhs(self, lvl, pairs):
-        if pairs:
-            check(self.lib.mgrit_hip_fas_rhs(self.h, lvl, self._pair_id(lvl, pairs)))
+        if not pairs:
+            return
+        if not self._device_transfer(lvl):
+            # mgrit.py:524-547 around the user's restriction: fine half on the device (one row per pair), the rows through
+            # restriction() into g of the coarse level, coarse half on the device
+            mg, pid = self.mg, self._pair_id(lvl, pairs)
+            rows = torch.zeros(len(pairs), self.ld[lvl], dtype=torch.float64, device=self.device)
+            check(self.lib.mgrit_hip_fas_fine_rows(self.h, lvl, pid, C.c_void_p(rows.data_ptr()), self.ld[lvl]))
+            self.sync()
+            defects = SlabVectorList(rows, self.n[lvl], mg.problem[lvl].vector_template, self.perm[lvl])
+            for p, (_, j) in enumerate(pairs):
+                mg.g[lvl + 1][j] = mg.restriction[lvl](defects[p])
+            check(self.lib.mgrit_hip_fas_coarse(self.h, lvl, pid))
+            return
+        check(self.lib.mgrit_hip_fas_rhs(self.h, lvl, self._pair_id(lvl, pairs)))
 
     # fused FAS residual (identity transfer, like steppers on both levels): see include/mgrit_hip.h
     def can_fuse_fas(self, lvl):
         tr = self.mg.transfer_objects[lvl]
         da, db = self.desc[lvl], self.desc[lvl + 1]
         same_forcing = len(da.get("forcing_time", [])) == len(db.get("forcing_time", []))
-        return (hasattr(tr, "device_transfer") and int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and
+        return (self._device_transfer(lvl) and int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and
                 da["kind"] == db["kind"] and da["kind"] in ("heat1d", "advection1d") and
                 self.n[lvl] == self.n[lvl + 1] and same_forcing)
 
@@ -611,7 +643,7 @@ class HipBackend:
     def can_fuse_ec(self, lvl):
         tr = self.mg.transfer_objects[lvl]
         da, db = self.desc[lvl], self.desc[lvl + 1]
-        return (hasattr(tr, "device_transfer") and int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and
+        return (self._device_transfer(lvl) and int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and
                 da["kind"] == db["kind"] and da["kind"] in ("heat1d", "advection1d") and self.n[lvl] == self.n[lvl + 1])
 
     def ec_relax(self, lvl, triples):
@@ -633,7 +665,7 @@ class HipBackend:
         """level 0, Heat1D with a separable forcing on both levels, identity transfer (weight and layout: the caller)"""
         tr = self.mg.transfer_objects[lvl]
         da, db = self.desc[lvl], self.desc[lvl + 1]
-        return (lvl == 0 and os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and hasattr(tr, "device_transfer") and
+        return (lvl == 0 and os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and self._device_transfer(lvl) and
                 int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and da["kind"] == db["kind"] == "heat1d" and
                 self.n[lvl] == self.n[lvl + 1] and da.get("forcing_rows") is None and db.get("forcing_rows") is None and
                 len(da.get("forcing_time", [])) == len(db.get("forcing_time", [])))
@@ -674,13 +706,21 @@ class HipBackend:
     def error_correction(self, lvl, pairs):
         if lvl == 0:
             self._residual_cache = None
-        if pairs:
+        if pairs and not self._device_transfer(lvl):     # mgrit.py:724-726 through the user's interpolation
+            mg = self.mg
+            for i, j in pairs:
+                mg.u[lvl][i] = mg.u[lvl][i] + mg.interpolation[lvl](mg.u[lvl + 1][j] - mg.v[lvl + 1][j])
+        elif pairs:
             check(self.lib.mgrit_hip_error_correction(self.h, lvl, self._pair_id(lvl, pairs)))
 
     def interpolate(self, lvl, pairs):
         if lvl == 0:
             self._residual_cache = None
-        if pairs:
+        if pairs and not self._device_transfer(lvl):     # mgrit.py:559-563
+            mg = self.mg
+            for i, j in pairs:
+                mg.u[lvl][i] = mg.interpolation[lvl](u=mg.u[lvl + 1][j])
+        elif pairs:
             check(self.lib.mgrit_hip_interpolate(self.h, lvl, self._pair_id(lvl, pairs)))
 
     def sync(self):

@@ -11,7 +11,7 @@ RELAX_F, RELAX_C, RELAX_CHAIN = 0, 1, 2
 TIMED_KINDS = ("relax_f", "relax_c", "chain", "residual", "jump", "restrict", "copy", "fas_rhs", "fas_fused",
                "error_correction", "interpolate", "ec_relax", "at_solve", "cf_fas", "ec_relax_res")
 STEPPER_HEAT1D, STEPPER_ADVECTION1D = 1, 2
-TRANSFER_COPY, TRANSFER_HEAT1D = 0, 1
+TRANSFER_COPY, TRANSFER_HEAT1D, TRANSFER_CALLER = 0, 1, 3
 MAX_N = 16384
 
 EXPORTS = {
@@ -65,6 +65,8 @@ EXPORTS = {
     "mgrit_hip_chain_clock": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mgrit_hip_intervals_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "mgrit_hip_fas_fine_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "mgrit_hip_fas_coarse": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_cf_fas": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_ec_relax_res": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgrit_hip_residual_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -211,13 +211,12 @@ class Mgrit:
         runs through the plugin path, i.e. through the user's Python code, like in the reference."""
         has_desc = [hasattr(p, "device_stepper") and p.device_stepper() is not None for p in problem]
         custom = [type(p).__name__ for p, d in zip(problem, has_desc) if d and not self._library_method(p, "step")]
-        custom += [type(t).__name__ for t in self.__dict__.get("_transfer_for_selection", ())
-                   if hasattr(t, "device_transfer") and not (self._library_method(t, "restriction") and
-                                                             self._library_method(t, "interpolation"))]
         if all(has_desc) and custom:
-            logging.warning('pymgrit_amd: %s override step() / restriction() / interpolation(): the hierarchy runs through '
-                            'these Python methods (plugin path), not through the MI355X kernels', sorted(set(custom)))
+            logging.warning('pymgrit_amd: %s override step(): the hierarchy runs through these Python methods (plugin path), '
+                            'not through the MI355X kernels', sorted(set(custom)))
             has_desc = [False] * len(problem)
+        # (a user's GridTransfer, or a library transfer with overridden restriction / interpolation, does NOT leave the device
+        # path: the 1-D engine applies such a transfer through its Python methods between the kernels, backend_hip.fas_rhs)
         if all(has_desc):
             from pymgrit_amd.core.backend_hip import HipBackend
             return HipBackend(self)

@@ -2200,6 +2200,8 @@ int mgrit_hip_level_transfer(mgrit_hip_engine *e, int lvl, int kind) {
     } else if (kind == MGRIT_HIP_TRANSFER_PERIODIC1D) {
         if (e->L[lvl].h2d || e->L[lvl + 1].h2d) return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D levels support the copy transfer only");
         if (nf != 2 * nc) return fail(MGRIT_HIP_EINVAL, "periodic transfer needs n_fine = 2*n_coarse (%d vs %d)", nf, nc);
+    } else if (kind == MGRIT_HIP_TRANSFER_CALLER) {
+        if (e->L[lvl].h2d || e->L[lvl + 1].h2d) return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D levels support the copy transfer only");
     } else return fail(MGRIT_HIP_EINVAL, "unknown transfer kind %d", kind);
     e->L[lvl].transfer = kind;
     return 0;
@@ -2375,11 +2377,18 @@ int mgrit_hip_jump(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev
     return 0;
 }
 
+static int caller_transfer(const Level &lf, int lvl) {
+    if (lf.transfer == MGRIT_HIP_TRANSFER_CALLER)
+        return fail(MGRIT_HIP_EUNSUPPORTED, "the transfer between levels %d and %d is applied by the caller", lvl, lvl + 1);
+    return 0;
+}
+
 int mgrit_hip_restrict_u(mgrit_hip_engine *e, int lvl, int pairs_id) {
     PairList *pl;
     int rc = get_pairs(e, lvl, pairs_id, &pl);
     if (rc) return rc;
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    if ((rc = caller_transfer(lf, lvl))) return rc;
     if ((rc = check_bound(lf, false)) || (rc = check_bound(lc, false))) return rc;
     if (pl->n == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_RESTRICT, lvl);
@@ -2401,11 +2410,39 @@ int mgrit_hip_copy_u_to_v(mgrit_hip_engine *e, int lvl_coarse) {
     return 0;
 }
 
+int mgrit_hip_fas_fine_rows(mgrit_hip_engine *e, int lvl, int pairs_id, double *rows, int ld_rows) {
+    PairList *pl;
+    int rc = get_pairs(e, lvl, pairs_id, &pl);
+    if (rc) return rc;
+    Level &lf = e->L[lvl];
+    if ((rc = check_bound(lf, lvl > 0))) return rc;
+    if (lf.h2d || is_2pts(lf)) return fail(MGRIT_HIP_EUNSUPPORTED, "split FAS right-hand side: 1-D one-point steppers only");
+    if (pl->n > 0 && (!rows || ld_rows < lf.dev.ld)) return fail(MGRIT_HIP_EINVAL, "rows buffer missing or narrower than the level's rows");
+    if (pl->n == 0) return 0;
+    Timed timed(e, MGRIT_HIP_T_FAS_RHS, lvl);
+    LAUNCH_BY_KIND(fas_fine_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_iota, rows, ld_rows, lvl > 0 ? 1 : 0);
+    return 0;
+}
+
+int mgrit_hip_fas_coarse(mgrit_hip_engine *e, int lvl, int pairs_id) {
+    PairList *pl;
+    int rc = get_pairs(e, lvl, pairs_id, &pl);
+    if (rc) return rc;
+    Level &lc = e->L[lvl + 1];
+    if ((rc = check_bound(lc, true))) return rc;
+    if (lc.h2d || is_2pts(lc)) return fail(MGRIT_HIP_EUNSUPPORTED, "split FAS right-hand side: 1-D one-point steppers only");
+    if (pl->n == 0) return 0;
+    Timed timed(e, MGRIT_HIP_T_FAS_RHS, lvl);
+    LAUNCH_BY_KIND(fas_coarse_kernel, lc, pl->n, lc.dev, pl->d_coarse);
+    return 0;
+}
+
 int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id) {
     PairList *pl;
     int rc = get_pairs(e, lvl, pairs_id, &pl);
     if (rc) return rc;
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    if ((rc = caller_transfer(lf, lvl))) return rc;
     if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
     if (pl->n == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_FAS_RHS, lvl);
@@ -2504,6 +2541,7 @@ static int interp_common(mgrit_hip_engine *e, int lvl, int pairs_id, int mode) {
     int rc = get_pairs(e, lvl, pairs_id, &pl);
     if (rc) return rc;
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    if ((rc = caller_transfer(lf, lvl))) return rc;
     if ((rc = check_bound(lf, false)) || (rc = check_bound(lc, mode == 1))) return rc;
     if (pl->n == 0) return 0;
     Timed timed(e, mode == 1 ? MGRIT_HIP_T_ERROR_CORRECTION : MGRIT_HIP_T_INTERPOLATE, lvl);

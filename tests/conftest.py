@@ -23,7 +23,7 @@ def oracle():
 # Order of the suite (matters under `pytest -x`): the C ABI and the single-process oracle comparisons first, every test
 # that starts other processes or rank threads last, so a fault of the multi-process harness can never hide a parity test.
 _ORDER = ["test_hip_abi", "test_hip_parity", "test_hip_heat2d", "test_hip_fuzz", "test_hip_bdf", "test_advection_sc",
-          "test_hip_output", "test_hip_forcing", "test_hip_plan", "test_hip_level_fusion", "test_at_mgrit", "test_local_conv"]
+          "test_hip_output", "test_hip_forcing", "test_hip_plan", "test_hip_level_fusion", "test_hip_user_transfer", "test_at_mgrit", "test_local_conv"]
 _LAST = ["test_hip_distributed", "test_hip_exchange_fuzz", "test_hip_bench_cli", "test_hip_full_size", "test_hip_rccl"]
 
 

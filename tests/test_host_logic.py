@@ -276,8 +276,9 @@ def test_device_application_without_gpu_fails_loudly():
 
 
 def test_user_subclass_overriding_step_runs_its_own_step():
-    """backend by type: a subclass of a device application that overrides step() (or a transfer that overrides restriction /
-    interpolation) runs through ITS methods on the plugin path -- the kernels would silently ignore the override"""
+    """backend by type: a subclass of a device application that overrides step() runs through ITS method on the plugin path
+    -- the kernels would silently ignore the override; a transfer that overrides restriction / interpolation runs through its
+    methods on either path (on the device path between the kernels: tests/test_hip_user_transfer.py)"""
     from pymgrit_amd import GridTransferCopy, Heat1D, Mgrit
     calls = []
 
