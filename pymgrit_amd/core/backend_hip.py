@@ -670,11 +670,29 @@ class HipBackend:
                 self.n[lvl] == self.n[lvl + 1] and da.get("forcing_rows") is None and db.get("forcing_rows") is None and
                 len(da.get("forcing_time", [])) == len(db.get("forcing_time", [])))
 
+    def can_fuse_level_up(self, lvl):
+        """any level pair of Heat1D with a separable forcing and the identity transfer: error correction + F-relaxation in one
+        pass (mgrit_hip_ec_relax_res; with the rows of g and without the residual on lvl > 0)"""
+        tr = self.mg.transfer_objects[lvl]
+        da, db = self.desc[lvl], self.desc[lvl + 1]
+        # Off unless PYMGRIT_AMD_FUSE_UP_COARSE=1. Measured on config 3 (round 2): its intervals correct the C-point they END
+        # on, so in a planned cycle a block waits for the chain of its own block only (ecf_kernel: of the next block too) and
+        # the drain of the block pipeline shrinks -- but the launch itself is slower than ecf_kernel (1.09 vs 0.90 ms per
+        # cycle: every interval reads its two boundary corrections), and with six blocks the sweep stream, not the chain,
+        # is what the cycle waits for: 11.1 ms against 10.8.
+        return (os.environ.get("PYMGRIT_AMD_FUSE_UP_COARSE", "") == "1" and
+                os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and self._device_transfer(lvl) and
+                int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and da["kind"] == db["kind"] == "heat1d" and
+                self.n[lvl] == self.n[lvl + 1] and da.get("forcing_rows") is None and db.get("forcing_rows") is None and
+                len(da.get("forcing_time", [])) == len(db.get("forcing_time", [])))
+
     def _intervals_id(self, lvl, intervals):
         def create():
             iid = C.c_int(-1)
             cols = [_i32([iv[k] for iv in intervals]) for k in range(6)]
-            chunk = int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK", "4"))
+            # level 0: chunks of 4 intervals (one extra row + Phi per chunk start); coarser levels: one interval per item --
+            # a block of a planned cycle holds only a few hundred of their intervals, and 4 in a row would leave CUs idle
+            chunk = int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK", "4")) if lvl == 0 else int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK_COARSE", "1"))
             res_len = len(self.mg._c_points(lvl))
             check(self.lib.mgrit_hip_intervals_create(self.h, lvl, len(intervals), _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]),
                                                       _ptr(cols[3]), _ptr(cols[4]), res_len, chunk, _ptr(cols[5]), C.byref(iid)))

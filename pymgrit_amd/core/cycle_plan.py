@@ -241,9 +241,11 @@ class Recorder:
             cs, ce, jcs, jce = _interval_cells(self, lvl, part)
             reads = self._cells("u", lvl + 1, jce) | self._cells("v", lvl + 1, jce) | self._cells("u", lvl + 1, jcs[jcs >= 0]) | \
                 self._cells("v", lvl + 1, jcs[jcs >= 0]) | self._cells("u", lvl, cs[jcs < 0])
+            if lvl > 0:
+                reads |= {("g", lvl, b)}
             n_f = int(np.sum(ce - cs - 1))
-            self._add("ec_relax_res", lvl, b, lambda p=part: real.ec_relax_res(lvl, p), reads, {("u", lvl, b), ("res", lvl, b)},
-                      3 * len(part) + n_f)
+            self._add("ec_relax_res", lvl, b, lambda p=part: real.ec_relax_res(lvl, p), reads,
+                      {("u", lvl, b), ("res", lvl, b)} if lvl == 0 else {("u", lvl, b)}, 3 * len(part) + n_f * (2 if lvl > 0 else 1))
 
     def residual_ready(self, points):
         self.host_after.append(lambda: self.real.residual_ready(points))

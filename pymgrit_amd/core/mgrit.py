@@ -431,6 +431,8 @@ class Mgrit:
         if fused is not None and lvl == 0 and self.conv_crit in (0, 2):   # correction + F-relaxation + the residual check's sums
             self.backend.ec_relax_res(lvl, fused)
             self.backend.residual_ready(self._c_points(0))
+        elif lvl > 0 and self._level_intervals(lvl, up=True) is not None:   # coarser level: the same pass with g, no residual
+            self.backend.ec_relax_res(lvl, self._level_intervals(lvl, up=True))
         elif self._can_fuse_ec(lvl):
             self._ec_f_relax(lvl)
         else:
@@ -477,7 +479,7 @@ class Mgrit:
             return [(st, ln, coarse_of.get(st - 1, -1)) for st, ln in runs]
         self.backend.ec_relax(lvl, self._cached(('ec_' + tag, lvl), build))
 
-    def _level_intervals(self, lvl):
+    def _level_intervals(self, lvl, up=False):
         """[(cstart, cend, cstart_coarse, cend_coarse, res_pos, keep)] of level lvl when its sweeps can run as whole-level passes
         (mgrit_hip_cf_fas / mgrit_hip_ec_relax_res), else None: one rank (no exchange point inside the pass), the library's own
         sweeps, weight 1, and a level whose F-points all lie between two local C-points."""
@@ -486,9 +488,11 @@ class Mgrit:
             own = all(getattr(type(self), name) is getattr(Mgrit, name) for name in
                       ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "compute_residual", "_exchange",
                        "_ec_f_relax"))
+            # up: the pass of the way up alone (error correction + F-relaxation), which exists for every level pair
+            can = getattr(be, "can_fuse_level_up" if up else "can_fuse_level", None)
             if not (own and self.comm_time_size == 1 and self.weight_c == 1.0 and lvl < self.lvl_max - 1 and
                     not getattr(self, "_sweep_timing", False) and     # per-sweep debug lines: sweep by sweep
-                    getattr(be, "can_fuse_level", None) is not None and be.can_fuse_level(lvl)):
+                    can is not None and can(lvl) and (not up or self._can_fuse_ec(lvl))):
                 return [None]
             pairs = self._pairs(lvl, skip_first=False)
             if len(pairs) < 2 or pairs[0][0] != 0 or self._c_points(lvl) != [p[0] for p in pairs[1:]]:
@@ -510,10 +514,10 @@ class Mgrit:
             need_v = 0 if (lvl == 0 and self.conv_crit in (0, 2)) else 2
             return [[(pairs[k][0], pairs[k + 1][0], pairs[k][1] if k >= 1 else -1, pairs[k + 1][1], k,
                       (1 if need_u(pairs[k + 1][1]) else 0) | need_v) for k in range(len(pairs) - 1)]]
-        got = self._cached(('intervals', lvl), build)[0]
+        got = self._cached(('intervals', lvl, up), build)[0]
         if got is None:
             return None
-        return self._cached(('intervals_list', lvl), lambda: got)
+        return self._cached(('intervals_list', lvl, up), lambda: got)
 
     def _can_fuse_ec(self, lvl):
         return (getattr(self.backend, "can_fuse_ec", None) is not None and self.backend.can_fuse_ec(lvl) and

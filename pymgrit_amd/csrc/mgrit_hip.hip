@@ -963,6 +963,9 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
     wq.end(t);
 }
 
+// (USE_G, !RES: the same pass on a coarser level -- error_correction + f_relax with the rows of g, every F-point stored, no
+// residual. Unlike ecf_kernel, whose interval corrects the C-point it STARTS from, an interval here corrects the C-point it
+// ends on: in a planned cycle a block of time points then needs the coarsest-level chain of ITS block only.)
 // error_correction + f_relax + compute_residual of level 0 in ONE pass (mgrit.py:715-726, 292-333 as Mgrit.iteration calls
 // them, mgrit.py:283-284, then 387-413 from convergence_criterion), identity transfer. Per interval (C_j, C_{j+1}]:
 //   F''      = Phi-propagation from the corrected C''_j, stored -- all of them, or with store_f = 0 only the last one (the
@@ -973,7 +976,7 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
 //                                                                 way up -- for the C-point a chunk starts from), stored
 //   out[res_pos] = || Phi_l(F''_last) - C''_{j+1} ||^2
 // 2 rows read + m written per interval instead of 2 + m (correction + F-relaxation) and 2 more for the residual.
-template <int FORCE>
+template <int FORCE, bool USE_G, bool RES>
 __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, double *__restrict__ out, int store_f) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
     WG_PROLOGUE;
@@ -997,7 +1000,13 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
         for (int it = i0; it < i0 + cnt; ++it) {
             const int cs = I.cstart[it], ce = I.cend[it], jc = I.cend_coarse[it];
             for (int i = cs + 1; i < ce; ++i) {
+                double gi[E];
+                if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);   // in flight while Phi runs
                 phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+                if (USE_G) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) x[e] = gi[e] + x[e];
+                }
                 if (store_f || i == ce - 1) store_row(L.u + (size_t)i * L.ld, sl, x);
             }
             double b[E];
@@ -1009,11 +1018,13 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
                 for (int e = 0; e < E; ++e) b[e] = b[e] + (w[e] - b[e]);
             }
             store_row(L.u + (size_t)ce * L.ld, sl, b);
-            phi_apply<KIND, FORCE>(x, ctx, L, ce, sm, t, lane, wave, G);
+            if (RES) {
+                phi_apply<KIND, FORCE>(x, ctx, L, ce, sm, t, lane, wave, G);
 #pragma unroll
-            for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
-            const double tot = block_sumsq(x, sm, L.n, t, lane, wave, G);
-            if (t == 0) out[I.res_pos[it]] = tot;
+                for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
+                const double tot = block_sumsq(x, sm, L.n, t, lane, wave, G);
+                if (t == 0) out[I.res_pos[it]] = tot;
+            }
 #pragma unroll
             for (int e = 0; e < E; ++e) x[e] = b[e];
         }
@@ -1456,8 +1467,10 @@ int setup_kernel_attrs() {
     FOR_EACH_STEPPER(ATTR_ALL)
     if ((rc = allow_big_lds(cfas_kernel<0>))) return rc;
     if ((rc = allow_big_lds(cfas_kernel<2>))) return rc;
-    if ((rc = allow_big_lds(ecfr_kernel<0>))) return rc;
-    if ((rc = allow_big_lds(ecfr_kernel<2>))) return rc;
+    if ((rc = allow_big_lds(ecfr_kernel<0, false, true>))) return rc;
+    if ((rc = allow_big_lds(ecfr_kernel<2, false, true>))) return rc;
+    if ((rc = allow_big_lds(ecfr_kernel<0, true, false>))) return rc;
+    if ((rc = allow_big_lds(ecfr_kernel<2, true, false>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<0>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<2>))) return rc;
     if ((rc = allow_big_lds(jump_kernel))) return rc;
@@ -2742,14 +2755,14 @@ int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_
     return 0;
 }
 
-static int fused_level_check(mgrit_hip_engine *e, int lvl, int ivals_id, const char *what) {
+static int fused_level_check(mgrit_hip_engine *e, int lvl, int ivals_id, const char *what, bool level0_only) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
-    if (lvl != 0) return fail(MGRIT_HIP_EUNSUPPORTED, "%s: level 0 only", what);
+    if (lvl != 0 && level0_only) return fail(MGRIT_HIP_EUNSUPPORTED, "%s: level 0 only", what);
     if (lvl + 1 >= e->n_levels || !e->L[lvl + 1].set) return fail(MGRIT_HIP_EINVAL, "level %d has no coarser level", lvl);
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     if (ivals_id < 0 || ivals_id >= (int)lf.ivals.size()) return fail(MGRIT_HIP_EINVAL, "bad interval-list id %d on level %d", ivals_id, lvl);
-    if ((rc = check_bound(lf, false)) || (rc = check_bound(lc, true))) return rc;
+    if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
     if (lf.dev.kind != MGRIT_HIP_STEPPER_HEAT1D || lc.dev.kind != MGRIT_HIP_STEPPER_HEAT1D || lf.transfer != MGRIT_HIP_TRANSFER_COPY ||
         lf.dev.n != lc.dev.n || force_mode(lf) != force_mode(lc) || force_mode(lf) == 3)
         return fail(MGRIT_HIP_EUNSUPPORTED, "%s needs Heat1D with separable forcing on both levels and the copy transfer", what);
@@ -2757,7 +2770,7 @@ static int fused_level_check(mgrit_hip_engine *e, int lvl, int ivals_id, const c
 }
 
 int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id) {
-    int rc = fused_level_check(e, lvl, ivals_id, "fused C-F-relaxation + FAS residual");
+    int rc = fused_level_check(e, lvl, ivals_id, "fused C-F-relaxation + FAS residual", true);
     if (rc) return rc;
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     const IntervalsDev &I = lf.ivals[ivals_id];
@@ -2771,16 +2784,23 @@ int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id) {
 }
 
 int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int ivals_id, int store_all_f) {
-    int rc = fused_level_check(e, lvl, ivals_id, "fused correction + F-relaxation + residual");
+    int rc = fused_level_check(e, lvl, ivals_id, "fused correction + F-relaxation + residual", false);
     if (rc) return rc;
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     const IntervalsDev &I = lf.ivals[ivals_id];
     if (I.n_chunks == 0) return 0;
+    const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
+    if (lvl > 0) {   // coarser level: rows of g, every F-point stored (the finer level's correction reads them), no residual
+        Timed timed(e, MGRIT_HIP_T_EC_RELAX, lvl);
+        if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1);
+        else hipLaunchKernelGGL((ecfr_kernel<2, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if ((rc = ensure_pinned(e, lf.ivals_n[ivals_id]))) return rc;
     Timed timed(e, MGRIT_HIP_T_EC_RELAX_RES, lvl);
-    const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
-    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
-    else hipLaunchKernelGGL((ecfr_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
+    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
+    else hipLaunchKernelGGL((ecfr_kernel<2, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -97,3 +97,20 @@ def test_c_point_storage_rebuilds_every_f_point(monkeypatch):
         assert np.array_equal(mg.backend.natural("u", 0), want) and np.array_equal(mg.conv[1:5], eager.conv[1:5])
         mg.iteration(lvl=0, cycle_type='V', iteration=4, first_f=True)
         assert mg.backend._f_stale and mg.backend.U[0] is mg.backend._U[0] and not mg.backend._f_stale
+
+
+@pytest.mark.parametrize("case", ["heat_nx33_V_nested", "heat_nx257_nt257", "heat_nx3100_wide_2lvl", "heat_nx33_F_nested"])
+def test_coarse_level_up_pass_bit_identical(case, monkeypatch):
+    """PYMGRIT_AMD_FUSE_UP_COARSE=1: error correction + F-relaxation of the coarser levels through the interval pass that
+    corrects the C-point an interval ends on (mgrit_hip_ec_relax_res on lvl > 0) -- same values as the default kernels"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    conv0, u0, _ = solve(case, True, blocks=1)
+    monkeypatch.setenv("PYMGRIT_AMD_FUSE_UP_COARSE", "1")
+    for blocks in (1, 3):
+        conv, u, mg = solve(case, True, blocks=blocks)
+        if mg.lvl_max > 2:
+            assert mg._level_intervals(1, up=True) is not None
+        assert np.array_equal(conv, conv0), (case, blocks)
+        for a, b in zip(u, u0):
+            assert np.array_equal(a, b), (case, blocks)
