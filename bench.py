@@ -262,9 +262,10 @@ def bench_advection(args):
     print(json.dumps(out), flush=True)
 
 
-KERNEL_OF = {"relax_f": "relax_kernel<1, 1, {g}, 0>", "relax_c": "relax_kernel<1, 1, {g}, 1>", "fas_fused": "fas_fused1_kernel<2>",
-             "ec_relax": "ecfr_kernel<2, true, false>", "residual": "residual_kernel<1, 1>", "chain": "chain2_kernel<1, true>",
-             "cf_fas": "cfas_kernel<2>", "ec_relax_res": "ecfr_kernel<2, false, true>"}
+KERNEL_OF = {"relax_f": "relax_kernel<1, 1, {g}, 0>", "relax_c": "relax_kernel<1, 1, {g}, 1>", "fas_fused": "fas_fused1_kernel<2, false>",
+             "ec_relax": "ecf_kernel<1, 1, {g}>", "residual": "residual_kernel<1, 1>", "chain": "chain2_kernel<1, true>",
+             "cf_fas": "cfas_kernel<2>", "ec_relax_res": "ecfr_kernel<2, false, true>", "relax_fc": "relax_kernel<1, 1, true, 3>",
+             "f_fas": "fas_fused1_kernel<2, true>"}
 LIMITED_BY = {"chain": "latency: the coarsest-level solve is sequential, one cross-workgroup exchange per step (measured floor "
                        "0.98 us/step = one store -> L2 -> load round trip); bytes are not what bounds it",
               "default": "HBM bandwidth (one 1024-thread workgroup per CU streaming rows; 6.29 TB/s copy ceiling of the guide)"}
@@ -285,6 +286,9 @@ def sweep_bytes(nts, m_list, dof):
         out[f"ec_relax L{lvl}"] = (C * 32.0 + F * phi) * dof
         # whole-level passes (level 0): the sweeps they replace, with those sweeps' algorithmic bytes
         out[f"cf_fas L{lvl}"] = out[f"relax_c L{lvl}"] + F * phi * dof + out[f"fas_fused L{lvl}"]
+        # coarser levels' way down in two passes: F-relaxation + C-relaxation, F-relaxation + FAS sweep
+        out[f"relax_fc L{lvl}"] = F * phi * dof + out[f"relax_c L{lvl}"]
+        out[f"f_fas L{lvl}"] = F * phi * dof + out[f"fas_fused L{lvl}"]
         out[f"ec_relax_res L{lvl}"] = out[f"ec_relax L{lvl}"] + C * 16.0 * dof
     out["residual L0"] = ((nts[0] - 1) // m_list[0]) * 16.0 * dof
     out[f"chain L{L - 1}"] = (nts[-1] - 1) * 24.0 * dof

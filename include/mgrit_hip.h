@@ -34,7 +34,11 @@ enum { MGRIT_HIP_TRANSFER_COPY = 0, MGRIT_HIP_TRANSFER_HEAT1D = 1, MGRIT_HIP_TRA
           any Python code): mgrit_hip_restrict_u / _fas_rhs / _error_correction / _interpolate refuse the level pair, the FAS
           right-hand side is taken in two halves around the caller's restriction (mgrit_hip_fas_fine_rows / _fas_coarse) */
        MGRIT_HIP_TRANSFER_CALLER = 3 };
-enum { MGRIT_HIP_RELAX_F = 0, MGRIT_HIP_RELAX_C = 1, MGRIT_HIP_RELAX_CHAIN = 2 };
+enum { MGRIT_HIP_RELAX_F = 0, MGRIT_HIP_RELAX_C = 1, MGRIT_HIP_RELAX_CHAIN = 2,
+       /* f_relax + c_relax (mgrit.py:270-275) of a level > 0 in one pass, valid right after the finer level's FAS sweep has
+          filled the level (u == v): a run = the F-points of an interval and the C-point closing it, started from v of the
+          C-point in front of it; only the closing C-point is stored (1-D one-point steppers, weight_c = 1) */
+       MGRIT_HIP_RELAX_FC = 3 };
 
 int mgrit_hip_abi_version(void);
 const char *mgrit_hip_last_error(void);
@@ -141,6 +145,15 @@ int mgrit_hip_fas_coarse(mgrit_hip_engine *e, int lvl, int pairs_id);
 int mgrit_hip_triples_create(mgrit_hip_engine *e, int lvl, int n, const int32_t *fine_idx, const int32_t *prev_fine_idx,
                              const int32_t *coarse_idx, int *id_out);
 int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id);
+/* mgrit_hip_fas_fused with options (Heat1D on both levels; 0 = mgrit_hip_fas_fused):
+ *   MGRIT_HIP_FAS_WITH_F_RELAX: the F-relaxation that precedes the sweep in Mgrit.iteration (mgrit.py:275, or :271 when
+ *       cf_iter = 0) is part of it: the F-points between the previous C-point and i are stepped through inside the pass,
+ *       u_k = g_k + Phi(u_{k-1}), and NOT stored -- nothing reads a level's F-points between this sweep and the error
+ *       correction + F-relaxation of the way up, which rewrites them. All points between the two C-points must be F-points.
+ *   MGRIT_HIP_FAS_SKIP_COARSE_U: u^{l+1}_j is not stored (a coarsest level whose forward_solve, mgrit.py:459-486, overwrites
+ *       every point but the first before anything reads it). */
+enum { MGRIT_HIP_FAS_WITH_F_RELAX = 1, MGRIT_HIP_FAS_SKIP_COARSE_U = 2 };
+int mgrit_hip_fas_fused_opts(mgrit_hip_engine *e, int lvl, int triples_id, int opts);
 /* v^{l+1}_j = u^{l+1}_j for the coarse slots of a pair list (row-wise part of mgrit.py:520) */
 int mgrit_hip_copy_pairs_u_to_v(mgrit_hip_engine *e, int lvl, int pairs_id);
 
@@ -204,7 +217,8 @@ int mgrit_hip_jump_host(mgrit_hip_engine *e, int lvl, int runs_id, const double 
 enum { MGRIT_HIP_T_RELAX_F = 0, MGRIT_HIP_T_RELAX_C = 1, MGRIT_HIP_T_CHAIN = 2, MGRIT_HIP_T_RESIDUAL = 3, MGRIT_HIP_T_JUMP = 4,
        MGRIT_HIP_T_RESTRICT = 5, MGRIT_HIP_T_COPY = 6, MGRIT_HIP_T_FAS_RHS = 7, MGRIT_HIP_T_FAS_FUSED = 8,
        MGRIT_HIP_T_ERROR_CORRECTION = 9, MGRIT_HIP_T_INTERPOLATE = 10, MGRIT_HIP_T_EC_RELAX = 11, MGRIT_HIP_T_AT = 12,
-       MGRIT_HIP_T_CF_FAS = 13, MGRIT_HIP_T_EC_RELAX_RES = 14, MGRIT_HIP_T_KINDS = 15 };
+       MGRIT_HIP_T_CF_FAS = 13, MGRIT_HIP_T_EC_RELAX_RES = 14, MGRIT_HIP_T_RELAX_FC = 15, MGRIT_HIP_T_F_FAS = 16,
+       MGRIT_HIP_T_KINDS = 17 };
 int mgrit_hip_set_timing(mgrit_hip_engine *e, int enabled);
 int mgrit_hip_last_kernel_ms(mgrit_hip_engine *e, float *ms);
 int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int *lvl, float *ms, int *n_out);

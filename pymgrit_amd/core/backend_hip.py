@@ -343,7 +343,7 @@ class HipBackend:
             self._residual_cache = None
         if not runs:
             return
-        code = {'F': hip_lib.RELAX_F, 'C': hip_lib.RELAX_C, 'CHAIN': hip_lib.RELAX_CHAIN}[mode]
+        code = {'F': hip_lib.RELAX_F, 'C': hip_lib.RELAX_C, 'CHAIN': hip_lib.RELAX_CHAIN, 'FC': hip_lib.RELAX_FC}[mode]
         check(self.lib.mgrit_hip_relax(self.h, lvl, self._run_id(lvl, runs), code, float(self.mg.weight_c)))
 
     def relax_chain_part(self, lvl, runs, resume):
@@ -569,7 +569,9 @@ class HipBackend:
                 da["kind"] == db["kind"] and da["kind"] in ("heat1d", "advection1d") and
                 self.n[lvl] == self.n[lvl + 1] and same_forcing)
 
-    def fas_fused(self, lvl, triples):
+    def fas_fused(self, lvl, triples, with_f_relax=False, skip_coarse_u=False):
+        """fused FAS sweep (mgrit_hip_fas_fused_opts): with_f_relax folds the F-relaxation in front of it into the pass (F-points
+        not stored), skip_coarse_u leaves u of a coarsest level that forward_solve overwrites unwritten"""
         if not triples:
             return
 
@@ -578,7 +580,8 @@ class HipBackend:
             fi, pr, co = (_i32([tr[k] for tr in triples]) for k in range(3))
             check(self.lib.mgrit_hip_triples_create(self.h, lvl, len(triples), _ptr(fi), _ptr(pr), _ptr(co), C.byref(tid)))
             return tid.value
-        check(self.lib.mgrit_hip_fas_fused(self.h, lvl, self._handle(self._pairs, lvl, triples, "triples", create)))
+        opts = (hip_lib.FAS_WITH_F_RELAX if with_f_relax else 0) | (hip_lib.FAS_SKIP_COARSE_U if skip_coarse_u else 0)
+        check(self.lib.mgrit_hip_fas_fused_opts(self.h, lvl, self._handle(self._pairs, lvl, triples, "triples", create), opts))
 
     def copy_pairs_u_to_v(self, lvl, pairs):
         if pairs:
@@ -669,6 +672,14 @@ class HipBackend:
                 int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and da["kind"] == db["kind"] == "heat1d" and
                 self.n[lvl] == self.n[lvl + 1] and da.get("forcing_rows") is None and db.get("forcing_rows") is None and
                 len(da.get("forcing_time", [])) == len(db.get("forcing_time", [])))
+
+    def can_fuse_coarse_down(self, lvl):
+        """lvl > 0, Heat1D with a separable forcing on lvl and lvl+1, identity transfer: the way down of the level as two
+        passes -- F-relaxation + C-relaxation (relax mode FC), F-relaxation + FAS residual (fas_fused with_f_relax)"""
+        da = self.desc[lvl]
+        return (lvl > 0 and os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and self.can_fuse_fas(lvl) and
+                da["kind"] == "heat1d" and da.get("forcing_rows") is None and self.desc[lvl + 1].get("forcing_rows") is None and
+                os.environ.get("MGRIT_HIP_FAS_TWO_PHASE", "") != "1")
 
     def can_fuse_level_up(self, lvl):
         """any level pair of Heat1D with a separable forcing and the identity transfer: error correction + F-relaxation in one

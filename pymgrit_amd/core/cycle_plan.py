@@ -148,7 +148,7 @@ class Recorder:
         for b, part in parts:
             st = np.asarray([r[0] for r in part], dtype=np.int64)
             n_pts = int(sum(r[1] for r in part))
-            reads = self._cells("u", lvl, st - 1)
+            reads = self._cells("v" if mode == 'FC' else "u", lvl, st - 1)   # mode FC starts its runs from v
             if lvl > 0:
                 reads |= {("g", lvl, b)}
             if mode == 'C' and mg.weight_c != 1.0:
@@ -250,7 +250,7 @@ class Recorder:
     def residual_ready(self, points):
         self.host_after.append(lambda: self.real.residual_ready(points))
 
-    def fas_fused(self, lvl, triples):
+    def fas_fused(self, lvl, triples, **opts):
         real = self.real
         for b, part in self._by_block(lvl, triples, 0):
             fi, pr, co = [np.asarray([p[k] for p in part], dtype=np.int64) for k in (0, 1, 2)]
@@ -258,7 +258,8 @@ class Recorder:
             if lvl > 0:
                 reads |= {("g", lvl, b)}
             writes = self._cells("u", lvl + 1, co) | self._cells("v", lvl + 1, co) | self._cells("g", lvl + 1, co)
-            self._add("fas_fused", lvl, b, lambda p=part: real.fas_fused(lvl, p), reads, writes, (7 if lvl > 0 else 6) * len(part))
+            self._add("fas_fused", lvl, b, lambda p=part: real.fas_fused(lvl, p, **opts), reads, writes,
+                      ((10 if opts.get("with_f_relax") else 7) if lvl > 0 else 6) * len(part))
 
 
 def _interval_cells(rec, lvl, part):

@@ -6,10 +6,11 @@ import os
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("PYMGRIT_AMD_LIB") or os.path.join(_PKG, "lib", "libmgrit_hip.so")   # (override: experiment builds)
 
-RELAX_F, RELAX_C, RELAX_CHAIN = 0, 1, 2
+RELAX_F, RELAX_C, RELAX_CHAIN, RELAX_FC = 0, 1, 2, 3
+FAS_WITH_F_RELAX, FAS_SKIP_COARSE_U = 1, 2
 # MGRIT_HIP_T_*: kinds of timed entry-point calls (mgrit_hip_timing_drain)
 TIMED_KINDS = ("relax_f", "relax_c", "chain", "residual", "jump", "restrict", "copy", "fas_rhs", "fas_fused",
-               "error_correction", "interpolate", "ec_relax", "at_solve", "cf_fas", "ec_relax_res")
+               "error_correction", "interpolate", "ec_relax", "at_solve", "cf_fas", "ec_relax_res", "relax_fc", "f_fas")
 STEPPER_HEAT1D, STEPPER_ADVECTION1D = 1, 2
 TRANSFER_COPY, TRANSFER_HEAT1D, TRANSFER_CALLER = 0, 1, 3
 MAX_N = 16384
@@ -52,6 +53,7 @@ EXPORTS = {
     "mgrit_hip_triples_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.POINTER(C.c_int)]),
     "mgrit_hip_fas_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_fas_fused_opts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgrit_hip_copy_pairs_u_to_v": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_error_correction": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_interpolate": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -413,6 +413,23 @@ class Mgrit:
         if lvl == self.lvl_max - 1:
             self.forward_solve(lvl=lvl)
             return
+        fresh, self._fresh_level = getattr(self, "_fresh_level", None) == lvl, None
+        coarse = self._coarse_down(lvl) if (fresh and first_f and lvl > 0) else None
+        if coarse is not None:
+            # a level the finer level's FAS sweep has just filled (u == v): F-relaxation + C-relaxation in one pass, then the
+            # F-relaxation folded into the FAS sweep (the F-points of the way down are stored by neither)
+            fc_runs, triples, head, skip_u = coarse
+            if self.cf_iter[lvl] == 1:
+                self.backend.relax(lvl, fc_runs, 'FC')
+            self.backend.restrict_u(lvl, head)
+            self.backend.fas_fused(lvl, triples, with_f_relax=True, skip_coarse_u=skip_u)
+            self.backend.copy_pairs_u_to_v(lvl, head)
+            self._fresh_level = lvl + 1
+            self.iteration(lvl=lvl + 1, cycle_type=cycle_type, iteration=iteration, first_f=True)
+            self._up(lvl, None)
+            if cycle_type == 'F':
+                self.iteration(lvl=lvl, cycle_type='V', iteration=iteration, first_f=False)
+            return
         if first_f and (lvl > 0 or iteration == 0):
             self.f_relax(lvl=lvl)
         fused = self._level_intervals(lvl)     # whole-level sweeps in one pass (device backend, one rank), or None
@@ -427,7 +444,14 @@ class Mgrit:
             self.backend.copy_pairs_u_to_v(lvl, head)
         else:
             self.fas_residual(lvl=lvl)
+        self._fresh_level = lvl + 1      # the next level starts from what the FAS sweep has just written (u == v there)
         self.iteration(lvl=lvl + 1, cycle_type=cycle_type, iteration=iteration, first_f=True)
+        self._up(lvl, fused)
+        if lvl != 0 and cycle_type == 'F':
+            self.iteration(lvl=lvl, cycle_type='V', iteration=iteration, first_f=False)
+
+    def _up(self, lvl, fused):
+        """error correction + F-relaxation of level lvl on the way up (mgrit.py:283-284), in the most fused form available"""
         if fused is not None and lvl == 0 and self.conv_crit in (0, 2):   # correction + F-relaxation + the residual check's sums
             self.backend.ec_relax_res(lvl, fused)
             self.backend.residual_ready(self._c_points(0))
@@ -438,8 +462,31 @@ class Mgrit:
         else:
             self.error_correction(lvl=lvl)
             self.f_relax(lvl=lvl)
-        if lvl != 0 and cycle_type == 'F':
-            self.iteration(lvl=lvl, cycle_type='V', iteration=iteration, first_f=False)
+
+    def _coarse_down(self, lvl):
+        """(fc_runs, triples, head, skip_coarse_u) when the way down of level lvl > 0 can run as two passes (relax mode FC,
+        fas_fused with_f_relax; backend_hip.can_fuse_coarse_down), else None: one rank, the library's own sweeps, weight 1,
+        cf_iter 0 or 1, every F-point between two local C-points."""
+        def build():
+            be = self.backend
+            own = all(getattr(type(self), name) is getattr(Mgrit, name) for name in
+                      ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "_exchange", "_ec_f_relax",
+                       "_fas_residual_fused"))
+            can = getattr(be, "can_fuse_coarse_down", None)
+            if not (own and self.comm_time_size == 1 and self.weight_c == 1.0 and 0 < lvl < self.lvl_max - 1 and
+                    self.cf_iter[lvl] in (0, 1) and not getattr(self, "_sweep_timing", False) and can is not None and can(lvl)):
+                return [None]
+            pairs = self._pairs(lvl, skip_first=False)
+            if len(pairs) < 2 or pairs[0][0] != 0:
+                return [None]
+            want = [(pairs[k][0] + 1, pairs[k + 1][0] - pairs[k][0] - 1) for k in range(len(pairs) - 1)]
+            if [tuple(r) for r in self._f_runs(lvl)] != want or any(ln < 1 for _, ln in want):
+                return [None]
+            fc_runs = [(st, ln + 1) for st, ln in want]                       # the F-points and the C-point closing them
+            triples = [(pairs[k][0], pairs[k - 1][0], pairs[k][1]) for k in range(1, len(pairs))]
+            skip_u = lvl + 1 == self.lvl_max - 1 and type(self).forward_solve is Mgrit.forward_solve
+            return [(fc_runs, triples, pairs[:1], skip_u)]
+        return self._cached(('coarse_down', lvl), build)[0]
 
     def f_relax(self, lvl: int, ec: bool = False) -> None:
         """F-relaxation (mgrit.py:292-333): every F-interval is propagated from its preceding point. Exchange:
@@ -512,8 +559,11 @@ class Mgrit:
                 c_next = {int(i) for i in self.index_local_c[lvl + 1]}
                 need_u = lambda j: j in c_next
             need_v = 0 if (lvl == 0 and self.conv_crit in (0, 2)) else 2
+            # ... and where the coarse level's first pass (relax mode FC, _coarse_down) starts its runs from v: its C-points
+            v_starts = {int(i) for i in self.index_local_c[lvl + 1]} if (not coarsest and self._coarse_down(lvl + 1) is not None) else set()
             return [[(pairs[k][0], pairs[k + 1][0], pairs[k][1] if k >= 1 else -1, pairs[k + 1][1], k,
-                      (1 if need_u(pairs[k + 1][1]) else 0) | need_v) for k in range(len(pairs) - 1)]]
+                      (1 if need_u(pairs[k + 1][1]) else 0) | need_v | (2 if pairs[k + 1][1] in v_starts else 0))
+                     for k in range(len(pairs) - 1)]]
         got = self._cached(('intervals', lvl, up), build)[0]
         if got is None:
             return None

@@ -614,7 +614,12 @@ extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
 // f_relax / c_relax / forward_solve (mgrit.py:292-370,459-486). ROLE only separates the launches by purpose (distinct
 // kernel symbols in rocprof traces; the weighted C-relaxation is the only one that re-reads the old u_i).
-enum { ROLE_F = 0, ROLE_C = 1, ROLE_C_WEIGHTED = 2 };
+// ROLE_FC: f_relax followed by c_relax (mgrit.py:270-275 on a level the FAS sweep of the finer level has just filled) in one
+// pass: a run = the F-points of an interval AND the C-point that closes it; the starting C-point is read from v (right after
+// the restriction v == u bit for bit, and v is not written by this pass, so no run sees a C-point its neighbour has already
+// relaxed); only the closing C-point is stored -- the F-points of the way down are read by nobody (the F-relaxation that
+// follows is folded into the FAS pass, fas_fused1_kernel PROP, and the way up rewrites them).
+enum { ROLE_F = 0, ROLE_C = 1, ROLE_C_WEIGHTED = 2, ROLE_FC = 3 };
 
 template <int KIND, int FORCE, bool USE_G, int ROLE>
 __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *__restrict__ run_start,
@@ -627,7 +632,7 @@ __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *
         wq.prefetch(t);
         const int start = run_start[r], len = run_len[r];
         double x[E], gi[E];
-        load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
+        load_row((ROLE == ROLE_FC ? L.v : L.u) + (size_t)(start - 1) * L.ld, sl, x);
         for (int i = start; i < start + len; ++i) {
             if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);  // in flight while Phi runs
             phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
@@ -641,7 +646,7 @@ __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *
 #pragma unroll
                 for (int k = 0; k < E; ++k) x[k] = x[k] * w + uo[k] * w1;
             }
-            store_row(L.u + (size_t)i * L.ld, sl, x);
+            if (ROLE != ROLE_FC || i == start + len - 1) store_row(L.u + (size_t)i * L.ld, sl, x);
         }
     }
     wq.end(t);
@@ -1038,10 +1043,14 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
 // scalar coefficients of the level in use reloaded in front of each Phi (scalar loads; both sets at once would not fit the
 // SGPR file). The partial g of the two-phase form never leaves the registers: 3 vectors read (+g_i), 3 written per C-point
 // instead of 4-5 and 4. Arithmetic identical to fas_fused_kernel.
-template <int FORCE>
+template <int FORCE, bool PROP>
 __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ fine_idx,
                                                           const int32_t *__restrict__ prev_idx,
-                                                          const int32_t *__restrict__ coarse_idx, int n_items, int use_g) {
+                                                          const int32_t *__restrict__ coarse_idx, int n_items, int use_g,
+                                                          int opts) {
+    // PROP (opts bit 0): the F-relaxation in front of the sweep (mgrit.py:275 / 271) is part of it -- the F-points between the
+    //   previous C-point ip and i are stepped through here, u_k = g_k + Phi(u_{k-1}), and not stored (nobody reads them before
+    //   the way up rewrites them); bit 1: u^{l+1}_j is not stored (a coarsest level that forward_solve overwrites unread)
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
     WG_PROLOGUE;
     Smem smc = sm;
@@ -1050,26 +1059,47 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         wq.prefetch(t);
         const int i = fine_idx[p], j = coarse_idx[p], ip = prev_idx[p];
         double x[E], w[E];
-        load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
-        load_row(L.u + (size_t)i * L.ld, sl, w);
-        store_row(Lc.u + (size_t)j * Lc.ld, sl, w);
-        store_row(Lc.v + (size_t)j * Lc.ld, sl, w);
-        if (use_g) {
-            double gi[E];
-            load_row(L.g + (size_t)i * L.ld, sl, gi);
-#pragma unroll
-            for (int k = 0; k < E; ++k) w[k] = gi[k] - w[k];
-        }
         if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);   // not kept alive across the coarse Phi below
-        phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
-        if (use_g) {
+        if (PROP) {
+            // ONE call site of the fine Phi for the F-steps and for the step onto the C-point (two inlined copies made the
+            // register allocator spill 250 VGPRs): every step is x = w + Phi(x) with w = g_k, and w = g_i - u_i for the last
+            load_row(L.u + (size_t)ip * L.ld, sl, x);
+            for (int k = ip + 1; k <= i; ++k) {
+                load_row(L.g + (size_t)k * L.ld, sl, w);   // in flight while Phi runs (PROP implies use_g)
+                if (k == i) {
+                    double ui[E];
+                    load_row(L.u + (size_t)i * L.ld, sl, ui);
+                    if (!(opts & 2)) store_row(Lc.u + (size_t)j * Lc.ld, sl, ui);
+                    store_row(Lc.v + (size_t)j * Lc.ld, sl, ui);
 #pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = w[k] + x[k];
+                    for (int e = 0; e < E; ++e) w[e] = w[e] - ui[e];
+                }
+                phi_apply<KIND, FORCE>(x, ctx, L, k, sm, t, lane, wave, G);
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[e] = w[e] + x[e];
+            }
             load_row(L.u + (size_t)i * L.ld, sl, w);   // u^l_i once more (one live vector less while Phi runs)
         } else {
-            load_row(L.u + (size_t)i * L.ld, sl, w);   // likewise: re-read (an L2 hit) instead of held across Phi
+            load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
+            load_row(L.u + (size_t)i * L.ld, sl, w);
+            if (!(opts & 2)) store_row(Lc.u + (size_t)j * Lc.ld, sl, w);
+            store_row(Lc.v + (size_t)j * Lc.ld, sl, w);
+            if (use_g) {
+                double gi[E];
+                load_row(L.g + (size_t)i * L.ld, sl, gi);
 #pragma unroll
-            for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
+                for (int k = 0; k < E; ++k) w[k] = gi[k] - w[k];
+            }
+            phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+            if (use_g) {
+#pragma unroll
+                for (int k = 0; k < E; ++k) x[k] = w[k] + x[k];
+                load_row(L.u + (size_t)i * L.ld, sl, w);   // u^l_i once more (one live vector less while Phi runs)
+            } else {
+                load_row(L.u + (size_t)i * L.ld, sl, w);   // likewise: re-read (an L2 hit) instead of held across Phi
+#pragma unroll
+                for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] + w[k];   // + v_j : the partial g of the coarse level
@@ -1457,6 +1487,7 @@ int setup_kernel_attrs() {
 #define ATTR_ALL(K, F)                                                                                              \
     ATTR_RELAX(K, F, false, ROLE_F) ATTR_RELAX(K, F, true, ROLE_F) ATTR_RELAX(K, F, false, ROLE_C)                   \
     ATTR_RELAX(K, F, true, ROLE_C) ATTR_RELAX(K, F, false, ROLE_C_WEIGHTED) ATTR_RELAX(K, F, true, ROLE_C_WEIGHTED)  \
+    ATTR_RELAX(K, F, true, ROLE_FC)                                                                                  \
     if ((rc = allow_big_lds(residual_kernel<K, F>))) return rc;                                                      \
     if ((rc = allow_big_lds(fas_fine_kernel<K, F>))) return rc;                                                      \
     if ((rc = allow_big_lds(fas_coarse_kernel<K, F>))) return rc;                                                    \
@@ -1471,8 +1502,10 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(ecfr_kernel<2, false, true>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<0, true, false>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<2, true, false>))) return rc;
-    if ((rc = allow_big_lds(fas_fused1_kernel<0>))) return rc;
-    if ((rc = allow_big_lds(fas_fused1_kernel<2>))) return rc;
+    if ((rc = allow_big_lds(fas_fused1_kernel<0, false>))) return rc;
+    if ((rc = allow_big_lds(fas_fused1_kernel<2, false>))) return rc;
+    if ((rc = allow_big_lds(fas_fused1_kernel<0, true>))) return rc;
+    if ((rc = allow_big_lds(fas_fused1_kernel<2, true>))) return rc;
     if ((rc = allow_big_lds(jump_kernel))) return rc;
 #define ATTR_2PTS(O, F)                                                                                              \
     if ((rc = allow_big_lds(relax2_kernel<O, F, false, false>, smem2_bytes(MAX_G2)))) return rc;                     \
@@ -2272,10 +2305,14 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     int rc = get_runs(e, lvl, runs_id, &rl);
     if (rc) return rc;
     Level &lv = e->L[lvl];
-    if (mode != MGRIT_HIP_RELAX_F && mode != MGRIT_HIP_RELAX_C && mode != MGRIT_HIP_RELAX_CHAIN) return fail(MGRIT_HIP_EINVAL, "bad relax mode %d", mode);
+    if (mode != MGRIT_HIP_RELAX_F && mode != MGRIT_HIP_RELAX_C && mode != MGRIT_HIP_RELAX_CHAIN && mode != MGRIT_HIP_RELAX_FC)
+        return fail(MGRIT_HIP_EINVAL, "bad relax mode %d", mode);
     if ((rc = check_bound(lv, lvl > 0))) return rc;
+    if (mode == MGRIT_HIP_RELAX_FC && (lvl == 0 || lv.h2d || is_2pts(lv) || weight_c != 1.0))
+        return fail(MGRIT_HIP_EUNSUPPORTED, "relax mode FC: 1-D one-point steppers on a level > 0, weight 1");
     if (rl->n == 0) return 0;
-    Timed timed(e, mode == MGRIT_HIP_RELAX_F ? MGRIT_HIP_T_RELAX_F : mode == MGRIT_HIP_RELAX_C ? MGRIT_HIP_T_RELAX_C : MGRIT_HIP_T_CHAIN, lvl);
+    Timed timed(e, mode == MGRIT_HIP_RELAX_F ? MGRIT_HIP_T_RELAX_F : mode == MGRIT_HIP_RELAX_CHAIN ? MGRIT_HIP_T_CHAIN :
+                   mode == MGRIT_HIP_RELAX_FC ? MGRIT_HIP_T_RELAX_FC : MGRIT_HIP_T_RELAX_C, lvl);
     if (lv.h2d) return h2d_relax(e, lvl, rl, mode, weight_c);
     if (is_2pts(lv)) {
         const bool use_g = lvl > 0, weighted = mode == MGRIT_HIP_RELAX_C && weight_c != 1.0;
@@ -2338,7 +2375,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     }
     {
         const bool use_g = lvl > 0;
-        const int role = mode == MGRIT_HIP_RELAX_F ? ROLE_F : (weight_c != 1.0) ? ROLE_C_WEIGHTED : ROLE_C;
+        const int role = mode == MGRIT_HIP_RELAX_F ? ROLE_F : mode == MGRIT_HIP_RELAX_FC ? ROLE_FC : (weight_c != 1.0) ? ROLE_C_WEIGHTED : ROLE_C;
         const double w = weight_c, w1 = 1.0 - weight_c;
         // persistent grid: as many workgroups as stay resident (LDS- and thread-limited), at most one per run
         const size_t lds = smem_bytes(lv.G);
@@ -2350,7 +2387,8 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
                            w, w1);
 #define RELAX_CASES(K, F)                                                                                          \
     RELAX_CASE(K, F, false, ROLE_F) RELAX_CASE(K, F, true, ROLE_F) RELAX_CASE(K, F, false, ROLE_C)                  \
-    RELAX_CASE(K, F, true, ROLE_C) RELAX_CASE(K, F, false, ROLE_C_WEIGHTED) RELAX_CASE(K, F, true, ROLE_C_WEIGHTED)
+    RELAX_CASE(K, F, true, ROLE_C) RELAX_CASE(K, F, false, ROLE_C_WEIGHTED) RELAX_CASE(K, F, true, ROLE_C_WEIGHTED) \
+    RELAX_CASE(K, F, true, ROLE_FC)
         FOR_EACH_STEPPER(RELAX_CASES)
         HIP_TRY(hipGetLastError());
     }
@@ -2502,7 +2540,9 @@ int mgrit_hip_triples_create(mgrit_hip_engine *e, int lvl, int n, const int32_t 
     return dev_upload(lv, e->stream, hp, &lv.pairs[*id_out].d_prev);
 }
 
-int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id) {
+int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id) { return mgrit_hip_fas_fused_opts(e, lvl, triples_id, 0); }
+
+int mgrit_hip_fas_fused_opts(mgrit_hip_engine *e, int lvl, int triples_id, int opts) {
     PairList *pl;
     int rc = get_pairs(e, lvl, triples_id, &pl);
     if (rc) return rc;
@@ -2512,19 +2552,25 @@ int mgrit_hip_fas_fused(mgrit_hip_engine *e, int lvl, int triples_id) {
     if (lf.h2d || lc.h2d || is_2pts(lf) || is_2pts(lc) || lf.transfer != MGRIT_HIP_TRANSFER_COPY || lf.dev.kind != lc.dev.kind ||
         force_mode(lf) != force_mode(lc) || lf.dev.n != lc.dev.n)
         return fail(MGRIT_HIP_EUNSUPPORTED, "fused FAS residual needs the copy transfer and like steppers on both levels");
+    if (opts & ~3) return fail(MGRIT_HIP_EINVAL, "unknown option bits %d", opts);
+    if ((opts & MGRIT_HIP_FAS_WITH_F_RELAX) && lvl == 0) return fail(MGRIT_HIP_EUNSUPPORTED, "FAS sweep with its F-relaxation: levels > 0");
     if (pl->n == 0) return 0;
-    Timed timed(e, MGRIT_HIP_T_FAS_FUSED, lvl);
+    Timed timed(e, (opts & MGRIT_HIP_FAS_WITH_F_RELAX) ? MGRIT_HIP_T_F_FAS : MGRIT_HIP_T_FAS_FUSED, lvl);
     const int use_g = lvl > 0 ? 1 : 0;
     if (lf.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && !two_phase_fas() && force_mode(lf) != 3) {   // one pass per C-point, coarse tables from L2
         const dim3 grid(persistent_grid(lf, pl->n)), block(lf.dev.T);
         const int fm = force_mode(lf);
         // forcing factors of both levels are streamed (FORCE 2, the same fma per term): one Phi per point does not pay for
         // keeping them in registers, and the registers are needed for the partial g that stays live across the coarse Phi
-        if (fm == 0) hipLaunchKernelGGL((fas_fused1_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);
-        else hipLaunchKernelGGL((fas_fused1_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);
+#define FAS1_CASE(F_, P_)                                                                                                  \
+    if ((fm == 0 ? 0 : 2) == F_ && ((opts & MGRIT_HIP_FAS_WITH_F_RELAX) != 0) == P_)                                        \
+        hipLaunchKernelGGL((fas_fused1_kernel<F_, P_>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, \
+                           pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g, opts);
+        FAS1_CASE(0, false) FAS1_CASE(2, false) FAS1_CASE(0, true) FAS1_CASE(2, true)
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    if (opts) return fail(MGRIT_HIP_EUNSUPPORTED, "fused FAS residual with options: Heat1D levels (one-pass form) only");
 #define FUSED_CASE(K_, F_)                                                                                         \
     if (lf.dev.kind == K_ && force_mode(lf) == F_)                                                                  \
         hipLaunchKernelGGL((fas_fused_kernel<K_, F_>), dim3(persistent_grid(lf, pl->n)), dim3(lf.dev.T), smem_bytes(lf.G),  \
