@@ -190,7 +190,11 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id);
  *                            the last one (which the next C-relaxation reads): nothing else of an MGRIT cycle reads an
  *                            F-point before the next F-relaxation rewrites it, and mgrit_hip_relax(mode F) over the level's
  *                            F-runs restores all of them bit for bit when the caller wants to look at the solution
- *                            (C-point storage, as in XBraid's default storage mode).
+ *                            (C-point storage, as in XBraid's default storage mode). store_all_f = 2: as 0, but the row
+ *                            of that last F-point receives Phi(u_{i-1}) -- the value the residual needs anyway -- instead of
+ *                            u_{i-1}: it is exactly what the C-relaxation of the next cycle assigns to the C-point
+ *                            (mgrit.py:365 with weight 1), so mgrit_hip_cf_fas(..., pre_relaxed = 1) reads it and skips that
+ *                            Phi. Any other reader of the level needs the F-relaxation first (it restores the row).
  * keep[i] (null: 3 everywhere) names the rows of lvl+1 that the closing C-point of interval i must receive from mgrit_hip_cf_fas:
  * bit 0 = u^{l+1} (not needed where the first sweep of lvl+1 overwrites it unread: its F-points when the level starts with an
  * F-relaxation, mgrit.py:270-271; every point but the first of a coarsest level solved by forward_solve, mgrit.py:459-486),
@@ -200,7 +204,7 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id);
 int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_t *cstart, const int32_t *cend,
                                const int32_t *cstart_coarse, const int32_t *cend_coarse, const int32_t *res_pos, int res_len,
                                int chunk, const int32_t *keep, int *id_out);
-int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int intervals_id);
+int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int intervals_id, int pre_relaxed);
 int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int intervals_id, int store_all_f);
 int mgrit_hip_residual_fetch(mgrit_hip_engine *e, int n, double *sumsq_host);
 

@@ -93,7 +93,9 @@ class HipBackend:
                 perm = hip_lib.row_permutation(n)
             self.perm.append(torch.from_numpy(np.asarray(perm, dtype=np.int64)).to(self.device))
         self._U, self.V, self.G, self.FB = [], [], [], {}
-        self._f_stale = False     # level-0 F-points (all but the last of every interval) await materialise()
+        self._f_stale = 0         # level-0 F-points: 0 all in place; 1 all but the last of every interval await materialise();
+                                  # 2 as 1, and the last one's row holds Phi of it (the next C-relaxation's value, cf_fas pre)
+        self._cycle_pre = False   # the state at the start of the running cycle was 2 (begin_cycle)
         self._runs, self._pairs = {}, {}
         self._described = [False] * mg.lvl_max
         self.chain_state, self.chain_handover, self._handover = {}, {}, {}
@@ -244,10 +246,21 @@ class HipBackend:
         output_fcn, mgrit.u[0][i], natural(), the U slabs -- gets the others rebuilt here by one F-relaxation from the
         C-points: the same Phi on the same values, so bit for bit what an every-point store would have left."""
         if self._f_stale:
-            self._f_stale = False
+            self._f_stale = 0
             cache = self._residual_cache          # an F-relaxation that rewrites identical values leaves the residual valid
             self.relax(0, self.mg._f_runs(0), 'F')
             self._residual_cache = cache
+
+    def _settle(self, lvl):
+        """before any sweep other than the two whole-level passes reads level 0: state 2 (the last F-point's row holds Phi of
+        it) is something only cf_fas understands"""
+        if lvl == 0 and self._f_stale == 2:
+            self.materialise()
+
+    def begin_cycle(self):
+        """start of Mgrit.iteration(lvl=0): the down pass of THIS cycle reads the rows the cycle before left, whatever the
+        cycle's own up pass does to later blocks in the meantime (planned cycle)"""
+        self._cycle_pre = self._f_stale == 2
 
     def natural(self, which, lvl):
         """host copy of a whole slab in natural x order, shape [n_local_points][n] (tests / post-processing)"""
@@ -265,6 +278,8 @@ class HipBackend:
 
     # -- exchange payloads: slab rows travel in place over RCCL ---------------------------------------
     def payload(self, lvl, idx, op=None):
+        if lvl == 0:
+            self.materialise()
         if op == 5 and self.chain_handover.get(lvl):   # forward-solve hand-over: the point and the chain's running state
             state = self.chain_state[lvl]
             if state is None:   # this rank has no step of its own on the level (it owns the first point only): a fresh start
@@ -339,6 +354,7 @@ class HipBackend:
 
     # -- sweeps ----------------------------------------------------------------------------------------
     def relax(self, lvl, runs, mode):
+        self._settle(lvl)
         if lvl == 0:
             self._residual_cache = None
         if not runs:
@@ -387,7 +403,7 @@ class HipBackend:
         state = plan.__dict__.setdefault("_hip", {"runs": 0, "graph": None, "failed": False})
         if state["graph"] is not None and graph_ok:
             state["graph"].replay()
-            self._f_stale = self._f_stale or state.get("f_stale", False)   # what the replayed launches did to the F-points
+            self._f_stale = max(self._f_stale, state.get("f_stale", 0))   # what the replayed launches did to the F-points
             return
         if graph_ok and state["runs"] >= 2 and not state["failed"]:
             import gc
@@ -407,7 +423,7 @@ class HipBackend:
                         gc.enable()
                 state["graph"] = graph
                 graph.replay()
-                self._f_stale = self._f_stale or state.get("f_stale", False)
+                self._f_stale = max(self._f_stale, state.get("f_stale", 0))
                 return
             except Exception as exc:   # noqa: BLE001 - capture is an optimisation: any refusal falls back to plain launches
                 state["failed"] = True
@@ -421,10 +437,10 @@ class HipBackend:
                 import warnings
                 warnings.warn(f"pymgrit_amd: cycle graph capture failed ({exc!r}); launching the cycle kernel by kernel")
         state["runs"] += 1
-        was, self._f_stale = self._f_stale, False
+        was, self._f_stale = self._f_stale, 0
         self._plan_issue(plan, self.stream)
         state["f_stale"] = self._f_stale          # does this cycle leave level-0 F-points to materialise()?
-        self._f_stale = self._f_stale or was
+        self._f_stale = max(self._f_stale, was)
 
     def _plan_issue(self, plan, main):
         if self._chain_stream is None:
@@ -468,6 +484,9 @@ class HipBackend:
             main.wait_event(last_side.event)
 
     def residual_norms(self, points):
+        cache = getattr(self, "_residual_cache", None)
+        if not (cache is not None and len(cache) == len(points) and (cache is points or cache == tuple(points))):
+            self._settle(0)     # the residual kernel reads the last F-points
         if not len(points):
             return []
         host = np.empty(len(points), dtype=np.float64)
@@ -481,6 +500,7 @@ class HipBackend:
     def residual_begin(self, points):
         """launch the residual kernel and return at once; the per-point sums of squares land in pinned host memory that the
         kernel writes directly (no copy command), residual_end() waits for the event recorded behind the kernel"""
+        self._settle(0)
         if not len(points):
             return None
         if not hasattr(self, "_res_ring"):
@@ -502,6 +522,7 @@ class HipBackend:
         return np.sqrt(buf.numpy())
 
     def save_last(self):
+        self.materialise()
         self.prev = self._U[0].clone()
         self.mg.save_values_last_iter = SlabVectorList(self.prev, self.n[0], self.mg.problem[0].vector_template,
                                                        self.perm[0])
@@ -521,6 +542,7 @@ class HipBackend:
             self._U[0].index_copy_(0, self._snap_idx, self._snap[slot])
 
     def jump_norms(self, points):
+        self.materialise()
         out = []
         if len(points):
             host = np.empty(len(points), dtype=np.float64)
@@ -544,6 +566,7 @@ class HipBackend:
         check(self.lib.mgrit_hip_copy_u_to_v(self.h, lvl))
 
     def fas_rhs(self, lvl, pairs):
+        self._settle(lvl)
         if not pairs:
             return
         if not self._device_transfer(lvl):
@@ -572,6 +595,7 @@ class HipBackend:
     def fas_fused(self, lvl, triples, with_f_relax=False, skip_coarse_u=False):
         """fused FAS sweep (mgrit_hip_fas_fused_opts): with_f_relax folds the F-relaxation in front of it into the pass (F-points
         not stored), skip_coarse_u leaves u of a coarsest level that forward_solve overwrites unwritten"""
+        self._settle(lvl)
         if not triples:
             return
 
@@ -651,6 +675,7 @@ class HipBackend:
 
     def ec_relax(self, lvl, triples):
         """error correction of the C-point in front of each run + the run's F-relaxation in one launch"""
+        self._settle(lvl)
         if lvl == 0:
             self._residual_cache = None
         if not triples:
@@ -715,7 +740,7 @@ class HipBackend:
         keep): keep = which rows of lvl+1 the closing C-point needs (bit 0: u, bit 1: v; include/mgrit_hip.h)"""
         if intervals:
             self._residual_cache = None
-            check(self.lib.mgrit_hip_cf_fas(self.h, lvl, self._intervals_id(lvl, intervals)))
+            check(self.lib.mgrit_hip_cf_fas(self.h, lvl, self._intervals_id(lvl, intervals), 1 if (lvl == 0 and self._cycle_pre) else 0))
 
     def ec_relax_res(self, lvl, intervals, base=0):
         """error_correction + f_relax + compute_residual; the per-point sums of squares stay in pinned host memory until
@@ -723,9 +748,12 @@ class HipBackend:
         PYMGRIT_AMD_STORE_ALL_F=1"""
         if intervals:
             lazy = lvl == 0 and os.environ.get("PYMGRIT_AMD_STORE_ALL_F", "") != "1"
-            check(self.lib.mgrit_hip_ec_relax_res(self.h, lvl, self._intervals_id(lvl, intervals), 0 if lazy else 1))
+            # 2: the last F-point's row gets Phi of it, which the next cycle's cf_fas takes as its C-relaxation -- when that pass
+            # IS the next reader of the level (cf_iter = 1: no plain C-relaxation in front of it)
+            mode = 1 if not lazy else (2 if (self.mg.cf_iter[0] == 1 and os.environ.get("PYMGRIT_AMD_NO_PRE_RELAX", "") != "1") else 0)
+            check(self.lib.mgrit_hip_ec_relax_res(self.h, lvl, self._intervals_id(lvl, intervals), mode))
             if lazy:
-                self._f_stale = True
+                self._f_stale = max(self._f_stale, 2 if mode == 2 else 1)
 
     def residual_ready(self, points):
         """the residual of exactly these level-0 points has been produced by the last ec_relax_res sweep(s) and level 0 has not

@@ -69,7 +69,7 @@ EXPORTS = {
                                              C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "mgrit_hip_fas_fine_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "mgrit_hip_fas_coarse": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
-    "mgrit_hip_cf_fas": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_cf_fas": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgrit_hip_ec_relax_res": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgrit_hip_residual_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
 }

@@ -392,7 +392,8 @@ class Mgrit:
                 return None
             blocks = 1
         from pymgrit_amd.core.cycle_plan import PlanUnsupported, record_cycle
-        key = (cycle_type, iteration == 0, bool(first_f), blocks, tuple(self.cf_iter), float(self.weight_c))
+        key = (cycle_type, iteration == 0, bool(first_f), blocks, tuple(self.cf_iter), float(self.weight_c),
+               bool(getattr(self.backend, "_cycle_pre", False)))   # (the down pass's launch argument, baked into a captured graph)
         if key not in self._plans:
             self._plan_recording = True
             try:
@@ -406,6 +407,7 @@ class Mgrit:
 
     def iteration(self, lvl: int, cycle_type: str, iteration: int, first_f: bool) -> None:
         if lvl == 0 and not self._plan_recording:
+            getattr(self.backend, "begin_cycle", lambda: None)()
             plan = self._planned(cycle_type, iteration, first_f)
             if plan is not None:
                 plan.run(self.backend)

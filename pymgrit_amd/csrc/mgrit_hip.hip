@@ -908,11 +908,14 @@ struct IntervalsDev {
 //   F'_last  = Phi_l^{m-1}(C'_j)                    the F-relaxation; its points are NOT stored: nothing reads a level's F-points
 //                                                   before the error correction + F-relaxation on the way up rewrites them
 //   C'_{j+1} = Phi_l(u_old[c_{j+1} - 1])            the C-relaxation, from the OLD last F-point of the interval (F rows are
-//                                                   never written here, so no other workgroup can have touched it)
+//                                                   never written here, so no other workgroup can have touched it). With
+//                                                   pre = 1 that row already HOLDS Phi_l(last F-point): the residual check of
+//                                                   the cycle before computed exactly this value (r = Phi(u_{i-1}) - u_i,
+//                                                   mgrit.py:401-405) and ecfr_kernel (store_f = 2) left it there
 //   u^{l+1}_{j+1} = v^{l+1}_{j+1} = C'_{j+1},   g^{l+1}_{j+1} = ((Phi_l(F'_last) - C'_{j+1}) + C'_{j+1}) - q
 // Rows through HBM per interval: 1 read + 3..5 written (IntervalsDev::keep) instead of 12 (C-relax 2, F-relax m, fused FAS 6). A chunk's first C-point is recomputed from its old F-point (one more Phi per chunk), not waited for.
 template <int FORCE>
-__global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, IntervalsDev I) {
+__global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, int pre) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
     WG_PROLOGUE;
     for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < I.n_chunks; wq.advance(t)) {
@@ -922,10 +925,12 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
         double x[E];
         {
             const int cs = I.cstart[i0];
-            if (I.chunk_start_coarse[k] >= 0) {   // C'_j of the chunk's first C-point, recomputed
+            if (I.chunk_start_coarse[k] >= 0) {   // C'_j of the chunk's first C-point, recomputed (pre: it is what the row holds)
                 load_row(L.u + (size_t)(cs - 1) * L.ld, sl, x);
-                if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);
-                phi_apply<KIND, FORCE, true>(x, ctx, L, cs, sm, t, lane, wave, G);
+                if (!pre) {
+                    if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);
+                    phi_apply<KIND, FORCE, true>(x, ctx, L, cs, sm, t, lane, wave, G);
+                }
             } else {
                 load_row(L.u + (size_t)cs * L.ld, sl, x);
             }
@@ -944,7 +949,7 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
             for (int i = cs + 1; i < ce; ++i) phi_apply<KIND, FORCE, true>(x, ctx, L, i, sm, t, lane, wave, G);
             double b[E];
             load_row(L.u + (size_t)(ce - 1) * L.ld, sl, b);   // (requested one Phi earlier it costs more in spills than it hides)
-            phi_apply<KIND, FORCE, true>(b, ctx, L, ce, sm, t, lane, wave, G);
+            if (!pre) phi_apply<KIND, FORCE, true>(b, ctx, L, ce, sm, t, lane, wave, G);
             store_row(L.u + (size_t)ce * L.ld, sl, b);
             const int keep = __builtin_amdgcn_readfirstlane(I.keep[it]);
             if (keep & 1) store_row(Lc.u + (size_t)jc * Lc.ld, sl, b);
@@ -973,9 +978,11 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
 // ends on: in a planned cycle a block of time points then needs the coarsest-level chain of ITS block only.)
 // error_correction + f_relax + compute_residual of level 0 in ONE pass (mgrit.py:715-726, 292-333 as Mgrit.iteration calls
 // them, mgrit.py:283-284, then 387-413 from convergence_criterion), identity transfer. Per interval (C_j, C_{j+1}]:
-//   F''      = Phi-propagation from the corrected C''_j, stored -- all of them, or with store_f = 0 only the last one (the
-//              point the next C-relaxation starts from): F-points are a function of the C-points, and an F-relaxation
-//              (mgrit_hip_relax mode F) rebuilds them bit for bit whenever somebody wants to see them
+//   F''      = Phi-propagation from the corrected C''_j, stored -- all of them (store_f = 1), or with store_f = 0 only the last
+//              one (the point the next C-relaxation starts from): F-points are a function of the C-points, and an F-relaxation
+//              (mgrit_hip_relax mode F) rebuilds them bit for bit whenever somebody wants to see them; store_f = 2 goes one
+//              step further and leaves Phi_l(F''_last) -- computed here for the residual -- in the last F-point's row: that IS
+//              the value the next cycle's C-relaxation assigns, so mgrit_hip_cf_fas(pre = 1) takes it without its own Phi
 //   C''_{j+1} = v^{l+1}_{j+1} + (u^{l+1}_{j+1} - v^{l+1}_{j+1})   (v^{l+1}_{j+1} IS u^l at that C-point, bit for bit: read from the
 //                                                                 fine row inside a chunk, from v -- which nobody writes on the
 //                                                                 way up -- for the C-point a chunk starts from), stored
@@ -1012,7 +1019,7 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
 #pragma unroll
                     for (int e = 0; e < E; ++e) x[e] = gi[e] + x[e];
                 }
-                if (store_f || i == ce - 1) store_row(L.u + (size_t)i * L.ld, sl, x);
+                if (store_f == 1 || (store_f == 0 && i == ce - 1)) store_row(L.u + (size_t)i * L.ld, sl, x);
             }
             double b[E];
             {   // v^{l+1}_{j+1} from the fine row itself (the same bits; only this chunk writes that row), see IntervalsDev::keep
@@ -1025,6 +1032,7 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
             store_row(L.u + (size_t)ce * L.ld, sl, b);
             if (RES) {
                 phi_apply<KIND, FORCE>(x, ctx, L, ce, sm, t, lane, wave, G);
+                if (store_f == 2) store_row(L.u + (size_t)(ce - 1) * L.ld, sl, x);   // Phi(last F-point): the next C-relaxation's value
 #pragma unroll
                 for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
                 const double tot = block_sumsq(x, sm, L.n, t, lane, wave, G);
@@ -2815,7 +2823,7 @@ static int fused_level_check(mgrit_hip_engine *e, int lvl, int ivals_id, const c
     return 0;
 }
 
-int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id) {
+int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id, int pre_relaxed) {
     int rc = fused_level_check(e, lvl, ivals_id, "fused C-F-relaxation + FAS residual", true);
     if (rc) return rc;
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
@@ -2823,8 +2831,8 @@ int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id) {
     if (I.n_chunks == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_CF_FAS, lvl);
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
-    if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I);
-    else hipLaunchKernelGGL((cfas_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I);
+    if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    else hipLaunchKernelGGL((cfas_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2843,6 +2851,7 @@ int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int ivals_id, int store
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    if (store_all_f < 0 || store_all_f > 2) return fail(MGRIT_HIP_EINVAL, "store_all_f %d outside 0..2", store_all_f);
     if ((rc = ensure_pinned(e, lf.ivals_n[ivals_id]))) return rc;
     Timed timed(e, MGRIT_HIP_T_EC_RELAX_RES, lvl);
     if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);

@@ -96,7 +96,17 @@ def test_c_point_storage_rebuilds_every_f_point(monkeypatch):
         assert not mg.backend._f_stale and np.array_equal(row, want[2])
         assert np.array_equal(mg.backend.natural("u", 0), want) and np.array_equal(mg.conv[1:5], eager.conv[1:5])
         mg.iteration(lvl=0, cycle_type='V', iteration=4, first_f=True)
+        assert mg.backend._f_stale == 2          # cf_iter = 1: the last F-point's row holds Phi of it (the next C-relaxation's value)
+        mg.convergence_criterion(iteration=5)
+        mg.c_relax(0)                            # a plain sweep on level 0 settles the rows first
+        assert not mg.backend._f_stale
+        mg.f_relax(0)
+        mg.iteration(lvl=0, cycle_type='V', iteration=5, first_f=True)
         assert mg.backend._f_stale and mg.backend.U[0] is mg.backend._U[0] and not mg.backend._f_stale
+    # the same solve with the pre-relaxed rows switched off: same history
+    monkeypatch.setenv("PYMGRIT_AMD_NO_PRE_RELAX", "1")
+    mg = run(False, None)
+    assert mg.backend._f_stale == 1 and np.array_equal(mg.conv[1:5], eager.conv[1:5])
 
 
 @pytest.mark.parametrize("case", ["heat_nx33_V_nested", "heat_nx257_nt257", "heat_nx3100_wide_2lvl", "heat_nx33_F_nested"])
