@@ -18,6 +18,11 @@ def short(name):
     return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
 
 
+def newest(paths):
+    """gpurun merges every call's output into the same directories: keep the most recent database only"""
+    return sorted(paths, key=os.path.getmtime)[-1:]
+
+
 def stats_from_db(db, dest):
     """rocprofv3 of ROCm 7.2 writes a rocpd SQLite database instead of CSV files: rebuild the --stats kernel table
     (same columns as <pid>_kernel_stats.csv) from its `kernels` view."""
@@ -44,7 +49,7 @@ def main(tag):
     for sub in ("stats", "stats_planned"):
         dest = os.path.join(out, f"{tag}_kernel_{sub}.csv")
         stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*kernel_stats.csv"))
-        dbs = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*.db"))
+        dbs = newest(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*.db")))
         if stats:
             shutil.copy(stats[0], dest)
         elif dbs:
@@ -56,7 +61,7 @@ def main(tag):
                 f.writelines(lines)
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        for db in glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{which}", "*", "*.db")):
+        for db in newest(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{which}", "*", "*.db"))):
             for name, value in counters_from_db(db, counter):
                 per[short(name)][counter].append(float(value))
         for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{which}", "*", "*counter_collection.csv")):
