@@ -277,14 +277,20 @@ __device__ __forceinline__ double to_sgpr(double v) {
 // prove the arrays unchanged and refuses s_load), and a vector load's result can only be waited for with s_waitcnt vmcnt,
 // which retires in order: the load issued at the top of a step then also waits for the row STORES of the step before it --
 // one exposed store round trip per Phi. Scalar loads count on lgkmcnt and leave the stores in flight.
+template <typename T>
+__device__ __forceinline__ const T *uniform_ptr(const T *p) {   // the address in SGPRs even where the compiler holds it in VGPRs
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<const T *>(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ int ld_uniform(const int32_t *p) {
     int v;
-    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(uniform_ptr(p)));
     return v;
 }
 __device__ __forceinline__ double ld_uniform(const double *p) {
     double v;
-    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(uniform_ptr(p)));
     return v;
 }
 
