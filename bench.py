@@ -262,10 +262,10 @@ def bench_advection(args):
     print(json.dumps(out), flush=True)
 
 
-KERNEL_OF = {"relax_f": "relax_kernel<1, 1, {g}, 0>", "relax_c": "relax_kernel<1, 1, {g}, 1>", "fas_fused": "fas_fused1_kernel<2, false>",
+KERNEL_OF = {"relax_f": "relax_kernel<1, 1, {g}, 0>", "relax_c": "relax_kernel<1, 1, {g}, 1>", "fas_fused": "fas_fused1_kernel<4, false>",
              "ec_relax": "ecf_kernel<1, 1, {g}>", "residual": "residual_kernel<1, 1>", "chain": "chain2_kernel<1, true>",
-             "cf_fas": "cfas_kernel<2>", "ec_relax_res": "ecfr_kernel<2, false, true>", "relax_fc": "relax_kernel<1, 1, true, 3>",
-             "f_fas": "fas_fused1_kernel<2, true>"}
+             "cf_fas": "cfas_kernel<2>", "ec_relax_res": "ecfr_kernel<4, false, true>", "relax_fc": "relax_kernel<1, 1, true, 3>",
+             "f_fas": "fas_fused1_kernel<4, true>"}
 LIMITED_BY = {"chain": "latency: the coarsest-level solve is sequential, one cross-workgroup exchange per step (measured floor "
                        "0.98 us/step = one store -> L2 -> load round trip); bytes are not what bounds it",
               "default": "HBM bandwidth (one 1024-thread workgroup per CU streaming rows; 6.29 TB/s copy ceiling of the guide)"}

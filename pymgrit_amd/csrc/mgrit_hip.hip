@@ -396,8 +396,17 @@ __device__ __forceinline__ void load_coef(Coef &c, const CSet *g) {
 
 // d <- u + dt*b(x, t_i), forcing folded as fma(s_k, tau_k*dt, .)  (L.tc[k][i] = tau_k(t_i)*dt_i)
 template <int FORCE>
-__device__ __forceinline__ void add_forcing(double (&x)[E], const StepCtx &ctx, const LevelDev &L, int i, int t) {
-    if (FORCE == 1) {
+__device__ __forceinline__ void add_forcing(double (&x)[E], const StepCtx &ctx, const LevelDev &L, int i, int t, const Smem &sm) {
+    if (FORCE == 4) {   // one separable term whose space factor the kernel has staged in LDS (stage_forcing): measured, streaming it
+                        // from L2 in every Phi (FORCE 2) costs 2 us per Phi on an idle chip and 4 us when every CU does it
+        const double c0 = ld_uniform(L.tc + i);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double2 sv = sm.tab[slot0(t) + q * 64];
+            x[2 * q] = fma(sv.x, c0, x[2 * q]);
+            x[2 * q + 1] = fma(sv.y, c0, x[2 * q + 1]);
+        }
+    } else if (FORCE == 1) {
         const double c0 = ld_uniform(L.tc + i);
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = fma(ctx.s0[k], c0, x[k]);
@@ -554,7 +563,8 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const Le
     ctx.parity ^= 1;
     double *ga = sm.ga + par * MAX_G, *gb = sm.gb + par * MAX_G;
     if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
-        add_forcing<FORCE>(x, ctx, L, i, t);
+        static_assert(FORCE != 4 || CLOSED, "FORCE 4 keeps the forcing factor where the correction table would be");
+        add_forcing<FORCE>(x, ctx, L, i, t, sm);
         heat_solve<CLOSED>(x, c, lc, sm, ga, gb, L.n, t, lane, wave, G);
     } else {
 #pragma unroll
@@ -606,6 +616,16 @@ __device__ __forceinline__ double block_sumsq(const double (&r)[E], const Smem &
 // ---------------------------------------------------------------------------------------------------------------
 // kernels (one workgroup per run / pair)
 // ---------------------------------------------------------------------------------------------------------------
+// FORCE 4: the (one) forcing space factor of level L into the LDS region a closed-form Phi leaves free. Every thread reads
+// back only what it wrote itself: no barrier.
+template <int FORCE>
+__device__ __forceinline__ void stage_forcing(const Smem &sm, const LevelDev &L, unsigned sl) {
+    if (FORCE == 4) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sm.tab[sl + q * 64] = L.sP[sl + q * 64];
+    }
+}
+
 extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
 #define WG_PROLOGUE                                                                        \
@@ -997,7 +1017,9 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
 template <int FORCE, bool USE_G, bool RES>
 __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, double *__restrict__ out, int store_f) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
+    constexpr bool CF = FORCE == 4;   // forcing factor in LDS, so every Phi in closed form
     WG_PROLOGUE;
+    stage_forcing<FORCE>(sm, L, sl);
     for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < I.n_chunks; wq.advance(t)) {
         const int k = wq.cur;
         wq.prefetch(t);
@@ -1020,7 +1042,7 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
             for (int i = cs + 1; i < ce; ++i) {
                 double gi[E];
                 if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);   // in flight while Phi runs
-                phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+                phi_apply<KIND, FORCE, CF>(x, ctx, L, i, sm, t, lane, wave, G);
                 if (USE_G) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) x[e] = gi[e] + x[e];
@@ -1037,7 +1059,7 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
             }
             store_row(L.u + (size_t)ce * L.ld, sl, b);
             if (RES) {
-                phi_apply<KIND, FORCE>(x, ctx, L, ce, sm, t, lane, wave, G);
+                phi_apply<KIND, FORCE, CF>(x, ctx, L, ce, sm, t, lane, wave, G);
                 if (store_f == 2) store_row(L.u + (size_t)(ce - 1) * L.ld, sl, x);   // Phi(last F-point): the next C-relaxation's value
 #pragma unroll
                 for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
@@ -1066,7 +1088,9 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
     //   previous C-point ip and i are stepped through here, u_k = g_k + Phi(u_{k-1}), and not stored (nobody reads them before
     //   the way up rewrites them); bit 1: u^{l+1}_j is not stored (a coarsest level that forward_solve overwrites unread)
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
+    constexpr bool CF = FORCE == 4;   // forcing factor in LDS, so every Phi in closed form
     WG_PROLOGUE;
+    stage_forcing<FORCE>(sm, L, sl);
     Smem smc = sm;
     for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < n_items; wq.advance(t)) {
         const int p = wq.cur;
@@ -1088,7 +1112,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
 #pragma unroll
                     for (int e = 0; e < E; ++e) w[e] = w[e] - ui[e];
                 }
-                phi_apply<KIND, FORCE>(x, ctx, L, k, sm, t, lane, wave, G);
+                phi_apply<KIND, FORCE, CF>(x, ctx, L, k, sm, t, lane, wave, G);
 #pragma unroll
                 for (int e = 0; e < E; ++e) x[e] = w[e] + x[e];
             }
@@ -1104,7 +1128,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
 #pragma unroll
                 for (int k = 0; k < E; ++k) w[k] = gi[k] - w[k];
             }
-            phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+            phi_apply<KIND, FORCE, CF>(x, ctx, L, i, sm, t, lane, wave, G);
             if (use_g) {
 #pragma unroll
                 for (int k = 0; k < E; ++k) x[k] = w[k] + x[k];
@@ -1124,7 +1148,15 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         smc.wf = const_cast<double *>(gc->pg);
         smc.lp = const_cast<double *>(gc->lp);
         smc.pt = const_cast<double2 *>(Lc.ptP) + (size_t)cj * 1024;
-        if (FORCE != 0) {
+        if (FORCE == 4 && (opts & 4)) {   // the coarse level's space factor is the fine level's, bit for bit: the LDS copy
+            const double ck = ld_uniform(Lc.tc + j);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double2 sv = sm.tab[sl + q * 64];
+                w[2 * q] = fma(sv.x, ck, w[2 * q]);
+                w[2 * q + 1] = fma(sv.y, ck, w[2 * q + 1]);
+            }
+        } else if (FORCE != 0) {
             for (int kk = 0; kk < Lc.K; ++kk) {
                 const double ck = ld_uniform(Lc.tc + (size_t)kk * Lc.n_pts + j);
 #pragma unroll
@@ -1251,6 +1283,8 @@ struct Level {
     std::vector<PairList> pairs;
     std::vector<IntervalsDev> ivals;   // mgrit_hip_intervals_create (device arrays live in allocs)
     std::vector<int> ivals_n;          // intervals per list
+    std::vector<double> s_host;        // forcing space factors as uploaded (row storage order): levels with equal factors share
+                                       // the LDS copy of the kernels that keep the factor there (FORCE 4)
     double *scratch = nullptr;
     size_t scratch_rows = 0;
     double *chain_state = nullptr;   // caller-owned [ld + CHAIN_STATE_TAIL]: carry-free part of the last point + carries
@@ -1514,12 +1548,15 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(cfas_kernel<2>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<0, false, true>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<2, false, true>))) return rc;
+    if ((rc = allow_big_lds(ecfr_kernel<4, false, true>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<0, true, false>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<2, true, false>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<0, false>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<2, false>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<0, true>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<2, true>))) return rc;
+    if ((rc = allow_big_lds(fas_fused1_kernel<4, false>))) return rc;
+    if ((rc = allow_big_lds(fas_fused1_kernel<4, true>))) return rc;
     if ((rc = allow_big_lds(jump_kernel))) return rc;
 #define ATTR_2PTS(O, F)                                                                                              \
     if ((rc = allow_big_lds(relax2_kernel<O, F, false, false>, smem2_bytes(MAX_G2)))) return rc;                     \
@@ -1612,6 +1649,7 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     if ((rc = dev_upload(lv, e->stream, cidx, &d_cidx))) return rc;
     if ((rc = dev_upload(lv, e->stream, dts, &d_dt))) return rc;
     if ((rc = dev_upload(lv, e->stream, tauv, &d_tau))) return rc;
+    lv.s_host = sT;
     if ((rc = dev_upload(lv, e->stream, sT, &d_sT))) return rc;
     if ((rc = dev_upload(lv, e->stream, cs, &d_cs))) return rc;
     if ((rc = dev_upload(lv, e->stream, tabT, &d_tabT))) return rc;
@@ -2576,11 +2614,14 @@ int mgrit_hip_fas_fused_opts(mgrit_hip_engine *e, int lvl, int triples_id, int o
         const int fm = force_mode(lf);
         // forcing factors of both levels are streamed (FORCE 2, the same fma per term): one Phi per point does not pay for
         // keeping them in registers, and the registers are needed for the partial g that stays live across the coarse Phi
+        // one forcing term: its space factor lives in LDS (FORCE 4, closed-form Phi); bit 2 tells the kernel that the coarse
+        // level's factor is the same vector (same spatial grid, same rhs), so the coarse Phi takes it from there too
+        const int kopts = opts | ((fm == 1 && lf.s_host == lc.s_host) ? 4 : 0);
 #define FAS1_CASE(F_, P_)                                                                                                  \
-    if ((fm == 0 ? 0 : 2) == F_ && ((opts & MGRIT_HIP_FAS_WITH_F_RELAX) != 0) == P_)                                        \
+    if ((fm == 0 ? 0 : fm == 1 ? 4 : 2) == F_ && ((opts & MGRIT_HIP_FAS_WITH_F_RELAX) != 0) == P_)                          \
         hipLaunchKernelGGL((fas_fused1_kernel<F_, P_>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, \
-                           pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g, opts);
-        FAS1_CASE(0, false) FAS1_CASE(2, false) FAS1_CASE(0, true) FAS1_CASE(2, true)
+                           pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g, kopts);
+        FAS1_CASE(0, false) FAS1_CASE(2, false) FAS1_CASE(4, false) FAS1_CASE(0, true) FAS1_CASE(2, true) FAS1_CASE(4, true)
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -2861,6 +2902,7 @@ int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int ivals_id, int store
     if ((rc = ensure_pinned(e, lf.ivals_n[ivals_id]))) return rc;
     Timed timed(e, MGRIT_HIP_T_EC_RELAX_RES, lvl);
     if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
+    else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
     else hipLaunchKernelGGL((ecfr_kernel<2, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
     HIP_TRY(hipGetLastError());
     return 0;
