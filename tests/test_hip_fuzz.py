@@ -1,7 +1,8 @@
 """Seeded random configurations of the 1-D steppers on the HIP path against the oracle (bit-exact states and residual norms):
 sizes around the group boundaries, coarsening factors 2..8, two to four levels, V and F cycles, weights, cf_iter, forcing on /
 off, non-uniform time grids. A wider sweep of the same generator: `python tests/test_hip_fuzz.py 200` (round 1, final build:
-10000 of 10000 seeds bit-exact)."""
+10000 of 10000 seeds bit-exact; round 2, with the whole-level passes, the closed-form correction and C-point storage: 20000 of
+20000)."""
 import sys
 
 import numpy as np
