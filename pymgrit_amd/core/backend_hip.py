@@ -382,6 +382,11 @@ class HipBackend:
         # 16384 / blocks / 4 chunks for 240 workgroups: with 6 blocks 2.8 rounds, with 8 blocks 2.1)
         return int(max(1, min(8, n_c // 680)))
 
+    def plan_allowed(self):
+        """planned cycles run sweeps and chain parts on two streams at once: only for the 1-D one-point steppers (the Heat2D
+        and two-point kernels share per-level work buffers between launches; measured with them switched on: wrong results)"""
+        return all(d["kind"] in ("heat1d", "advection1d") for d in self.desc)
+
     def plan_single_block(self):
         """a cycle too small to be cut into blocks is still planned (as one block, program order): what pays there is the
         replay of the whole cycle as one hipGraph (plan_run)"""

@@ -376,7 +376,8 @@ class Mgrit:
                   ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "forward_solve", "_exchange",
                    "_ec_f_relax", "_fas_residual_fused", "_relax_f"))
         usable = (self.comm_time_size == 1 and self.lvl_max > 1 and own and self._dry is None and
-                  not getattr(self, "_sweep_timing", False))     # per-sweep debug timing reports the sweeps in program order
+                  not getattr(self, "_sweep_timing", False) and     # per-sweep debug timing reports the sweeps in program order
+                  getattr(self.backend, "plan_allowed", lambda: True)())
         if probe_usable:
             return int(usable)
         return max(want, 1) if usable else 1

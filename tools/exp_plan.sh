@@ -1,9 +1,11 @@
 cd $GRAFT_REPO_ROOT
-for b in 3 4 5 6 7 8; do
-  timeout -k 10 120 python bench.py --no-cpu-baseline --plan-blocks $b --steps 10 --warmup 3 2>/dev/null | python -c "
+PYMGRIT_AMD_PLAN_BLOCKS=4 timeout -k 10 600 python -m pytest tests/test_hip_heat2d.py -m gpu -x -q 2>&1 | tail -3
+for b in 8 16; do
+  PYMGRIT_AMD_PLAN_BLOCKS=$b timeout -k 10 300 python bench.py --workload heat2d --steps 3 --warmup 3 2>gpurun_out/h2d_err_$b.log | python -c "
 import sys,json
 for ln in sys.stdin:
     if ln.startswith('{'):
-        b=json.loads(ln); print('blocks',$b,'ms',round(b['ms_per_step'],3),'chain us/step',round(b['config']['chain_us_per_step'],3))
+        b=json.loads(ln); print('heat2d graph blocks',$b,'ms',round(b['ms_per_step'],2), 'frac', round(b['roofline']['frac'],3))
 "
+  tail -3 gpurun_out/h2d_err_$b.log | grep -v amdgpu
 done
