@@ -323,3 +323,44 @@ def test_library_method_detection():
     plain.step = lambda *a: None
     assert not Mgrit._library_method(plain, "step")
     assert Mgrit._library_method(GridTransferCopy(), "restriction")
+
+
+def test_fused_pass_lists_of_the_device_path():
+    """host side of the whole-level passes (Mgrit._level_intervals / _coarse_down): interval lists, which coarse rows the down
+    pass must store (include/mgrit_hip.h, keep), run lists of the coarse-level passes -- checked against a stand-in backend that
+    only answers the capability questions"""
+    from pymgrit_amd import Heat1D, Mgrit
+    grids = [np.linspace(0, 1, 65), np.linspace(0, 1, 17), np.linspace(0, 1, 5)]
+    prob = [Heat1D(x_start=0, x_end=1, nx=9, a=1, t_interval=t) for t in grids]
+    for p in prob:
+        p.device_stepper = lambda: None          # host path: no GPU here
+    mg = Mgrit(prob, logging_lvl=30, max_iter=1)
+
+    class Caps:
+        def __init__(self, real):
+            self.real = real
+
+        def __getattr__(self, name):
+            return getattr(self.real, name)
+        can_fuse_level = staticmethod(lambda lvl: lvl == 0)
+        can_fuse_coarse_down = staticmethod(lambda lvl: lvl > 0)
+        can_fuse_ec = staticmethod(lambda lvl: True)
+    mg.backend = Caps(mg.backend)
+    iv = mg._level_intervals(0)
+    assert len(iv) == 16 and iv[0][:5] == (0, 4, -1, 1, 0) and iv[5][:5] == (20, 24, 5, 6, 5)
+    keep = [t[5] for t in iv]
+    # u of level 1 only at its C-points (every 4th point), v there too (the coarse level's first pass starts its runs from v);
+    # conv_crit 0: the way up takes v from the fine C-point, so nowhere else
+    assert keep == [3 if (k + 1) % 4 == 0 else 0 for k in range(16)]
+    fc_runs, triples, head, skip_u = mg._coarse_down(1)
+    assert fc_runs == [(1, 4), (5, 4), (9, 4), (13, 4)] and head == [(0, 0)] and skip_u
+    assert triples == [(4, 0, 1), (8, 4, 2), (12, 8, 3), (16, 12, 4)]
+    assert mg._coarse_down(0) is None and mg._coarse_down(2) is None
+    # a jump criterion does not use the fused way up: v is needed at every closing C-point
+    mg2 = Mgrit(prob, logging_lvl=30, max_iter=1, conv_crit=1)
+    mg2.backend = Caps(mg2.backend)
+    assert all(t[5] & 2 for t in mg2._level_intervals(0))
+    # weight != 1, or cf_iter = 2 on level 1: no coarse-level passes
+    mg3 = Mgrit(prob, logging_lvl=30, max_iter=1, cf_iter=[1, 2])
+    mg3.backend = Caps(mg3.backend)
+    assert mg3._coarse_down(1) is None and [t[5] for t in mg3._level_intervals(0)] == [1 if (k + 1) % 4 == 0 else 0 for k in range(16)]
