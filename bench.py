@@ -320,10 +320,35 @@ def sweep_table(mg, be, nts, m_list, dof, cycle, cycles=3):
     for key, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         kind = key.split()[0]
         sym = KERNEL_OF.get(kind, kind).format(g="true" if not key.endswith("L0") else "false")
+        if kind == "chain" and dof <= 1024:
+            sym = "chain_kernel<1, 1, true, true>"    # one group of values: the single-workgroup chain, no exchange
         table[key] = {"kernel_symbol": sym, "launches_per_cycle": n / cycles, "ms_per_launch": tot / n, "ms_per_cycle": tot / cycles,
                       "algorithmic_bytes_per_cycle": alg.get(key, 0.0),
                       "limited_by": LIMITED_BY.get(kind, LIMITED_BY["default"])}
     return table
+
+
+OTHER_CONFIGS = (["--nx", "1024", "--nt", "4097", "--steps", "200", "--warmup", "20", "--no-cpu-baseline"],
+                 ["--workload", "heat2d", "--steps", "3", "--warmup", "1"],
+                 ["--workload", "advection", "--steps", "10", "--warmup", "3"])
+
+
+def other_configs(timeout=150):
+    """BASELINE configs[1], [3], [4] on this GPU, one child process each: workload, ms per cycle, updates/s, the roofline row"""
+    import subprocess
+    rows = []
+    for extra in OTHER_CONFIGS:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra, capture_output=True, text=True, timeout=timeout)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            b = json.loads(line)
+            rf = b.get("roofline", {})
+            rows.append({"workload": b["config"]["workload"], "ms_per_step": b["ms_per_step"], "value": b["value"], "unit": b["unit"],
+                         "steps": b["steps"], "warmup": b["warmup"],
+                         "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launch_ms")}})
+        except Exception as exc:   # noqa: BLE001 - secondary numbers: report, never fail the headline
+            rows.append({"workload": " ".join(extra), "error": repr(exc)[:300]})
+    return rows
 
 
 def self_launch(n):
@@ -568,6 +593,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx)
             out["iters_to_tol"] = iters_to_tol(problem, nx)
+            if (nx, nt0) == (16384, 65537) and not args.all_configs and not args.at_k:
+                # the other GPU configurations of BASELINE.json, each measured in a child process of its own AFTER everything
+                # above, folded into this ONE line (the full lines: --all-configs); a failure there never touches the headline
+                out["other_configs"] = other_configs()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -577,9 +606,7 @@ def main():
         del mg, be, problem
         torch.cuda.empty_cache()
         me = os.path.abspath(__file__)
-        for extra in (["--nx", "1024", "--nt", "4097", "--steps", "200", "--warmup", "20", "--no-cpu-baseline"],
-                      ["--workload", "heat2d", "--steps", "3", "--warmup", "1"],
-                      ["--workload", "advection", "--steps", "10", "--warmup", "3"]):
+        for extra in OTHER_CONFIGS:
             r = subprocess.run([sys.executable, me] + extra, capture_output=True, text=True)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             print(lines[-1] if lines and r.returncode == 0 else json.dumps({"config": {"workload": " ".join(extra)}, "error": r.stderr[-400:]}),
