@@ -10,7 +10,8 @@ F-relax) + the residual-norm convergence check -- exactly what Mgrit.solve() doe
 value = time-point-DOF updates per second = (Phi applications of the cycle, SURVEY 3.5 work model) x DOFs / wall time,
 inputs resident in HBM. "sweeps" lists every sweep of the cycle with its device time (HIP events around every entry point on
 the engine's stream, three extra cycles in program order) and SURVEY 8d's algorithmic bytes; "roofline" is the row with the
-largest share of the cycle.
+largest share of the cycle. "other_configs": BASELINE configs[1], [3], [4] on the same GPU, measured in child
+processes after the headline numbers (full lines: --all-configs).
 """
 import argparse
 import json
