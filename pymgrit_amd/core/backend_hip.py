@@ -380,6 +380,10 @@ class HipBackend:
         # measured on config 3 (4097 coarsest points, round 2): 4 blocks 12.2 ms, 5 11.3, 6 10.8, 7 11.9, 8 13.3 -- more blocks
         # shorten the fill and drain of the block pipeline, fewer keep the launches large (a level-0 pass of one block is
         # 16384 / blocks / 4 chunks for 240 workgroups: with 6 blocks 2.8 rounds, with 8 blocks 2.1)
+        # ... and only where the coarsest solve is long against the sweeps: Heat1D states wider than one group (config 3).
+        # Measured on config 5 (advection_1d, 4 levels, 2 groups per state): one block 26.3 ms per F-cycle, two 30.1, six 32.1.
+        if any(d["kind"] != "heat1d" for d in self.desc) or max(self.n) <= 1024:
+            return 1
         return int(max(1, min(8, n_c // 680)))
 
     def plan_allowed(self):
