@@ -266,3 +266,40 @@ def test_general_forcing_matches_reference(oracle):
     for variant in (0, 1):
         conv = oracle.OracleProblem(c["levels"], variant=variant, **c["opts"]).solve()
         assert len(conv) == len(ref) and np.all(np.abs(conv - ref) <= 1e-9 * ref + 2e-11), (variant, conv, ref)
+
+
+@pytest.mark.parametrize("nx,dt", [(16384, 2.0 / 65536), (16384, 2.0 / 4096), (1024, 2.0 / 4096), (33, 0.1), (17, 1e-3), (7, 1e-6),
+                                   (3102, 0.125), (2052, 0.01)])
+def test_closed_form_correction_table(oracle, nx, dt):
+    """The rank-one correction table of the arithmetic spec is defined in closed form since round 2 (DESIGN.md 3.1:
+    w_j = (rho^j - rho^(2n-j)) / (kappa (1 - rho^2)), assembled from group / lane / element powers). Pin it to the textbook
+    definition it replaces -- gamma * A^{-1} e0 by the two serial recurrences -- evaluated here in extended precision: the entries
+    agree to a few ulp of the LARGEST entry times the conditioning of 1 - rho^2 (the correction enters a step as z0 * w_j, so the
+    largest entry is the scale that matters)."""
+    import cases
+    n = nx - 2
+    spec = cases.heat_level_spec(nx, np.array([0.0, dt]))
+    op = oracle.OracleProblem([spec], variant=1)
+    c = op.cset(0, dt)
+    ld = np.longdouble
+    fac = ld(spec["fac"])
+    beta, D = ld(dt) * fac, ld(dt) * (2 * fac) + 1
+    kappa = (D + np.sqrt((D - 2 * beta) * (D + 2 * beta))) / 2
+    rho = beta / kappa
+    y = np.empty(n, dtype=ld)
+    y[0] = 1
+    for j in range(1, n):
+        y[j] = rho * y[j - 1]
+    w = np.empty(n, dtype=ld)
+    z = y[n - 1]
+    w[n - 1] = z
+    for j in range(n - 2, -1, -1):
+        z = rho * z + y[j]
+        w[j] = z
+    w = w / kappa
+    gamma = beta * rho / (1 + beta * rho * w[0])
+    ref = np.asarray(gamma * w, dtype=np.float64)
+    assert abs(c["rho"] - float(rho)) <= 2e-16 * float(rho)
+    # rho itself is a rounded double: 1 - rho^2 carries its relative error 1 / (1 - rho) times over, in either form of the table
+    tol = 4e-16 * (4.0 + 1.0 / (1.0 - float(rho)))
+    assert np.max(np.abs(c["tab"] - ref)) <= tol * np.max(np.abs(ref)), (np.max(np.abs(c["tab"] - ref)) / np.max(np.abs(ref)), tol)
