@@ -436,6 +436,24 @@ class Mgrit:
         if first_f and (lvl > 0 or iteration == 0):
             self.f_relax(lvl=lvl)
         fused = self._level_intervals(lvl)     # whole-level sweeps in one pass (device backend, one rank), or None
+        shard = self._rank_intervals(lvl) if (fused is None and self.comm_time_size > 1 and self.cf_iter[lvl] >= 1) else None
+        if shard is not None:
+            # several ranks: the same down pass on the rank's COMPLETE intervals (both C-points local); the first local C-point,
+            # the partial intervals at the two ends and every exchange point as in the sweep-by-sweep form
+            intervals, c0_run, edge_runs = shard
+            for _ in range(self.cf_iter[lvl] - 1):
+                self.c_relax(lvl=lvl)
+                self.f_relax(lvl=lvl)
+            self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
+                           recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=2)
+            self.backend.relax(lvl, c0_run, 'C')                    # the first local C-point (its interval began on the rank before)
+            self.backend.cf_fas(lvl, intervals)                     # C-relaxation, F-relaxation, FAS residual of the complete intervals
+            self.f_relax(lvl=lvl, runs=edge_runs)                   # ops 0 / 1 and the partial intervals
+            self._fas_residual_fused(lvl, skip_triples=True)        # ops 3 / 4 and the first local C-point
+            self._fresh_level = lvl + 1
+            self.iteration(lvl=lvl + 1, cycle_type=cycle_type, iteration=iteration, first_f=True)
+            self._up(lvl, None)
+            return
         down = fused is not None and self.cf_iter[lvl] >= 1
         for _ in range(self.cf_iter[lvl] - (1 if down else 0)):
             self.c_relax(lvl=lvl)
@@ -466,6 +484,46 @@ class Mgrit:
             self.error_correction(lvl=lvl)
             self.f_relax(lvl=lvl)
 
+    def _rank_intervals(self, lvl):
+        """several ranks, level 0: (intervals, c0_run, edge_runs) when the rank's complete intervals -- both C-points local -- can
+        take the down pass mgrit_hip_cf_fas, else None. intervals: as _level_intervals (every coarse row kept: the exchanges and
+        the generic sweeps of the coarser level read them); c0_run: the first local C-point as a run list for the generic
+        C-relaxation (empty on rank 0, whose first point is never relaxed); edge_runs: the F-runs in front of the first and behind
+        the last local C-point (the partial intervals this rank shares with its neighbours)."""
+        def build():
+            be = self.backend
+            own = all(getattr(type(self), name) is getattr(Mgrit, name) for name in
+                      ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "_exchange", "_ec_f_relax",
+                       "_fas_residual_fused", "_relax_f"))
+            can = getattr(be, "can_fuse_level", None)
+            if not (os.environ.get("PYMGRIT_AMD_NO_RANK_FUSION", "") != "1" and own and lvl == 0 and self.lvl_max > 1 and
+                    self.weight_c == 1.0 and self.global_conv_crit and not getattr(self, "_sweep_timing", False) and
+                    can is not None and can(lvl) and getattr(be, "can_fuse_fas", lambda l: False)(lvl)):
+                return [None]
+            pairs = self._pairs(lvl, skip_first=False)               # (fine slot, coarse slot) of every local C-point
+            if len(pairs) < 3:
+                return [None]
+            c0, ck = pairs[0][0], pairs[-1][0]
+            runs = [tuple(r) for r in self._f_runs(lvl)]
+            inner = [(pairs[k][0] + 1, pairs[k + 1][0] - pairs[k][0] - 1) for k in range(len(pairs) - 1)]
+            edge = [r for r in runs if r[0] < c0 or r[0] > ck]
+            if any(ln < 1 for _, ln in inner) or sorted(inner + edge) != sorted(runs) or len(edge) > 2:
+                return [None]
+            relaxed = set(self._c_points(lvl))
+            if any(p[0] not in relaxed for p in pairs[1:]):
+                return [None]
+            first_relaxed = c0 in relaxed                            # False on rank 0 (global point 0)
+            if first_relaxed and c0 < 1:
+                return [None]
+            ivals = [(pairs[k][0], pairs[k + 1][0], pairs[k][1] if (k >= 1 or first_relaxed) else -1, pairs[k + 1][1], k, 3)
+                     for k in range(len(pairs) - 1)]
+            return [(ivals, [(c0, 1)] if first_relaxed else [], edge)]
+        got = self._cached(('rank_intervals', lvl), build)[0]
+        if got is None:
+            return None
+        return (self._cached(('rank_intervals_list', lvl), lambda: got[0]), self._cached(('rank_c0', lvl), lambda: got[1]),
+                self._cached(('rank_edge', lvl), lambda: got[2]))
+
     def _coarse_down(self, lvl):
         """(fc_runs, triples, head, skip_coarse_u) when the way down of level lvl > 0 can run as two passes (relax mode FC,
         fas_fused with_f_relax; backend_hip.can_fuse_coarse_down), else None: one rank, the library's own sweeps, weight 1,
@@ -491,7 +549,7 @@ class Mgrit:
             return [(fc_runs, triples, pairs[:1], skip_u)]
         return self._cached(('coarse_down', lvl), build)[0]
 
-    def f_relax(self, lvl: int, ec: bool = False) -> None:
+    def f_relax(self, lvl: int, ec: bool = False, runs=None) -> None:
         """F-relaxation (mgrit.py:292-333): every F-interval is propagated from its preceding point. Exchange:
         op 0 = last local C-point to the next owner's ghost; op 1 = hand-off inside an F-interval that straddles a
         rank boundary (comm_front / comm_back).
@@ -500,8 +558,8 @@ class Mgrit:
         t0 = time.time()
         self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_c_point[lvl] else None,
                        recv_idx=0 if self.first_is_f_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=0)
-        runs = self._f_runs(lvl)
-        if runs:
+        runs = self._f_runs(lvl) if runs is None else runs     # (runs: the boundary runs of a rank whose complete intervals
+        if runs:                                                # a whole-level pass has already relaxed, _rank_intervals)
             front, back = self.comm_front[lvl], self.comm_back[lvl]
             if front and back and len(runs) == 1:
                 self._exchange(lvl, recv_idx=0, src=self.get_from[lvl], op=1)
@@ -511,13 +569,14 @@ class Mgrit:
                 self._relax_f(lvl, 'f_all', runs, ec)
             else:
                 lo, hi = (1 if front else 0), (len(runs) - 1 if back else len(runs))
+                tag = '' if runs is self._f_runs(lvl) else '_b'
                 if back:  # the interval feeding the next rank goes first
-                    self._relax_f(lvl, 'f_last', self._cached(('f_last', lvl), lambda: runs[-1:]), ec)
+                    self._relax_f(lvl, 'f_last' + tag, self._cached(('f_last' + tag, lvl), lambda: runs[-1:]), ec)
                     self._exchange(lvl, send_idx=self._last_slot(lvl), dest=self.send_to[lvl], op=1)
-                self._relax_f(lvl, 'f_mid', self._cached(('f_mid', lvl), lambda: runs[lo:hi]), ec)
+                self._relax_f(lvl, 'f_mid' + tag, self._cached(('f_mid' + tag, lvl), lambda: runs[lo:hi]), ec)
                 if front:
                     self._exchange(lvl, recv_idx=0, src=self.get_from[lvl], op=1)
-                    self._relax_f(lvl, 'f_first', self._cached(('f_first', lvl), lambda: runs[:1]), ec)
+                    self._relax_f(lvl, 'f_first' + tag, self._cached(('f_first' + tag, lvl), lambda: runs[:1]), ec)
         self._log_sweep("F-relax", t0)
 
     def _relax_f(self, lvl, tag, runs, ec):
@@ -672,7 +731,7 @@ class Mgrit:
         self.backend.fas_rhs(lvl, self._pairs(lvl, skip_first=True))
         self._log_sweep("Fas residual", t0)
 
-    def _fas_residual_fused(self, lvl: int) -> None:
+    def _fas_residual_fused(self, lvl: int, skip_triples: bool = False) -> None:
         """Same sweep as fas_residual with the device backend's fused kernel: every local C-point whose previous
         C-point is local too is handled in one pass (restriction, clone into v, FAS right-hand side); the first local
         C-point goes through the separate kernels because its v_{j-1} is the ghost that arrives with op 4."""
@@ -684,7 +743,8 @@ class Mgrit:
         self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
                        recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=3)
         be.restrict_u(lvl, head)
-        be.fas_fused(lvl, triples)
+        if not skip_triples:      # (skip: the whole-level pass of the rank's complete intervals has done exactly these)
+            be.fas_fused(lvl, triples)
         self._exchange(lvl + 1,
                        send_idx=int(self.index_local[lvl + 1][-1]) if self.send_to[lvl + 1] >= 0 else None,
                        recv_idx=0 if self.get_from[lvl + 1] >= 0 else None,
