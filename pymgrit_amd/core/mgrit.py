@@ -418,6 +418,24 @@ class Mgrit:
             return
         fresh, self._fresh_level = getattr(self, "_fresh_level", None) == lvl, None
         coarse = self._coarse_down(lvl) if (fresh and first_f and lvl > 0) else None
+        crank = self._coarse_down_rank(lvl) if (coarse is None and fresh and first_f and lvl > 0 and self.comm_time_size > 1) else None
+        if crank is not None:
+            # several ranks: the two coarse-level passes on the rank's complete intervals; the first local C-point, the partial
+            # intervals at the two ends and every exchange point as in the sweep-by-sweep form
+            fc_runs, c0_run, edge_runs = crank
+            self.f_relax(lvl=lvl, runs=edge_runs)                        # first F-relaxation: ops 0 / 1, partial intervals
+            self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
+                           recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=2)
+            self.backend.relax(lvl, c0_run, 'C')
+            self.backend.relax(lvl, fc_runs, 'FC')                       # ... and C-relaxation, complete intervals
+            self.f_relax(lvl=lvl, runs=edge_runs)                        # second F-relaxation: ops 0 / 1, partial intervals
+            self._fas_residual_fused(lvl, with_f_relax=True)             # ... folded into the FAS pass for the complete intervals
+            self._fresh_level = lvl + 1
+            self.iteration(lvl=lvl + 1, cycle_type=cycle_type, iteration=iteration, first_f=True)
+            self._up(lvl, None)
+            if cycle_type == 'F':
+                self.iteration(lvl=lvl, cycle_type='V', iteration=iteration, first_f=False)
+            return
         if coarse is not None:
             # a level the finer level's FAS sweep has just filled (u == v): F-relaxation + C-relaxation in one pass, then the
             # F-relaxation folded into the FAS sweep (the F-points of the way down are stored by neither)
@@ -483,6 +501,38 @@ class Mgrit:
         else:
             self.error_correction(lvl=lvl)
             self.f_relax(lvl=lvl)
+
+    def _coarse_down_rank(self, lvl):
+        """several ranks, a level > 0 the finer level's FAS sweep has just filled: (fc_runs, c0_run, edge_runs) when the rank's
+        complete intervals can take the two coarse-level passes (relax mode FC, fas_fused with_f_relax), else None"""
+        def build():
+            be = self.backend
+            own = all(getattr(type(self), name) is getattr(Mgrit, name) for name in
+                      ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "_exchange", "_ec_f_relax",
+                       "_fas_residual_fused", "_relax_f"))
+            can = getattr(be, "can_fuse_coarse_down", None)
+            if not (os.environ.get("PYMGRIT_AMD_NO_RANK_FUSION", "") != "1" and
+                    os.environ.get("PYMGRIT_AMD_NO_RANK_FUSION_COARSE", "") != "1" and own and 0 < lvl < self.lvl_max - 1 and
+                    self.weight_c == 1.0 and self.cf_iter[lvl] == 1 and self.global_conv_crit and
+                    not getattr(self, "_sweep_timing", False) and can is not None and can(lvl)):
+                return [None]
+            pairs = self._pairs(lvl, skip_first=False)
+            if len(pairs) < 3:
+                return [None]
+            c0, ck = pairs[0][0], pairs[-1][0]
+            runs = [tuple(r) for r in self._f_runs(lvl)]
+            inner = [(pairs[k][0] + 1, pairs[k + 1][0] - pairs[k][0] - 1) for k in range(len(pairs) - 1)]
+            edge = [r for r in runs if r[0] < c0 or r[0] > ck]
+            relaxed = set(self._c_points(lvl))
+            if (any(ln < 1 for _, ln in inner) or sorted(inner + edge) != sorted(runs) or len(edge) > 2 or
+                    any(p[0] not in relaxed for p in pairs[1:]) or (c0 in relaxed and c0 < 1)):
+                return [None]
+            return [([(st, ln + 1) for st, ln in inner], [(c0, 1)] if c0 in relaxed else [], edge)]
+        got = self._cached(('coarse_down_rank', lvl), build)[0]
+        if got is None:
+            return None
+        return (self._cached(('cdr_fc', lvl), lambda: got[0]), self._cached(('cdr_c0', lvl), lambda: got[1]),
+                self._cached(('cdr_edge', lvl), lambda: got[2]))
 
     def _rank_intervals(self, lvl):
         """several ranks, level 0: (intervals, c0_run, edge_runs) when the rank's complete intervals -- both C-points local -- can
@@ -731,7 +781,7 @@ class Mgrit:
         self.backend.fas_rhs(lvl, self._pairs(lvl, skip_first=True))
         self._log_sweep("Fas residual", t0)
 
-    def _fas_residual_fused(self, lvl: int, skip_triples: bool = False) -> None:
+    def _fas_residual_fused(self, lvl: int, skip_triples: bool = False, with_f_relax: bool = False) -> None:
         """Same sweep as fas_residual with the device backend's fused kernel: every local C-point whose previous
         C-point is local too is handled in one pass (restriction, clone into v, FAS right-hand side); the first local
         C-point goes through the separate kernels because its v_{j-1} is the ghost that arrives with op 4."""
@@ -744,7 +794,10 @@ class Mgrit:
                        recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=3)
         be.restrict_u(lvl, head)
         if not skip_triples:      # (skip: the whole-level pass of the rank's complete intervals has done exactly these)
-            be.fas_fused(lvl, triples)
+            if with_f_relax:      # the F-relaxation of the triples' intervals is part of the pass (their F-points are not stored)
+                be.fas_fused(lvl, triples, with_f_relax=True)
+            else:
+                be.fas_fused(lvl, triples)
         self._exchange(lvl + 1,
                        send_idx=int(self.index_local[lvl + 1][-1]) if self.send_to[lvl + 1] >= 0 else None,
                        recv_idx=0 if self.get_from[lvl + 1] >= 0 else None,
