@@ -206,6 +206,10 @@ int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_
                                int chunk, const int32_t *keep, int *id_out);
 int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int intervals_id, int pre_relaxed);
 int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int intervals_id, int store_all_f);
+/* the same pass with the per-point sums of squares written to sumsq_out[res_pos] (device-accessible memory of the caller, e.g.
+ * pinned host memory) instead of the engine's buffer: a rank of a sharded run fills the values of its complete intervals this
+ * way and the first local C-point's through mgrit_hip_residual */
+int mgrit_hip_ec_relax_res_to(mgrit_hip_engine *e, int lvl, int intervals_id, int store_all_f, double *sumsq_out);
 int mgrit_hip_residual_fetch(mgrit_hip_engine *e, int n, double *sumsq_host);
 
 /* Same two reductions with the result delivered to HOST memory (sumsq_host[r], r < n_runs) when the call returns: the

@@ -261,6 +261,7 @@ class HipBackend:
         """start of Mgrit.iteration(lvl=0): the down pass of THIS cycle reads the rows the cycle before left, whatever the
         cycle's own up pass does to later blocks in the meantime (planned cycle)"""
         self._cycle_pre = self._f_stale == 2
+        self._res_open = None       # a pre-filled residual slot nobody asked for belongs to the cycle before
 
     def natural(self, which, lvl):
         """host copy of a whole slab in natural x order, shape [n_local_points][n] (tests / post-processing)"""
@@ -493,6 +494,9 @@ class HipBackend:
             main.wait_event(last_side.event)
 
     def residual_norms(self, points):
+        if getattr(self, "_res_open", None) is not None:      # several ranks: the way up has pre-filled most of the values
+            handle = self.residual_begin(points)
+            return self.residual_end(handle)
         cache = getattr(self, "_residual_cache", None)
         if not (cache is not None and len(cache) == len(points) and (cache is points or cache == tuple(points))):
             self._settle(0)     # the residual kernel reads the last F-points
@@ -506,19 +510,41 @@ class HipBackend:
         check(self.lib.mgrit_hip_residual_host(self.h, 0, self._point_run_id(0, points), _ptr(host)))
         return np.sqrt(host)
 
+    def _ring_slot(self, n):
+        if not hasattr(self, "_res_ring"):
+            self._res_ring, self._res_next = [], 0
+        if len(self._res_ring) < 8:
+            self._res_ring.append(torch.empty(n, dtype=torch.float64, pin_memory=True))
+        buf = self._res_ring[self._res_next % len(self._res_ring)]
+        self._res_next += 1
+        return buf
+
+    def residual_reserve(self, points, n_head):
+        """several ranks: the slot the next residual_begin() / residual_norms() of exactly these points will deliver. The way up
+        (ec_relax_res with out=) fills points[n_head:] -- the closing C-points of the rank's complete intervals --, the residual
+        kernel later only the n_head points in front of them (they need the ghost point that arrives with op 7)."""
+        buf = self._ring_slot(len(points))
+        self._res_open = (tuple(points), int(n_head), buf)
+        return buf
+
+    def _open_slot(self, points):
+        """(buffer, head points still to compute) when the way up has pre-filled a slot for exactly these points"""
+        op, self._res_open = getattr(self, "_res_open", None), None
+        if op is not None and op[0] == tuple(points):
+            return op[2], list(points[:op[1]])
+        return None, None
+
     def residual_begin(self, points):
         """launch the residual kernel and return at once; the per-point sums of squares land in pinned host memory that the
         kernel writes directly (no copy command), residual_end() waits for the event recorded behind the kernel"""
         self._settle(0)
         if not len(points):
             return None
-        if not hasattr(self, "_res_ring"):
-            self._res_ring, self._res_next = [], 0
-        if len(self._res_ring) < 8:
-            self._res_ring.append(torch.empty(len(points), dtype=torch.float64, pin_memory=True))
-        buf = self._res_ring[self._res_next % len(self._res_ring)]
-        self._res_next += 1
-        check(self.lib.mgrit_hip_residual(self.h, 0, self._point_run_id(0, points), C.c_void_p(buf.data_ptr())))
+        buf, head = self._open_slot(points)
+        if buf is None:
+            buf, head = self._ring_slot(len(points)), points
+        if len(head):
+            check(self.lib.mgrit_hip_residual(self.h, 0, self._point_run_id(0, head), C.c_void_p(buf.data_ptr())))
         ev = torch.cuda.Event()
         ev.record(self.stream)
         return buf, ev
@@ -750,6 +776,12 @@ class HipBackend:
         if intervals:
             self._residual_cache = None
             check(self.lib.mgrit_hip_cf_fas(self.h, lvl, self._intervals_id(lvl, intervals), 1 if (lvl == 0 and self._cycle_pre) else 0))
+
+    def ec_relax_res_to(self, lvl, intervals, buf):
+        """several ranks: error_correction + f_relax + the residual sums of the rank's complete intervals (every F-point stored:
+        neighbours and the generic sweeps read them), sums into the reserved slot `buf` (residual_reserve)"""
+        if intervals:
+            check(self.lib.mgrit_hip_ec_relax_res_to(self.h, lvl, self._intervals_id(lvl, intervals), 1, C.c_void_p(buf.data_ptr())))
 
     def ec_relax_res(self, lvl, intervals, base=0):
         """error_correction + f_relax + compute_residual; the per-point sums of squares stay in pinned host memory until

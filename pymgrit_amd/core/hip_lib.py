@@ -71,6 +71,7 @@ EXPORTS = {
     "mgrit_hip_fas_coarse": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_cf_fas": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgrit_hip_ec_relax_res": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mgrit_hip_ec_relax_res_to": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mgrit_hip_residual_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
 }
 

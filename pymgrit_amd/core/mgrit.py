@@ -491,6 +491,18 @@ class Mgrit:
 
     def _up(self, lvl, fused):
         """error correction + F-relaxation of level lvl on the way up (mgrit.py:283-284), in the most fused form available"""
+        shard = self._rank_intervals_up(lvl) if (fused is None and lvl == 0 and self.comm_time_size > 1) else None
+        if shard is not None:
+            # several ranks: correction + F-relaxation + residual sums of the rank's complete intervals in one pass; the first
+            # local C-point is corrected up front (the interval it closes belongs to the rank before), the partial intervals at
+            # the two ends follow as plain F-relaxations with their exchange points; the residual of the first local C-point is
+            # the residual kernel's (it needs the ghost point of op 7)
+            intervals, c0_pair, edge_runs, n_head = shard
+            buf = self.backend.residual_reserve(self._c_points(0), n_head)
+            self.backend.error_correction(lvl, c0_pair)
+            self.backend.ec_relax_res_to(lvl, intervals, buf)
+            self.f_relax(lvl=lvl, runs=edge_runs)
+            return
         if fused is not None and lvl == 0 and self.conv_crit in (0, 2):   # correction + F-relaxation + the residual check's sums
             self.backend.ec_relax_res(lvl, fused)
             self.backend.residual_ready(self._c_points(0))
@@ -501,6 +513,35 @@ class Mgrit:
         else:
             self.error_correction(lvl=lvl)
             self.f_relax(lvl=lvl)
+
+    def _rank_intervals_up(self, lvl):
+        """several ranks, level 0, residual criterion: (intervals, c0_pair, edge_runs, n_head) for the way up on the rank's complete
+        intervals (mgrit_hip_ec_relax_res_to), else None. res_pos of an interval = position of its closing C-point among the
+        rank's relaxed C-points (the order of the residual values); n_head = how many of those lie in front of the first closing
+        point (1: the first local C-point on ranks > 0; 0 on rank 0)."""
+        def build():
+            down = self._rank_intervals(lvl)
+            if (down is None or self.conv_crit != 0 or os.environ.get("PYMGRIT_AMD_NO_RANK_FUSION_UP", "") == "1" or
+                    not self._can_fuse_ec(lvl) or getattr(self.backend, "residual_reserve", None) is None):
+                return [None]
+            ivals, c0_run, edge = down
+            cpts = self._c_points(lvl)
+            pos = {c: i for i, c in enumerate(cpts)}
+            if any(iv[1] not in pos for iv in ivals):
+                return [None]
+            n_head = pos[ivals[0][1]]
+            if n_head != len(c0_run) or [pos[iv[1]] for iv in ivals] != list(range(n_head, n_head + len(ivals))) or \
+                    n_head + len(ivals) != len(cpts):
+                return [None]
+            up = [(cs, ce, jcs, jce, pos[ce], keep) for (cs, ce, jcs, jce, _, keep) in ivals]
+            corrected = dict(self._pairs(lvl, skip_first=True))
+            c0_pair = [(c0_run[0][0], corrected[c0_run[0][0]])] if c0_run else []
+            return [(up, c0_pair, edge, n_head)]
+        got = self._cached(('rank_intervals_up', lvl), build)[0]
+        if got is None:
+            return None
+        return (self._cached(('riu_list', lvl), lambda: got[0]), self._cached(('riu_c0', lvl), lambda: got[1]),
+                self._cached(('riu_edge', lvl), lambda: got[2]), got[3])
 
     def _coarse_down_rank(self, lvl):
         """several ranks, a level > 0 the finer level's FAS sweep has just filled: (fc_runs, c0_run, edge_runs) when the rank's

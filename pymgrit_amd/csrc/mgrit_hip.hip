@@ -2884,7 +2884,18 @@ int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id, int pre_relaxed
     return 0;
 }
 
+static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int store_all_f, double *out_caller);
+
 int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int ivals_id, int store_all_f) {
+    return ec_relax_res_impl(e, lvl, ivals_id, store_all_f, nullptr);
+}
+
+int mgrit_hip_ec_relax_res_to(mgrit_hip_engine *e, int lvl, int ivals_id, int store_all_f, double *sumsq_out) {
+    if (!sumsq_out) return fail(MGRIT_HIP_EINVAL, "null output");
+    return ec_relax_res_impl(e, lvl, ivals_id, store_all_f, sumsq_out);
+}
+
+static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int store_all_f, double *out_caller) {
     int rc = fused_level_check(e, lvl, ivals_id, "fused correction + F-relaxation + residual", false);
     if (rc) return rc;
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
@@ -2899,11 +2910,12 @@ int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int ivals_id, int store
         return 0;
     }
     if (store_all_f < 0 || store_all_f > 2) return fail(MGRIT_HIP_EINVAL, "store_all_f %d outside 0..2", store_all_f);
-    if ((rc = ensure_pinned(e, lf.ivals_n[ivals_id]))) return rc;
+    if (!out_caller && (rc = ensure_pinned(e, lf.ivals_n[ivals_id]))) return rc;
+    double *out = out_caller ? out_caller : e->pinned;
     Timed timed(e, MGRIT_HIP_T_EC_RELAX_RES, lvl);
-    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
-    else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
-    else hipLaunchKernelGGL((ecfr_kernel<2, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, e->pinned, store_all_f);
+    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f);
+    else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f);
+    else hipLaunchKernelGGL((ecfr_kernel<2, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f);
     HIP_TRY(hipGetLastError());
     return 0;
 }
