@@ -70,3 +70,37 @@ def test_bench_two_gpus_over_rccl():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     b = _last_json(r.stdout)
     assert b["n_gpus"] == 2 and b["nccl_ranks"] == 2 and b["exchange"]["device_resident_messages"] == b["exchange"]["messages_total"]
+
+
+def test_rccl_stack_comes_up_on_one_gpu(tmp_path):
+    """what CAN be exercised of the RCCL transport on a one-GPU box: a one-rank nccl process group with the device bound at
+    initialisation (eager communicator), a sub-group split off it, a collective on device memory, the time communicator on top
+    of it -- the calls every rank of a sharded run makes before its first exchange (the exchanges themselves need two devices)"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    script = tmp_path / "one_rank_nccl.py"
+    script.write_text('''
+import os, sys, socket
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+x = torch.ones(1024, dtype=torch.float64, device="cuda")
+dist.all_reduce(x)
+dist.barrier()
+g = dist.new_group([0], backend="nccl")
+dist.all_reduce(x, group=g)
+side = dist.new_group([0], backend="gloo")
+from pymgrit_amd.core.comm import resolve_comm
+comm = resolve_comm(None)
+comm.prepare()
+assert comm.size == 1 and comm.backend == "nccl" and comm.allgather_object(3) == [3]
+torch.cuda.synchronize()
+assert float(x[0]) == 1.0
+dist.destroy_process_group()
+print("RCCL_OK")
+''' % ROOT)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
