@@ -233,6 +233,12 @@ class HipBackend:
 
     def _forget_residual(self):
         self._residual_cache = None
+        self._write_gen = getattr(self, "_write_gen", 0) + 1      # a Vector has been written into a slab from outside
+
+    def write_generation(self):
+        """changes whenever slab contents have been written from outside the sweeps (mgrit.u[lvl][i] = vec, set_natural):
+        Mgrit._head re-injects the first time point then"""
+        return getattr(self, "_write_gen", 0)
 
     @property
     def U(self):
@@ -271,8 +277,9 @@ class HipBackend:
         return slab[:, self.perm[lvl]].cpu().numpy()
 
     def set_natural(self, which, lvl, values):
-        self._residual_cache = None
         """upload a [n_local_points][n] host array given in natural x order"""
+        self._residual_cache = None
+        self._write_gen = getattr(self, "_write_gen", 0) + 1
         slab = {"u": self._U, "v": self.V, "g": self.G}[which][lvl]
         slab.zero_()
         slab[:, self.perm[lvl]] = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64)).to(slab.device)

@@ -247,6 +247,9 @@ class Recorder:
             self._add("ec_relax_res", lvl, b, lambda p=part: real.ec_relax_res(lvl, p), reads,
                       {("u", lvl, b), ("res", lvl, b)} if lvl == 0 else {("u", lvl, b)}, 3 * len(part) + n_f * (2 if lvl > 0 else 1))
 
+    def write_generation(self):
+        return getattr(self.real, "write_generation", lambda: None)()
+
     def residual_ready(self, points):
         self.host_after.append(lambda: self.real.residual_ready(points))
 

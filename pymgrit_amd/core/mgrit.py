@@ -394,14 +394,18 @@ class Mgrit:
             blocks = 1
         from pymgrit_amd.core.cycle_plan import PlanUnsupported, record_cycle
         key = (cycle_type, iteration == 0, bool(first_f), blocks, tuple(self.cf_iter), float(self.weight_c),
-               bool(getattr(self.backend, "_cycle_pre", False)))   # (the down pass's launch argument, baked into a captured graph)
+               bool(getattr(self.backend, "_cycle_pre", False)),   # (the down pass's launch argument, baked into a captured graph)
+               getattr(self.backend, "write_generation", lambda: None)(),
+               frozenset(self.__dict__.get('_head_done', ())))          # which injections of the first time point the cycle still holds
         if key not in self._plans:
             self._plan_recording = True
+            held = set(self.__dict__.get('_head_done', ()))
             try:
                 self._plans[key] = record_cycle(self, self.backend, blocks, lambda: self.iteration(
                     lvl=0, cycle_type=cycle_type, iteration=iteration, first_f=first_f))
             except PlanUnsupported:
                 self._plans[key] = None
+                self._head_done = held      # nothing of the abandoned recording has run
             finally:
                 self._plan_recording = False
         return self._plans[key]
@@ -442,9 +446,9 @@ class Mgrit:
             fc_runs, triples, head, skip_u = coarse
             if self.cf_iter[lvl] == 1:
                 self.backend.relax(lvl, fc_runs, 'FC')
-            self.backend.restrict_u(lvl, head)
+            self._head(lvl, head, 'u')
             self.backend.fas_fused(lvl, triples, with_f_relax=True, skip_coarse_u=skip_u)
-            self.backend.copy_pairs_u_to_v(lvl, head)
+            self._head(lvl, head, 'v')
             self._fresh_level = lvl + 1
             self.iteration(lvl=lvl + 1, cycle_type=cycle_type, iteration=iteration, first_f=True)
             self._up(lvl, None)
@@ -478,9 +482,9 @@ class Mgrit:
             self.f_relax(lvl=lvl)
         if down:      # the last C-relaxation + F-relaxation + the FAS residual: one pass
             head = self._cached(('pair_head', lvl), lambda: self._pairs(lvl, skip_first=False)[:1])
-            self.backend.restrict_u(lvl, head)
+            self._head(lvl, head, 'u')
             self.backend.cf_fas(lvl, fused)
-            self.backend.copy_pairs_u_to_v(lvl, head)
+            self._head(lvl, head, 'v')
         else:
             self.fas_residual(lvl=lvl)
         self._fresh_level = lvl + 1      # the next level starts from what the FAS sweep has just written (u == v there)
@@ -488,6 +492,28 @@ class Mgrit:
         self._up(lvl, fused)
         if lvl != 0 and cycle_type == 'F':
             self.iteration(lvl=lvl, cycle_type='V', iteration=iteration, first_f=False)
+
+    def _head(self, lvl, head, which):
+        """one rank: the first point of the time grid is relaxed and corrected by nobody, so its injection into level lvl+1
+        (u, then the clone into v: mgrit.py:498-500, 520) writes the same row in every cycle -- two launches of a few microseconds
+        that a small hierarchy notices. Done once, and again after anything has been written into the slabs from outside."""
+        done = self.__dict__.setdefault('_head_done', set())
+        gen = getattr(self.backend, "write_generation", lambda: None)()
+        if gen is None:
+            done.clear()
+        elif gen != self.__dict__.get('_head_gen'):
+            done.clear()
+            self._head_gen = gen
+        if (lvl, which) in done:
+            return
+        if which == 'u':
+            self.backend.restrict_u(lvl, head)
+            for key in [k for k in done if k[0] > lvl or k == (lvl, 'v')]:   # the levels below copy from the row just written (nested
+                done.discard(key)                                           # iteration reaches them before level 0 has injected)
+        else:
+            self.backend.copy_pairs_u_to_v(lvl, head)
+        if gen is not None:      # (while a cycle is being recorded: the recorded cycle runs right away and does it; the cycles
+            done.add((lvl, which))   # recorded after it leave it out; _planned keys its plans by the write generation)
 
     def _up(self, lvl, fused):
         """error correction + F-relaxation of level lvl on the way up (mgrit.py:283-284), in the most fused form available"""
@@ -807,6 +833,10 @@ class Mgrit:
         """Inject the C-points and the FAS right-hand side into level lvl+1 (mgrit.py:488-549). op 3 = ghost refresh on
         lvl, op 4 = last local point of lvl+1 to the next owner's ghost."""
         t0 = time.time()
+        held = self.__dict__.get('_head_done')
+        if held:      # this sweep injects the first time point itself: what the levels below hold of it (_head) is out of date
+            for key in [k for k in held if k[0] >= lvl]:
+                held.discard(key)
         if getattr(self.backend, "can_fuse_fas", None) is not None and self.backend.can_fuse_fas(lvl):
             self._fas_residual_fused(lvl)
             self._log_sweep("Fas residual", t0)

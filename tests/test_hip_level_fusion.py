@@ -124,3 +124,33 @@ def test_coarse_level_up_pass_bit_identical(case, monkeypatch):
         assert np.array_equal(conv, conv0), (case, blocks)
         for a, b in zip(u, u0):
             assert np.array_equal(a, b), (case, blocks)
+
+
+@pytest.mark.parametrize("blocks", [1, None])
+def test_first_time_point_is_injected_again_after_a_write(blocks):
+    """one rank: the injection of the first time point into the coarser levels is done once and left out of the following
+    cycles (nobody relaxes or corrects that point); a write into the level-0 slab from outside brings it back, so the cycles
+    after it are those of a solver that started from the written state"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from pymgrit_amd import Mgrit
+    prob, tr, opts = dist_worker.build_problem("heat_nx257_nt257", "hip")
+    rng = np.random.default_rng(7)
+
+    def cycles(mg, first, n):
+        for it in range(first, first + n):
+            mg.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True)
+            mg.convergence_criterion(iteration=it + 1)
+
+    a = Mgrit(prob, transfer=tr, logging_lvl=30, plan_blocks=blocks, **opts)
+    cycles(a, 0, 3)
+    assert a._head_done                                   # the later cycles of `a` ran without the injections
+    state = rng.random(a.backend.natural("u", 0).shape)  # every point new, the first one included
+    a.backend.set_natural("u", 0, state)
+    cycles(a, 3, 3)
+    b = Mgrit(prob, transfer=tr, logging_lvl=30, plan_blocks=blocks, **opts)
+    b.backend.set_natural("u", 0, state)
+    cycles(b, 3, 3)
+    for lvl in range(len(prob)):
+        assert np.array_equal(a.backend.natural("u", lvl), b.backend.natural("u", lvl)), lvl
+    assert np.array_equal(a.conv[4:7], b.conv[4:7])
