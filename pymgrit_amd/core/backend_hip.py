@@ -280,6 +280,8 @@ class HipBackend:
         """upload a [n_local_points][n] host array given in natural x order"""
         self._residual_cache = None
         self._write_gen = getattr(self, "_write_gen", 0) + 1
+        if which == "u" and lvl == 0:
+            self._f_stale = 0      # every row replaced: nothing of the last cycle's C-point storage is left to rebuild
         slab = {"u": self._U, "v": self.V, "g": self.G}[which][lvl]
         slab.zero_()
         slab[:, self.perm[lvl]] = torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64)).to(slab.device)
