@@ -772,7 +772,9 @@ class HipBackend:
             cols = [_i32([iv[k] for iv in intervals]) for k in range(6)]
             # level 0: chunks of 4 intervals (one extra row + Phi per chunk start); coarser levels: one interval per item --
             # a block of a planned cycle holds only a few hundred of their intervals, and 4 in a row would leave CUs idle
-            chunk = int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK", "4")) if lvl == 0 else int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK_COARSE", "1"))
+            # (0 = chosen by the library from the level's size: 4 on config 3, 1 where the level has fewer intervals than the chip
+            # holds workgroups)
+            chunk = int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK", "0")) if lvl == 0 else int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK_COARSE", "1"))
             res_len = len(self.mg._c_points(lvl))
             check(self.lib.mgrit_hip_intervals_create(self.h, lvl, len(intervals), _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]),
                                                       _ptr(cols[3]), _ptr(cols[4]), res_len, chunk, _ptr(cols[5]), C.byref(iid)))

@@ -2814,10 +2814,15 @@ int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_
     int rc = check_level(e, lvl);
     if (rc) return rc;
     if (lvl + 1 >= e->n_levels || !e->L[lvl + 1].set) return fail(MGRIT_HIP_EINVAL, "level %d has no described coarser level", lvl);
-    if (n < 0 || chunk < 1 || res_len < n || !id_out || (n > 0 && (!cstart || !cend || !cstart_coarse || !cend_coarse || !res_pos)))
+    if (n < 0 || chunk < 0 || res_len < n || !id_out || (n > 0 && (!cstart || !cend || !cstart_coarse || !cend_coarse || !res_pos)))
         return fail(MGRIT_HIP_EINVAL, "bad interval list");
     Level &lv = e->L[lvl];
     const Level &lc = e->L[lvl + 1];
+    if (chunk == 0) {   // by the level's size: walking several intervals in a row saves a row and a Phi per interval joined, but a
+                        // level with fewer intervals than the chip holds workgroups wants every one of them running at once
+        const int per_slot = res_len / (2 * 256 * wgs_per_cu(lv));
+        chunk = per_slot >= 4 ? 4 : per_slot >= 2 ? 2 : 1;
+    }
     for (int i = 0; i < n; ++i) {
         if (cstart[i] < 0 || cend[i] >= lv.dev.n_pts || cend[i] - cstart[i] < 2)
             return fail(MGRIT_HIP_EINVAL, "interval %d = (%d,%d]: two C-points of the local grid with an F-point between them", i, cstart[i], cend[i]);
