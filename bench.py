@@ -207,6 +207,8 @@ def bench_heat2d(args):
                         "kernel": "level-0 F-relax = per Phi 2 x h2d_fwd_kernel + 2 x h2d_inv_kernel (f64 MFMA, half-size transforms) + rhs + epilogue",
                         "flops_per_phi": flops_per_phi,
                         "launch_ms": f_ms, "us_per_phi": 1e3 * f_ms / n_f}}
+    out["sweeps"] = timed_sweeps(mg, be, cycle, cycles=1)
+    out["cycle"] = {"sum_of_sweep_ms_in_program_order": sum(r["ms_per_cycle"] for r in out["sweeps"].values())}
     print(json.dumps(out), flush=True)
 
 
@@ -260,6 +262,8 @@ def bench_advection(args):
     counts = cycle_phi_counts([len(p.t) for p in prob], [2, 2, 2], 'F')
     out["config"]["phi_per_cycle_by_level"] = counts
     out["value"] = sum(c * d for c, d in zip(counts, out["config"]["dof_by_level"])) * args.steps / elapsed
+    out["sweeps"] = timed_sweeps(mg, be, cycle)
+    out["cycle"] = {"sum_of_sweep_ms_in_program_order": sum(r["ms_per_cycle"] for r in out["sweeps"].values())}
     print(json.dumps(out), flush=True)
 
 
@@ -294,6 +298,31 @@ def sweep_bytes(nts, m_list, dof):
     out["residual L0"] = ((nts[0] - 1) // m_list[0]) * 16.0 * dof
     out[f"chain L{L - 1}"] = (nts[-1] - 1) * 24.0 * dof
     return out
+
+
+def timed_sweeps(mg, be, cycle, cycles=2):
+    """per (sweep, level): launches and device milliseconds per cycle in program order (HIP events around every entry point,
+    mgrit_hip_set_timing); no byte model -- the secondary workloads' tables"""
+    keep = mg._plan_request
+    mg._plan_request = 1
+    try:
+        cycle(1)
+        be.sync()
+        be.set_timing(True)
+        be.timing_drain()
+        for _ in range(cycles):
+            cycle(1)
+        recs = be.timing_drain(max_records=65536)
+        be.set_timing(False)
+    finally:
+        mg._plan_request = keep
+    agg = {}
+    for kind, lvl, ms in recs:
+        a = agg.setdefault(f"{kind} L{lvl}", [0, 0.0])
+        a[0] += 1
+        a[1] += ms
+    return {key: {"launches_per_cycle": n / cycles, "ms_per_launch": tot / n, "ms_per_cycle": tot / cycles}
+            for key, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])}
 
 
 def sweep_table(mg, be, nts, m_list, dof, cycle, cycles=3):

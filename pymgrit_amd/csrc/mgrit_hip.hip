@@ -60,7 +60,7 @@ int fail(int code, const char *fmt, ...) {
 // ---------------------------------------------------------------------------------------------------------------
 struct CSet {
     double rho, ik, scal, gc;
-    double pi_full, pi_last;  // heat: Pt[0] of a full / of the last group
+    double pi_full, pi_last;  // heat: Pt[0] of a full / of the last group; advection: pi_last = rho^(((n-1) mod 16) + 1)
     double pg[MAX_G], qg[MAX_G], qg2[MAX_G];  // heat: per-group factors of the rank-one correction (build_cset_heat1d)
     double pw[E + 1];   // rho^k
     double sc[6];       // rho^(E*2^s)
@@ -582,8 +582,10 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const Le
         __syncthreads();
         double c_last = 0.0;
         const double cm = fwd_chain(c, li < G ? ga[li] : 0.0, G, wave, lane, c_last);
-        const int ll = (jl % GROUP) / E, kl = jl % E;
-        const double ylast = fma(c.pw[kl + 1], sm.lp[ll] * c_last, gb[0]);
+        const int ll = (jl % GROUP) / E;
+        // (c.pi_last = c.pw[(n-1) % 16 + 1], picked by the host: indexed here, at a position known only at run time, the whole coefficient set
+        // would move from registers into scratch memory)
+        const double ylast = fma(c.pi_last, sm.lp[ll] * c_last, gb[0]);
         const double xl = ylast * c.scal;
         const double cf = lc.f_in * cm;
 #pragma unroll
@@ -1481,6 +1483,7 @@ void build_cset_advection1d(CSet &c, std::vector<double> &tab, int n, double fac
         p = p * r;
     }
     c.scal = 1.0 / (1.0 - tab[n - 1]);
+    c.pi_last = c.pw[(n - 1) % E + 1];   // the power at the last unknown's position inside its lane (the periodic closure reads it)
 }
 
 template <typename T>
@@ -1500,6 +1503,18 @@ int dev_upload(Level &lv, hipStream_t st, const std::vector<T> &h, T **out) {
 // MGRIT_HIP_CHAIN_PLAIN=1: forward_solve with the plain per-step arithmetic of 3.3 everywhere (measurement switch)
 bool plain_chain() {
     static const bool v = [] { const char *s = std::getenv("MGRIT_HIP_CHAIN_PLAIN"); return s && s[0] == '1'; }();
+    return v;
+}
+
+// MGRIT_HIP_CHAIN_LOCAL_G: widest state (in groups of 1024 values) whose chain runs inside ONE workgroup (chain_local_kernel);
+// default 4 = all that fit its LDS (measured per step, advection: 0.90 / 1.13 / 1.12 us at 2 / 3 / 4 groups against 1.37 / 1.42 /
+// 1.44 us with one workgroup per group), 0 = never (measurement switch; the results do not depend on it)
+int chain_local_max_g() {
+    static const int v = [] {
+        const char *s = std::getenv("MGRIT_HIP_CHAIN_LOCAL_G");
+        const int g = s ? std::atoi(s) : CHAIN_LOCAL_MAX_G;
+        return g < 0 ? 0 : g > CHAIN_LOCAL_MAX_G ? CHAIN_LOCAL_MAX_G : g;
+    }();
     return v;
 }
 
@@ -1544,6 +1559,10 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(ecf_kernel<K, F, true>))) return rc;                                                     \
     if ((rc = allow_big_lds(at_kernel<K, F>))) return rc;
     FOR_EACH_STEPPER(ATTR_ALL)
+#define ATTR_CHAIN_LOCAL(K, F)                                                                                       \
+    if ((rc = allow_big_lds(chain_local_kernel<K, F, false>, chain_local_lds(CHAIN_LOCAL_MAX_G)))) return rc;          \
+    if ((rc = allow_big_lds(chain_local_kernel<K, F, true>, chain_local_lds(CHAIN_LOCAL_MAX_G)))) return rc;
+    FOR_EACH_STEPPER(ATTR_CHAIN_LOCAL)
     if ((rc = allow_big_lds(cfas_kernel<0>))) return rc;
     if ((rc = allow_big_lds(cfas_kernel<2>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<0, false, true>))) return rc;
@@ -2415,6 +2434,15 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
                 continue;
             }
             lv.chain_resume = false;
+            if (lv.G >= 2 && lv.G <= chain_local_max_g()) {   // a few groups: all workers in one workgroup, totals through LDS
+#define CHAIN_LOCAL_CASE(K, F, G_)                                                                            \
+    if (lv.dev.kind == K && fm == F && use_g == G_)                                                            \
+        hipLaunchKernelGGL((chain_local_kernel<K, F, G_>), dim3(1), dim3(2 * lv.G * LANES), chain_local_lds(lv.G), e->stream, lv.dev, st, ln, e->chain_err);
+#define CHAIN_LOCAL_CASES(K, F) CHAIN_LOCAL_CASE(K, F, false) CHAIN_LOCAL_CASE(K, F, true)
+                FOR_EACH_STEPPER(CHAIN_LOCAL_CASES)
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
 #define CHAIN_CASE(K, F, G_, S_)                                                                              \
     if (lv.dev.kind == K && fm == F && use_g == G_ && (lv.G == 1) == S_)                                       \
         hipLaunchKernelGGL((chain_kernel<K, F, G_, S_>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, e->sched, sel);

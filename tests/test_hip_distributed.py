@@ -79,3 +79,30 @@ def test_sharded_hip_matches_the_oracle(oracle, case, world):
     oconv = op.solve()
     assert len(conv) == len(oconv) and np.max(np.abs(conv - oconv) / oconv) <= 1e-10, (conv, oconv)
     assert np.array_equal(u, op.state("u", 0))
+
+
+@pytest.mark.parametrize("case,plain", [("advection_nx2049_wide", False), ("advection_nx4000_wide_F", False), ("heat_nx2050_wide", True),
+                                        ("heat_nx1500_wide_F", True)])
+def test_chain_inside_one_workgroup_is_bit_identical(oracle, case, plain, monkeypatch):
+    """states of 2..4 groups: the coarsest-level chain with all its workers in ONE workgroup and the group totals exchanged
+    through LDS (chain_local_kernel, the default) gives the bits of the chain with one workgroup per group and the totals
+    exchanged through L2 (MGRIT_HIP_CHAIN_LOCAL_G=0) -- and of the oracle; on two ranks as well"""
+    import torch
+    import cases
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    if plain:
+        monkeypatch.setenv("MGRIT_HIP_CHAIN_PLAIN", "1")     # Heat1D: the per-step form (the overlapped chain is a kernel of its own)
+    monkeypatch.delenv("MGRIT_HIP_CHAIN_LOCAL_G", raising=False)
+    conv, u = launch(1, case, mode="hip")
+    conv2, u2 = launch(2, case, mode="hip", backend="gloo")
+    monkeypatch.setenv("MGRIT_HIP_CHAIN_LOCAL_G", "0")
+    conv0, u0 = launch(1, case, mode="hip")
+    assert np.array_equal(conv, conv0) and np.array_equal(u, u0)
+    assert np.array_equal(conv2, conv0) and np.array_equal(u2, u0)
+    if not plain:
+        c = {**cases.solve_cases(), **cases.extra_cases()}[case]
+        op = oracle.OracleProblem(c["levels"], transfer=c.get("transfer"), variant=1, **dict(c["opts"]))
+        oconv = op.solve()
+        assert len(conv) == len(oconv) and np.max(np.abs(conv - oconv) / oconv) <= 1e-10, (conv, oconv)
+        assert np.array_equal(u, op.state("u", 0))
