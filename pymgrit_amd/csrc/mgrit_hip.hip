@@ -88,6 +88,8 @@ struct LevelDev {
     const double *chT;    // overlapped chain, null when the level does not qualify: V3 row [ld], then
                           // Q1, V1, V2 as [2][1024] each (full / last group), then a1 b1 a2 b2 [2] each, a3[16], b3[16]
     int n, ld, T, n_pts, K, kind;
+    int stream_rows;      // the level's slabs are far larger than the caches (n_pts * ld * 8 B > 256 MB): rows written by the
+                          // whole-level passes are stored with the non-temporal hint (store_row_nt)
     // launch-time fields (set per launch by the host, not part of the level description):
     int *sched;           // null: persistent workgroups walk their items with stride gridDim.x. Else {next, xcc0, done}: items
                           // are drawn from a device-wide queue head (see WgQueue)
@@ -208,6 +210,27 @@ __device__ __forceinline__ void store_row(double *__restrict__ row, unsigned s0,
     double2 *r2 = reinterpret_cast<double2 *>(row) + s0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) r2[q * 64] = make_double2(x[2 * q], x[2 * q + 1]);
+}
+
+// The same store with the non-temporal hint, for the rows the whole-level passes write and nobody reads again while they could
+// still sit in L2 (a pass writes gigabytes, an XCD's L2 holds 4 MB): written the plain way they push the tables every Phi reads
+// -- forcing factors, Pt, coefficient sets -- out of L2, and the Phi that follows a row store pays for it (measured with
+// wall-clock stamps inside cfas_kernel: the Phi after the C-point stores takes 8 us where an F-step takes 4.3). Planned cycle of
+// config 3: 8.9 -> 8.55 ms. Not for rows the NEXT sweep of a level reads right away from a small level (relax mode FC got slower).
+__device__ __forceinline__ void store_row_nt(double *__restrict__ row, unsigned s0, const double (&x)[E], int streaming) {
+    if (!streaming) {   // (wave-uniform) a level that fits the caches: the next sweep finds the row there
+        store_row(row, s0, x);
+        return;
+    }
+    typedef double dv2 __attribute__((ext_vector_type(2)));
+    dv2 *r2 = reinterpret_cast<dv2 *>(row) + s0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        dv2 v;
+        v.x = x[2 * q];
+        v.y = x[2 * q + 1];
+        __builtin_nontemporal_store(v, r2 + q * 64);
+    }
 }
 
 // cross-lane moves of a double inside one wave, DPP / readlane (no LDS)
@@ -702,7 +725,7 @@ __global__ void __launch_bounds__(1024) ecf_kernel(LevelDev L, LevelDev Lc, cons
             load_row(Lc.u + (size_t)j * Lc.ld, sl, uc);
 #pragma unroll
             for (int k = 0; k < E; ++k) x[k] = x[k] + (uc[k] - x[k]);
-            store_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
+            store_row_nt(L.u + (size_t)(start - 1) * L.ld, sl, x, L.stream_rows);
         }
         for (int i = start; i < start + len; ++i) {
             if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);
@@ -711,7 +734,7 @@ __global__ void __launch_bounds__(1024) ecf_kernel(LevelDev L, LevelDev Lc, cons
 #pragma unroll
                 for (int k = 0; k < E; ++k) x[k] = gi[k] + x[k];
             }
-            store_row(L.u + (size_t)i * L.ld, sl, x);
+            store_row_nt(L.u + (size_t)i * L.ld, sl, x, L.stream_rows);
         }
     }
     wq.end(t);
@@ -978,10 +1001,10 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
             double b[E];
             load_row(L.u + (size_t)(ce - 1) * L.ld, sl, b);   // (requested one Phi earlier it costs more in spills than it hides)
             if (!pre) phi_apply<KIND, FORCE, true>(b, ctx, L, ce, sm, t, lane, wave, G);
-            store_row(L.u + (size_t)ce * L.ld, sl, b);
+            store_row_nt(L.u + (size_t)ce * L.ld, sl, b, L.stream_rows);
             const int keep = __builtin_amdgcn_readfirstlane(I.keep[it]);
-            if (keep & 1) store_row(Lc.u + (size_t)jc * Lc.ld, sl, b);
-            if (keep & 2) store_row(Lc.v + (size_t)jc * Lc.ld, sl, b);
+            if (keep & 1) store_row_nt(Lc.u + (size_t)jc * Lc.ld, sl, b, Lc.stream_rows);
+            if (keep & 2) store_row_nt(Lc.v + (size_t)jc * Lc.ld, sl, b, Lc.stream_rows);
             phi_apply<KIND, FORCE, true>(x, ctx, L, ce, sm, t, lane, wave, G);
 #pragma unroll
             for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
@@ -993,7 +1016,7 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
                 x[2 * q] = x[2 * q] - w.x;
                 x[2 * q + 1] = x[2 * q + 1] - w.y;
             }
-            store_row(Lc.g + (size_t)jc * Lc.ld, sl, x);
+            store_row_nt(Lc.g + (size_t)jc * Lc.ld, sl, x, Lc.stream_rows);
 #pragma unroll
             for (int e = 0; e < E; ++e) x[e] = b[e];
         }
@@ -1049,7 +1072,7 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
 #pragma unroll
                     for (int e = 0; e < E; ++e) x[e] = gi[e] + x[e];
                 }
-                if (store_f == 1 || (store_f == 0 && i == ce - 1)) store_row(L.u + (size_t)i * L.ld, sl, x);
+                if (store_f == 1 || (store_f == 0 && i == ce - 1)) store_row_nt(L.u + (size_t)i * L.ld, sl, x, L.stream_rows);
             }
             double b[E];
             {   // v^{l+1}_{j+1} from the fine row itself (the same bits; only this chunk writes that row), see IntervalsDev::keep
@@ -1059,10 +1082,10 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
 #pragma unroll
                 for (int e = 0; e < E; ++e) b[e] = b[e] + (w[e] - b[e]);
             }
-            store_row(L.u + (size_t)ce * L.ld, sl, b);
+            store_row_nt(L.u + (size_t)ce * L.ld, sl, b, L.stream_rows);
             if (RES) {
                 phi_apply<KIND, FORCE, CF>(x, ctx, L, ce, sm, t, lane, wave, G);
-                if (store_f == 2) store_row(L.u + (size_t)(ce - 1) * L.ld, sl, x);   // Phi(last F-point): the next C-relaxation's value
+                if (store_f == 2) store_row_nt(L.u + (size_t)(ce - 1) * L.ld, sl, x, L.stream_rows);   // Phi(last F-point): the next C-relaxation's value
 #pragma unroll
                 for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
                 const double tot = block_sumsq(x, sm, L.n, t, lane, wave, G);
@@ -1109,8 +1132,8 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
                 if (k == i) {
                     double ui[E];
                     load_row(L.u + (size_t)i * L.ld, sl, ui);
-                    if (!(opts & 2)) store_row(Lc.u + (size_t)j * Lc.ld, sl, ui);
-                    store_row(Lc.v + (size_t)j * Lc.ld, sl, ui);
+                    if (!(opts & 2)) store_row_nt(Lc.u + (size_t)j * Lc.ld, sl, ui, Lc.stream_rows);
+                    store_row_nt(Lc.v + (size_t)j * Lc.ld, sl, ui, Lc.stream_rows);
 #pragma unroll
                     for (int e = 0; e < E; ++e) w[e] = w[e] - ui[e];
                 }
@@ -1122,8 +1145,8 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         } else {
             load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
             load_row(L.u + (size_t)i * L.ld, sl, w);
-            if (!(opts & 2)) store_row(Lc.u + (size_t)j * Lc.ld, sl, w);
-            store_row(Lc.v + (size_t)j * Lc.ld, sl, w);
+            if (!(opts & 2)) store_row_nt(Lc.u + (size_t)j * Lc.ld, sl, w, Lc.stream_rows);
+            store_row_nt(Lc.v + (size_t)j * Lc.ld, sl, w, Lc.stream_rows);
             if (use_g) {
                 double gi[E];
                 load_row(L.g + (size_t)i * L.ld, sl, gi);
@@ -1179,7 +1202,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         }
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
-        store_row(Lc.g + (size_t)j * Lc.ld, sl, x);
+        store_row_nt(Lc.g + (size_t)j * Lc.ld, sl, x, Lc.stream_rows);
     }
     wq.end(t);
 }
@@ -1615,6 +1638,7 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     lv.G = G;
     LevelDev &d = lv.dev;
     d.n = n; d.ld = ld; d.T = T; d.n_pts = n_pts; d.K = K; d.kind = kind;
+    d.stream_rows = (size_t)n_pts * (size_t)ld * sizeof(double) > ((size_t)256 << 20) ? 1 : 0;
     // coefficient sets keyed by the bit pattern of dt = t[i] - t[i-1] (the reference uses each step's own dt)
     std::vector<double> dts(n_pts > 0 ? n_pts : 0, 0.0), uniq;
     std::vector<int32_t> cidx(n_pts > 0 ? n_pts : 0, 0);
@@ -1719,6 +1743,7 @@ int level_heat1d_2pts(mgrit_hip_engine *e, int lvl, int n_pts, const double *t_l
     lv.order = order;
     LevelDev &d = lv.dev;
     d.n = n; d.ld = ld; d.T = T; d.n_pts = n_pts; d.K = K; d.kind = MGRIT_HIP_STEPPER_HEAT1D_2PTS;
+    d.stream_rows = 0;
     const size_t np = n_pts > 0 ? n_pts : 0;
     std::vector<double> uniq, hc(np * 4, 0.0), fs(np * 2, 0.0), dts(np, 0.0);
     std::vector<int32_t> cidx2(np * 2, 0);
@@ -2248,7 +2273,7 @@ int mgrit_hip_level_heat2d(mgrit_hip_engine *e, int lvl, int n_pts_local, const 
     if ((rc = dev_upload(lv, e->stream, h->dts, &d_dt))) return rc;
     H.bc = d_bc; H.W = d_W; H.S = d_S; H.tstop = d_tau; H.dt = d_dt;
     lv.dev.kind = MGRIT_HIP_STEPPER_HEAT2D;
-    lv.dev.n = nx * ny; lv.dev.ld = ld; lv.dev.T = 0; lv.dev.n_pts = n_pts_local; lv.dev.K = K;
+    lv.dev.n = nx * ny; lv.dev.ld = ld; lv.dev.T = 0; lv.dev.n_pts = n_pts_local; lv.dev.K = K; lv.dev.stream_rows = 0;
     lv.G = 0;
     lv.set = true;
     return 0;
