@@ -233,6 +233,23 @@ __device__ __forceinline__ void store_row_nt(double *__restrict__ row, unsigned 
     }
 }
 
+// ... and the rows such a pass reads once (measured on config 3, program order: cfas 2.77 -> 2.46 ms, ecfr 1.92 -> 1.73, relax
+// mode FC 0.65 -> 0.58; the stand-alone F- / C-relaxation keeps the plain loads: 1.5 % slower with the hint)
+__device__ __forceinline__ void load_row_nt(const double *__restrict__ row, unsigned s0, double (&x)[E], int streaming) {
+    if (!streaming) {
+        load_row(row, s0, x);
+        return;
+    }
+    typedef double dv2 __attribute__((ext_vector_type(2)));
+    const dv2 *r2 = reinterpret_cast<const dv2 *>(row) + s0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const dv2 v = __builtin_nontemporal_load(r2 + q * 64);
+        x[2 * q] = v.x;
+        x[2 * q + 1] = v.y;
+    }
+}
+
 // cross-lane moves of a double inside one wave, DPP / readlane (no LDS)
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
@@ -683,9 +700,9 @@ __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *
         wq.prefetch(t);
         const int start = run_start[r], len = run_len[r];
         double x[E], gi[E];
-        load_row((ROLE == ROLE_FC ? L.v : L.u) + (size_t)(start - 1) * L.ld, sl, x);
+        load_row_nt((ROLE == ROLE_FC ? L.v : L.u) + (size_t)(start - 1) * L.ld, sl, x, ROLE == ROLE_FC ? L.stream_rows : 0);
         for (int i = start; i < start + len; ++i) {
-            if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);  // in flight while Phi runs
+            if (USE_G) load_row_nt(L.g + (size_t)i * L.ld, sl, gi, ROLE == ROLE_FC ? L.stream_rows : 0);  // in flight while Phi runs
             phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
             if (USE_G) {
 #pragma unroll
@@ -717,18 +734,18 @@ __global__ void __launch_bounds__(1024) ecf_kernel(LevelDev L, LevelDev Lc, cons
         wq.prefetch(t);
         const int start = run_start[r], len = run_len[r], j = ec_coarse[r];
         double x[E], gi[E];
-        load_row(L.u + (size_t)(start - 1) * L.ld, sl, x);
+        load_row_nt(L.u + (size_t)(start - 1) * L.ld, sl, x, L.stream_rows);
         if (j >= 0) {
             // v^{l+1}_j is not read: fas_residual made it the clone of u^l at this very C-point (identity transfer) and nothing
             // has touched level l since (iteration(): fas_residual(l), iteration(l+1), then this), so v_j == x bit for bit
             double uc[E];
-            load_row(Lc.u + (size_t)j * Lc.ld, sl, uc);
+            load_row_nt(Lc.u + (size_t)j * Lc.ld, sl, uc, Lc.stream_rows);
 #pragma unroll
             for (int k = 0; k < E; ++k) x[k] = x[k] + (uc[k] - x[k]);
             store_row_nt(L.u + (size_t)(start - 1) * L.ld, sl, x, L.stream_rows);
         }
         for (int i = start; i < start + len; ++i) {
-            if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);
+            if (USE_G) load_row_nt(L.g + (size_t)i * L.ld, sl, gi, L.stream_rows);
             phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
             if (USE_G) {
 #pragma unroll
@@ -977,13 +994,13 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
         {
             const int cs = I.cstart[i0];
             if (I.chunk_start_coarse[k] >= 0) {   // C'_j of the chunk's first C-point, recomputed (pre: it is what the row holds)
-                load_row(L.u + (size_t)(cs - 1) * L.ld, sl, x);
+                load_row_nt(L.u + (size_t)(cs - 1) * L.ld, sl, x, L.stream_rows);
                 if (!pre) {
                     if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);
                     phi_apply<KIND, FORCE, true>(x, ctx, L, cs, sm, t, lane, wave, G);
                 }
             } else {
-                load_row(L.u + (size_t)cs * L.ld, sl, x);
+                load_row_nt(L.u + (size_t)cs * L.ld, sl, x, L.stream_rows);
             }
         }
         for (int it = i0; it < i0 + cnt; ++it) {
@@ -999,7 +1016,7 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
             if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);   // not kept alive across the coarse Phi
             for (int i = cs + 1; i < ce; ++i) phi_apply<KIND, FORCE, true>(x, ctx, L, i, sm, t, lane, wave, G);
             double b[E];
-            load_row(L.u + (size_t)(ce - 1) * L.ld, sl, b);   // (requested one Phi earlier it costs more in spills than it hides)
+            load_row_nt(L.u + (size_t)(ce - 1) * L.ld, sl, b, L.stream_rows);   // (requested one Phi earlier it costs more in spills than it hides)
             if (!pre) phi_apply<KIND, FORCE, true>(b, ctx, L, ce, sm, t, lane, wave, G);
             store_row_nt(L.u + (size_t)ce * L.ld, sl, b, L.stream_rows);
             const int keep = __builtin_amdgcn_readfirstlane(I.keep[it]);
@@ -1054,19 +1071,19 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
             const int cs = I.cstart[i0], js = I.chunk_start_coarse[k];
             if (js >= 0) {   // the corrected value of the chunk's first C-point (stored by the chunk that ends on it)
                 double w[E];
-                load_row(Lc.v + (size_t)js * Lc.ld, sl, x);
-                load_row(Lc.u + (size_t)js * Lc.ld, sl, w);
+                load_row_nt(Lc.v + (size_t)js * Lc.ld, sl, x, Lc.stream_rows);
+                load_row_nt(Lc.u + (size_t)js * Lc.ld, sl, w, Lc.stream_rows);
 #pragma unroll
                 for (int e = 0; e < E; ++e) x[e] = x[e] + (w[e] - x[e]);
             } else {
-                load_row(L.u + (size_t)cs * L.ld, sl, x);
+                load_row_nt(L.u + (size_t)cs * L.ld, sl, x, L.stream_rows);
             }
         }
         for (int it = i0; it < i0 + cnt; ++it) {
             const int cs = I.cstart[it], ce = I.cend[it], jc = I.cend_coarse[it];
             for (int i = cs + 1; i < ce; ++i) {
                 double gi[E];
-                if (USE_G) load_row(L.g + (size_t)i * L.ld, sl, gi);   // in flight while Phi runs
+                if (USE_G) load_row_nt(L.g + (size_t)i * L.ld, sl, gi, L.stream_rows);   // in flight while Phi runs
                 phi_apply<KIND, FORCE, CF>(x, ctx, L, i, sm, t, lane, wave, G);
                 if (USE_G) {
 #pragma unroll
@@ -1077,8 +1094,8 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
             double b[E];
             {   // v^{l+1}_{j+1} from the fine row itself (the same bits; only this chunk writes that row), see IntervalsDev::keep
                 double w[E];
-                load_row(L.u + (size_t)ce * L.ld, sl, b);
-                load_row(Lc.u + (size_t)jc * Lc.ld, sl, w);
+                load_row_nt(L.u + (size_t)ce * L.ld, sl, b, L.stream_rows);
+                load_row_nt(Lc.u + (size_t)jc * Lc.ld, sl, w, Lc.stream_rows);
 #pragma unroll
                 for (int e = 0; e < E; ++e) b[e] = b[e] + (w[e] - b[e]);
             }
@@ -1126,9 +1143,9 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         if (PROP) {
             // ONE call site of the fine Phi for the F-steps and for the step onto the C-point (two inlined copies made the
             // register allocator spill 250 VGPRs): every step is x = w + Phi(x) with w = g_k, and w = g_i - u_i for the last
-            load_row(L.u + (size_t)ip * L.ld, sl, x);
+            load_row_nt(L.u + (size_t)ip * L.ld, sl, x, L.stream_rows);
             for (int k = ip + 1; k <= i; ++k) {
-                load_row(L.g + (size_t)k * L.ld, sl, w);   // in flight while Phi runs (PROP implies use_g)
+                load_row_nt(L.g + (size_t)k * L.ld, sl, w, L.stream_rows);   // in flight while Phi runs (PROP implies use_g)
                 if (k == i) {
                     double ui[E];
                     load_row(L.u + (size_t)i * L.ld, sl, ui);
@@ -1167,7 +1184,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] + w[k];   // + v_j : the partial g of the coarse level
         // ---- coarse Phi on v_{j-1} = u^l_{ip}
-        load_row(L.u + (size_t)ip * L.ld, sl, w);
+        load_row_nt(L.u + (size_t)ip * L.ld, sl, w, L.stream_rows);
         const int cj = ld_uniform(Lc.cidx + j);
         const CSet *gc = Lc.cs + cj;
         smc.wf = const_cast<double *>(gc->pg);
