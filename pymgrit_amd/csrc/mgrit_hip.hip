@@ -944,12 +944,14 @@ __device__ __forceinline__ void phi_other_level(double (&w)[E], StepCtx &ctx, co
             }
         }
     }
-    Coef cc;
-    load_coef(cc, gc);
+    // the other level's scalars take the PLACE of the caller's (ctx.c): with a second set beside it ~120 wave-uniform doubles
+    // would be live at once, more than the SGPR file holds. The caller reloads its own set afterwards, unconditionally, so
+    // that the compiler sees ctx.c dead across this call.
+    load_coef(ctx.c, gc);
     const LaneCoef lcc = lane_coef(gc->lp, lane);
     const int par = ctx.parity;
     ctx.parity ^= 1;
-    heat_solve<true>(w, cc, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
+    heat_solve<true>(w, ctx.c, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
 }
 
 // Interval list of the fused level sweeps below: item = the interval from one C-point to the next,
@@ -1013,7 +1015,7 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
 #pragma unroll
                 for (int q = 0; q < 8; ++q) sm.tab[sl + q * 64] = make_double2(w[2 * q], w[2 * q + 1]);   // parked in LDS
             }
-            if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);   // not kept alive across the coarse Phi
+            load_coef(ctx.c, L.cs + (ctx.cur >= 0 ? ctx.cur : 0));   // back to this level's set (ctx.cur < 0: any set, phi_apply loads the right one)
             for (int i = cs + 1; i < ce; ++i) phi_apply<KIND, FORCE, true>(x, ctx, L, i, sm, t, lane, wave, G);
             double b[E];
             load_row_nt(L.u + (size_t)(ce - 1) * L.ld, sl, b, L.stream_rows);   // (requested one Phi earlier it costs more in spills than it hides)
@@ -1209,7 +1211,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
                 }
             }
         }
-        {
+        {   // (a set of its own here: in the place of ctx.c, as in phi_other_level, this kernel measured 3 % slower)
             Coef cc;
             load_coef(cc, gc);
             const LaneCoef lcc = lane_coef(gc->lp, lane);
