@@ -755,12 +755,15 @@ class HipBackend:
         pass (mgrit_hip_ec_relax_res; with the rows of g and without the residual on lvl > 0)"""
         tr = self.mg.transfer_objects[lvl]
         da, db = self.desc[lvl], self.desc[lvl + 1]
-        # Off unless PYMGRIT_AMD_FUSE_UP_COARSE=1. Measured on config 3 (round 2): its intervals correct the C-point they END
-        # on, so in a planned cycle a block waits for the chain of its own block only (ecf_kernel: of the next block too) and
-        # the drain of the block pipeline shrinks -- but the launch itself is slower than ecf_kernel (1.09 vs 0.90 ms per
-        # cycle: every interval reads its two boundary corrections), and with six blocks the sweep stream, not the chain,
-        # is what the cycle waits for: 11.1 ms against 10.8.
-        return (os.environ.get("PYMGRIT_AMD_FUSE_UP_COARSE", "") == "1" and
+        # Its intervals correct the C-point they END on, so in a planned cycle a block waits for the chain part of its own block
+        # only (ecf_kernel: of the next block too). The launch itself is slower than ecf_kernel (every interval reads its two
+        # boundary corrections), so it pays only together with the merged launch of the first blocks' way up (cycle_plan.py,
+        # Recorder.up_merge) that it makes possible: config 3, six blocks, 8.60 -> 8.24 ms; alone 8.46. On by default exactly
+        # there (a planned cycle of five or more blocks); PYMGRIT_AMD_FUSE_UP_COARSE=1 / 0 forces it on / off.
+        want = os.environ.get("PYMGRIT_AMD_FUSE_UP_COARSE", "")
+        if want not in ("0", "1"):
+            want = "1" if self.mg.plan_blocks() >= 5 else "0"
+        return (want == "1" and
                 os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and self._device_transfer(lvl) and
                 int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and da["kind"] == db["kind"] == "heat1d" and
                 self.n[lvl] == self.n[lvl + 1] and da.get("forcing_rows") is None and db.get("forcing_rows") is None and

@@ -71,6 +71,9 @@ class Recorder:
     def __init__(self, mg, backend, n_blocks):
         self.mg, self.real = mg, backend
         self.K, self.block_of = block_maps(mg.t, n_blocks)
+        # blocks at the front of the time grid whose way up goes into one launch (0 / 1: none): half of them when the cycle has
+        # five or more blocks (measured on config 3 with six: three 8.24 ms, two 8.35, four 9.2, none 8.46-8.60)
+        self.up_merge = int(os.environ.get("PYMGRIT_AMD_PLAN_UP_MERGE", str(self.K // 2 if self.K >= 5 else 0)))
         self.nodes = []
         self.host_after = []        # host-only bookkeeping calls of the cycle: run after every execution of the plan
         self._last_write, self._readers = {}, {}
@@ -122,6 +125,22 @@ class Recorder:
             out.append((int(b), part))
         return out
 
+    def _by_group(self, lvl, items, key_slot):
+        """way up: like _by_block, but the first blocks of the time grid -- whose coarsest-level chain parts have long finished
+        when the way down of the last block has (the chain starts behind the first block's way down and is faster than the
+        sweeps that feed it) -- go into ONE launch: a launch over four sixths of a level runs at nearly the full-width rate,
+        four one-sixth launches do not. [(first block, IndexList, member blocks)]"""
+        parts = self._by_block(lvl, items, key_slot)
+        merge = self.up_merge
+        if merge <= 1 or len(parts) <= 1:
+            return [(b, part, (b,)) for b, part in parts]
+        head = [(b, part) for b, part in parts if b < merge]
+        out = []
+        if head:
+            out.append((head[0][0], IndexList(it for _, part in head for it in part), tuple(b for b, _ in head)))
+        out.extend((b, part, (b,)) for b, part in parts if b >= merge)
+        return out
+
     def _split_runs(self, lvl, runs):
         """runs cut at block borders (a run continued in the next block reads the last point of its first part)"""
         out = []
@@ -169,13 +188,13 @@ class Recorder:
         if not triples:
             return
         real = self.real
-        for b, part in self._by_block(lvl, triples, 0):
+        for b, part, members in self._by_group(lvl, triples, 0):
             st = np.asarray([t[0] for t in part], dtype=np.int64)
             co = np.asarray([t[2] for t in part], dtype=np.int64)
             n_pts = int(sum(t[1] for t in part))
             front = self._cells("u", lvl, st - 1)
-            reads = front | self._cells("u", lvl + 1, co[co >= 0]) | ({("g", lvl, b)} if lvl > 0 else set())
-            writes = {("u", lvl, b)} | self._cells("u", lvl, (st - 1)[co >= 0])
+            reads = front | self._cells("u", lvl + 1, co[co >= 0]) | ({("g", lvl, m) for m in members} if lvl > 0 else set())
+            writes = {("u", lvl, m) for m in members} | self._cells("u", lvl, (st - 1)[co >= 0])
             self._add("ec_relax", lvl, b, lambda p=part: real.ec_relax(lvl, p), reads, writes,
                       2 * len(part) + int(np.count_nonzero(co >= 0)) + n_pts * (2 if lvl > 0 else 1))
 
@@ -237,15 +256,16 @@ class Recorder:
 
     def ec_relax_res(self, lvl, intervals):
         real = self.real
-        for b, part in self._by_block(lvl, intervals, 1):
+        for b, part, members in self._by_group(lvl, intervals, 1):
             cs, ce, jcs, jce = _interval_cells(self, lvl, part)
             reads = self._cells("u", lvl + 1, jce) | self._cells("v", lvl + 1, jce) | self._cells("u", lvl + 1, jcs[jcs >= 0]) | \
                 self._cells("v", lvl + 1, jcs[jcs >= 0]) | self._cells("u", lvl, cs[jcs < 0])
             if lvl > 0:
-                reads |= {("g", lvl, b)}
+                reads |= {("g", lvl, m) for m in members}
             n_f = int(np.sum(ce - cs - 1))
+            own = {("u", lvl, m) for m in members}
             self._add("ec_relax_res", lvl, b, lambda p=part: real.ec_relax_res(lvl, p), reads,
-                      {("u", lvl, b), ("res", lvl, b)} if lvl == 0 else {("u", lvl, b)}, 3 * len(part) + n_f * (2 if lvl > 0 else 1))
+                      own | {("res", lvl, m) for m in members} if lvl == 0 else own, 3 * len(part) + n_f * (2 if lvl > 0 else 1))
 
     def write_generation(self):
         return getattr(self.real, "write_generation", lambda: None)()
