@@ -1612,6 +1612,7 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(ecfr_kernel<4, false, true>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<0, true, false>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<2, true, false>))) return rc;
+    if ((rc = allow_big_lds(ecfr_kernel<4, true, false>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<0, false>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<2, false>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<0, true>))) return rc;
@@ -2982,6 +2983,7 @@ static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int sto
     if (lvl > 0) {   // coarser level: rows of g, every F-point stored (the finer level's correction reads them), no residual
         Timed timed(e, MGRIT_HIP_T_EC_RELAX, lvl);
         if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1);
+        else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1);   // one term: its space factor in LDS
         else hipLaunchKernelGGL((ecfr_kernel<2, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1);
         HIP_TRY(hipGetLastError());
         return 0;
