@@ -39,6 +39,28 @@ def test_planned_cycle_bit_identical(case):
             assert np.array_equal(a, b), (case, blocks)
 
 
+@pytest.mark.parametrize("merge", [None, "2", "5"])
+def test_merged_way_up_bit_identical(monkeypatch, merge):
+    """eight blocks: the way up of the first blocks is ONE launch per level (cycle_plan.Recorder.up_merge: half of the blocks
+    by default from five blocks on, with the coarser levels' way up through the interval pass); same numbers as program order"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    conv0, u0, _ = solve("heat_config2", 1)
+    if merge is None:
+        monkeypatch.delenv("PYMGRIT_AMD_PLAN_UP_MERGE", raising=False)
+    else:
+        monkeypatch.setenv("PYMGRIT_AMD_PLAN_UP_MERGE", merge)
+    conv, u, mg = solve("heat_config2", 8)
+    plan = next(p for p in mg._plans.values() if p is not None and p.n_blocks > 1)
+    want = plan.n_blocks - (int(merge) if merge else plan.n_blocks // 2) + 1
+    for lvl in (0, 1):
+        ups = [n for n in plan.nodes if n.name == "ec_relax_res" and n.lvl == lvl]
+        assert len(ups) == want, (lvl, [n.chunk for n in ups])
+    assert np.array_equal(conv, conv0)
+    for a, b in zip(u, u0):
+        assert np.array_equal(a, b)
+
+
 def test_planned_wide_chain_against_oracle(oracle):
     """wide states, many coarsest points: the chain parts continue each other through the hand-over state; residual history
     equal to the oracle's (same arithmetic spec) and the state bit-exact"""
