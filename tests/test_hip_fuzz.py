@@ -3,7 +3,8 @@ sizes around the group boundaries, coarsening factors 2..8, two to four levels, 
 off, non-uniform time grids. A wider sweep of the same generator: `python tests/test_hip_fuzz.py 200` (round 1, final build:
 10000 of 10000 seeds bit-exact; round 2, with the whole-level passes, the closed-form correction and C-point storage: 20000 of
 20000; end of round 2, with the one-workgroup chain, the non-temporal row accesses and the library-chosen chunks:
-`python tests/test_hip_fuzz.py 40000 50000` -- 40000 of 40000 new seeds, and 12000 of 12000 from seed 30000)."""
+`python tests/test_hip_fuzz.py 40000 50000` -- 40000 of 40000 new seeds, 12000 of 12000 from seed 30000, and on the final build
+30000 of 30000 from seed 100000)."""
 import sys
 
 import numpy as np
