@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MGRIT_HIP_ABI_VERSION 2
+#define MGRIT_HIP_ABI_VERSION 3
 #define MGRIT_HIP_E 16            /* elements per lane (arithmetic spec) */
 #define MGRIT_HIP_MAX_N 16384     /* max DOFs per time point for the register-resident steppers */
 #define MGRIT_HIP_MAX_N_2PTS 4096 /* two-point steppers: max DOFs per time point of a pair (two coefficient sets in LDS) */
@@ -227,7 +227,7 @@ enum { MGRIT_HIP_T_RELAX_F = 0, MGRIT_HIP_T_RELAX_C = 1, MGRIT_HIP_T_CHAIN = 2, 
        MGRIT_HIP_T_RESTRICT = 5, MGRIT_HIP_T_COPY = 6, MGRIT_HIP_T_FAS_RHS = 7, MGRIT_HIP_T_FAS_FUSED = 8,
        MGRIT_HIP_T_ERROR_CORRECTION = 9, MGRIT_HIP_T_INTERPOLATE = 10, MGRIT_HIP_T_EC_RELAX = 11, MGRIT_HIP_T_AT = 12,
        MGRIT_HIP_T_CF_FAS = 13, MGRIT_HIP_T_EC_RELAX_RES = 14, MGRIT_HIP_T_RELAX_FC = 15, MGRIT_HIP_T_F_FAS = 16,
-       MGRIT_HIP_T_KINDS = 17 };
+       MGRIT_HIP_T_EXCHANGE = 17, MGRIT_HIP_T_KINDS = 18 };
 int mgrit_hip_set_timing(mgrit_hip_engine *e, int enabled);
 int mgrit_hip_last_kernel_ms(mgrit_hip_engine *e, float *ms);
 int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int *lvl, float *ms, int *n_out);
@@ -243,6 +243,61 @@ int mgrit_hip_chain_clock(mgrit_hip_engine *e, double *mhz, double *us_per_step)
  * land on XCD 0 only 32 - n_cus per CU-slot stay) and the chain launches take their workers from XCD 0: the two run side by
  * side on two streams. 0 (default): every sweep fills the chip, the chain's workers are the blocks with blockIdx % 8 == 0. */
 int mgrit_hip_set_reserve(mgrit_hip_engine *e, int n_cus);
+
+/*
+ * Ghost exchange between the owners of neighbouring time points: Mgrit.send / Mgrit.receive (mgrit.py:693-713, pickled mpi4py
+ * isend + blocking recv matched by tag) and their call sites -- f_relax ops 0 / 1 (mgrit.py:306,310,317,331), c_relax op 2
+ * (mgrit.py:348,352), compute_residual op 7 (mgrit.py:399,403), forward_solve op 5 (mgrit.py:469,484), fas_residual ops 3 / 4
+ * (mgrit.py:504-517). Here a message is a whole slab row moved by a STREAM operation of the engine (on the stream of
+ * mgrit_hip_set_stream, like every sweep): ordered against the kernels that produce and consume the row by the stream
+ * alone, one host call, capturable into a hipGraph with the sweeps around it. Messages of one link are matched by their
+ * order, which is the order of the exchange points of Mgrit.iteration -- the same on both owners.
+ *
+ * A link (handle 0 .. MGRIT_HIP_MAX_LINKS-1, chosen by the caller) is ONE direction of one pair of ranks:
+ *   mgrit_hip_link_attach   an RCCL communicator (ncclSend / ncclRecv over xGMI on an MI355X node); peer = the other rank in
+ *                           it. Either any ncclComm_t the caller already has, or one made here: mgrit_hip_comm_unique_id on
+ *                           one rank (128 bytes, passed to the others by the caller), mgrit_hip_comm_init_rank on every rank
+ *                           of it (= ncclCommInitRank, collective), mgrit_hip_comm_destroy at the end (abort != 0:
+ *                           ncclCommAbort). pymgrit_amd makes a two-rank communicator per link and channel, so that a
+ *                           communicator is only ever used from one stream at a time and a send waiting for its receiver never
+ *                           holds back a receive from another rank. The caller keeps ownership of attached communicators.
+ *   mgrit_hip_link_mailbox  all ranks in ONE process on ONE GPU (tests, bench.py --emulate-rank): both ends name the same
+ *                           mailbox (mgrit_hip_mailbox_create: n_slots rows of slot_doubles doubles in device memory); a send
+ *                           copies the row into slot `slot`, a receive copies it out -- who may touch which slot when is the
+ *                           caller's hand-shake (pymgrit_amd/core/comm.py, LoopbackComm). RCCL links ignore `slot`.
+ * librccl is loaded on first use (no link-time dependency); without it the RCCL entry points return MGRIT_HIP_EUNSUPPORTED.
+ *
+ * mgrit_hip_exchange: ONE exchange point of operation op (0-5, 7) on level lvl: send row send_idx of u^lvl over send_link
+ * (send_link < 0: nothing to send), then receive row recv_idx over recv_link (< 0: nothing). Operation 5 (the hand-over of
+ * forward_solve) with handover = mgrit_hip_chain_state_len(lvl) > 0 moves the chain's running state behind the point and
+ * arms mgrit_hip_chain_resume on the receiving side. mgrit_hip_send / mgrit_hip_recv: the same for count doubles at any
+ * device address (rows the caller has staged, e.g. by mgrit_hip_error_correction_to).
+ * mgrit_hip_sync_bounded: mgrit_hip_sync that gives up after timeout_s seconds -- a peer that never sends or never receives
+ * must end in an error of this rank, not in a silent stall: the links are aborted (ncclCommAbort) and an error is returned.
+ */
+#define MGRIT_HIP_MAX_LINKS 16
+int mgrit_hip_comm_unique_id(void *id_out_128_bytes);
+int mgrit_hip_comm_init_rank(void **nccl_comm_out, const void *unique_id_128_bytes, int nranks, int rank);
+int mgrit_hip_comm_destroy(void *nccl_comm, int abort);
+int mgrit_hip_link_attach(mgrit_hip_engine *e, int link, void *nccl_comm, int peer);
+int mgrit_hip_mailbox_create(void **mailbox_out, int n_slots, int slot_doubles);
+int mgrit_hip_mailbox_destroy(void *mailbox);
+int mgrit_hip_link_mailbox(mgrit_hip_engine *e, int link, void *mailbox);
+int mgrit_hip_link_stats(mgrit_hip_engine *e, int link, uint64_t *messages_sent, uint64_t *bytes_sent, uint64_t *messages_received);
+int mgrit_hip_links_close(mgrit_hip_engine *e, int abort);
+int mgrit_hip_exchange(mgrit_hip_engine *e, int lvl, int op, int send_link, int send_idx, int send_slot, int recv_link,
+                       int recv_idx, int recv_slot, int handover);
+int mgrit_hip_send(mgrit_hip_engine *e, int link, int slot, const double *rows, int count);
+int mgrit_hip_recv(mgrit_hip_engine *e, int link, int slot, double *rows, int count);
+int mgrit_hip_sync_bounded(mgrit_hip_engine *e, double timeout_s);
+/* Mgrit.error_correction (mgrit.py:715-726) of the pairs with the corrected rows written to rows_out[p] (device, row stride
+ * ld_out >= the level's) instead of back into u^l: a rank sends the corrected value of its LAST C-point to the next owner
+ * (op 0 of the F-relaxation that follows, mgrit.py:306) before the whole-level pass that corrects it in place has run. */
+int mgrit_hip_error_correction_to(mgrit_hip_engine *e, int lvl, int pairs_id, double *rows_out, int ld_out);
+/* copies the n per-point sums of squares of the last mgrit_hip_ec_relax_res pass (the engine's pinned buffer) to dst
+ * (device-accessible, e.g. pinned host memory) on the stream: a replayed cycle always writes the engine's buffer, a solver
+ * that looks at its stopping values some cycles late (Mgrit._solve_pipelined) keeps each cycle's values in a slot of its own */
+int mgrit_hip_residual_stash(mgrit_hip_engine *e, int n, double *dst);
 
 #ifdef __cplusplus
 }

@@ -219,6 +219,37 @@ class HipBackend:
                 raise MgritHipError(f"transfer {type(tr).__name__} is applied through its Python methods, which the "
                                     f"{self.desc[lvl]['kind']} levels do not support (they take GridTransferCopy)")
             check(self.lib.mgrit_hip_level_transfer(self.h, lvl, kind))
+        # ghost rows as stream operations of the engine (mgrit_hip_exchange) when the time communicator offers links
+        # (RcclTimeComm, LoopbackComm): opening them is collective -- every rank is in its constructor at this point
+        self.device_links = False
+        comm = mg.comm_time
+        if mg.comm_time_size > 1 and getattr(comm, "device_exchange", False) and \
+                os.environ.get("PYMGRIT_AMD_EXCHANGE", "") != "torch":
+            from pymgrit_amd.core.comm import links_needed
+            comm.open_links(self, links_needed(mg))
+            self.device_links = True
+
+    def exchange(self, lvl, op, send_idx=None, dest=None, recv_idx=None, src=None):
+        """one exchange point (reference mgrit.py:693-713) as stream operations of the engine: mgrit_hip_exchange sends row
+        send_idx of u^lvl to rank dest and receives row recv_idx from rank src (ncclSend / ncclRecv on an RCCL link); the
+        hand-over of forward_solve (op 5) takes the chain's running state along"""
+        from pymgrit_amd.core.comm import CH_CHAIN, CH_SWEEP
+        comm, ch = self.mg.comm_time, (CH_CHAIN if op == 5 else CH_SWEEP)
+        if lvl == 0 and send_idx is not None:
+            self.materialise()
+        sl = ss = rl = rs = -1
+        if send_idx is not None:
+            sl, ss = comm.send_begin(self, dest, ch)
+        if recv_idx is not None:
+            rl, rs = comm.recv_begin(self, src, ch)
+            self._residual_cache = None
+        check(self.lib.mgrit_hip_exchange(self.h, lvl, op, sl, -1 if send_idx is None else int(send_idx), ss, rl,
+                                          -1 if recv_idx is None else int(recv_idx), rs,
+                                          int(self.chain_handover.get(lvl, 0) or 0) if op == 5 else 0))
+        if send_idx is not None:
+            comm.send_end(self, dest, ch)
+        if recv_idx is not None:
+            comm.recv_end(self, src, ch)
 
     def _host_transfers(self):
         return any(not self._device_transfer(lvl) for lvl in range(self.mg.lvl_max - 1))
@@ -836,7 +867,10 @@ class HipBackend:
             check(self.lib.mgrit_hip_interpolate(self.h, lvl, self._pair_id(lvl, pairs)))
 
     def sync(self):
-        check(self.lib.mgrit_hip_sync(self.h))
+        if getattr(self, "device_links", False):   # a neighbour that never sends or never receives must end in an error here
+            check(self.lib.mgrit_hip_sync_bounded(self.h, float(getattr(self.mg.comm_time, "timeout_s", 120.0))))
+        else:
+            check(self.lib.mgrit_hip_sync(self.h))
 
     # -- measurement hooks (bench.py) ------------------------------------------------------------------
     def set_timing(self, on):

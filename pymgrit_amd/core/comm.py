@@ -200,19 +200,392 @@ class TorchTimeComm:
         return result
 
 
-_default_comm = {}   # process group -> its TorchTimeComm: the per-neighbour links and the side group are created once per
-                     # group and shared by every solver instance of the process (new_group is collective and never freed)
+# ----------------------------------------------------------------------------------------------------------------------
+# Device exchange: ghost rows as stream operations of the HIP engine (include/mgrit_hip.h: mgrit_hip_exchange)
+# ----------------------------------------------------------------------------------------------------------------------
+CH_SWEEP, CH_CHAIN = 0, 1     # channel of a link: every exchange point but op 5 / the hand-over of forward_solve (op 5)
+
+
+class _EngineLinks:
+    """link handles of one engine: (peer, direction, channel) -> handle index of include/mgrit_hip.h"""
+
+    def __init__(self):
+        self.handle = {}
+
+    def add(self, key):
+        from pymgrit_amd.core import hip_lib
+        if key not in self.handle:
+            if len(self.handle) >= hip_lib.MAX_LINKS:
+                raise RuntimeError("more exchange links than the engine has handles")
+            self.handle[key] = len(self.handle)
+        return self.handle[key]
+
+
+def links_needed(mg):
+    """the directed links (src, dst, channel) this rank takes part in, from the layout of every level (Mgrit.send_to /
+    get_from, reference mgrit.py:816-827): channel CH_CHAIN for the hand-over of the coarsest level's forward solve"""
+    rank, need = mg.comm_time_rank, set()
+    for lvl in range(mg.lvl_max):
+        for src, dst in ((mg.get_from[lvl], rank), (rank, mg.send_to[lvl])):
+            if src >= 0 and dst >= 0 and src != dst:
+                need.add((int(src), int(dst), CH_SWEEP))
+                if lvl == mg.lvl_max - 1:
+                    need.add((int(src), int(dst), CH_CHAIN))
+    return sorted(need)
+
+
+class RcclTimeComm(TorchTimeComm):
+    """TorchTimeComm whose ghost rows travel under the C ABI: ncclSend / ncclRecv issued by libmgrit_hip.so on the engine's
+    streams (mgrit_hip_exchange), one two-rank RCCL communicator per directed link and channel. torch.distributed keeps the
+    host-side collectives (rendezvous of the unique ids, the stopping values, barriers). Default time communicator when the
+    process group's backend is "nccl"; PYMGRIT_AMD_EXCHANGE=torch keeps every exchange in torch.distributed."""
+    device_exchange = True
+
+    def __init__(self, group=None):
+        super().__init__(group)
+        self._comms = {}       # (src, dst, channel) -> ncclComm_t (c_void_p), created once per process group
+        self._engines = {}     # id(backend) -> _EngineLinks
+        self.timeout_s = float(os.environ.get("PYMGRIT_AMD_EXCHANGE_TIMEOUT", "120"))
+
+    def open_links(self, backend, need):
+        """collective: every rank names the links it takes part in; the sending rank of a link makes the unique id, everybody
+        learns all ids, and the two ends of each link create its communicator -- links in ONE global order on all ranks
+        (senders of even rank first: those run in parallel), so no two ranks ever wait for each other crosswise."""
+        import ctypes as C
+        from pymgrit_amd.core import hip_lib
+        lib = hip_lib.load()
+        all_need = sorted({tuple(k) for part in self.allgather_object(list(need)) for k in part})
+        missing = [k for k in all_need if k not in self._comms]
+        if missing:
+            mine = {}
+            for k in missing:
+                if k[0] == self.rank:
+                    buf = C.create_string_buffer(128)
+                    hip_lib.check(lib.mgrit_hip_comm_unique_id(buf))
+                    mine[k] = buf.raw
+            ids = {}
+            for part in self.allgather_object(mine):
+                ids.update(part)
+            for k in sorted(missing, key=lambda k: (k[0] % 2, k)):
+                if self.rank in k[:2]:
+                    comm = C.c_void_p()
+                    hip_lib.check(lib.mgrit_hip_comm_init_rank(C.byref(comm), ids[k], 2, 0 if k[0] == self.rank else 1))
+                    self._comms[k] = comm
+        links = self._engines[id(backend)] = _EngineLinks()
+        for k in need:
+            k = tuple(k)
+            send = k[0] == self.rank
+            h = links.add((k[1] if send else k[0], 'send' if send else 'recv', k[2]))
+            hip_lib.check(lib.mgrit_hip_link_attach(backend.h, h, self._comms[k], 1 if send else 0))
+
+    def send_begin(self, backend, dest, channel):
+        self.stats["messages"] += 1
+        self.stats["device_messages"] += 1
+        return self._engines[id(backend)].handle[(int(dest), 'send', channel)], 0
+
+    def recv_begin(self, backend, src, channel):
+        return self._engines[id(backend)].handle[(int(src), 'recv', channel)], 0
+
+    def send_end(self, backend, dest, channel):
+        return None
+
+    recv_end = send_end
+
+    def cycle_begin(self, backend, sends, recvs):
+        return None
+
+    def cycle_end(self, backend, sends, recvs):
+        for key, n in sends.items():
+            self.stats["messages"] += n
+            self.stats["device_messages"] += n
+
+    def close(self):
+        from pymgrit_amd.core import hip_lib
+        lib = hip_lib.load()
+        for comm in self._comms.values():
+            lib.mgrit_hip_comm_destroy(comm, 0)
+        self._comms = {}
+
+
+class _LoopLink:
+    """one directed link of a LoopbackWorld: a mailbox in device memory + the host-side counters of the hand-shake"""
+
+    def __init__(self, mailbox, n_ring, n_cycle):
+        self.mailbox, self.n_ring, self.n_cycle = mailbox, n_ring, n_cycle
+        self.sent = self.received = 0            # single messages (ring slots)
+        self.cyc_sent = self.cyc_received = 0    # whole cycles of a planned run (cycle slots)
+
+
+class LoopbackWorld:
+    """All ranks of a run in ONE process on ONE GPU: ranks are threads (or, frozen, a single rank replaying against what its
+    neighbours last sent: bench.py --emulate-rank). Ghost rows go through mailboxes in device memory (mgrit_hip_link_mailbox):
+    a send copies the row into a slot, a receive copies it out, both as operations of the ONE stream all ranks share -- so
+    the device executes them in the order the hosts enqueued them, and the hand-shake only has to make a receiver enqueue
+    after its sender (and a sender reuse a slot after its receiver): host-side counters under one condition variable.
+    Single messages use a ring of slots; the messages of a planned cycle (core/cycle_plan.py) use fixed slots -- the k-th
+    message of the cycle on a link always the same one, as a captured graph needs it -- and shake hands once per cycle."""
+
+    N_RING, N_CYCLE = {CH_SWEEP: 64, CH_CHAIN: 8}, {CH_SWEEP: 128, CH_CHAIN: 8}
+
+    def __init__(self, size):
+        import threading
+        self.size = int(size)
+        self.cond = threading.Condition()
+        self.barrier_obj = threading.Barrier(self.size)
+        self.links, self.objects, self.gathers, self.queues = {}, {}, {}, {}
+        self.frozen = False        # no hand-shake: a single rank against the slots' last contents
+        self.stream = None
+        self.timeout = float(os.environ.get("PYMGRIT_AMD_LOOPBACK_TIMEOUT", "120"))
+
+    def comm(self, rank):
+        return LoopbackComm(self, rank)
+
+    def link(self, key, slot_doubles):
+        import ctypes as C
+        from pymgrit_amd.core import hip_lib
+        with self.cond:
+            ln = self.links.get(key)
+            if ln is None:
+                lib = hip_lib.load()
+                n_ring, n_cycle = self.N_RING[key[2]], self.N_CYCLE[key[2]]
+                mb = C.c_void_p()
+                hip_lib.check(lib.mgrit_hip_mailbox_create(C.byref(mb), n_ring + n_cycle, int(slot_doubles)))
+                ln = self.links[key] = _LoopLink(mb, n_ring, n_cycle)
+                ln.slot_doubles = int(slot_doubles)
+            elif ln.slot_doubles < slot_doubles:
+                raise RuntimeError("loopback link reused with wider rows")
+            return ln
+
+    def wait(self, pred, what):
+        """cond is held by the caller"""
+        if not self.cond.wait_for(pred, timeout=self.timeout):
+            raise RuntimeError(f"loopback exchange: {what} did not happen within {self.timeout} s (deadlock?)")
+
+    def close(self):
+        from pymgrit_amd.core import hip_lib
+        lib = hip_lib.load()
+        for ln in self.links.values():
+            lib.mgrit_hip_mailbox_destroy(ln.mailbox)
+        self.links = {}
+
+
+class LoopbackComm:
+    """time communicator of one rank of a LoopbackWorld (see there)"""
+    device_exchange = True
+    async_gather = True
+
+    def __init__(self, world, rank):
+        self.world, self.rank, self.size = world, int(rank), world.size
+        self._engines, self._objseq, self._gseq = {}, 0, 0
+        self.stats = {"messages": 0, "bytes": 0, "device_messages": 0}
+
+    def Get_rank(self):
+        return self.rank
+
+    def Get_size(self):
+        return self.size
+
+    def prepare(self):
+        return None
+
+    def drain(self):
+        return None
+
+    def barrier(self):
+        if not self.world.frozen:
+            self.world.barrier_obj.wait(timeout=self.world.timeout)
+
+    def allgather_object(self, obj):
+        w = self.world
+        if w.frozen:
+            raise RuntimeError("a frozen loopback world has no collectives")
+        self._objseq += 1
+        with w.cond:
+            w.objects.setdefault(self._objseq, {})[self.rank] = obj
+            w.cond.notify_all()
+            w.wait(lambda: len(w.objects[self._objseq]) == w.size, "all-gather")
+            return [w.objects[self._objseq][r] for r in range(w.size)]
+
+    def iallgather_floats(self, values, max_count):
+        w = self.world
+        self._gseq += 1
+        seq = self._gseq
+        with w.cond:
+            w.gathers.setdefault(seq, {})[self.rank] = [float(v) for v in values]
+            w.cond.notify_all()
+
+        class _Handle:
+            def result(_self):
+                with w.cond:
+                    w.wait(lambda: len(w.gathers[seq]) == w.size, "stopping values")
+                    return [list(w.gathers[seq][r]) for r in range(w.size)]
+        return _Handle()
+
+    def exchange(self, send=None, recv=None):
+        """host-driven exchange (small Python payloads; rows of runs that do not use the device exchange): first-in first-out
+        queue per directed pair; tensors are cloned on the shared stream"""
+        import copy
+        import queue
+        w, result = self.world, None
+        if send is not None:
+            payload, dest = send
+            item = payload.detach().clone() if torch.is_tensor(payload) else copy.deepcopy(payload)
+            with w.cond:
+                q = w.queues.setdefault((self.rank, int(dest)), queue.Queue())
+            q.put(item)
+        if recv is not None:
+            buf, src = recv
+            with w.cond:
+                q = w.queues.setdefault((int(src), self.rank), queue.Queue())
+            item = q.get(timeout=w.timeout)
+            if buf is not None and hasattr(buf, "copy_"):
+                buf.copy_(item)
+                result = buf
+            else:
+                result = item
+        return result
+
+    # ---- device exchange ------------------------------------------------------------------------------------------------
+    def open_links(self, backend, need):
+        from pymgrit_amd.core import hip_lib
+        lib = hip_lib.load()
+        w = self.world
+        with w.cond:    # mailboxes order their copies by the ONE stream all ranks enqueue on
+            if w.stream is None:
+                w.stream = backend.stream.cuda_stream
+            elif w.stream != backend.stream.cuda_stream:
+                raise RuntimeError("loopback ranks must share one stream")
+        links = self._engines[id(backend)] = _EngineLinks()
+        links.of = {}
+        for k in need:
+            k = tuple(k)
+            send = k[0] == self.rank
+            ln = w.link(k, 2 * max(backend.ld) + 64 if k[2] == CH_CHAIN else max(backend.ld))
+            h = links.add((k[1] if send else k[0], 'send' if send else 'recv', k[2]))
+            links.of[h] = ln
+            hip_lib.check(lib.mgrit_hip_link_mailbox(backend.h, h, ln.mailbox))
+
+    def _link(self, backend, peer, direction, channel):
+        links = self._engines[id(backend)]
+        h = links.handle[(int(peer), direction, channel)]
+        return h, links.of[h]
+
+    def send_begin(self, backend, dest, channel):
+        h, ln = self._link(backend, dest, 'send', channel)
+        w = self.world
+        self.stats["messages"] += 1
+        self.stats["device_messages"] += 1
+        if w.frozen:
+            return h, 0
+        with w.cond:     # the slot is free once the message n_ring places back has been taken
+            w.wait(lambda: ln.sent - ln.received < ln.n_ring, "a free mailbox slot")
+            return h, ln.sent % ln.n_ring
+
+    def send_end(self, backend, dest, channel):
+        _, ln = self._link(backend, dest, 'send', channel)
+        with self.world.cond:
+            ln.sent += 1
+            self.world.cond.notify_all()
+
+    def recv_begin(self, backend, src, channel):
+        h, ln = self._link(backend, src, 'recv', channel)
+        w = self.world
+        if w.frozen:
+            return h, 0
+        with w.cond:     # ... and the copy out is enqueued behind the copy in
+            w.wait(lambda: ln.sent > ln.received, f"the send of rank {src} to rank {self.rank}")
+            return h, ln.received % ln.n_ring
+
+    def recv_end(self, backend, src, channel):
+        _, ln = self._link(backend, src, 'recv', channel)
+        with self.world.cond:
+            ln.received += 1
+            self.world.cond.notify_all()
+
+    def cycle_slot(self, backend, peer, direction, channel, ordinal):
+        """(handle, slot) of the ordinal-th message of a planned cycle on a link"""
+        h, ln = self._link(backend, peer, direction, channel)
+        if ordinal >= ln.n_cycle:
+            raise RuntimeError("a planned cycle with more messages on a link than the loopback mailbox has cycle slots")
+        return h, ln.n_ring + ordinal
+
+    def cycle_begin(self, backend, sends, recvs):
+        """before a planned cycle is issued (launch by launch or as one graph): its receives after the sender's cycle, its
+        sends after the receiver has issued the cycle before"""
+        w = self.world
+        if w.frozen:
+            return
+        with w.cond:
+            for (peer, ch) in recvs:
+                _, ln = self._link(backend, peer, 'recv', ch)
+                w.wait(lambda ln=ln: ln.cyc_sent > ln.cyc_received and ln.sent == ln.received, f"the cycle of rank {peer}")
+            for (peer, ch) in sends:
+                _, ln = self._link(backend, peer, 'send', ch)
+                w.wait(lambda ln=ln: ln.cyc_sent == ln.cyc_received, f"rank {peer} taking the cycle before")
+
+    def cycle_end(self, backend, sends, recvs):
+        w = self.world
+        for n in sends.values():
+            self.stats["messages"] += n
+            self.stats["device_messages"] += n
+        if w.frozen:
+            return
+        with w.cond:
+            for (peer, ch) in sends:
+                self._link(backend, peer, 'send', ch)[1].cyc_sent += 1
+            for (peer, ch) in recvs:
+                self._link(backend, peer, 'recv', ch)[1].cyc_received += 1
+            w.cond.notify_all()
+
+
+def run_loopback_ranks(size, target, timeout=600):
+    """target(comm) on `size` threads that share the current GPU and stream; returns (world, per-rank results)"""
+    import threading
+    world = LoopbackWorld(size)
+    out, err = [None] * size, [None] * size
+
+    def work(r):
+        try:
+            out[r] = target(world.comm(r))
+        except BaseException as exc:   # noqa: BLE001 - handed to the caller
+            err[r] = exc
+            world.barrier_obj.abort()
+    threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(size)]
+    for t in threads:
+        t.start()
+    import time
+    deadline = time.time() + timeout
+    for t in threads:
+        t.join(max(0.0, deadline - time.time()))
+    if any(e is not None for e in err):
+        raise [e for e in err if e is not None][0]
+    if any(t.is_alive() for t in threads):
+        raise RuntimeError(f"loopback ranks still running after {timeout} s")
+    return world, out
+
+
+_default_comm = {}   # id(process group) -> (the group, its time communicator): the per-neighbour links and the side group are
+                     # created once per group and shared by every solver instance of the process (new_group is collective and
+                     # never freed)
 
 
 def resolve_comm(comm_time):
-    """``comm_time=None`` -> the default process group when torch.distributed is initialised, else serial."""
+    """``comm_time=None`` -> the default process group when torch.distributed is initialised, else serial: RcclTimeComm
+    (ghost rows under the C ABI) on the "nccl" backend, TorchTimeComm (rows through torch.distributed, staged through the host
+    for device slabs) on "gloo"."""
     if comm_time is None:
         if not (dist.is_available() and dist.is_initialized()):
+            _default_comm.clear()
             return SerialComm()
-        key = id(dist.group.WORLD)
-        comm = _default_comm.get(key)
-        if comm is None or comm.backend != dist.get_backend():
-            comm = _default_comm[key] = TorchTimeComm()
+        world = dist.group.WORLD
+        held = _default_comm.get(id(world))
+        # (the id of a destroyed group may be reused: the entry must hold THIS group object)
+        if held is None or held[0] is not world or held[1].backend != dist.get_backend():
+            _default_comm.clear()
+            device = dist.get_backend() == "nccl" and os.environ.get("PYMGRIT_AMD_EXCHANGE", "rccl") != "torch"
+            held = _default_comm[id(world)] = (world, RcclTimeComm() if device else TorchTimeComm())
+        comm = held[1]
+        comm.stats = {"messages": 0, "bytes": 0, "device_messages": 0}    # counters per solver, not per process
         return comm
     if hasattr(comm_time, "exchange") and hasattr(comm_time, "Get_rank"):
         return comm_time

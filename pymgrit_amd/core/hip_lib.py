@@ -10,10 +10,11 @@ RELAX_F, RELAX_C, RELAX_CHAIN, RELAX_FC = 0, 1, 2, 3
 FAS_WITH_F_RELAX, FAS_SKIP_COARSE_U = 1, 2
 # MGRIT_HIP_T_*: kinds of timed entry-point calls (mgrit_hip_timing_drain)
 TIMED_KINDS = ("relax_f", "relax_c", "chain", "residual", "jump", "restrict", "copy", "fas_rhs", "fas_fused",
-               "error_correction", "interpolate", "ec_relax", "at_solve", "cf_fas", "ec_relax_res", "relax_fc", "f_fas")
+               "error_correction", "interpolate", "ec_relax", "at_solve", "cf_fas", "ec_relax_res", "relax_fc", "f_fas", "exchange")
 STEPPER_HEAT1D, STEPPER_ADVECTION1D = 1, 2
 TRANSFER_COPY, TRANSFER_HEAT1D, TRANSFER_CALLER = 0, 1, 3
 MAX_N = 16384
+MAX_LINKS = 16
 
 EXPORTS = {
     # name: (restype, argtypes)
@@ -73,6 +74,22 @@ EXPORTS = {
     "mgrit_hip_ec_relax_res": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgrit_hip_ec_relax_res_to": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mgrit_hip_residual_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    # ghost exchange under the ABI (links: RCCL two-rank communicators / mailboxes)
+    "mgrit_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mgrit_hip_comm_init_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_comm_destroy": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgrit_hip_link_attach": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "mgrit_hip_mailbox_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "mgrit_hip_mailbox_destroy": (C.c_int, [C.c_void_p]),
+    "mgrit_hip_link_mailbox": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mgrit_hip_link_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "mgrit_hip_links_close": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgrit_hip_exchange": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mgrit_hip_send": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "mgrit_hip_recv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "mgrit_hip_sync_bounded": (C.c_int, [C.c_void_p, C.c_double]),
+    "mgrit_hip_error_correction_to": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "mgrit_hip_residual_stash": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
 }
 
 _lib = None
@@ -93,7 +110,7 @@ def load():
         for name, (res, args) in EXPORTS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.mgrit_hip_abi_version() != 2:
+        if lib.mgrit_hip_abi_version() != 3:
             raise MgritHipError("libmgrit_hip.so ABI version mismatch")
         _lib = lib
     return _lib

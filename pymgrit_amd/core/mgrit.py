@@ -345,6 +345,10 @@ class Mgrit:
         if self._dry == 'recv':
             send_idx = None
         backend = self._real_backend if self._dry else self.backend
+        if self._dry is None and self.global_conv_crit and getattr(backend, "device_links", False):
+            if send_idx is not None or recv_idx is not None:    # rows as stream operations of the engine (mgrit_hip_exchange)
+                backend.exchange(lvl, op, send_idx=send_idx, dest=dest, recv_idx=recv_idx, src=src)
+            return
         kw = {'op': op} if op == 5 else {}     # op 5 (forward-solve hand-over): a backend may send more than the point itself
         send = (backend.payload(lvl, send_idx, **kw), dest) if send_idx is not None else None
         recv = (backend.recv_buffer(lvl, recv_idx, **kw), src) if recv_idx is not None else None

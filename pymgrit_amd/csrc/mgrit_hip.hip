@@ -17,7 +17,10 @@
 //
 // gfx950 only. No CUDA paths, no fallbacks: every entry point fails when no HIP device is usable.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is loaded on first use (mgrit_hip_comm.inc)
+#include <dlfcn.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -26,6 +29,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mgrit_hip.h"
@@ -1254,7 +1258,9 @@ __global__ void restrict_rows_kernel(const double *__restrict__ src, int src_ld,
 // linear interpolation of examples/example_spatial_coarsening.py:58-82
 __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, const int32_t *__restrict__ f_idx,
                                    const double *__restrict__ uc, const double *__restrict__ vc, int c_ld, int T_c,
-                                   const int32_t *__restrict__ c_idx, int n_f, int n_c, int kind, int mode) {
+                                   const int32_t *__restrict__ c_idx, int n_f, int n_c, int kind, int mode,
+                                   double *__restrict__ rows_out = nullptr, int ld_out = 0) {
+    // rows_out (mode 1): the corrected row goes to rows_out[p] instead of back into u^l (mgrit_hip_error_correction_to)
     const int p = blockIdx.x, pos = blockIdx.y * blockDim.x + threadIdx.x;
     if (pos >= f_ld) return;
     double *f = uf + (size_t)f_idx[p] * f_ld;
@@ -1279,7 +1285,8 @@ __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, c
             if (i < n_c) val = val + 1.0 / 2.0 * at(row_pos(i));
         }
     }
-    f[pos] = mode == 0 ? val : f[pos] + val;
+    if (rows_out) rows_out[(size_t)p * ld_out + pos] = f[pos] + val;
+    else f[pos] = mode == 0 ? val : f[pos] + val;
 }
 
 #include "mgrit_hip_2pts.inc"
@@ -1336,7 +1343,21 @@ struct Level {
     bool chain_overlapped = true;    // mgrit_hip_chain_enable: the caller's (global) word on the overlapped chain
 };
 
+// ghost exchange (mgrit_hip_comm.inc): one direction of one pair of ranks
+enum { LINK_NONE = 0, LINK_RCCL = 1, LINK_MAILBOX = 2 };
+struct Mailbox { double *slots = nullptr; int n_slots = 0, slot_doubles = 0; };
+struct Link {
+    int kind = LINK_NONE;
+    ncclComm_t comm = nullptr;   // LINK_RCCL
+    int peer = 0;                // the peer's rank inside comm
+    Mailbox *mb = nullptr;       // LINK_MAILBOX (caller-owned)
+    uint64_t messages = 0, bytes = 0, messages_in = 0;
+};
+
 }  // namespace
+
+struct mgrit_hip_engine;
+namespace { void links_close(mgrit_hip_engine *e, bool abort); }
 
 struct mgrit_hip_engine {
     int n_levels = 0;
@@ -1357,6 +1378,9 @@ struct mgrit_hip_engine {
     double *pinned = nullptr;     // host staging buffer for small read-backs
     size_t pinned_len = 0;
     hipEvent_t ev_read = nullptr;
+    std::vector<Link> links;      // mgrit_hip_link_*: the rank's ends of its exchange links
+    double *xscratch = nullptr;   // exchange scratch (zeros of a fresh chain state / a dropped hand-over)
+    size_t xscratch_len = 0;
 };
 
 namespace {
@@ -2201,6 +2225,8 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
     if (e->chain_err) (void)hipHostFree(e->chain_err);
     if (e->pinned) (void)hipHostFree(e->pinned);
     if (e->ev_read) (void)hipEventDestroy(e->ev_read);
+    links_close(e, false);
+    if (e->xscratch) (void)hipFree(e->xscratch);
     for (auto &r : e->trecs) { (void)hipEventDestroy(r.ev0); (void)hipEventDestroy(r.ev1); }
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     delete e;
@@ -2734,7 +2760,7 @@ static int interp_common(mgrit_hip_engine *e, int lvl, int pairs_id, int mode) {
     Timed timed(e, mode == 1 ? MGRIT_HIP_T_ERROR_CORRECTION : MGRIT_HIP_T_INTERPOLATE, lvl);
     dim3 grid(pl->n, (lf.dev.ld + 255) / 256);
     hipLaunchKernelGGL(interp_rows_kernel, grid, dim3(256), 0, e->stream, lf.dev.u, lf.dev.ld, lf.dev.T, pl->d_fine, lc.dev.u,
-                       lc.dev.v, lc.dev.ld, lc.dev.T, pl->d_coarse, lf.dev.n, lc.dev.n, lf.transfer, mode);
+                       lc.dev.v, lc.dev.ld, lc.dev.T, pl->d_coarse, lf.dev.n, lc.dev.n, lf.transfer, mode, (double *)nullptr, 0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -3047,3 +3073,5 @@ int mgrit_hip_set_stream(mgrit_hip_engine *e, void *stream) {
 }
 
 }  // extern "C"
+
+#include "mgrit_hip_comm.inc"

@@ -1,0 +1,164 @@
+"""Ghost exchange under the C ABI (include/mgrit_hip.h: mgrit_hip_exchange, reference Mgrit.send / Mgrit.receive,
+mgrit.py:693-713). The box has ONE GPU, so several ranks live in one process as threads sharing the GPU and its stream
+(pymgrit_amd.core.comm.LoopbackWorld): every exchange point is the same stream operation of the engine as on an RCCL link,
+with a mailbox in device memory in the place of ncclSend / ncclRecv. Sharded runs must equal the one-rank run bit for bit.
+The RCCL entry points themselves run on a one-rank communicator (a rank sending to itself), launch by launch and captured
+into a hipGraph."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+
+
+def solve_ranks(case, world, depth=None, plan_blocks=None):
+    """the case of tests/dist_worker.py on `world` loopback ranks (threads); returns (conv, owned level-0 rows in time order)"""
+    from dist_worker import build_problem
+    from pymgrit_amd import AtMgrit, Mgrit
+    from pymgrit_amd.core.comm import run_loopback_ranks
+
+    def target(comm):
+        prob, tr, opts = build_problem(case, "hip")
+        opts = dict(opts)
+        make = Mgrit
+        if "_at_k" in opts:
+            k = opts.pop("_at_k")
+            make = lambda *a, **kw: AtMgrit(k, 0, *a, **kw)   # noqa: E731
+        if depth is not None:
+            opts["pipeline_depth"] = depth
+        if plan_blocks is not None:
+            opts["plan_blocks"] = plan_blocks
+        mg = make(prob, transfer=tr, logging_lvl=30, comm_time=comm, **opts)
+        assert comm.size == 1 or mg.backend.device_links
+        conv = mg.solve()["conv"]
+        owned = [int(i) for i in mg.index_local[0]]
+        vals = np.array([np.asarray(mg.u[0][i].pack(), dtype=np.float64).ravel() for i in owned])
+        return conv, vals, comm.stats["device_messages"]
+    world_obj, res = run_loopback_ranks(world, target)
+    world_obj.close()
+    for conv, _, _ in res[1:]:
+        assert np.array_equal(conv, res[0][0])
+    assert world == 1 or sum(r[2] for r in res) > 0, "no row travelled through the device exchange"
+    return res[0][0], np.concatenate([r[1] for r in res if r[1].size], axis=0)
+
+
+CASES = [("heat_nx33_V_nested", [2, 3]), ("heat_nx257_nt257", [2, 4]), ("heat_nx33_F_nonested", [3]), ("heat_nx33_V_jump", [2]),
+         ("heat_spatial_coarsening", [2]), ("advection_3lvl_F", [2]), ("h2d:be_3lvl_F_bc", [2, 3]), ("advsc:adv_sc_F", [3]),
+         ("heat_nx33_procs_without_points", [4]), ("bdf:bdf2_example_small", [2, 3]), ("heat_nx2050_wide", [2, 3]),
+         ("heat_nx1500_wide_F", [2])]
+
+
+@pytest.mark.parametrize("case,sizes", CASES, ids=[c for c, _ in CASES])
+def test_device_exchange_equals_single_rank(case, sizes):
+    _gpu()
+    from test_distributed import launch
+    conv1, u1 = launch(1, case, mode="hip")
+    for world in sizes:
+        conv, u = solve_ranks(case, world)
+        assert np.array_equal(conv, conv1), (case, world, conv, conv1)
+        assert np.array_equal(u, u1), (case, world, np.abs(u - u1).max())
+
+
+@pytest.mark.parametrize("case,world,depth", [("heat_nx33_V_nested", 3, 1), ("heat_nx257_nt257", 2, 0), ("heat_nx2050_wide", 3, 2),
+                                              ("heat_nx257_nt257", 4, 4)])
+def test_device_exchange_pipelined(case, world, depth):
+    _gpu()
+    from test_distributed import launch
+    conv1, u1 = launch(1, case, mode="hip")
+    conv, u = solve_ranks(case, world, depth=depth)
+    assert np.array_equal(conv, conv1) and np.array_equal(u, u1)
+
+
+def _engine_with_rows(lib, n_rows, n=100):
+    ld = lib.mgrit_hip_row_stride(n)
+    eng = C.c_void_p()
+    stream = torch.cuda.current_stream()
+    assert lib.mgrit_hip_create(C.byref(eng), 1, C.c_void_p(stream.cuda_stream)) == 0
+    t = np.ascontiguousarray(np.linspace(0, 1, n_rows))
+    assert lib.mgrit_hip_level_heat1d(eng, 0, n_rows, C.c_void_p(t.ctypes.data), n, ld, 1.0, 0, None, None) == 0
+    u = torch.arange(n_rows * ld, dtype=torch.float64, device="cuda").reshape(n_rows, ld).contiguous()
+    assert lib.mgrit_hip_level_bind(eng, 0, C.c_void_p(u.data_ptr()), None, None) == 0
+    return eng, u, ld
+
+
+def test_rccl_link_on_a_one_rank_communicator():
+    """ncclSend / ncclRecv through mgrit_hip_exchange, mgrit_hip_send / mgrit_hip_recv: a communicator of ONE rank whose two
+    links both point at that rank (the send and the receive of an exchange point form one RCCL group); then the same exchange
+    point captured into a hipGraph and replayed, as a planned cycle does it"""
+    _gpu()
+    from pymgrit_amd.core import hip_lib
+    lib = hip_lib.load()
+    uid = C.create_string_buffer(128)
+    assert lib.mgrit_hip_comm_unique_id(uid) == 0, lib.mgrit_hip_last_error()
+    comm = C.c_void_p()
+    assert lib.mgrit_hip_comm_init_rank(C.byref(comm), uid.raw, 1, 0) == 0, lib.mgrit_hip_last_error()
+    eng, u, ld = _engine_with_rows(lib, 6)
+    graph = None
+    try:
+        assert lib.mgrit_hip_link_attach(eng, 0, comm, 0) == 0 and lib.mgrit_hip_link_attach(eng, 1, comm, 0) == 0
+        assert lib.mgrit_hip_link_attach(eng, 1, comm, 0) != 0      # already open
+        want = u.clone()
+        assert lib.mgrit_hip_exchange(eng, 0, 0, 0, 5, 0, 1, 0, 0, 0) == 0, lib.mgrit_hip_last_error()
+        assert lib.mgrit_hip_sync_bounded(eng, 30.0) == 0, lib.mgrit_hip_last_error()
+        want[0] = want[5]
+        assert torch.equal(u, want)
+        sent, nbytes, got = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        assert lib.mgrit_hip_link_stats(eng, 0, C.byref(sent), C.byref(nbytes), C.byref(got)) == 0
+        assert (sent.value, nbytes.value) == (1, 8 * ld)
+        # captured: graph replay moves the CURRENT contents of row 4 into row 1, every time
+        graph = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        assert lib.mgrit_hip_set_stream(eng, C.c_void_p(cap.cuda_stream)) == 0
+        try:
+            with torch.cuda.graph(graph, stream=cap, capture_error_mode="thread_local"):
+                assert lib.mgrit_hip_exchange(eng, 0, 2, 0, 4, 0, 1, 1, 0, 0) == 0, lib.mgrit_hip_last_error()
+        finally:
+            lib.mgrit_hip_set_stream(eng, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        for k in range(3):
+            u[4] = float(k + 7)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(u[1], u[4]) and float(u[1][3]) == k + 7
+        assert lib.mgrit_hip_exchange(eng, 0, 6, 0, 4, 0, 1, 1, 0, 0) != 0      # op 6 carries no row
+        assert lib.mgrit_hip_exchange(eng, 0, 0, 0, 9, 0, -1, 0, 0, 0) != 0     # row out of range
+        assert lib.mgrit_hip_exchange(eng, 0, 0, 7, 1, 0, -1, 0, 0, 0) != 0     # link not open
+    finally:
+        if graph is not None:
+            graph.reset()      # (ncclCommDestroy waits for every graph that captured the communicator to be gone)
+        torch.cuda.synchronize()
+        lib.mgrit_hip_destroy(eng)
+        lib.mgrit_hip_comm_destroy(comm, 0)
+
+
+def test_mailbox_link_and_bounded_sync():
+    _gpu()
+    from pymgrit_amd.core import hip_lib
+    lib = hip_lib.load()
+    eng, u, ld = _engine_with_rows(lib, 4)
+    mb = C.c_void_p()
+    assert lib.mgrit_hip_mailbox_create(C.byref(mb), 3, ld) == 0
+    try:
+        assert lib.mgrit_hip_link_mailbox(eng, 2, mb) == 0
+        want = u.clone()
+        assert lib.mgrit_hip_exchange(eng, 0, 0, 2, 3, 1, -1, -1, 0, 0) == 0        # row 3 into slot 1
+        assert lib.mgrit_hip_exchange(eng, 0, 0, -1, -1, 0, 2, 0, 1, 0) == 0        # slot 1 into row 0
+        assert lib.mgrit_hip_sync_bounded(eng, 10.0) == 0
+        want[0] = want[3]
+        assert torch.equal(u, want)
+        assert lib.mgrit_hip_exchange(eng, 0, 0, 2, 3, 3, -1, -1, 0, 0) != 0        # slot out of range
+        stage = torch.full((ld,), 3.5, dtype=torch.float64, device="cuda")
+        assert lib.mgrit_hip_send(eng, 2, 0, C.c_void_p(stage.data_ptr()), ld) == 0
+        assert lib.mgrit_hip_recv(eng, 2, 0, C.c_void_p(u[2].data_ptr()), ld) == 0
+        torch.cuda.synchronize()
+        assert float(u[2][5]) == 3.5
+    finally:
+        lib.mgrit_hip_destroy(eng)
+        lib.mgrit_hip_mailbox_destroy(mb)

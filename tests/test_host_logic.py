@@ -257,7 +257,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert declared == set(hip_lib.EXPORTS), declared ^ set(hip_lib.EXPORTS)
     loaded = hip_lib.load()
-    assert loaded.mgrit_hip_abi_version() == 2
+    assert loaded.mgrit_hip_abi_version() == 3
     assert loaded.mgrit_hip_row_stride(16382) == 16384 and loaded.mgrit_hip_row_stride(3) == 1024
     perm = hip_lib.row_permutation(16382)
     assert len(set(perm.tolist())) == 16382 and perm.max() < 16384
