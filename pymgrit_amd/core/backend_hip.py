@@ -229,27 +229,64 @@ class HipBackend:
             comm.open_links(self, links_needed(mg))
             self.device_links = True
 
-    def exchange(self, lvl, op, send_idx=None, dest=None, recv_idx=None, src=None):
+    def _xlink(self, peer, direction, ch, ordinal):
+        """((link handle, slot), done): a single message shakes hands with its peer now (LoopbackComm: the receiver enqueues
+        behind the sender; RCCL links: nothing to do); the ordinal-th message of a planned cycle has its slot fixed, the
+        hand-shake was the cycle's (plan_run)"""
+        comm = self.mg.comm_time
+        if ordinal is not None:
+            return comm.cycle_slot(self, peer, direction, ch, ordinal), None
+        if direction == 'send':
+            return comm.send_begin(self, peer, ch), lambda: comm.send_end(self, peer, ch)
+        return comm.recv_begin(self, peer, ch), lambda: comm.recv_end(self, peer, ch)
+
+    def exchange(self, lvl, op, send_idx=None, dest=None, recv_idx=None, src=None, raw=False, ordinals=(None, None)):
         """one exchange point (reference mgrit.py:693-713) as stream operations of the engine: mgrit_hip_exchange sends row
         send_idx of u^lvl to rank dest and receives row recv_idx from rank src (ncclSend / ncclRecv on an RCCL link); the
-        hand-over of forward_solve (op 5) takes the chain's running state along"""
+        hand-over of forward_solve (op 5) takes the chain's running state along. raw: the caller knows what
+        the row holds (C-point storage: no materialise() in front of the send)"""
         from pymgrit_amd.core.comm import CH_CHAIN, CH_SWEEP
-        comm, ch = self.mg.comm_time, (CH_CHAIN if op == 5 else CH_SWEEP)
-        if lvl == 0 and send_idx is not None:
+        ch = CH_CHAIN if op == 5 else CH_SWEEP
+        if lvl == 0 and send_idx is not None and not raw:
             self.materialise()
         sl = ss = rl = rs = -1
+        done = []
         if send_idx is not None:
-            sl, ss = comm.send_begin(self, dest, ch)
+            (sl, ss), fin = self._xlink(dest, 'send', ch, ordinals[0])
+            done.append(fin)
         if recv_idx is not None:
-            rl, rs = comm.recv_begin(self, src, ch)
+            (rl, rs), fin = self._xlink(src, 'recv', ch, ordinals[1])
+            done.append(fin)
             self._residual_cache = None
         check(self.lib.mgrit_hip_exchange(self.h, lvl, op, sl, -1 if send_idx is None else int(send_idx), ss, rl,
                                           -1 if recv_idx is None else int(recv_idx), rs,
                                           int(self.chain_handover.get(lvl, 0) or 0) if op == 5 else 0))
-        if send_idx is not None:
-            comm.send_end(self, dest, ch)
+        for fin in done:
+            if fin is not None:
+                fin()
+
+    def exchange_staged(self, lvl, op, pair, dest=None, recv_idx=None, src=None, ordinals=(None, None)):
+        """the same exchange point with the CORRECTED value of the C-point `pair` = [(fine slot, coarse slot)] as the row sent
+        (mgrit_hip_error_correction_to into a staging row): an aligned rank sends its last C-point before the whole-level pass
+        that corrects it in place has run (Mgrit._x0)"""
+        from pymgrit_amd.core.comm import CH_SWEEP
+        ld = self.ld[lvl]
+        if not hasattr(self, "_stage"):
+            self._stage = {}
+        if lvl not in self._stage:
+            self._stage[lvl] = torch.zeros(ld, dtype=torch.float64, device=self.device)
+        stage = self._stage[lvl]
+        check(self.lib.mgrit_hip_error_correction_to(self.h, lvl, self._pair_id(lvl, pair), C.c_void_p(stage.data_ptr()), ld))
+        (sl, ss), fin = self._xlink(dest, 'send', CH_SWEEP, ordinals[0])
+        check(self.lib.mgrit_hip_send(self.h, sl, ss, C.c_void_p(stage.data_ptr()), ld))
+        if fin is not None:
+            fin()
         if recv_idx is not None:
-            comm.recv_end(self, src, ch)
+            (rl, rs), fin = self._xlink(src, 'recv', CH_SWEEP, ordinals[1])
+            self._residual_cache = None
+            check(self.lib.mgrit_hip_recv(self.h, rl, rs, C.c_void_p(self._U[lvl][int(recv_idx)].data_ptr()), ld))
+            if fin is not None:
+                fin()
 
     def _host_transfers(self):
         return any(not self._device_transfer(lvl) for lvl in range(self.mg.lvl_max - 1))
@@ -282,6 +319,7 @@ class HipBackend:
         every level-0 interval's F-points, only the last one. Whoever wants to SEE the solution -- the end of Mgrit.solve(),
         output_fcn, mgrit.u[0][i], natural(), the U slabs -- gets the others rebuilt here by one F-relaxation from the
         C-points: the same Phi on the same values, so bit for bit what an every-point store would have left."""
+        self._cycle_pre = False     # whatever the cycle's down pass was promised (begin_cycle), the rows are plain again
         if self._f_stale:
             self._f_stale = 0
             cache = self._residual_cache          # an F-relaxation that rewrites identical values leaves the residual valid
@@ -450,9 +488,20 @@ class HipBackend:
         of 5-20 us each, and without the graph their launch cost, not their run time, is what a cycle takes.
         PYMGRIT_AMD_PLAN_GRAPH=0 keeps the launch-by-launch form."""
         graph_ok = os.environ.get("PYMGRIT_AMD_PLAN_GRAPH", "1") != "0" and not getattr(self, "_timing_on", False)
+        comm = self.mg.comm_time if getattr(plan, "sends", None) or getattr(plan, "recvs", None) else None
+        if comm is not None:     # several ranks: the cycle's messages shake hands once (LoopbackComm; RCCL links match by order)
+            comm.cycle_begin(self, plan.sends, plan.recvs)
+        try:
+            self._plan_run(plan, graph_ok)
+        finally:
+            if comm is not None:
+                comm.cycle_end(self, plan.sends, plan.recvs)
+
+    def _plan_run(self, plan, graph_ok):
         state = plan.__dict__.setdefault("_hip", {"runs": 0, "graph": None, "failed": False})
         if state["graph"] is not None and graph_ok:
-            state["graph"].replay()
+            with torch.cuda.stream(self.stream):      # (the engine's stream, whatever the caller has made current since)
+                state["graph"].replay()
             self._f_stale = max(self._f_stale, state.get("f_stale", 0))   # what the replayed launches did to the F-points
             return
         if graph_ok and state["runs"] >= 2 and not state["failed"]:
@@ -472,7 +521,8 @@ class HipBackend:
                     if gc_was_on:
                         gc.enable()
                 state["graph"] = graph
-                graph.replay()
+                with torch.cuda.stream(self.stream):
+                    graph.replay()
                 self._f_stale = max(self._f_stale, state.get("f_stale", 0))
                 return
             except Exception as exc:   # noqa: BLE001 - capture is an optimisation: any refusal falls back to plain launches
@@ -488,9 +538,11 @@ class HipBackend:
                 warnings.warn(f"pymgrit_amd: cycle graph capture failed ({exc!r}); launching the cycle kernel by kernel")
         state["runs"] += 1
         was, self._f_stale = self._f_stale, 0
-        self._plan_issue(plan, self.stream)
-        state["f_stale"] = self._f_stale          # does this cycle leave level-0 F-points to materialise()?
-        self._f_stale = max(self._f_stale, was)
+        try:
+            self._plan_issue(plan, self.stream)
+            state["f_stale"] = self._f_stale          # does this cycle leave level-0 F-points to materialise()?
+        finally:
+            self._f_stale = max(self._f_stale, was)   # (also when a launch failed: rows that awaited materialise() still do)
 
     def _plan_issue(self, plan, main):
         if self._chain_stream is None:
@@ -577,6 +629,15 @@ class HipBackend:
     def residual_begin(self, points):
         """launch the residual kernel and return at once; the per-point sums of squares land in pinned host memory that the
         kernel writes directly (no copy command), residual_end() waits for the event recorded behind the kernel"""
+        cache = getattr(self, "_residual_cache", None)
+        if len(points) and cache is not None and len(cache) == len(points) and (cache is points or cache == tuple(points)):
+            # the way up (ec_relax_res) has left exactly these values in the engine's pinned buffer: a copy of their own for a
+            # solver that looks at them some cycles late -- the next cycle overwrites the engine's buffer
+            buf = self._ring_slot(len(points))
+            check(self.lib.mgrit_hip_residual_stash(self.h, len(points), C.c_void_p(buf.data_ptr())))
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            return buf, ev
         self._settle(0)
         if not len(points):
             return None

@@ -291,6 +291,10 @@ class RcclTimeComm(TorchTimeComm):
 
     recv_end = send_end
 
+    def cycle_slot(self, backend, peer, direction, channel, ordinal):
+        """(handle, slot) of the ordinal-th message of a planned cycle on a link: RCCL matches by order, no slots"""
+        return self._engines[id(backend)].handle[(int(peer), direction, channel)], 0
+
     def cycle_begin(self, backend, sends, recvs):
         return None
 

@@ -75,15 +75,22 @@ class Recorder:
         # five or more blocks (measured on config 3 with six: three 8.24 ms, two 8.35, four 9.2, none 8.46-8.60)
         self.up_merge = int(os.environ.get("PYMGRIT_AMD_PLAN_UP_MERGE", str(self.K // 2 if self.K >= 5 else 0)))
         self.nodes = []
+        self.sends, self.recvs = {}, {}     # (peer rank, channel) -> messages of the cycle on that link (several ranks)
         self.host_after = []        # host-only bookkeeping calls of the cycle: run after every execution of the plan
         self._last_write, self._readers = {}, {}
         self.row_bytes = [8.0 * getattr(backend, "ld", [1] * mg.lvl_max)[lvl] if hasattr(backend, "ld") else 8.0
                           for lvl in range(mg.lvl_max)]
 
-    # anything that is not a sweep (capability queries like can_fuse_ec) is answered by the real backend
+    # anything that is not a sweep (capability queries like can_fuse_ec, plan_blocks; plain attributes) is answered by the real
+    # backend; a SWEEP the recorder has no dependency rule for ends the recording (the cycle then runs in program order)
+    PASS_THROUGH = ("can_", "plan_")
+    PASS_NAMES = frozenset(("device_links", "chain_handover", "chain_state", "_cycle_pre", "ld", "n", "desc", "name"))
+
     def __getattr__(self, name):
-        if name.startswith("can_"):
+        if name.startswith(self.PASS_THROUGH) or name in self.PASS_NAMES:
             return getattr(self.real, name)
+        if name.startswith("__"):
+            raise AttributeError(name)
         raise PlanUnsupported(name)
 
     # ---- graph construction -------------------------------------------------------------------------------------------
@@ -183,6 +190,43 @@ class Recorder:
                 rows = len(part) + n_pts * (2 if lvl > 0 else 1)
                 self._add("relax_" + mode, lvl, b, lambda p=part: real.relax(lvl, p, mode), reads, {("u", lvl, b)}, rows)
             first = False
+
+    # ---- exchange points (several ranks; backend_hip.exchange: stream operations of the engine) ------------------------------
+    # A send reads the row it sends, a receive writes the ghost row; the messages of one link keep their recorded order (the
+    # two owners of a link match messages by order): a pseudo-cell per link and direction that every message "writes".
+    # The hand-over of the coarsest level's forward solve (op 5) runs on the chain's stream, like the chain parts around it.
+    def _ordinal(self, table, peer, ch):
+        k = table.get((int(peer), ch), 0)
+        table[(int(peer), ch)] = k + 1
+        return k
+
+    def exchange(self, lvl, op, send_idx=None, dest=None, recv_idx=None, src=None, raw=False, ordinals=None):
+        from pymgrit_amd.core.comm import CH_CHAIN, CH_SWEEP
+        real, ch = self.real, (CH_CHAIN if op == 5 else CH_SWEEP)
+        stream = "chain" if op == 5 else "sweep"
+        extra = {("chain", lvl, 0)} if op == 5 else set()
+        if send_idx is not None:
+            k = self._ordinal(self.sends, dest, ch)
+            self._add("send", lvl, int(self.block_of[lvl][send_idx]),
+                      lambda k=k: real.exchange(lvl, op, send_idx=send_idx, dest=dest, raw=True, ordinals=(k, None)),
+                      self._cells("u", lvl, [send_idx]) | extra, {("xs", int(dest), ch)}, 1, stream=stream, cost=8e-6)
+        if recv_idx is not None:
+            k = self._ordinal(self.recvs, src, ch)
+            self._add("recv", lvl, int(self.block_of[lvl][recv_idx]),
+                      lambda k=k: real.exchange(lvl, op, recv_idx=recv_idx, src=src, raw=True, ordinals=(None, k)),
+                      set(), self._cells("u", lvl, [recv_idx]) | extra | {("xr", int(src), ch)}, 1, stream=stream, cost=8e-6)
+
+    def exchange_staged(self, lvl, op, pair, dest=None, recv_idx=None, src=None, ordinals=None):
+        from pymgrit_amd.core.comm import CH_SWEEP
+        real = self.real
+        fi, co = int(pair[0][0]), int(pair[0][1])
+        k = self._ordinal(self.sends, dest, CH_SWEEP)
+        self._add("send_corrected", lvl, int(self.block_of[lvl][fi]),
+                  lambda k=k: real.exchange_staged(lvl, op, pair, dest=dest, ordinals=(k, None)),
+                  self._cells("u", lvl, [fi]) | self._cells("u", lvl + 1, [co]) | self._cells("v", lvl + 1, [co]),
+                  {("xs", int(dest), CH_SWEEP), ("stage", lvl, 0)}, 3, cost=1e-5)
+        if recv_idx is not None:
+            self.exchange(lvl, op, recv_idx=recv_idx, src=src)
 
     def ec_relax(self, lvl, triples):
         if not triples:
@@ -294,8 +338,9 @@ class Plan:
     """the scheduled cycle: `order` = nodes in issue order (a topological order of the graph); per node the stream it runs on
     and the nodes of the OTHER stream it has to wait for"""
 
-    def __init__(self, nodes, n_blocks, host_after=()):
+    def __init__(self, nodes, n_blocks, host_after=(), sends=None, recvs=None):
         self.nodes, self.n_blocks, self.host_after = nodes, n_blocks, list(host_after)
+        self.sends, self.recvs = dict(sends or {}), dict(recvs or {})     # messages per (peer rank, channel) of one cycle
         self.order = schedule(nodes)
         self.makespan = max((n.finish for n in nodes), default=0.0)
         self.has_chain = any(n.stream == "chain" for n in nodes)
@@ -367,4 +412,4 @@ def record_cycle(mg, backend, n_blocks, walk):
         walk()
     finally:
         mg.backend = backend
-    return Plan(rec.nodes, rec.K, rec.host_after)
+    return Plan(rec.nodes, rec.K, rec.host_after, rec.sends, rec.recvs)

@@ -141,6 +141,7 @@ class Mgrit:
             self.step.append(problem[lvl].step)
             self.create_u_v_g(lvl=lvl)
         self.backend.finalize()
+        self._aligned = self._detect_aligned()
         # logging.DEBUG: the reference reports the time of every sweep (mgrit.py:333,370,486,549); on the device path the lines
         # also carry the DEVICE time of the sweep's kernels (HIP events around every entry point, mgrit_hip_set_timing)
         self._sweep_timing = logging_lvl <= logging.DEBUG and hasattr(self.backend, "timing_drain")
@@ -224,6 +225,72 @@ class Mgrit:
             raise Exception('Mixed hierarchy: every level must be a device application (device_stepper()) or none')
         from pymgrit_amd.core.backend_plugin import PluginBackend
         return PluginBackend(self)
+
+    def _detect_aligned(self) -> bool:
+        """Several ranks whose shares of the time grid all END ON A C-POINT of every level (BASELINE configs 2-5 on 2 / 4 / 8
+        ranks: nt - 1 a multiple of the rank count times every coarsening factor): a rank's local grid then looks
+        like a one-rank grid -- slot 0 (the ghost point, a C-point of every level owned by the rank before) takes the place of
+        the first time point, which nobody relaxes or corrects, and whole intervals follow. Such a rank runs the one-rank
+        machinery (whole-level passes, C-point storage, pre-relaxed C-points, the planned cycle) with the exchange points of
+        the reference refreshing slot 0 (ops 0 / 4 / 5; ops 1 / 2 / 3 / 7 never fire). Decided by all ranks together."""
+        size, rank = self.comm_time_size, self.comm_time_rank
+        if size == 1 or not getattr(self.backend, "device_links", False) or not self.global_conv_crit or \
+                os.environ.get("PYMGRIT_AMD_NO_ALIGNED", "") == "1":
+            if size > 1 and getattr(self.backend, "device_links", False):
+                self.comm_time.allgather_object(False)
+            return False
+        ok = self.lvl_max >= 2
+        for lvl in range(self.lvl_max):
+            if not ok:
+                break
+            n_own = len(self.index_local[lvl])
+            ok = n_own >= 1 and (rank == 0 or (bool(self._ghost[lvl]) and self.get_from[lvl] == rank - 1)) and \
+                (rank == size - 1 or self.send_to[lvl] == rank + 1) and (rank != 0 or self.get_from[lvl] < 0) and \
+                (rank != size - 1 or self.send_to[lvl] < 0)
+            if ok and lvl < self.lvl_max - 1:
+                ok = (not self.comm_front[lvl] and not self.comm_back[lvl] and not self.first_is_c_point[lvl] and
+                      not self.last_is_f_point[lvl] and len(self.index_local_c[lvl]) >= 1 and
+                      bool(self._is_c_local[lvl][-1]) and bool(self._is_c_local[lvl][0]) and
+                      (rank == 0 or bool(self.first_is_f_point[lvl])) and (rank == size - 1 or bool(self.last_is_c_point[lvl])))
+        return all(self.comm_time.allgather_object(bool(ok)))
+
+    def _one_rank_like(self) -> bool:
+        """no exchange point falls INSIDE a whole-level pass: one rank, or ranks whose shares end on C-points (_detect_aligned)"""
+        return self.comm_time_size == 1 or getattr(self, "_aligned", False)
+
+    def _xpairs(self, lvl):
+        """(fine slot, coarse slot) of the level's local C-points including the frozen one in front: the first point of the time
+        grid on rank 0 (it is an owned C-point there), the ghost point (slot 0 on both levels) on an aligned rank > 0"""
+        def build():
+            own = self._pairs(lvl, skip_first=False)
+            return ([(0, 0)] + list(own)) if (self.comm_time_rank > 0 and getattr(self, "_aligned", False)) else own
+        return self._cached(('xpair', lvl), build)
+
+    def _x0(self, lvl, send_row=None, staged=None):
+        """op 0, the exchange point at the head of an F-relaxation (mgrit.py:304-311): the last local C-point to the next
+        owner's ghost slot. send_row: the row that HOLDS that value when it is not the point's own row (pre-relaxed C-points);
+        staged: the (fine, coarse) pair whose corrected value is sent before the pass that corrects it in place has run"""
+        send = self._last_slot(lvl) if self.last_is_c_point[lvl] else None
+        recv = 0 if self.first_is_f_point[lvl] else None
+        if send is None and recv is None:
+            return
+        if staged is not None and send is not None:
+            self.backend.exchange_staged(lvl, 0, staged, dest=self.send_to[lvl], recv_idx=recv, src=self.get_from[lvl])
+        else:
+            self.backend.exchange(lvl, 0, send_idx=(send_row if (send_row is not None and send is not None) else send),
+                                  dest=self.send_to[lvl], recv_idx=recv, src=self.get_from[lvl], raw=True)
+
+    def _x4(self, lvl):
+        """op 4 of fas_residual(lvl) (mgrit.py:511-517): the last local point of lvl+1 to the next owner's ghost slot, then the
+        clone of the received ghost into v (mgrit.py:520)"""
+        up = lvl + 1
+        send = int(self.index_local[up][-1]) if self.send_to[up] >= 0 else None
+        recv = 0 if self.get_from[up] >= 0 else None
+        if send is None and recv is None:
+            return
+        self.backend.exchange(up, 4, send_idx=send, dest=self.send_to[up], recv_idx=recv, src=self.get_from[up], raw=True)
+        if recv is not None:
+            self.backend.copy_pairs_u_to_v(lvl, self._cached(('pair_ghost_x', lvl), lambda: [(0, 0)]))
 
     def _log_sweep(self, what: str, t0: float) -> None:
         """the reference's per-sweep debug line (same wording), plus the device time of the sweep's kernels"""
@@ -368,7 +435,7 @@ class Mgrit:
         """Blocks of time points of a planned cycle (core/cycle_plan.py); 1 = the cycle runs in program order. The plan
         reorders the launches of ONE rank's cycle, so it needs a cycle without exchange points (one rank) whose sweeps are
         the library's own (a subclass that overrides a sweep keeps the program order)."""
-        if self._dry is not None or self.comm_time_size != 1:
+        if self._dry is not None or not self._one_rank_like():
             return 0 if probe_usable else 1
         if self._plan_request is not None:
             want = int(self._plan_request)
@@ -379,7 +446,7 @@ class Mgrit:
         own = all(getattr(type(self), name) is getattr(Mgrit, name) for name in
                   ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "forward_solve", "_exchange",
                    "_ec_f_relax", "_fas_residual_fused", "_relax_f"))
-        usable = (self.comm_time_size == 1 and self.lvl_max > 1 and own and self._dry is None and
+        usable = (self._one_rank_like() and self.lvl_max > 1 and own and self._dry is None and
                   not getattr(self, "_sweep_timing", False) and     # per-sweep debug timing reports the sweeps in program order
                   getattr(self.backend, "plan_allowed", lambda: True)())
         if probe_usable:
@@ -391,7 +458,7 @@ class Mgrit:
         blocks = self.plan_blocks()
         if blocks <= 1:
             # one block = program order; the device backend still replays it as one graph launch (small hierarchies)
-            single = (self._plan_request is None and not os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS") and self.comm_time_size == 1
+            single = (self._plan_request is None and not os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS") and self._one_rank_like()
                       and self.plan_blocks(probe_usable=True) and getattr(self.backend, "plan_single_block", lambda: False)())
             if not single:
                 return None
@@ -416,6 +483,11 @@ class Mgrit:
 
     def iteration(self, lvl: int, cycle_type: str, iteration: int, first_f: bool) -> None:
         if lvl == 0 and not self._plan_recording:
+            if first_f and iteration == 0:
+                # the cycle opens with a plain F-relaxation of level 0 (mgrit.py:273-275): whatever the cycle before left for the
+                # whole-level down pass alone (pre-relaxed C-points, backend_hip._f_stale == 2) is put back in place first, so
+                # that no cycle ever starts in that state with a level-0 sweep in front of the pass
+                getattr(self.backend, "materialise", lambda: None)()
             getattr(self.backend, "begin_cycle", lambda: None)()
             plan = self._planned(cycle_type, iteration, first_f)
             if plan is not None:
@@ -448,11 +520,20 @@ class Mgrit:
             # a level the finer level's FAS sweep has just filled (u == v): F-relaxation + C-relaxation in one pass, then the
             # F-relaxation folded into the FAS sweep (the F-points of the way down are stored by neither)
             fc_runs, triples, head, skip_u = coarse
+            ranks = self.comm_time_size > 1     # aligned ranks: the exchange points of the sweeps this pass stands for
+            if ranks:
+                self._x0(lvl)                   # f_relax (mgrit.py:271)
             if self.cf_iter[lvl] == 1:
                 self.backend.relax(lvl, fc_runs, 'FC')
+                if ranks:
+                    self._x0(lvl)               # f_relax (mgrit.py:275), behind the C-relaxation
             self._head(lvl, head, 'u')
             self.backend.fas_fused(lvl, triples, with_f_relax=True, skip_coarse_u=skip_u)
             self._head(lvl, head, 'v')
+            if ranks:
+                if skip_u and self.send_to[lvl + 1] >= 0:   # the one row of u^{l+1} that op 4 sends
+                    self.backend.restrict_u(lvl, self._cached(('pair_last', lvl), lambda: [self._xpairs(lvl)[-1]]))
+                self._x4(lvl)                   # fas_residual (mgrit.py:511-520)
             self._fresh_level = lvl + 1
             self.iteration(lvl=lvl + 1, cycle_type=cycle_type, iteration=iteration, first_f=True)
             self._up(lvl, None)
@@ -485,10 +566,24 @@ class Mgrit:
             self.c_relax(lvl=lvl)
             self.f_relax(lvl=lvl)
         if down:      # the last C-relaxation + F-relaxation + the FAS residual: one pass
-            head = self._cached(('pair_head', lvl), lambda: self._pairs(lvl, skip_first=False)[:1])
+            head = self._cached(('pair_head_x', lvl), lambda: self._pairs(lvl, skip_first=False)[:1] if self.comm_time_rank == 0 else [])
+            if self.comm_time_size > 1:
+                # aligned ranks: op 0 of the F-relaxation inside the pass (mgrit.py:306-310) wants the RELAXED last C-point, which
+                # the pass itself computes. With pre-relaxed C-points (backend_hip._f_stale == 2) the cycle before has left exactly
+                # that value in the row of the last F-point; otherwise it is computed up front by a C-relaxation of that one
+                # point (the pass recomputes the same bits from the same F-point)
+                last = self._last_slot(lvl)
+                if getattr(self.backend, "_cycle_pre", False) and lvl == 0:
+                    self._x0(lvl, send_row=last - 1)
+                else:
+                    if self.last_is_c_point[lvl]:
+                        self.backend.relax(lvl, self._cached(('c_last', lvl), lambda: [(last, 1)]), 'C')
+                    self._x0(lvl)
             self._head(lvl, head, 'u')
             self.backend.cf_fas(lvl, fused)
             self._head(lvl, head, 'v')
+            if self.comm_time_size > 1:
+                self._x4(lvl)
         else:
             self.fas_residual(lvl=lvl)
         self._fresh_level = lvl + 1      # the next level starts from what the FAS sweep has just written (u == v there)
@@ -534,9 +629,14 @@ class Mgrit:
             self.f_relax(lvl=lvl, runs=edge_runs)
             return
         if fused is not None and lvl == 0 and self.conv_crit in (0, 2):   # correction + F-relaxation + the residual check's sums
+            if self.comm_time_size > 1:     # aligned ranks: op 0 of the F-relaxation (mgrit.py:306-310) carries the CORRECTED last
+                # C-point, which the pass corrects in place only later
+                self._x0(lvl, staged=self._cached(('pair_last', lvl), lambda: [self._xpairs(lvl)[-1]]))
             self.backend.ec_relax_res(lvl, fused)
             self.backend.residual_ready(self._c_points(0))
         elif lvl > 0 and self._level_intervals(lvl, up=True) is not None:   # coarser level: the same pass with g, no residual
+            if self.comm_time_size > 1:
+                self._x0(lvl, staged=self._cached(('pair_last', lvl), lambda: [self._xpairs(lvl)[-1]]))
             self.backend.ec_relax_res(lvl, self._level_intervals(lvl, up=True))
         elif self._can_fuse_ec(lvl):
             self._ec_f_relax(lvl)
@@ -655,10 +755,10 @@ class Mgrit:
                       ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "_exchange", "_ec_f_relax",
                        "_fas_residual_fused"))
             can = getattr(be, "can_fuse_coarse_down", None)
-            if not (own and self.comm_time_size == 1 and self.weight_c == 1.0 and 0 < lvl < self.lvl_max - 1 and
+            if not (own and self._one_rank_like() and self.weight_c == 1.0 and 0 < lvl < self.lvl_max - 1 and
                     self.cf_iter[lvl] in (0, 1) and not getattr(self, "_sweep_timing", False) and can is not None and can(lvl)):
                 return [None]
-            pairs = self._pairs(lvl, skip_first=False)
+            pairs = self._xpairs(lvl)
             if len(pairs) < 2 or pairs[0][0] != 0:
                 return [None]
             want = [(pairs[k][0] + 1, pairs[k + 1][0] - pairs[k][0] - 1) for k in range(len(pairs) - 1)]
@@ -667,7 +767,7 @@ class Mgrit:
             fc_runs = [(st, ln + 1) for st, ln in want]                       # the F-points and the C-point closing them
             triples = [(pairs[k][0], pairs[k - 1][0], pairs[k][1]) for k in range(1, len(pairs))]
             skip_u = lvl + 1 == self.lvl_max - 1 and type(self).forward_solve is Mgrit.forward_solve
-            return [(fc_runs, triples, pairs[:1], skip_u)]
+            return [(fc_runs, triples, pairs[:1] if self.comm_time_rank == 0 else [], skip_u)]
         return self._cached(('coarse_down', lvl), build)[0]
 
     def f_relax(self, lvl: int, ec: bool = False, runs=None) -> None:
@@ -720,11 +820,11 @@ class Mgrit:
                        "_ec_f_relax"))
             # up: the pass of the way up alone (error correction + F-relaxation), which exists for every level pair
             can = getattr(be, "can_fuse_level_up" if up else "can_fuse_level", None)
-            if not (own and self.comm_time_size == 1 and self.weight_c == 1.0 and lvl < self.lvl_max - 1 and
+            if not (own and self._one_rank_like() and self.weight_c == 1.0 and lvl < self.lvl_max - 1 and
                     not getattr(self, "_sweep_timing", False) and     # per-sweep debug lines: sweep by sweep
                     can is not None and can(lvl) and (not up or self._can_fuse_ec(lvl))):
                 return [None]
-            pairs = self._pairs(lvl, skip_first=False)
+            pairs = self._xpairs(lvl)
             if len(pairs) < 2 or pairs[0][0] != 0 or self._c_points(lvl) != [p[0] for p in pairs[1:]]:
                 return [None]
             runs = self._f_runs(lvl)
@@ -744,8 +844,11 @@ class Mgrit:
             need_v = 0 if (lvl == 0 and self.conv_crit in (0, 2)) else 2
             # ... and where the coarse level's first pass (relax mode FC, _coarse_down) starts its runs from v: its C-points
             v_starts = {int(i) for i in self.index_local_c[lvl + 1]} if (not coarsest and self._coarse_down(lvl + 1) is not None) else set()
+            # aligned ranks: the last local point travels to the next owner (op 4: u^{l+1}) and its corrected value is staged for
+            # op 0 of the way up from u^{l+1} and v^{l+1} (Mgrit._x0): both rows are kept there
+            last = len(pairs) - 2 if (self.comm_time_size > 1 and self.send_to[lvl + 1] >= 0) else -1
             return [[(pairs[k][0], pairs[k + 1][0], pairs[k][1] if k >= 1 else -1, pairs[k + 1][1], k,
-                      (1 if need_u(pairs[k + 1][1]) else 0) | need_v | (2 if pairs[k + 1][1] in v_starts else 0))
+                      (3 if k == last else 0) | (1 if need_u(pairs[k + 1][1]) else 0) | need_v | (2 if pairs[k + 1][1] in v_starts else 0))
                      for k in range(len(pairs) - 1)]]
         got = self._cached(('intervals', lvl, up), build)[0]
         if got is None:

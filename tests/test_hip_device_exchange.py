@@ -40,6 +40,10 @@ def solve_ranks(case, world, depth=None, plan_blocks=None):
         conv = mg.solve()["conv"]
         owned = [int(i) for i in mg.index_local[0]]
         vals = np.array([np.asarray(mg.u[0][i].pack(), dtype=np.float64).ravel() for i in owned])
+        DIAG[(case, world, comm.rank)] = {
+            "aligned": getattr(mg, "_aligned", False), "fused0": mg._level_intervals(0) is not None if mg.lvl_max > 1 else False,
+            "graphs": sum(1 for p in mg._plans.values() if p is not None and getattr(p, "_hip", {}).get("graph") is not None),
+            "plans": sum(1 for p in mg._plans.values() if p is not None), "messages": comm.stats["device_messages"]}
         return conv, vals, comm.stats["device_messages"]
     world_obj, res = run_loopback_ranks(world, target)
     world_obj.close()
@@ -47,6 +51,9 @@ def solve_ranks(case, world, depth=None, plan_blocks=None):
         assert np.array_equal(conv, res[0][0])
     assert world == 1 or sum(r[2] for r in res) > 0, "no row travelled through the device exchange"
     return res[0][0], np.concatenate([r[1] for r in res if r[1].size], axis=0)
+
+
+DIAG = {}     # (case, world, rank) -> what the last solve of that rank used
 
 
 CASES = [("heat_nx33_V_nested", [2, 3]), ("heat_nx257_nt257", [2, 4]), ("heat_nx33_F_nonested", [3]), ("heat_nx33_V_jump", [2]),
@@ -73,6 +80,37 @@ def test_device_exchange_pipelined(case, world, depth):
     from test_distributed import launch
     conv1, u1 = launch(1, case, mode="hip")
     conv, u = solve_ranks(case, world, depth=depth)
+    assert np.array_equal(conv, conv1) and np.array_equal(u, u1)
+
+
+# shares of the time grid that end on a C-point of every level: the one-rank machinery on every rank (Mgrit._detect_aligned)
+ALIGNED = [("heat_nx33_V_nested", [2, 4]), ("heat_nx33_V_nonested", [2, 4]), ("heat_nx33_F_nested", [2, 4]), ("heat_nx33_F_nonested", [4]),
+           ("heat_nx33_V_cf2", [2]), ("heat_nx33_V_cflist", [4]), ("heat_nx33_V_cf0", [2, 4]), ("heat_nx33_V_tnorm3", [2]),
+           ("heat_nx33_V_jump", [4]), ("heat_nx33_V_weight13", [2]), ("heat_nx33_2lvl_m8", [2, 4]),
+           ("heat_nx33_noforcing", [4]), ("heat_nx257_nt257", [2, 8, 16]), ("heat_example_F5", [2, 4]), ("heat_config2", [2, 8]),
+           ("heat_nx2050_wide", [2, 4]), ("heat_nx1500_wide_F", [2]), ("heat_nx3100_wide_2lvl", [2, 4]),
+           ("heat_spatial_coarsening_F", [2]), ("advection_3lvl_F", [4]), ("advection_nx2049_wide", [2, 4])]
+
+
+@pytest.mark.parametrize("case,sizes", ALIGNED, ids=[c for c, _ in ALIGNED])
+def test_aligned_ranks_equal_single_rank(case, sizes, monkeypatch):
+    """launch by launch, as planned cycles (one block: program order replayed as a graph; two blocks: the chain of a block beside
+    the sweeps of the other), and with the stopping value examined late"""
+    _gpu()
+    conv1, u1 = solve_ranks(case, 1)
+    for world in sizes:
+        for blocks, depth in ((None, None), (1, 0), (2, None), (None, 3)):
+            conv, u = solve_ranks(case, world, depth=depth, plan_blocks=blocks)
+            assert np.array_equal(conv, conv1), (case, world, blocks, depth, conv, conv1)
+            assert np.array_equal(u, u1), (case, world, blocks, depth, np.abs(u - u1).max())
+    if case in ("heat_config2", "heat_nx257_nt257", "heat_nx2050_wide"):     # ... and it WAS the one-rank machinery that ran
+        for r in range(sizes[-1]):
+            d = DIAG[(case, sizes[-1], r)]
+            assert d["aligned"] and d["fused0"] and d["plans"] >= 1 and d["messages"] > 0, d
+        if case == "heat_config2":      # enough cycles of one shape for the capture (third execution on)
+            assert all(DIAG[(case, sizes[-1], r)]["graphs"] >= 1 for r in range(sizes[-1])), DIAG
+    monkeypatch.setenv("PYMGRIT_AMD_NO_ALIGNED", "1")     # the generic rank path on the same splits
+    conv, u = solve_ranks(case, sizes[0])
     assert np.array_equal(conv, conv1) and np.array_equal(u, u1)
 
 
