@@ -381,6 +381,128 @@ def other_configs(timeout=150):
     return rows
 
 
+def bench_emulated(args):
+    """`--emulate-rank r/P` (r a rank number or `all`): the time-sharded run of BASELINE configs[2] on P ranks, rehearsed on ONE GPU.
+    All P ranks are built in this process (threads sharing the GPU and its stream, pymgrit_amd.core.comm.LoopbackWorld); every
+    exchange point is the stream operation of the engine it is on an RCCL link (mgrit_hip_exchange), with a mailbox in device
+    memory in the place of ncclSend / ncclRecv. After warm-up cycles of ALL ranks together (true ghost rows), rank r replays its
+    cycle alone against what its neighbours sent last (frozen mailboxes: receives complete at once, sends go nowhere): device
+    time per cycle of that shard and the host time to enqueue it -- what a rank of the real job costs when it never waits for
+    a neighbour. A step = one V-cycle + its residual values kept for the (lagged) stopping test + the C-point snapshot of
+    the pipelined solve loop (Mgrit._pl_advance), i.e. everything a rank does per iteration but the collectives.
+    `all`: also the P ranks together on the one GPU (lockstep, true data): the whole job's work per cycle on one device."""
+    import threading
+    import torch
+    from pymgrit_amd import Heat1D, Mgrit
+    from pymgrit_amd.core.comm import LoopbackWorld
+    torch.cuda.set_device(0)
+    which, P = args.emulate_rank.split("/")
+    P = int(P)
+    ranks = list(range(P)) if which == "all" else [int(which)]
+    nx, nt0 = args.nx, args.nt
+    nts = [nt0, (nt0 - 1) // 4 + 1, (nt0 - 1) // 16 + 1]
+    t0 = np.linspace(0, 2.0 * (nt0 - 1) / 65536, nt0)
+    grids = [t0, t0[::4], t0[::16]]
+    dof = nx - 2
+    counts = phi_counts(nts, [4, 4])
+    world = LoopbackWorld(P)
+    gate = threading.Barrier(P)
+    out, err = {}, []
+
+    def one_cycle(mg, it, pl):
+        mg.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True)
+        handle = mg.backend.residual_begin(mg._c_points(0))
+        mg.backend.snapshot_cpoints(it % 6, pl)
+        return handle
+
+    def work(q):
+        try:
+            comm = world.comm(q)
+            problem = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=init_cond, rhs_separable=[(rhs_space, rhs_time)],
+                              t_interval=g) for g in grids]
+            mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=False, max_iter=1000, tol=0.0, logging_lvl=30,
+                       comm_time=comm, plan_blocks=args.plan_blocks)
+            be = mg.backend
+            pl = [int(i) for i in mg.index_local_c[0]]
+            handles = [one_cycle(mg, 0, pl)]
+            for k in range(args.warmup + 3):          # all ranks together: true ghost rows, plans recorded and captured
+                handles.append(one_cycle(mg, 1 + k, pl))
+            for h in handles:
+                be.residual_end(h)
+            be.sync()
+            gate.wait()
+            lock = {}
+            if which == "all":     # the whole job on the one device: every rank's cycle, in lockstep
+                gate.wait()
+                t_a = time.perf_counter()
+                hs = [one_cycle(mg, 10 + k, pl) for k in range(args.steps)]
+                for h in hs:
+                    be.residual_end(h)
+                be.sync()
+                gate.wait()
+                lock["all_ranks_ms_per_cycle"] = 1e3 * (time.perf_counter() - t_a) / args.steps
+            out[q] = (mg, be, pl, comm, lock)
+            gate.wait()
+        except BaseException as exc:   # noqa: BLE001
+            err.append(exc)
+            gate.abort()
+    threads = [threading.Thread(target=work, args=(q,), daemon=True) for q in range(P)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if err:
+        raise err[0]
+    world.frozen = True
+    rows = []
+    for r in ranks:
+        mg, be, pl, comm, lock = out[r]
+        for k in range(3):
+            be.residual_end(one_cycle(mg, 100 + k, pl))
+        be.sync()
+        sent0 = comm.stats["messages"]
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        hs = [one_cycle(mg, 200 + k, pl) for k in range(args.steps)]
+        t_host = time.perf_counter() - t_a
+        for h in hs:
+            be.residual_end(h)
+        be.sync()
+        el = time.perf_counter() - t_a
+        share = [c // P for c in counts]
+        row = {"rank": r, "ms_per_cycle": 1e3 * el / args.steps, "host_enqueue_ms_per_cycle": 1e3 * t_host / args.steps,
+               "messages_sent_per_cycle": (comm.stats["messages"] - sent0) / args.steps, "aligned": bool(getattr(mg, "_aligned", False)),
+               "plan_blocks": mg.plan_blocks(),
+               "cycle_graph": any(p is not None and getattr(p, "_hip", {}).get("graph") is not None for p in mg._plans.values()),
+               "local_points_by_level": [len(t) for t in mg.t]}
+        if os.environ.get("BENCH_EMULATE_PLAN"):
+            plan = [pp for k, pp in mg._plans.items() if pp is not None and not k[1]][-1]
+            for n in plan.order:
+                print(f"{n.start*1e3:7.3f}-{n.finish*1e3:7.3f} {n.stream:5s} #{n.idx:3d} {n.name:14s} L{n.lvl} b{n.chunk}  preds "
+                      f"{sorted(plan.nodes[q].idx for q in n.preds)}", file=sys.stderr)
+        if args.emulate_sweeps:
+            def cyc(it):
+                be.residual_end(one_cycle(mg, 300, pl))
+            row["sweeps"] = timed_sweeps(mg, be, cyc)
+        row.update(lock)
+        rows.append(row)
+    worst = max(rows, key=lambda x: x["ms_per_cycle"])
+    updates = float(sum(c * dof for c in counts))
+    res = {"metric": "time-point-DOF updates/sec per MGRIT V-cycle (EMULATED rank of a sharded run, one GPU)",
+           "value": updates / P / (worst["ms_per_cycle"] * 1e-3), "unit": "time-point-DOF updates/s (this rank's share)",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": worst["ms_per_cycle"], "higher_is_better": True,
+           "dtype": "f64", "data": "synthetic", "vs_baseline": None,
+           "config": {"workload": f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle + residual values + C-point snapshot: rank(s) "
+                                  f"{which} of {P} emulated on one GPU (loopback exchange)", "emulated_ranks": P,
+                      "phi_per_cycle_by_level_whole_job": counts, "dof": dof},
+           "ranks": rows}
+    if which == "all":
+        res["all_ranks_on_one_gpu_ms_per_cycle"] = max(x.get("all_ranks_ms_per_cycle", 0.0) for x in rows)
+        res["exchange"] = {"messages_per_cycle": sum(x["messages_sent_per_cycle"] for x in rows),
+                           "note": "point-to-point ghost rows of all ranks per V-cycle (SURVEY 2b: 24-27 at P=4)"}
+    print(json.dumps(res), flush=True)
+
+
 def self_launch(n):
     """`python bench.py --gpus N` with no launcher environment: run the same command line under torch.distributed.run
     (one rank per GPU, rendezvous on 127.0.0.1 at a free port) as a CHILD process and pass its output and exit code on."""
@@ -427,9 +549,15 @@ def main():
                          "process of its own)")
     ap.add_argument("--workload", default="heat1d", choices=["heat1d", "heat2d", "advection"],
                     help="heat1d = BASELINE configs[2] (default, the driver's run); heat2d = configs[3] on one GPU")
+    ap.add_argument("--emulate-rank", dest="emulate_rank", default=None,
+                    help="r/P or all/P: rank r of a P-rank sharded run emulated on this ONE GPU (loopback exchange): ms per "
+                         "cycle of that shard and host enqueue ms per cycle")
+    ap.add_argument("--emulate-sweeps", dest="emulate_sweeps", action="store_true", help="with --emulate-rank: per-sweep device times")
     ap.add_argument("--nx2d", type=int, default=512)
     ap.add_argument("--nt2d", type=int, default=16385)
     args = ap.parse_args()
+    if args.emulate_rank:
+        return bench_emulated(args)
     if args.workload == "heat2d":
         return bench_heat2d(args)
     if args.workload == "advection":

@@ -463,6 +463,13 @@ class HipBackend:
         # Measured on config 5 (advection_1d, 4 levels, 2 groups per state): one block 26.3 ms per F-cycle, two 30.1, six 32.1.
         if any(d["kind"] != "heat1d" for d in self.desc) or max(self.n) <= 1024:
             return 1
+        if self.mg.comm_time_size > 1:
+            # a rank of a sharded run (bench.py --emulate-rank, config 3): its share of the coarsest level is short, and a launch
+            # over a fraction of a rank's intervals costs nearly what the launch over all of them costs (a few rounds of
+            # workgroups, each a handful of sequential Phi) -- measured per cycle of one rank: 8 ranks (513 coarsest points) one
+            # block 1.71 ms, two 1.77-2.07, three 1.97-2.56; 4 ranks (1025) one 3.3, two 2.92, three 2.93-3.07; 2 ranks (2049)
+            # two 6.25, three 5.9-6.2, four 5.27
+            return int(max(1, min(4, n_c // 512)))
         return int(max(1, min(8, n_c // 680)))
 
     def plan_allowed(self):
@@ -489,6 +496,10 @@ class HipBackend:
         PYMGRIT_AMD_PLAN_GRAPH=0 keeps the launch-by-launch form."""
         graph_ok = os.environ.get("PYMGRIT_AMD_PLAN_GRAPH", "1") != "0" and not getattr(self, "_timing_on", False)
         comm = self.mg.comm_time if getattr(plan, "sends", None) or getattr(plan, "recvs", None) else None
+        if comm is not None and plan.n_blocks > 2 and os.environ.get("PYMGRIT_AMD_PLAN_GRAPH", "") != "1":
+            # a rank's cycle of three and more blocks runs faster launch by launch than as one graph (measured, one rank of two
+            # on config 3, four blocks: 5.27 against 6.13 ms; with two blocks the graph wins: 2.92 against 3.33 on one rank of four)
+            graph_ok = False
         if comm is not None:     # several ranks: the cycle's messages shake hands once (LoopbackComm; RCCL links match by order)
             comm.cycle_begin(self, plan.sends, plan.recvs)
         try:
@@ -854,7 +865,10 @@ class HipBackend:
         # there (a planned cycle of five or more blocks); PYMGRIT_AMD_FUSE_UP_COARSE=1 / 0 forces it on / off.
         want = os.environ.get("PYMGRIT_AMD_FUSE_UP_COARSE", "")
         if want not in ("0", "1"):
-            want = "1" if self.mg.plan_blocks() >= 5 else "0"
+            # (a rank of a sharded run: from two blocks on -- its way up of a block would otherwise wait for the chain part of
+            # the next block, and the rank has few blocks to hide that behind)
+            blocks = self.mg.plan_blocks()
+            want = "1" if (blocks >= 5 or (blocks >= 2 and self.mg.comm_time_size > 1)) else "0"
         return (want == "1" and
                 os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and self._device_transfer(lvl) and
                 int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and da["kind"] == db["kind"] == "heat1d" and

@@ -106,7 +106,7 @@ def test_aligned_ranks_equal_single_rank(case, sizes, monkeypatch):
     if case in ("heat_config2", "heat_nx257_nt257", "heat_nx2050_wide"):     # ... and it WAS the one-rank machinery that ran
         for r in range(sizes[-1]):
             d = DIAG[(case, sizes[-1], r)]
-            assert d["aligned"] and d["fused0"] and d["plans"] >= 1 and d["messages"] > 0, d
+            assert d["aligned"] and d["fused0"] and d["plans"] >= 1 and (d["messages"] > 0 or r == sizes[-1] - 1), d
         if case == "heat_config2":      # enough cycles of one shape for the capture (third execution on)
             assert all(DIAG[(case, sizes[-1], r)]["graphs"] >= 1 for r in range(sizes[-1])), DIAG
     monkeypatch.setenv("PYMGRIT_AMD_NO_ALIGNED", "1")     # the generic rank path on the same splits
