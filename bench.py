@@ -209,6 +209,23 @@ def bench_heat2d(args):
                         "launch_ms": f_ms, "us_per_phi": 1e3 * f_ms / n_f}}
     out["sweeps"] = timed_sweeps(mg, be, cycle, cycles=1)
     out["cycle"] = {"sum_of_sweep_ms_in_program_order": sum(r["ms_per_cycle"] for r in out["sweeps"].values())}
+    # the roofline row = the launch kind with the largest share of the cycle's device time, priced with the Phi it applies
+    N0, N1 = nt0 - 1, (nt0 - 1) // 8
+    phi_per_launch = {"relax_f L0": n_f, "relax_c L0": N1, "residual L0": N1, "fas_rhs L0": 2 * N1, "chain L1": N1}
+    for key, row in out["sweeps"].items():
+        if key in phi_per_launch:
+            row["phi_per_launch"] = phi_per_launch[key]
+            row["tflops"] = phi_per_launch[key] * flops_per_phi / (row["ms_per_launch"] * 1e-3) / 1e12
+            row["mfma_frac"] = row["tflops"] / FP64_MFMA_PEAK_TFLOPS
+    dominant = max(out["sweeps"], key=lambda k: out["sweeps"][k]["ms_per_cycle"])
+    drow = out["sweeps"][dominant]
+    out["roofline_level0_f_relax"] = out["roofline"]
+    out["roofline"] = {"bound": "mfma", "achieved": drow.get("tflops"), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": drow.get("mfma_frac"), "traffic": None, "kernel": f"{dominant}: per Phi 2 x h2d_fwd_kernel + 2 x "
+                       "h2d_inv_kernel (f64 MFMA, half-size transforms) + rhs + epilogue", "flops_per_phi": flops_per_phi,
+                       "launch_ms": drow["ms_per_launch"], "launches_per_cycle": drow["launches_per_cycle"], "ms_per_cycle": drow["ms_per_cycle"],
+                       "limited_by": "MFMA issue + operand traffic of the batched half-size transforms" if not dominant.startswith("chain") else
+                       "latency: the sequential coarsest-level solve, one state per step (64 output tiles for 256 CUs)"}
     print(json.dumps(out), flush=True)
 
 
@@ -264,6 +281,32 @@ def bench_advection(args):
     out["value"] = sum(c * d for c, d in zip(counts, out["config"]["dof_by_level"])) * args.steps / elapsed
     out["sweeps"] = timed_sweeps(mg, be, cycle)
     out["cycle"] = {"sum_of_sweep_ms_in_program_order": sum(r["ms_per_cycle"] for r in out["sweeps"].values())}
+    # SURVEY 8d algorithmic bytes per launch of every sweep kind (Phi = 16 n B on level 0, 24 n B on coarser levels; residual
+    # 16 n per C-point; fas_residual per C-point (16|24) n_l + 32 n_{l+1}; error_correction per C-point 16 n_l + 16 n_{l+1}),
+    # and the roofline row = the launch kind with the largest share of the cycle's device time
+    dofs, Ns = out["config"]["dof_by_level"], [len(p.t) - 1 for p in prob]
+    for key, row in out["sweeps"].items():
+        kind, lv = key.split()[0], int(key.split()[1][1:])
+        n, N = dofs[lv], Ns[lv]
+        F, C = (N - N // 2, N // 2) if lv < len(prob) - 1 else (0, N)
+        phi = 16.0 if lv == 0 else 24.0
+        nc = dofs[lv + 1] if lv + 1 < len(dofs) else n
+        alg = {"relax_f": F * phi * n, "relax_c": C * phi * n, "chain": N * 24.0 * n, "residual": C * 16.0 * n,
+               "fas_rhs": C * (phi * n + 32.0 * nc), "fas_fused": C * (phi * n + 32.0 * nc), "ec_relax": C * 32.0 * n + F * phi * n,
+               "error_correction": C * (16.0 * n + 16.0 * nc), "restrict": C * (8.0 * n + 8.0 * nc), "copy": None}.get(kind)
+        if kind == "copy":
+            alg = (Ns[lv + 1] + 1 if lv + 1 < len(Ns) else N) * 16.0 * nc
+        row["algorithmic_bytes_per_launch"] = alg
+        row["algorithmic_GBps"] = alg / (row["ms_per_launch"] * 1e-3) / 1e9 if alg else None
+    dominant = max(out["sweeps"], key=lambda k: out["sweeps"][k]["ms_per_cycle"])
+    drow = out["sweeps"][dominant]
+    out["roofline_level0_f_relax"] = out["roofline"]
+    out["roofline"] = {"bound": "hbm", "achieved": drow["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": drow["algorithmic_GBps"] / HBM_PEAK_GBS if drow["algorithmic_GBps"] else None, "traffic": None,
+                       "kernel": f"{dominant} ({'chain_local_kernel<2, 0, true>' if dominant.startswith('chain') else 'relax/transfer kernels'})",
+                       "launch_ms": drow["ms_per_launch"], "launches_per_cycle": drow["launches_per_cycle"], "ms_per_cycle": drow["ms_per_cycle"],
+                       "algorithmic_bytes_per_launch": drow["algorithmic_bytes_per_launch"],
+                       "limited_by": "latency: sequential coarsest-level solve, one group exchange per step" if dominant.startswith("chain") else "HBM bandwidth"}
     print(json.dumps(out), flush=True)
 
 
@@ -325,6 +368,20 @@ def timed_sweeps(mg, be, cycle, cycles=2):
             for key, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])}
 
 
+def pmc_traffic(nx, nt0, world):
+    """per-kernel HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload
+    (tools/profile_round.sh -> profiles/<tag>_traffic.json; program order, full-width launches), or ({}, None)"""
+    if not (world == 1 and nx == 16384 and nt0 == 65537):
+        return {}, None
+    for tag in ("r03", "r02", "r01"):
+        tfile = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
+        if os.path.exists(tfile):
+            return json.load(open(tfile))["kernels"], (f"profiles/{tag}_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                                       f"passes, KiB units, read side doubled per the guide's gfx950 note; committed "
+                                                       f"with the round, not collected in this run)")
+    return {}, None
+
+
 def sweep_table(mg, be, nts, m_list, dof, cycle, cycles=3):
     from pymgrit_amd.core import hip_lib
     keep = mg._plan_request
@@ -375,7 +432,8 @@ def other_configs(timeout=150):
             rf = b.get("roofline", {})
             rows.append({"workload": b["config"]["workload"], "ms_per_step": b["ms_per_step"], "value": b["value"], "unit": b["unit"],
                          "steps": b["steps"], "warmup": b["warmup"],
-                         "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launch_ms")}})
+                         "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launch_ms",
+                                                             "launches_per_cycle", "ms_per_cycle", "limited_by")}})
         except Exception as exc:   # noqa: BLE001 - secondary numbers: report, never fail the headline
             rows.append({"workload": " ".join(extra), "error": repr(exc)[:300]})
     return rows
@@ -501,6 +559,26 @@ def bench_emulated(args):
         res["exchange"] = {"messages_per_cycle": sum(x["messages_sent_per_cycle"] for x in rows),
                            "note": "point-to-point ghost rows of all ranks per V-cycle (SURVEY 2b: 24-27 at P=4)"}
     print(json.dumps(res), flush=True)
+
+
+def sharded_emulation(ms_one_gpu, timeout=150):
+    """the time-sharded run rehearsed on this ONE GPU (bench.py --emulate-rank r/P, child processes): device time per cycle of
+    the middle rank of 2, 4 and 8 when it never waits for a neighbour, its host enqueue time, and what that bounds the
+    N-GPU cycle by. Not a multi-GPU measurement: RCCL latency and the wait for the neighbour's hand-over are not in it."""
+    import subprocess
+    rows = []
+    for P in (2, 4, 8):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--emulate-rank", f"{P // 2}/{P}", "--steps", "20", "--warmup", "3"],
+                               capture_output=True, text=True, timeout=timeout)
+            b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            k = b["ranks"][0]
+            rows.append({"ranks": P, "rank": k["rank"], "ms_per_cycle": k["ms_per_cycle"], "host_enqueue_ms_per_cycle": k["host_enqueue_ms_per_cycle"],
+                         "messages_sent_per_cycle": k["messages_sent_per_cycle"], "plan_blocks": k["plan_blocks"], "cycle_graph": k["cycle_graph"],
+                         "aligned": k["aligned"], "one_gpu_ms_over_rank_ms": ms_one_gpu / k["ms_per_cycle"]})
+        except Exception as exc:   # noqa: BLE001 - secondary numbers: report, never fail the headline
+            rows.append({"ranks": P, "error": repr(exc)[:300]})
+    return rows
 
 
 def self_launch(n):
@@ -662,10 +740,19 @@ def main():
     # these are the kernel times a rocprofv3 --kernel-trace --stats run of `bench.py --plan-blocks 1` shows per kernel)
     table = sweep_table(mg, be, nts, [4, 4], dof, cycle)
     local_share = 1.0 / world      # the table holds THIS rank's launches: its share of the job's bytes
+    pmc, pmc_src = pmc_traffic(nx, nt0, world)
     for row in table.values():
+        # algorithmic = SURVEY 8d's bytes of the SWEEPS a launch stands for (a whole-level pass stands for two or three of them
+        # and keeps the state in registers between them, so it moves far fewer bytes than that); physical = what the HBM
+        # counters saw. Only physical bytes are priced against the HBM roofline.
         row["algorithmic_bytes_per_cycle"] *= local_share
+        k = pmc.get(row["kernel_symbol"])
+        phys = k["hbm_bytes_per_launch"] * row["launches_per_cycle"] if k else None
+        row["physical_bytes_per_cycle"] = phys
+        row["physical_GBps"] = phys / (row["ms_per_cycle"] * 1e-3) / 1e9 if (phys and row["ms_per_cycle"]) else None
+        row["physical_frac"] = row["physical_GBps"] / HBM_PEAK_GBS if row["physical_GBps"] else None
+        row["fused_vs_unfused_bytes"] = row["algorithmic_bytes_per_cycle"] / phys if phys else None
         row["algorithmic_GBps"] = row["algorithmic_bytes_per_cycle"] / (row["ms_per_cycle"] * 1e-3) / 1e9 if row["ms_per_cycle"] else None
-        row["frac_of_hbm_peak"] = row["algorithmic_GBps"] / HBM_PEAK_GBS if row["algorithmic_GBps"] else None
     # the north_star's sweep-only figure: level-0 F-relax + C-relax + F-relax as launches of their own (inside a cycle they
     # may be part of a whole-level pass)
     be.set_timing(True)
@@ -691,14 +778,16 @@ def main():
     cycle_bytes = sum(r["algorithmic_bytes_per_cycle"] for r in table.values()) / local_share
     ms_step = 1e3 * elapsed / args.steps
 
-    traffic, traffic_src = None, None  # HBM bytes per launch of the dominant kernel from the committed PMC passes (N=1, same workload)
-    for tag in ("r02", "r01"):
-        tfile = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
-        if world == 1 and nx == 16384 and nt0 == 65537 and os.path.exists(tfile):
-            k = json.load(open(tfile))["kernels"].get(dom["kernel_symbol"])
-            if k:
-                traffic, traffic_src = k["hbm_bytes_per_launch"], f"profiles/{tag}_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run)"
-                break
+    k = pmc.get(dom["kernel_symbol"])
+    traffic, traffic_src = (k["hbm_bytes_per_launch"], pmc_src) if k else (None, None)
+    phys_cycle = sum(r["physical_bytes_per_cycle"] or 0.0 for r in table.values()) if pmc else None
+    # Phi applications the ENGINE performs per cycle (the work model behind `value` counts the sweeps of the reference's cycle,
+    # SURVEY 3.5): with pre-relaxed C-points the level-0 C-relaxation's Phi is the residual check's of the cycle before
+    applied = list(counts)
+    if not args.at_k and mg.cf_iter[0] == 1 and os.environ.get("PYMGRIT_AMD_NO_PRE_RELAX", "") != "1" and mg._level_intervals(0) is not None:
+        applied[0] -= (nts[0] - 1) // 4
+    dom_alg = dom["algorithmic_bytes_per_cycle"] / max(dom["launches_per_cycle"], 1)
+    dom_gbs = dom_alg / (dom["ms_per_launch"] * 1e-3) / 1e9
 
     out = {
         "metric": "time-point-DOF updates/sec per MGRIT V-cycle", "value": updates_per_cycle * args.steps / elapsed,
@@ -709,23 +798,27 @@ def main():
                                f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle + residual check "
                                f"(BASELINE configs[{2 if (nx, nt0) == (16384, 65537) else 1 if (nx, nt0) == (1024, 4097) else '-'}]; "
                                f"time points sharded over {world} GPU(s))",
-                   "phi_per_cycle_by_level": counts, "dof": dof, "pipeline_depth": mg.pipeline_depth(),
+                   "phi_per_cycle_by_level": counts, "phi_applied_by_level": applied, "dof": dof, "pipeline_depth": mg.pipeline_depth(),
                    "plan_blocks": mg.plan_blocks(), "chain_shader_mhz": chain_clock[0], "chain_us_per_step": chain_clock[1],
                    "cycle_graph": any(p is not None and getattr(p, "_hip", {}).get("graph") is not None for p in mg._plans.values())},
         # the kernel that takes the largest share of the cycle's device time (this rank), priced against the HBM roofline with
         # SURVEY 8d's algorithmic bytes; `limited_by` says what really bounds it
-        "roofline": {"bound": "hbm", "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": dom["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_src,
+        "roofline": {"bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": f"{dom['kernel_symbol']} ({dominant})", "launch_ms": dom["ms_per_launch"],
                      "launches_per_cycle": dom["launches_per_cycle"], "ms_per_cycle": dom["ms_per_cycle"],
-                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_cycle"] / max(dom["launches_per_cycle"], 1),
-                     "limited_by": dom["limited_by"]},
+                     "algorithmic_bytes_per_launch": dom_alg, "limited_by": dom["limited_by"]},
         "sweeps": table,
-        "cycle": {"algorithmic_bytes": cycle_bytes, "algorithmic_GBps": cycle_bytes / (ms_step * 1e-3) / 1e9,
-                  "frac_of_hbm_peak": cycle_bytes / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+        "cycle": {"algorithmic_bytes": cycle_bytes, "physical_bytes": phys_cycle,
+                  "physical_GBps": phys_cycle / (ms_step * 1e-3) / 1e9 if phys_cycle else None,
+                  "physical_frac": phys_cycle / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world) if phys_cycle else None,
+                  "fused_vs_unfused_bytes": cycle_bytes / phys_cycle if phys_cycle else None,
+                  "physical_bytes_source": pmc_src,
                   "sum_of_sweep_ms_in_program_order": sum(r["ms_per_cycle"] for r in table.values()),
-                  "note": "whole V-cycle + residual check: SURVEY 8d bytes of all sweeps / wall time of a step; in a planned "
-                          "cycle the chain runs beside the sweeps, so a step is shorter than the sum of its sweeps"},
+                  "note": "whole V-cycle + residual check. algorithmic = SURVEY 8d bytes of every sweep of the reference's cycle; "
+                          "physical = HBM bytes of the kernels that run (PMC); physical_frac = physical bytes / wall time of a "
+                          "step / 8 TB/s. In a planned cycle the chain runs beside the sweeps, so a step is shorter than the "
+                          "sum of its sweeps"},
         "fcf_relax_level0": {"ms": fcf_ms, "algorithmic_GBps": fcf_gbs,
                              "frac_of_hbm_peak": fcf_gbs / (HBM_PEAK_GBS * world),
                              "updates_per_s": (2 * (N0 * 3 // 4) + N0 // 4) * dof / (fcf_ms * 1e-3),
@@ -755,6 +848,7 @@ def main():
                 # the other GPU configurations of BASELINE.json, each measured in a child process of its own AFTER everything
                 # above, folded into this ONE line (the full lines: --all-configs); a failure there never touches the headline
                 out["other_configs"] = other_configs()
+                out["sharded_rank_emulation"] = sharded_emulation(ms_step)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
