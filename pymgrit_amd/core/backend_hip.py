@@ -201,7 +201,7 @@ class HipBackend:
             assert slen.value == self.chain_handover[lvl]
             self.chain_state[lvl] = torch.zeros(slen.value, dtype=torch.float64, device=self.device)
             check(self.lib.mgrit_hip_chain_bind(self.h, lvl, C.c_void_p(self.chain_state[lvl].data_ptr())))
-        mg.u.append(SlabVectorList(u, n, tmpl, self.perm[lvl], on_write=self._forget_residual,
+        mg.u.append(SlabVectorList(u, n, tmpl, self.perm[lvl], on_write=self._before_write if lvl == 0 else self._forget_residual,
                                    on_read=self.materialise if lvl == 0 else None))
         mg.v.append(SlabVectorList(v, n, tmpl, self.perm[lvl]) if v is not None else None)
         mg.g.append(SlabVectorList(g, n, tmpl, self.perm[lvl]) if g is not None else None)
@@ -298,6 +298,13 @@ class HipBackend:
         tr = self.mg.transfer_objects[lvl]
         lib_method = type(self.mg)._library_method
         return hasattr(tr, "device_transfer") and lib_method(tr, "restriction") and lib_method(tr, "interpolation")
+
+    def _before_write(self):
+        """mgrit.u[0][i] = vec under C-point storage: the F-points the last cycle left out are put in place FIRST -- the write
+        replaces one row of a complete solution, as it does in the reference; rebuilt afterwards they would overwrite a written
+        F-point, or follow a written C-point"""
+        self.materialise()
+        self._forget_residual()
 
     def _forget_residual(self):
         self._residual_cache = None
@@ -661,11 +668,27 @@ class HipBackend:
         ev.record(self.stream)
         return buf, ev
 
+    def _wait_event(self, ev):
+        """several ranks on RCCL links: a neighbour that never sends or never receives must end in an ERROR of this rank (and with
+        it of the job), not in a silent stall -- bounded wait, then the links are aborted (ncclCommAbort)"""
+        if not getattr(self, "device_links", False):
+            ev.synchronize()
+            return
+        import time
+        limit = float(getattr(self.mg.comm_time, "timeout_s", 120.0))
+        t0 = time.perf_counter()
+        while not ev.query():
+            if time.perf_counter() - t0 > limit:
+                self.lib.mgrit_hip_links_close(self.h, 1)
+                raise MgritHipError(f"rank {self.mg.comm_time_rank}: the cycle did not finish within {limit} s (a neighbouring rank "
+                                    f"never sent or never received): exchange links aborted")
+            time.sleep(2e-5)
+
     def residual_end(self, handle):
         if handle is None:
             return []
         buf, ev = handle
-        ev.synchronize()
+        self._wait_event(ev)
         return np.sqrt(buf.numpy())
 
     def save_last(self):

@@ -93,8 +93,10 @@ class NotSeparable(Exception):
 
 def detect_separable(rhs, x, t, who='Heat1D'):
     """Find (s, tau) with rhs(x,t) = s(x)*tau(t) to rounding, or K=0 for a zero forcing; raises NotSeparable otherwise.
-    The shape of the forcing is compared at 16 times spread over the grid (tau itself is evaluated from rhs at a pivot
-    point for every time point, so its time dependence is exact whatever it is)."""
+    The full spatial shape of the forcing is compared at 16 times spread over the grid, and at EVERY time point on a sub-grid
+    of up to 9 probe points (a forcing whose shape deviates only between the 16 probe times must not pass: the device would
+    run with a wrong forcing, silently); tau itself is evaluated from rhs at a pivot point for every time point, so its time
+    dependence is exact whatever it is."""
     nx = x.shape[0]
     probes = np.unique(t[np.unique(np.linspace(0, len(t) - 1, 16).astype(int))])
     samples = [np.asarray(rhs(x, float(tp)), dtype=np.float64) * np.ones(nx) for tp in probes]
@@ -107,10 +109,23 @@ def detect_separable(rhs, x, t, who='Heat1D'):
 
     def tau_fn(tt, _xp=xp, _den=s_vec[piv]):
         return float(np.asarray(rhs(_xp, tt), dtype=np.float64).ravel()[0]) / _den
+    refusal = NotSeparable(f'{who}: rhs(x,t) is not of the separable form s(x)*tau(t); pass rhs_separable=[(s_fn, '
+                           'tau_fn), ...] to run on the MI355X engine')
     for tp, smp in zip(probes, samples):
         if np.max(np.abs(smp - s_vec * tau_fn(float(tp)))) > 1e-12 * max(norms):
-            raise NotSeparable(f'{who}: rhs(x,t) is not of the separable form s(x)*tau(t); pass rhs_separable=[(s_fn, '
-                               'tau_fn), ...] to run on the MI355X engine')
+            raise refusal
+    sub = np.unique(np.concatenate((np.linspace(0, nx - 1, 8).astype(int), [piv])))
+    xs, ss = x[sub], s_vec[sub]
+    k_piv = int(np.nonzero(sub == piv)[0][0])
+    scale = 0.0
+    rows = []
+    for tp in t:      # one rhs call per time point on the sub-grid: the pivot's value is tau(t) * s[piv]
+        row = np.asarray(rhs(xs, float(tp)), dtype=np.float64) * np.ones(xs.shape[0])
+        rows.append(row)
+        scale = max(scale, float(np.max(np.abs(row))))
+    for row in rows:
+        if np.max(np.abs(row - ss * (row[k_piv] / s_vec[piv]))) > 1e-12 * max(scale, max(norms)):
+            raise refusal
     return [s_vec], [tau_fn]
 
 

@@ -165,6 +165,27 @@ def test_rccl_link_on_a_one_rank_communicator():
             graph.replay()
             torch.cuda.synchronize()
             assert torch.equal(u[1], u[4]) and float(u[1][3]) == k + 7
+        # ... and with the hand-over of the coarsest level's solve on a second captured stream, as a cycle of several blocks has it
+        graph2 = torch.cuda.CUDAGraph()
+        side, fork, join = torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event()
+        torch.cuda.synchronize()
+        try:
+            with torch.cuda.graph(graph2, stream=cap, capture_error_mode="thread_local"):
+                assert lib.mgrit_hip_set_stream(eng, C.c_void_p(cap.cuda_stream)) == 0
+                assert lib.mgrit_hip_exchange(eng, 0, 0, 0, 4, 0, 1, 1, 0, 0) == 0, lib.mgrit_hip_last_error()
+                fork.record(cap)
+                side.wait_event(fork)
+                assert lib.mgrit_hip_set_stream(eng, C.c_void_p(side.cuda_stream)) == 0
+                assert lib.mgrit_hip_exchange(eng, 0, 5, 0, 5, 0, 1, 2, 0, 0) == 0, lib.mgrit_hip_last_error()
+                join.record(side)
+                cap.wait_event(join)
+        finally:
+            lib.mgrit_hip_set_stream(eng, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        u[4], u[5] = 21.0, 22.0
+        graph2.replay()
+        torch.cuda.synchronize()
+        assert float(u[1][0]) == 21.0 and float(u[2][0]) == 22.0
+        graph2.reset()
         assert lib.mgrit_hip_exchange(eng, 0, 6, 0, 4, 0, 1, 1, 0, 0) != 0      # op 6 carries no row
         assert lib.mgrit_hip_exchange(eng, 0, 0, 0, 9, 0, -1, 0, 0, 0) != 0     # row out of range
         assert lib.mgrit_hip_exchange(eng, 0, 0, 7, 1, 0, -1, 0, 0, 0) != 0     # link not open

@@ -1,0 +1,143 @@
+"""State-machine fuzz of the device path: random interleavings of the PUBLIC calls of Mgrit -- iteration (V / F, first and later
+iterations, with and without the leading F-relaxation), f_relax / c_relax on any level, a two-level cycle by hand (fas_residual,
+relaxations or the coarsest solve, error_correction, f_relax), convergence_criterion, reads of single vectors (mgrit.u[0][i]),
+writes (mgrit.u[0][i] = v, a whole slab), solve -- with the planned cycle, the whole-level passes, C-point storage and the
+pre-relaxed C-points switched at random, against the ORACLE driven through the same calls (reference order of every sweep:
+mgrit.py:261-290, 292-370, 488-549, 715-726). What a caller can see must agree bit for bit at every point where it looks: the
+level-0 solution (reads trigger the F-relaxation that rebuilds what C-point storage left out), the per-point residual norms,
+the stopping values. The five code paths of Mgrit.iteration and the backend's staleness states (_f_stale 0/1/2, _cycle_pre,
+_head_done, write generation, cached residuals) are what this walks through."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+SHAPES = {"narrow3": (33, (65, 17, 5)), "wide3": (2050, (65, 17, 5)), "two8": (33, (65, 9)), "narrow3_long": (130, (257, 65, 17))}
+SWITCHES = ("PYMGRIT_AMD_STORE_ALL_F", "PYMGRIT_AMD_NO_PRE_RELAX", "PYMGRIT_AMD_NO_LEVEL_FUSION", "PYMGRIT_AMD_FUSE_UP_COARSE")
+
+
+def build(shape, rng, oracle, monkeypatch):
+    from pymgrit_amd import Heat1D, Mgrit
+    nx, nts = SHAPES[shape]
+    for name in SWITCHES:
+        monkeypatch.delenv(name, raising=False)
+        if rng.random() < 0.3:
+            monkeypatch.setenv(name, "1")
+    cycle = 'F' if (len(nts) > 2 and rng.random() < 0.3) else 'V'
+    cf = int(rng.choice([1, 1, 1, 0, 2]))
+    nested = bool(rng.random() < 0.5)
+    blocks = [None, 1, 2, 3][int(rng.integers(4))]
+    grids = [cases.lin(2, nt) for nt in nts]
+    prob = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=cases.init_cond, rhs_separable=[(cases.rhs_space, cases.rhs_time)],
+                   t_interval=g) for g in grids]
+    mg = Mgrit(prob, cf_iter=cf, cycle_type=cycle, nested_iteration=nested, max_iter=40, tol=0.0, logging_lvl=30, plan_blocks=blocks)
+    op = oracle.OracleProblem([cases.heat_level_spec(nx, g) for g in grids], variant=1, cf_iter=cf, cycle_type=cycle,
+                              nested_iteration=nested, max_iter=40, tol=0.0)
+    op.setup()
+    return mg, op, (shape, cycle, cf, nested, blocks, [n for n in SWITCHES if os.environ.get(n)])
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_random_call_sequences_match_the_oracle(oracle, seed, monkeypatch):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    run_sequence(oracle, seed, monkeypatch)
+
+
+def run_sequence(oracle, seed, monkeypatch, stop_at=None):
+    rng = np.random.default_rng(1000 + seed)
+    shape = list(SHAPES)[seed % len(SHAPES)]
+    mg, op, tag = build(shape, rng, oracle, monkeypatch)
+    be, L, n_pts = mg.backend, mg.lvl_max, len(mg.t[0])
+    trace = []
+
+    def look():
+        got, want = be.natural("u", 0), op.state("u", 0)
+        assert np.array_equal(got, want), (tag, trace, float(np.abs(got - want).max()))
+
+    look()      # after the constructor (nested iteration or the plain initial guess)
+    it, checks = 0, 0
+    for step in range(int(rng.integers(12, 30))):
+        kind = rng.choice(["iteration", "iteration", "iteration", "check", "relax", "by_hand", "read", "write_row", "write_slab",
+                           "look", "iteration_no_first_f"])
+        trace.append(str(kind))
+        if kind in ("iteration", "iteration_no_first_f"):
+            first_f = kind == "iteration"
+            number = 0 if rng.random() < 0.2 else max(it, 1)
+            ctype = mg.cycle_type
+            mg.iteration(lvl=0, cycle_type=ctype, iteration=int(number), first_f=first_f)
+            op.iteration(0, ctype, int(number), first_f)
+            it += 1
+        elif kind == "check":
+            checks += 1
+            if rng.random() < 0.5:
+                norms = np.asarray(mg.compute_residual())
+                assert np.array_equal(norms, op.residual_norms()), (tag, trace)
+            mg.convergence_criterion(iteration=min(checks, mg.iter_max))
+            r = op.residual_norms()
+            want = float(np.sqrt(np.sum(r * r)))
+            assert abs(mg.conv[min(checks, mg.iter_max)] - want) <= 1e-13 * max(want, 1e-300), (tag, trace, mg.conv[:checks + 1], want)
+        elif kind == "relax":
+            lvl = int(rng.integers(0, L - 1))
+            for _ in range(int(rng.integers(1, 3))):
+                if rng.random() < 0.5:
+                    mg.f_relax(lvl), op.f_relax(lvl)
+                else:
+                    mg.c_relax(lvl), op.c_relax(lvl)
+        elif kind == "by_hand":      # a two-level cycle on a random level pair, sweep by sweep through the public methods
+            lvl = int(rng.integers(0, L - 1))
+            if lvl > 0:                      # bring the level into the state a cycle would present it in: u, v, g from above
+                for lv in range(lvl):
+                    mg.fas_residual(lv), op.fas_residual(lv)
+            mg.fas_residual(lvl), op.fas_residual(lvl)
+            if lvl + 1 == L - 1:
+                mg.forward_solve(lvl + 1), op.forward_solve(lvl + 1)
+            else:
+                mg.f_relax(lvl + 1), op.f_relax(lvl + 1)
+                mg.c_relax(lvl + 1), op.c_relax(lvl + 1)
+                mg.f_relax(lvl + 1), op.f_relax(lvl + 1)
+            mg.error_correction(lvl), op.error_correction(lvl)
+            mg.f_relax(lvl), op.f_relax(lvl)
+            for lv in range(lvl - 1, -1, -1):
+                mg.error_correction(lv), op.error_correction(lv)
+                mg.f_relax(lv), op.f_relax(lv)
+        elif kind == "read":
+            i = int(rng.integers(0, n_pts))
+            assert np.array_equal(np.asarray(mg.u[0][i].get_values()), op.state("u", 0)[i]), (tag, trace, i)
+        elif kind == "write_row":
+            i = int(rng.integers(1, n_pts))
+            vec = mg.problem[0].vector_template.clone_zero()
+            vals = rng.standard_normal(op.n[0])
+            vec.set_values(vals.copy())
+            mg.u[0][i] = vec
+            op.state("u", 0)[i] = vals
+        elif kind == "write_slab":
+            vals = rng.standard_normal((n_pts, op.n[0]))
+            vals[0] = op.state("u", 0)[0]
+            be.set_natural("u", 0, vals)
+            op.state("u", 0)[:] = vals
+        else:
+            look()
+        if os.environ.get("FUZZ_LOOK_ALWAYS"):      # (debugging aid: find the first step after which the states differ)
+            look()
+        if stop_at is not None and step + 1 >= stop_at:     # (debugging aid: look once, after exactly stop_at calls)
+            look()
+            return trace
+    look()
+    # ... and a solve() from wherever the sequence has left the solver: same history, same solution
+    mg.iter_max, mg.tol = 3, 0.0
+    mg.conv = np.zeros(4)
+    mg.solve()
+    conv = mg.conv[1:4]     # (the unfiltered history: solve() drops exact zeros, and a small problem converges to exactly 0)
+    want = []
+    for k in range(3):
+        op.iteration(0, mg.cycle_type, k, True)
+        r = op.residual_norms()
+        want.append(float(np.sqrt(np.sum(r * r))))
+    assert np.allclose(conv, want, rtol=1e-13, atol=0.0), (tag, trace, conv, want)
+    look()

@@ -364,3 +364,21 @@ def test_fused_pass_lists_of_the_device_path():
     mg3 = Mgrit(prob, logging_lvl=30, max_iter=1, cf_iter=[1, 2])
     mg3.backend = Caps(mg3.backend)
     assert mg3._coarse_down(1) is None and [t[5] for t in mg3._level_intervals(0)] == [1 if (k + 1) % 4 == 0 else 0 for k in range(16)]
+
+
+def test_detect_separable_checks_every_time_point():
+    """a forcing whose spatial shape deviates only BETWEEN the 16 full-shape probe times is refused (the general forcing rows take
+    over), a separable one is accepted unchanged"""
+    from pymgrit_amd.heat.heat_1d import NotSeparable, detect_separable
+    x = np.linspace(0, 1, 67)[1:-1]
+    t = np.linspace(0, 2, 257)
+    s, tau = detect_separable(lambda xx, tt: np.sin(np.pi * xx) * np.cos(tt), x, t)
+    assert len(s) == 1 and abs(tau[0](0.5) * s[0][10] - np.sin(np.pi * x[10]) * np.cos(0.5)) < 1e-14
+    probes = set(np.unique(t[np.unique(np.linspace(0, len(t) - 1, 16).astype(int))]).tolist())
+    odd = float([tp for tp in t if tp not in probes][40])
+
+    def rhs(xx, tt):
+        base = np.sin(np.pi * xx) * np.cos(tt)
+        return base + (xx ** 2 if abs(tt - odd) < 1e-12 else 0.0)
+    with pytest.raises(NotSeparable):
+        detect_separable(rhs, x, t)

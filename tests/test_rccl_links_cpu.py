@@ -1,0 +1,94 @@
+"""RcclTimeComm.open_links without a GPU: two and four gloo ranks with a stand-in for libmgrit_hip.so whose
+mgrit_hip_comm_init_rank BLOCKS until the other end of the link has called it with the same unique id (as ncclCommInitRank does):
+every rank must create exactly the links it takes part in, both ends with the same id and opposite roles, in an order that
+never lets two ranks wait for each other crosswise."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+WORKER = r'''
+import ctypes as C, json, os, sys, time
+sys.path.insert(0, sys.argv[5]); sys.path.insert(0, os.path.join(sys.argv[5], "tests"))
+import torch.distributed as dist
+rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+from pymgrit_amd.core import comm as cm, hip_lib
+store = dist.distributed_c10d._get_default_store()
+log = []
+
+class FakeLib:
+    n = 0
+    def mgrit_hip_comm_unique_id(self, buf):
+        FakeLib.n += 1
+        raw = (f"id-{rank}-{FakeLib.n}".encode()).ljust(128, b".")
+        C.memmove(buf, raw, 128)
+        return 0
+    def mgrit_hip_comm_init_rank(self, out_ref, uid, nranks, r):
+        key = "link/" + bytes(uid).decode().strip(".")
+        store.add(key, 1)                       # rendezvous of the two ends: blocks like ncclCommInitRank
+        t0 = time.time()
+        while int(store.add(key, 0)) < 2:
+            if time.time() - t0 > 30:
+                raise RuntimeError("deadlock in link creation: " + key)
+            time.sleep(0.01)
+        log.append(("init", bytes(uid).decode().strip("."), nranks, r))
+        return 0
+    def mgrit_hip_link_attach(self, h, handle, comm, peer):
+        log.append(("attach", handle, peer))
+        return 0
+hip_lib._lib = FakeLib()
+hip_lib.check = lambda rc: None if rc == 0 else (_ for _ in ()).throw(RuntimeError(rc))
+
+class Backend:
+    h = None
+# a chain of ranks (every rank talks to rank+1 on both channels) plus one link that skips a rank (ranks without coarse points)
+need = []
+if rank + 1 < world:
+    need += [(rank, rank + 1, cm.CH_SWEEP), (rank, rank + 1, cm.CH_CHAIN)]
+if rank > 0:
+    need += [(rank - 1, rank, cm.CH_SWEEP), (rank - 1, rank, cm.CH_CHAIN)]
+if world >= 4 and rank in (0, 2):
+    need += [(0, 2, cm.CH_SWEEP)]
+tc = cm.RcclTimeComm()
+be = Backend()
+tc.open_links(be, need)
+links = tc._engines[id(be)].handle
+json.dump({"log": log, "links": {f"{k[0]}/{k[1]}/{k[2]}": v for k, v in links.items()}, "need": need}, open(os.path.join(out, f"r{rank}.json"), "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_open_links_is_collective_and_crosswise_free(world):
+    import json
+    import socket
+    out = tempfile.mkdtemp(prefix="rccl_links_")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    script = os.path.join(out, "worker.py")
+    open(script, "w").write(WORKER)
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), out, os.path.dirname(HERE)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=120)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    res = [json.load(open(os.path.join(out, f"r{r}.json"))) for r in range(world)]
+    ids = {}
+    for r, d in enumerate(res):
+        inits = [e for e in d["log"] if e[0] == "init"]
+        assert len(inits) == len(d["need"])                      # one communicator per link this rank takes part in
+        assert len(d["links"]) == len(d["need"])                 # ... and one engine handle each
+        for _, uid, nranks, role in inits:
+            assert nranks == 2
+            ids.setdefault(uid, []).append((r, role))
+    for uid, ends in ids.items():                                # both ends, the id's maker (the sender) as rank 0 of the pair
+        assert sorted(role for _, role in ends) == [0, 1], (uid, ends)
+        sender = int(uid.split("-")[1])
+        assert dict(ends)[sender] == 0, (uid, ends)
