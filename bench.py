@@ -167,7 +167,7 @@ def bench_heat2d(args):
     t0 = np.linspace(0, 1, nt0)
     prob = [Heat2D(x_start=0, x_end=1, y_start=0, y_end=1, nx=nx, ny=nx, a=1.0, method="BE",
                    init_cond=lambda x, y: np.sin(np.pi * x) * np.sin(np.pi * y), t_interval=t) for t in (t0, t0[::8])]
-    mg = Mgrit(prob, cf_iter=1, nested_iteration=False, max_iter=1, tol=0.0, logging_lvl=30)
+    mg = Mgrit(prob, cf_iter=1, nested_iteration=False, max_iter=1, tol=0.0, logging_lvl=30, plan_blocks=args.plan_blocks)
     be = mg.backend
     dof = nx * nx
     counts = phi_counts([nt0, (nt0 - 1) // 8 + 1], [8])
@@ -468,6 +468,7 @@ def bench_emulated(args):
     out, err = {}, []
 
     def one_cycle(mg, it, pl):
+        mg.backend.mirror_cpoints(it % 6, pl)
         mg.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True)
         handle = mg.backend.residual_begin(mg._c_points(0))
         mg.backend.snapshot_cpoints(it % 6, pl)

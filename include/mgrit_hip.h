@@ -298,6 +298,13 @@ int mgrit_hip_error_correction_to(mgrit_hip_engine *e, int lvl, int pairs_id, do
  * (device-accessible, e.g. pinned host memory) on the stream: a replayed cycle always writes the engine's buffer, a solver
  * that looks at its stopping values some cycles late (Mgrit._solve_pipelined) keeps each cycle's values in a slot of its own */
 int mgrit_hip_residual_stash(mgrit_hip_engine *e, int n, double *dst);
+/* C-point mirror: from the next level-0 mgrit_hip_ec_relax_res pass on (stream order), every corrected C-point u^0_i (mgrit.py:
+ * 724-726) is ALSO stored to row row0 + res_pos of the device slab `rows` ([>= row0 + res_len][ld]); NULL switches it off. A
+ * solver that examines its stopping value some cycles late keeps the level-0 C-points of every cycle it may have to return to
+ * (Mgrit._solve_pipelined): the pass that writes them writes the copy too, instead of a gather over the level afterwards. The
+ * slab is named through a word in device memory that a one-thread kernel on the stream updates, so a captured cycle follows
+ * it; row0 is fixed with the first call. */
+int mgrit_hip_cpoint_mirror(mgrit_hip_engine *e, double *rows, int row0);
 
 #ifdef __cplusplus
 }

@@ -460,9 +460,13 @@ class HipBackend:
     def plan_blocks(self):
         """how many blocks of time points a planned cycle uses by default (1 = program order): the overlap pays when the
         coarsest-level solve is long; Heat2D / two-point levels keep the program order"""
-        if any(d["kind"] not in ("heat1d", "advection1d") for d in self.desc) or self.mg.lvl_max < 2 or self._host_transfers():
+        if any(d["kind"] not in ("heat1d", "advection1d", "heat2d") for d in self.desc) or self.mg.lvl_max < 2 or self._host_transfers():
             return 1
         n_c = len(self.mg.t[-1])
+        if any(d["kind"] == "heat2d" for d in self.desc):
+            # the coarsest-level solve (six launches per step) beside the batched sweeps of other blocks; measured on config 4
+            # (2049 coarsest points): one block 619 ms per cycle, two 593, four 578, eight 574
+            return int(os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS_HEAT2D", str(max(1, min(8, n_c // 256)))))
         # measured on config 3 (4097 coarsest points, round 2): 4 blocks 12.2 ms, 5 11.3, 6 10.8, 7 11.9, 8 13.3 -- more blocks
         # shorten the fill and drain of the block pipeline, fewer keep the launches large (a level-0 pass of one block is
         # 16384 / blocks / 4 chunks for 240 workgroups: with 6 blocks 2.8 rounds, with 8 blocks 2.1)
@@ -480,9 +484,10 @@ class HipBackend:
         return int(max(1, min(8, n_c // 680)))
 
     def plan_allowed(self):
-        """planned cycles run sweeps and chain parts on two streams at once: only for the 1-D one-point steppers (the Heat2D
-        and two-point kernels share per-level work buffers between launches; measured with them switched on: wrong results)"""
-        return all(d["kind"] in ("heat1d", "advection1d") for d in self.desc)
+        """planned cycles run sweeps and chain parts on two streams at once: the 1-D one-point steppers and Heat2D (whose
+        coarsest-level chain has work buffers of its own since round 3: H2DHost::Wc0); the two-point kernels share per-level work
+        buffers between launches"""
+        return all(d["kind"] in ("heat1d", "advection1d", "heat2d") for d in self.desc)
 
     def plan_single_block(self):
         """a cycle too small to be cut into blocks is still planned (as one block, program order): what pays there is the
@@ -502,6 +507,8 @@ class HipBackend:
         of 5-20 us each, and without the graph their launch cost, not their run time, is what a cycle takes.
         PYMGRIT_AMD_PLAN_GRAPH=0 keeps the launch-by-launch form."""
         graph_ok = os.environ.get("PYMGRIT_AMD_PLAN_GRAPH", "1") != "0" and not getattr(self, "_timing_on", False)
+        if any(d["kind"] == "heat2d" for d in self.desc):
+            graph_ok = False     # (six launches per step of the coarsest-level solve: tens of thousands of nodes per cycle)
         comm = self.mg.comm_time if getattr(plan, "sends", None) or getattr(plan, "recvs", None) else None
         if comm is not None and plan.n_blocks > 2 and os.environ.get("PYMGRIT_AMD_PLAN_GRAPH", "") != "1":
             # a rank's cycle of three and more blocks runs faster launch by launch than as one graph (measured, one rank of two
@@ -521,6 +528,8 @@ class HipBackend:
             with torch.cuda.stream(self.stream):      # (the engine's stream, whatever the caller has made current since)
                 state["graph"].replay()
             self._f_stale = max(self._f_stale, state.get("f_stale", 0))   # what the replayed launches did to the F-points
+            if state.get("mirror_hit") and getattr(self, "_mirror_on", False):
+                self._mirror_hit = True
             return
         if graph_ok and state["runs"] >= 2 and not state["failed"]:
             import gc
@@ -542,6 +551,8 @@ class HipBackend:
                 with torch.cuda.stream(self.stream):
                     graph.replay()
                 self._f_stale = max(self._f_stale, state.get("f_stale", 0))
+                if state.get("mirror_hit") and getattr(self, "_mirror_on", False):
+                    self._mirror_hit = True
                 return
             except Exception as exc:   # noqa: BLE001 - capture is an optimisation: any refusal falls back to plain launches
                 state["failed"] = True
@@ -559,6 +570,7 @@ class HipBackend:
         try:
             self._plan_issue(plan, self.stream)
             state["f_stale"] = self._f_stale          # does this cycle leave level-0 F-points to materialise()?
+            state["mirror_hit"] = bool(getattr(self, "_mirror_hit", False))
         finally:
             self._f_stale = max(self._f_stale, was)   # (also when a launch failed: rows that awaited materialise() still do)
 
@@ -698,11 +710,37 @@ class HipBackend:
                                                        self.perm[0])
 
     # -- C-point snapshots of level 0 (pipelined solve, Mgrit._solve_pipelined): rows copied inside HBM ------------
-    def snapshot_cpoints(self, slot, points):
+    def _snap_slot(self, slot, points):
         if not hasattr(self, "_snap"):
             self._snap, self._snap_idx = {}, torch.as_tensor(np.asarray(points, dtype=np.int64), device=self.device)
         if slot not in self._snap:
             self._snap[slot] = torch.empty((len(points), self.ld[0]), dtype=torch.float64, device=self.device)
+            if len(points):   # every row valid from the start: the mirror never writes a point nobody corrects (the first time point)
+                torch.index_select(self._U[0], 0, self._snap_idx, out=self._snap[slot])
+        return self._snap[slot]
+
+    def mirror_cpoints(self, slot, points):
+        """the level-0 pass of the way up of the NEXT cycle (mgrit_hip_ec_relax_res) writes every corrected C-point into snapshot
+        slot `slot` as well (mgrit_hip_cpoint_mirror): snapshot_cpoints(slot) after that cycle then has nothing left to copy.
+        slot None: off."""
+        if slot is None:
+            if getattr(self, "_mirror_on", False):
+                check(self.lib.mgrit_hip_cpoint_mirror(self.h, None, self._mirror_row0))
+            self._mirror_on, self._mirror_slot, self._mirror_hit = False, None, False
+            return
+        if not len(points) or os.environ.get("PYMGRIT_AMD_NO_CPOINT_MIRROR", "") == "1":
+            return
+        rows = self._snap_slot(slot, points)
+        # row of a corrected C-point in the slot = its position among the relaxed C-points (res_pos) + the points in front of them
+        # that nobody corrects (the first time point on rank 0)
+        self._mirror_row0 = len(points) - len(self.mg._c_points(0))
+        check(self.lib.mgrit_hip_cpoint_mirror(self.h, C.c_void_p(rows.data_ptr()), self._mirror_row0))
+        self._mirror_on, self._mirror_slot, self._mirror_hit = True, slot, False
+
+    def snapshot_cpoints(self, slot, points):
+        if getattr(self, "_mirror_slot", None) == slot and getattr(self, "_mirror_hit", False) and slot in getattr(self, "_snap", {}):
+            return     # the cycle's own pass has written them there
+        self._snap_slot(slot, points)
         if len(points):
             torch.index_select(self._U[0], 0, self._snap_idx, out=self._snap[slot])
 
@@ -936,6 +974,8 @@ class HipBackend:
             # IS the next reader of the level (cf_iter = 1: no plain C-relaxation in front of it)
             mode = 1 if not lazy else (2 if (self.mg.cf_iter[0] == 1 and os.environ.get("PYMGRIT_AMD_NO_PRE_RELAX", "") != "1") else 0)
             check(self.lib.mgrit_hip_ec_relax_res(self.h, lvl, self._intervals_id(lvl, intervals), mode))
+            if lvl == 0 and getattr(self, "_mirror_on", False):
+                self._mirror_hit = True
             if lazy:
                 self._f_stale = max(self._f_stale, 2 if mode == 2 else 1)
 

@@ -90,6 +90,7 @@ EXPORTS = {
     "mgrit_hip_sync_bounded": (C.c_int, [C.c_void_p, C.c_double]),
     "mgrit_hip_error_correction_to": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "mgrit_hip_residual_stash": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mgrit_hip_cpoint_mirror": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
 }
 
 _lib = None

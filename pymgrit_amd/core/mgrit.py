@@ -466,6 +466,7 @@ class Mgrit:
         from pymgrit_amd.core.cycle_plan import PlanUnsupported, record_cycle
         key = (cycle_type, iteration == 0, bool(first_f), blocks, tuple(self.cf_iter), float(self.weight_c),
                bool(getattr(self.backend, "_cycle_pre", False)),   # (the down pass's launch argument, baked into a captured graph)
+               bool(getattr(self.backend, "_mirror_on", False)),   # (likewise: the C-point mirror of the way up)
                getattr(self.backend, "write_generation", lambda: None)(),
                frozenset(self.__dict__.get('_head_done', ())))          # which injections of the first time point the cycle still holds
         if key not in self._plans:
@@ -1080,6 +1081,8 @@ class Mgrit:
                 if self._pl_resolve(gate) < self.tol and stop_on_tol:
                     return gate
             self.solve_iter = it + 1
+            # (the C-point snapshot of this iteration, written by the cycle's own way up where that is the whole-level pass)
+            getattr(self.backend, "mirror_cpoints", lambda *a: None)((it + 1) % pl["slots"], pl["snap_points"])
             self.iteration(lvl=0, cycle_type=self.cycle_type, iteration=it, first_f=True)
             # residual of this iteration: launched now, read one trip later, so the host never waits for the device to
             # finish the iteration it has just queued (it stays one iteration ahead of it)
@@ -1118,6 +1121,7 @@ class Mgrit:
                 self.f_relax(lvl=0)
             self.iteration(lvl=0, cycle_type=self.cycle_type, iteration=keep - 1, first_f=True)
             pl["executed"] = pl["resolved"] = keep
+        getattr(self.backend, "mirror_cpoints", lambda *a: None)(None, None)
         self.conv[keep + 1:] = 0.0
         self.solve_iter = keep
         return keep

@@ -338,6 +338,13 @@ __device__ __forceinline__ double ld_uniform(const double *p) {
     return v;
 }
 
+// a device-resident pointer that a kernel earlier on the stream may have changed (plain load, then made wave-uniform)
+__device__ __forceinline__ double *ld_uniform_ptr(double *const *p) {
+    const unsigned long long a = *reinterpret_cast<const volatile unsigned long long *>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<double *>(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ Smem carve_smem(char *base, int T) {
     Smem s;
     s.tab = reinterpret_cast<double2 *>(base);
@@ -1063,11 +1070,15 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
 //   out[res_pos] = || Phi_l(F''_last) - C''_{j+1} ||^2
 // 2 rows read + m written per interval instead of 2 + m (correction + F-relaxation) and 2 more for the residual.
 template <int FORCE, bool USE_G, bool RES>
-__global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, double *__restrict__ out, int store_f) {
+__global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, double *__restrict__ out, int store_f,
+                                                    double *const *__restrict__ mirror, int mirror_row0) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
     constexpr bool CF = FORCE == 4;   // forcing factor in LDS, so every Phi in closed form
     WG_PROLOGUE;
     stage_forcing<FORCE>(sm, L, sl);
+    // C-point mirror (mgrit_hip_cpoint_mirror): every corrected C-point also goes to row mirror_row0 + res_pos of the slab the
+    // caller has named for THIS cycle (read once per workgroup: the caller changes it between cycles, on the stream)
+    double *const mir = (RES && mirror) ? ld_uniform_ptr(mirror) : nullptr;
     for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < I.n_chunks; wq.advance(t)) {
         const int k = wq.cur;
         wq.prefetch(t);
@@ -1106,6 +1117,7 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
                 for (int e = 0; e < E; ++e) b[e] = b[e] + (w[e] - b[e]);
             }
             store_row_nt(L.u + (size_t)ce * L.ld, sl, b, L.stream_rows);
+            if (RES && mir) store_row_nt(mir + (size_t)(mirror_row0 + I.res_pos[it]) * L.ld, sl, b, 1);
             if (RES) {
                 phi_apply<KIND, FORCE, CF>(x, ctx, L, ce, sm, t, lane, wave, G);
                 if (store_f == 2) store_row_nt(L.u + (size_t)(ce - 1) * L.ld, sl, x, L.stream_rows);   // Phi(last F-point): the next C-relaxation's value
@@ -1321,6 +1333,9 @@ struct H2DHost {
     double *Fye = nullptr, *Fyo = nullptr, *FyeT = nullptr, *FyoT = nullptr;
     double *W0 = nullptr, *W1 = nullptr, *rowsq = nullptr;
     size_t cap_items = 0;
+    double *Wc0 = nullptr, *Wc1 = nullptr;   // one item each: the work buffers of the coarsest-level chain, which in a planned
+                                             // cycle steps on a second stream BESIDE sweeps that apply this level's Phi too (the
+                                             // coarse half of the FAS right-hand side of another block of time points)
 };
 
 struct Level {
@@ -1378,6 +1393,8 @@ struct mgrit_hip_engine {
     double *pinned = nullptr;     // host staging buffer for small read-backs
     size_t pinned_len = 0;
     hipEvent_t ev_read = nullptr;
+    double **mirror_cur = nullptr;   // device word: the slab that mirrors the corrected level-0 C-points of the running cycle
+    int mirror_row0 = 0;
     std::vector<Link> links;      // mgrit_hip_link_*: the rank's ends of its exchange links
     double *xscratch = nullptr;   // exchange scratch (zeros of a fresh chain state / a dropped hand-over)
     size_t xscratch_len = 0;
@@ -1944,32 +1961,39 @@ int h2d_dinv(mgrit_hip_engine *e, Level &lv, uint64_t dtbits, double **out) {
 }
 
 // U (in W0) = interior of Phi applied to the rows in_slab[plan.d_in[b]] for the steps plan.d_step[b]  (theta > 0)
-int h2d_phi_batch(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab) {
+int h2d_phi_batch(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab, bool chain = false) {
     H2DHost &h = *lv.h2d;
     const H2DDev &H = h.dev;
     if (H.theta == 0.0) return 0;  // explicit: evaluated inside the epilogue kernels
     int rc;
-    if ((rc = h2d_reserve(lv, std::min(H2D_MAX_BATCH, std::max(pl.count, 1))))) return rc;
+    const size_t per = (size_t)H.Mi * H.Mj;
+    chain = chain && pl.count == 1;
+    if (chain && !h.Wc0) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.Wc0), sizeof(double) * per));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.Wc1), sizeof(double) * per));
+    }
+    if (!chain && (rc = h2d_reserve(lv, std::min(H2D_MAX_BATCH, std::max(pl.count, 1))))) return rc;
+    double *const W0 = chain ? h.Wc0 : h.W0, *const W1 = chain ? h.Wc1 : h.W1;
     double *dinv = nullptr;
     if ((rc = h2d_dinv(e, lv, pl.dtbits, &dinv))) return rc;
-    const size_t per = (size_t)H.Mi * H.Mj;
     hipLaunchKernelGGL(h2d_rhs_kernel, dim3((H.Mj + 255) / 256, H.Mi, pl.count), dim3(256), 0, e->stream, H, in_slab, pl.d_in,
-                       pl.d_step, h.W0);
+                       pl.d_step, W0);
     // W1[j][i'] = x to spectral slots ; W0[i'][j'] = y to spectral slots, o D ; W1[j'][i] = x back ; W0[i][j] = y back = U
     const dim3 fx(H.Mj / 64, H.Mi / 64, pl.count), fy(H.Mi / 64, H.Mj / 64, pl.count);        // (n tiles, slot tiles, items)
     const dim3 ix(H.Mj / 64, h.HPx / 64, pl.count), iy(H.Mi / 64, h.HPy / 64, pl.count);      // (n tiles, i tiles, items)
-    hipLaunchKernelGGL((h2d_fwd_kernel<false>), fx, dim3(256), 0, e->stream, h.Fxe, h.Fxo, H.mi, h.HPx, h.W0, H.Mj, h.W1, nullptr, per);
-    hipLaunchKernelGGL((h2d_fwd_kernel<true>), fy, dim3(256), 0, e->stream, h.Fye, h.Fyo, H.mj, h.HPy, h.W1, H.Mi, h.W0, dinv, per);
-    hipLaunchKernelGGL(h2d_inv_kernel, ix, dim3(256), 0, e->stream, h.FxeT, h.FxoT, H.mi, h.HPx, h.W0, H.Mj, h.W1, per);
-    hipLaunchKernelGGL(h2d_inv_kernel, iy, dim3(256), 0, e->stream, h.FyeT, h.FyoT, H.mj, h.HPy, h.W1, H.Mi, h.W0, per);
+    hipLaunchKernelGGL((h2d_fwd_kernel<false>), fx, dim3(256), 0, e->stream, h.Fxe, h.Fxo, H.mi, h.HPx, W0, H.Mj, W1, nullptr, per);
+    hipLaunchKernelGGL((h2d_fwd_kernel<true>), fy, dim3(256), 0, e->stream, h.Fye, h.Fyo, H.mj, h.HPy, W1, H.Mi, W0, dinv, per);
+    hipLaunchKernelGGL(h2d_inv_kernel, ix, dim3(256), 0, e->stream, h.FxeT, h.FxoT, H.mi, h.HPx, W0, H.Mj, W1, per);
+    hipLaunchKernelGGL(h2d_inv_kernel, iy, dim3(256), 0, e->stream, h.FyeT, h.FyoT, H.mj, h.HPy, W1, H.Mi, W0, per);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int h2d_finish(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab, double *dst_slab, int dst_ld,
-               const double *a_slab, const double *b_slab, int op, int use_g, double w) {
+               const double *a_slab, const double *b_slab, int op, int use_g, double w, bool chain = false) {
     const H2DDev &H = lv.h2d->dev;
-    hipLaunchKernelGGL(h2d_finish_kernel, dim3((H.ny + 127) / 128, H.nx, pl.count), dim3(128), 0, e->stream, H, lv.h2d->W0, in_slab,
+    hipLaunchKernelGGL(h2d_finish_kernel, dim3((H.ny + 127) / 128, H.nx, pl.count), dim3(128), 0, e->stream, H,
+                       (chain && pl.count == 1 && lv.h2d->Wc0) ? lv.h2d->Wc0 : lv.h2d->W0, in_slab,
                        pl.d_in, pl.d_step, dst_slab, dst_ld, pl.d_dst, a_slab, pl.d_a, b_slab, pl.d_b, op, use_g, w, 1.0 - w);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1995,9 +2019,10 @@ int h2d_relax(mgrit_hip_engine *e, int lvl, RunList *rl, int mode, double weight
         rl->h2d_relax_built = true;
     }
     const int op = mode == MGRIT_HIP_RELAX_C ? H2D_OP_C : H2D_OP_F;
+    const bool chain = mode == MGRIT_HIP_RELAX_CHAIN && lv.h2d->dev.theta != 0.0;   // its own work buffers (H2DHost::Wc0)
     for (const H2DPlan &pl : rl->h2d_relax) {
-        if ((rc = h2d_phi_batch(e, lv, pl, lv.dev.u))) return rc;
-        if ((rc = h2d_finish(e, lv, pl, lv.dev.u, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, op, lvl > 0 ? 1 : 0, weight_c))) return rc;
+        if ((rc = h2d_phi_batch(e, lv, pl, lv.dev.u, chain))) return rc;
+        if ((rc = h2d_finish(e, lv, pl, lv.dev.u, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, op, lvl > 0 ? 1 : 0, weight_c, chain))) return rc;
     }
     return 0;
 }
@@ -2215,6 +2240,8 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
             if (lv.h2d->W0) (void)hipFree(lv.h2d->W0);
             if (lv.h2d->W1) (void)hipFree(lv.h2d->W1);
             if (lv.h2d->rowsq) (void)hipFree(lv.h2d->rowsq);
+            if (lv.h2d->Wc0) (void)hipFree(lv.h2d->Wc0);
+            if (lv.h2d->Wc1) (void)hipFree(lv.h2d->Wc1);
             delete lv.h2d;
         }
         for (void *p : lv.allocs) (void)hipFree(p);
@@ -2227,6 +2254,7 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
     if (e->ev_read) (void)hipEventDestroy(e->ev_read);
     links_close(e, false);
     if (e->xscratch) (void)hipFree(e->xscratch);
+    if (e->mirror_cur) (void)hipFree(e->mirror_cur);
     for (auto &r : e->trecs) { (void)hipEventDestroy(r.ev0); (void)hipEventDestroy(r.ev1); }
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
     delete e;
@@ -3008,9 +3036,9 @@ static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int sto
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
     if (lvl > 0) {   // coarser level: rows of g, every F-point stored (the finer level's correction reads them), no residual
         Timed timed(e, MGRIT_HIP_T_EC_RELAX, lvl);
-        if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1);
-        else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1);   // one term: its space factor in LDS
-        else hipLaunchKernelGGL((ecfr_kernel<2, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1);
+        if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);
+        else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);   // one term: its space factor in LDS
+        else hipLaunchKernelGGL((ecfr_kernel<2, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -3018,9 +3046,11 @@ static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int sto
     if (!out_caller && (rc = ensure_pinned(e, lf.ivals_n[ivals_id]))) return rc;
     double *out = out_caller ? out_caller : e->pinned;
     Timed timed(e, MGRIT_HIP_T_EC_RELAX_RES, lvl);
-    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f);
-    else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f);
-    else hipLaunchKernelGGL((ecfr_kernel<2, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f);
+    double *const *mirror = e->mirror_cur;   // null until mgrit_hip_cpoint_mirror has been called
+    const int row0 = e->mirror_row0;
+    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
+    else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
+    else hipLaunchKernelGGL((ecfr_kernel<2, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
