@@ -84,6 +84,12 @@ int mgrit_hip_level_advection1d(mgrit_hip_engine *e, int lvl, int n_pts_local, c
  * sine transforms (even/odd split of the sine matrix) on the FP64 matrix cores per step. */
 int mgrit_hip_level_heat2d(mgrit_hip_engine *e, int lvl, int n_pts_local, const double *t_local, int nx, int ny, int ld,
                            double fx, double fy, double theta, const double *bc, int K, const double *S, const double *tau);
+/* General forcing rhs(x, y, t) of a Heat2D level described with K = 0 (the reference takes any callable, heat/heat_2d.py:148,
+ * 289-320, 346-356): rows = DEVICE slab [n_pts_local][Mi][Mj] (Mi, Mj = the interior nx-2, ny-2 padded as mgrit_hip_heat2d_padded
+ * reports; pads zero), rows[i] = rhs(x, y, t_i) -- not multiplied by a step size: the theta-scheme weighs both ends of a step,
+ * theta*dt*rhs(t_i) + (1-theta)*dt*rhs(t_{i-1}). Caller-owned like the state slabs; NULL switches it off. +8 B per DOF and Phi. */
+int mgrit_hip_heat2d_padded(mgrit_hip_engine *e, int lvl, int *Mi, int *Mj);
+int mgrit_hip_level_heat2d_forcing_rows(mgrit_hip_engine *e, int lvl, const double *rows);
 /* Device slabs u, v, g of Mgrit.create_u_v_g (mgrit.py:840-858); v and g may be NULL on level 0. */
 int mgrit_hip_level_bind(mgrit_hip_engine *e, int lvl, double *u, double *v, double *g);
 /* Hand-over state of forward_solve (mgrit.py:459-486) between the owners of a level (op 5, mgrit.py:468-485): a level whose

@@ -729,6 +729,7 @@ static void heat2d_step(orc_stepper *st, int nt, int i_stop, double t_start, dou
                 double v = fma(-dt, h2d_lap(st, u, gi, gj), u[p]);
                 for (int k = 0; k < st->K; ++k)
                     v = fma(st->s[((size_t)k * mi + (gi - 1)) * mj + (gj - 1)], dt * st->tau[(size_t)k * nt + i_stop - 1], v);
+                if (st->frows) v = fma(st->frows[((size_t)(i_stop - 1) * mi + (gi - 1)) * mj + (gj - 1)], dt, v);
                 out[p] = v;
             }
         return;
@@ -754,11 +755,16 @@ static void heat2d_step(orc_stepper *st, int nt, int i_stop, double t_start, dou
             if (th == 1.0) {
                 v = u[p];
                 for (int k = 0; k < st->K; ++k) v = fma(st->s[((size_t)k * mi + a) * mj + b], st->tau[(size_t)k * nt + i_stop] * dt, v);
+                if (st->frows) v = fma(st->frows[((size_t)i_stop * mi + a) * mj + b], dt, v);
             } else {
                 v = fma(-thdt, h2d_lap(st, u, a + 1, b + 1), u[p]);
                 for (int k = 0; k < st->K; ++k)
                     v = fma(st->s[((size_t)k * mi + a) * mj + b],
                             thdt * st->tau[(size_t)k * nt + i_stop] + thdt1 * st->tau[(size_t)k * nt + i_stop - 1], v);
+                if (st->frows) {
+                    v = fma(st->frows[((size_t)i_stop * mi + a) * mj + b], thdt, v);
+                    v = fma(st->frows[((size_t)(i_stop - 1) * mi + a) * mj + b], thdt1, v);
+                }
             }
             if (st->has_w) v = fma(thdt, st->W[(size_t)a * mj + b], v);
             B[(size_t)a * Mj + b] = v;
@@ -873,6 +879,17 @@ void orc_problem_set_forcing_rows(orc_problem *p, int lvl, const double *rows) {
     free(st->frows);
     st->frows = (double *)malloc(sizeof(double) * (size_t)L->nt * st->n);
     memcpy(st->frows, rows, sizeof(double) * (size_t)L->nt * st->n);
+}
+
+/* general forcing of a heat2d level (described with K = 0): rows[i][a][b] = rhs(x_a, y_b, t_i) on the mi x mj interior, NOT yet
+ * multiplied by a step size -- the theta-scheme weighs the two ends of a step itself (heat_2d.py:289-320, 346-356) */
+void orc_problem_set_forcing_rows_2d(orc_problem *p, int lvl, const double *rows) {
+    orc_level *L = &p->L[lvl];
+    orc_stepper *st = &L->st;
+    size_t per = (size_t)st->mi * st->mj;
+    free(st->frows);
+    st->frows = (double *)malloc(sizeof(double) * (size_t)L->nt * per);
+    memcpy(st->frows, rows, sizeof(double) * (size_t)L->nt * per);
 }
 
 /* two-point heat stepper: n values per time point of the pair (state = 2n), order = 1 (BDF1) or 2 (BDF2);

@@ -43,6 +43,7 @@ def lib():
         L.orc_problem_set_level_heat1d.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_int,
                                                    dp, dp, dp, C.c_int]
         L.orc_problem_set_forcing_rows.argtypes = [C.c_void_p, C.c_int, dp]
+        L.orc_problem_set_forcing_rows_2d.argtypes = [C.c_void_p, C.c_int, dp]
         L.orc_problem_set_level_heat1d_2pts.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, C.c_int, C.c_double, C.c_double,
                                                         C.c_int, C.c_int, dp, dp, dp, dp, C.c_int]
         L.orc_sumsq_spec_2pts.restype = C.c_double
@@ -211,6 +212,9 @@ class OracleProblem:
                 bc, u0 = _f64(s["bc"]), _f64(np.asarray(s["u0"]).ravel())
                 L.orc_problem_set_level_heat2d(self.h, lvl, t.size, _dp(t), nx, ny, float(s["fx"]), float(s["fy"]),
                                                float(s["theta"]), _dp(bc), K, _dp(sa), _dp(ta), _dp(u0))
+                if s.get("b_rows") is not None:   # general forcing: [nt][nx-2][ny-2] values rhs(x, y, t_i)
+                    rows = _f64(np.asarray(s["b_rows"]).reshape(t.size, (nx - 2) * (ny - 2)))
+                    L.orc_problem_set_forcing_rows_2d(self.h, lvl, _dp(rows))
             elif s["kind"] == "dahlquist":
                 n = 1
                 L.orc_problem_set_level_dahlquist(self.h, lvl, t.size, _dp(t), float(s["lambda"]),

@@ -166,6 +166,21 @@ class HipBackend:
             bc = np.ascontiguousarray(np.asarray(d["bc"], dtype=np.float64).ravel())
             check(self.lib.mgrit_hip_level_heat2d(self.h, lvl, n_pts, _ptr(t_local), nx, ny, ld, float(d["fx"]), float(d["fy"]),
                                                   float(d["theta"]), _ptr(bc), K, _ptr(S), _ptr(tau)))
+            if d.get("forcing_rows") is not None:
+                # general forcing: rhs(x, y, t_i) on the padded interior for every local point (the theta-scheme weighs the two
+                # ends of a step itself), uploaded in blocks
+                Mi, Mj = C.c_int(0), C.c_int(0)
+                check(self.lib.mgrit_hip_heat2d_padded(self.h, lvl, C.byref(Mi), C.byref(Mj)))
+                Mi, Mj = Mi.value, Mj.value
+                rows = torch.zeros((max(n_pts, 1), Mi * Mj), dtype=torch.float64, device=self.device)
+                for a in range(0, n_pts, 256):
+                    z = min(n_pts, a + 256)
+                    host = np.zeros((z - a, Mi, Mj))
+                    for i in range(a, z):
+                        host[i - a, :nx - 2, :ny - 2] = d["forcing_rows"](float(t_local[i]))
+                    rows[a:z].copy_(torch.from_numpy(host.reshape(z - a, Mi * Mj)))
+                self.FB[lvl] = rows
+                check(self.lib.mgrit_hip_level_heat2d_forcing_rows(self.h, lvl, C.c_void_p(rows.data_ptr())))
         else:
             raise MgritHipError(f"unknown device stepper kind {d['kind']!r}")
         u = torch.zeros((n_pts, ld), dtype=torch.float64, device=self.device)

@@ -37,6 +37,8 @@ EXPORTS = {
     "mgrit_hip_level_advection1d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]),
     "mgrit_hip_level_heat2d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                          C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mgrit_hip_heat2d_padded": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mgrit_hip_level_heat2d_forcing_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mgrit_hip_level_bind": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mgrit_hip_chain_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_chain_state_len": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

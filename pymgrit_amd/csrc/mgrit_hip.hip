@@ -2371,6 +2371,24 @@ int mgrit_hip_level_forcing_rows(mgrit_hip_engine *e, int lvl, const double *row
     return 0;
 }
 
+int mgrit_hip_heat2d_padded(mgrit_hip_engine *e, int lvl, int *Mi, int *Mj) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    if (!e->L[lvl].h2d || !Mi || !Mj) return fail(MGRIT_HIP_EINVAL, "level %d is not a Heat2D level", lvl);
+    *Mi = e->L[lvl].h2d->dev.Mi; *Mj = e->L[lvl].h2d->dev.Mj;
+    return 0;
+}
+
+int mgrit_hip_level_heat2d_forcing_rows(mgrit_hip_engine *e, int lvl, const double *rows) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    Level &lv = e->L[lvl];
+    if (!lv.h2d) return fail(MGRIT_HIP_EUNSUPPORTED, "level %d is not a Heat2D level", lvl);
+    if (rows && lv.h2d->dev.K != 0) return fail(MGRIT_HIP_EINVAL, "level %d already has %d separable forcing terms", lvl, lv.h2d->dev.K);
+    lv.h2d->dev.fb = rows;
+    return 0;
+}
+
 int mgrit_hip_chain_enable(mgrit_hip_engine *e, int lvl, int on) {
     int rc = check_level(e, lvl);
     if (rc) return rc;

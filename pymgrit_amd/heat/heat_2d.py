@@ -21,6 +21,10 @@ from pymgrit_amd.core.application import Application
 from pymgrit_amd.core.vector import Vector
 
 
+class NotSeparable2D(Exception):
+    """rhs(x, y, t) is not of the form S0(x, y) + S1(x, y) * t"""
+
+
 class VectorHeat2D(Vector):
     def __init__(self, nx, ny):
         super().__init__()
@@ -205,7 +209,7 @@ class Heat2D(Application):
         msg = ('Heat2D: rhs(x,y,t) is not of the form S0(x,y) + S1(x,y)*t; pass rhs_separable=[(S_fn, tau_fn), ...] to run on '
                'the MI355X engine')
         if np.max(np.abs(s0 + s1 * ts[1] - f[1])) > 1e-12 * scale:
-            raise Exception(msg)
+            raise NotSeparable2D(msg)
         # the fit must hold at EVERY time point, not only at the three it was made from (a forcing like cos(2t)*x*y on
         # [0, 2 pi] agrees with a constant there): checked on a 6 x 6 sub-grid of probe points for all t
         pi = np.unique(np.linspace(0, shape[0] - 1, 6).astype(int))
@@ -215,7 +219,7 @@ class Heat2D(Application):
         for tt in self.t:
             got = np.asarray(self.rhs(x=xp, y=yp, t=float(tt)), dtype=np.float64) * np.ones((pi.size, pj.size))
             if np.max(np.abs(p0 + p1 * float(tt) - got)) > 1e-11 * scale:
-                raise Exception(msg)
+                raise NotSeparable2D(msg)
         terms = [(s0, lambda t: 1.0)]
         if np.max(np.abs(s1)) > 0:
             terms.append((s1, lambda t: t))
@@ -225,14 +229,21 @@ class Heat2D(Application):
         if self._device_desc is None:
             xi, yi = self.x_2d[1:-1], self.y_2d[:, 1:-1]
             shape = (self.nx - 2, self.ny - 2)
+            rows = None
             if self._separable is not None:
                 terms = [(np.asarray(s_fn(xi, yi), dtype=np.float64) * np.ones(shape), tau_fn)
                          for s_fn, tau_fn in self._separable]
             else:
-                terms = self._detect_separable()
+                try:
+                    terms = self._detect_separable()
+                except NotSeparable2D:
+                    # any other callable (the reference takes whatever rhs(x, y, t) returns, heat_2d.py:148,289-320): the engine
+                    # streams precomputed rows rhs(x, y, t_i) on the interior, one per time point (+8 B per DOF and Phi)
+                    terms = []
+                    rows = lambda tt, _xi=xi, _yi=yi, _sh=shape: np.asarray(self.rhs(x=_xi, y=_yi, t=tt), dtype=np.float64) * np.ones(_sh)  # noqa: E731
             self._device_desc = {
                 "kind": "heat2d", "n": self.nx * self.ny, "nx": self.nx, "ny": self.ny, "fx": self.fx, "fy": self.fy,
                 "theta": float(self.theta), "bc": self.boundary_values(),
                 "forcing_space": np.array([s for s, _ in terms], dtype=np.float64).reshape(len(terms), *shape),
-                "forcing_time": [tau for _, tau in terms]}
+                "forcing_time": [tau for _, tau in terms], "forcing_rows": rows}
         return self._device_desc

@@ -372,6 +372,44 @@ def make_heat2d():
     print("wrote heat2d fixtures", {k: v["conv"][:2] for k, v in meta["solve"].items()})
 
 
+def h2d_general_rhs(x, y, t):   # neither separable nor linear in time: what only a general callable can express
+    return np.exp(x * t) * y + np.cos(3 * t + y) * x
+
+
+def make_heat2d_general():
+    """Heat2D with a forcing that is NOT of the form S0 + S1*t (the reference takes any callable, heat_2d.py:148,289-320):
+    one known-answer step per method and small solves; tests/golden/heat2d_general.json/.npz"""
+    from pymgrit.heat.heat_2d import Heat2D, VectorHeat2D
+    meta, arrays = {"phi": [], "solve": {}}, {}
+    for k, method in enumerate(("BE", "CN", "FE")):
+        nx, ny = 11, 14
+        app = Heat2D(x_start=0, x_end=H2D_X_END, y_start=0, y_end=H2D_Y_END, nx=nx, ny=ny, a=0.05 if method == "FE" else H2D_A,
+                     rhs=h2d_general_rhs, method=method, t_start=0, t_stop=1, nt=33, **H2D_BC)
+        u = VectorHeat2D(nx, ny)
+        u.set_values(h2d_input(app.x_2d, app.y_2d, k) * np.ones((nx, ny)))
+        arrays[f"phi_{method}"] = np.asarray(app.step(u, app.t[3], app.t[4]).get_values()).reshape(nx, ny)
+        meta["phi"].append({"key": f"phi_{method}", "method": method, "nx": nx, "ny": ny, "k": k, "i_stop": 4})
+
+    def solve(name, nx, ny, nts, method, a, **kw):
+        t0 = np.linspace(0, 1, nts[0])
+        ts = [t0]
+        for n in nts[1:]:
+            ts.append(ts[-1][::(len(ts[-1]) - 1) // (n - 1)])
+        prob = [Heat2D(x_start=0, x_end=H2D_X_END, y_start=0, y_end=H2D_Y_END, nx=nx, ny=ny, a=a, rhs=h2d_general_rhs, method=method,
+                       t_interval=t, **H2D_BC) for t in ts]
+        m = Mgrit(problem=prob, logging_lvl=QUIET, **kw)
+        info = m.solve()
+        meta["solve"][name] = {"conv": [float(c) for c in info["conv"]], "nx": nx, "ny": ny, "nts": nts, "method": method, "a": a}
+        arrays["solve_" + name] = np.asarray(m.u[0][len(prob[0].t) - 1].get_values())
+    solve("general_be_3lvl", 12, 10, [65, 17, 5], "BE", H2D_A, tol=1e-9, max_iter=8)
+    solve("general_cn_2lvl_F", 10, 13, [65, 33], "CN", 0.1, tol=1e-9, max_iter=8, nested_iteration=False)
+    solve("general_fe_2lvl", 8, 8, [257, 65], "FE", 0.05, tol=1e-9, max_iter=6, nested_iteration=False)
+    with open(os.path.join(HERE, "heat2d_general.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    np.savez_compressed(os.path.join(HERE, "heat2d_general.npz"), **arrays)
+    print("wrote heat2d_general fixtures", {k: v["conv"][:2] for k, v in meta["solve"].items()})
+
+
 # --------------------------------------------------------------------------------------------------
 # Advection1D with periodic spatial coarsening (BASELINE config 5 shrunk). The reference has no periodic transfer class;
 # the fixture runs the REFERENCE Mgrit with a user GridTransfer that states the periodic full-weighting / linear
@@ -699,6 +737,9 @@ def ref_results():
 
 def main():
     os.makedirs(HERE, exist_ok=True)
+    if "--only-heat2d-general" in sys.argv:
+        make_heat2d_general()
+        sys.exit(0)
     if "--only-heat2d" in sys.argv:
         make_heat2d()
         return
@@ -742,6 +783,7 @@ def main():
     with open(os.path.join(HERE, "solve.json"), "w") as f:
         json.dump(sol, f, separators=(",", ":"))
     make_heat2d()
+    make_heat2d_general()
     make_advection_sc()
     make_bdf()
     make_local_conv()

@@ -156,3 +156,43 @@ def test_config4_full_size_properties():
     U[::8, :512 * 512] = (2.0 * scale[:, None] * base.reshape(1, -1)).to(U.device)
     mg.f_relax(0)
     assert torch.equal(ref_rows * 2.0, U[8 * 1000 + 1:8 * 1000 + 8])
+
+
+@pytest.mark.parametrize("method", ["BE", "CN", "FE"])
+def test_general_forcing_sweeps_bit_exact(oracle, method):
+    """rhs(x, y, t) that is not S0 + S1*t (the reference takes any callable, heat_2d.py:148,289-320): the engine streams
+    precomputed rows (mgrit_hip_level_heat2d_forcing_rows); every sweep against the oracle's rows form, bit for bit"""
+    assert torch.cuda.is_available()
+    a = 0.05 if method == "FE" else cases.H2D_A
+    prob = [cases.h2d_general_app(20, 17, t, method, a) for t in cases.h2d_grids([33, 9, 3])]
+    mg, op = _pair(oracle, prob)
+    assert mg.backend.desc[0]["forcing_rows"] is not None and type(mg.backend).__name__ == "HipBackend"
+    _randomize(mg, op, 5)
+    for lvl in range(mg.lvl_max - 1):
+        mg.f_relax(lvl); op.f_relax(lvl)
+        _equal(mg, op)
+        mg.c_relax(lvl); op.c_relax(lvl)
+        _equal(mg, op)
+        mg.fas_residual(lvl); op.fas_residual(lvl)
+        _equal(mg, op)
+    mg.forward_solve(mg.lvl_max - 1); op.forward_solve(mg.lvl_max - 1)
+    _equal(mg, op)
+    got, ref = np.array(mg.compute_residual()), op.residual_norms()
+    assert np.array_equal(got, ref)
+
+
+def test_general_forcing_solves_match_oracle_and_reference(oracle):
+    from pymgrit_amd import Mgrit
+    assert torch.cuda.is_available()
+    meta, arr = cases.load_json("heat2d_general.json"), np.load(cases.GOLDEN + "/heat2d_general.npz")
+    for name, rec in meta["solve"].items():
+        prob = [cases.h2d_general_app(rec["nx"], rec["ny"], t, rec["method"], rec["a"]) for t in cases.h2d_grids(rec["nts"])]
+        opts = dict(tol=1e-9, max_iter=8 if "fe" not in name else 6, nested_iteration=name == "general_be_3lvl")
+        mg = Mgrit(prob, logging_lvl=30, **opts)
+        conv = mg.solve()["conv"]
+        oconv = oracle.OracleProblem([cases.h2d_level_spec(a) for a in prob], **opts).solve()
+        assert len(conv) == len(oconv) and np.max(np.abs(conv - oconv) / oconv) <= 1e-10, (name, conv, oconv)
+        ref = np.asarray(rec["conv"])
+        assert len(conv) == len(ref) and np.all(np.abs(conv - ref) <= 1e-9 * ref + 2e-11), (name, conv, ref)
+        last = np.asarray(mg.u[0][len(prob[0].t) - 1].get_values())
+        assert np.max(np.abs(last - arr["solve_" + name])) <= 1e-10 * max(1.0, np.max(np.abs(last))), name

@@ -5,17 +5,25 @@
 #   <tag>_fetch/_write   separate --pmc FETCH_SIZE / WRITE_SIZE passes (program order)
 #   <tag>_bench*.log     plain bench lines (default run with the CPU baseline; --all-configs)
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=$PWD/gpurun_out
 mkdir -p "$out"
 export TMPDIR=/tmp
 B="$PWD/bench.py"
 cd /tmp
-timeout -k 10 300 python3 "$B" --all-configs > "$out/${tag}_bench_all.log" 2> "$out/${tag}_bench_all.err" || exit 1
+timeout -k 10 500 python3 "$B" --all-configs > "$out/${tag}_bench_all.log" 2> "$out/${tag}_bench_all.err" || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_bench_program_order.log" 2>&1 || exit 2
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_planned" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-ramp > "$out/${tag}_bench_planned.log" 2>&1 || exit 3
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_fetch" -- python3 "$B" --steps 4 --warmup 2 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_fetch.log" 2>&1 || exit 4
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$out/${tag}_write" -- python3 "$B" --steps 4 --warmup 2 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_write.log" 2>&1 || exit 5
+# the other BASELINE configurations and one emulated rank of the sharded run: kernel summaries
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_config2" -- python3 "$B" --nx 1024 --nt 4097 --steps 100 --warmup 10 --no-cpu-baseline --no-ramp > "$out/${tag}_bench_config2.log" 2>&1 || exit 6
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_heat2d" -- python3 "$B" --workload heat2d --steps 2 --warmup 1 > "$out/${tag}_bench_heat2d.log" 2>&1 || exit 7
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_advection" -- python3 "$B" --workload advection --steps 10 --warmup 3 > "$out/${tag}_bench_advection.log" 2>&1 || exit 8
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_rank3of8" -- python3 "$B" --emulate-rank 3/8 --steps 20 --warmup 3 > "$out/${tag}_bench_rank3of8.log" 2>&1 || exit 9
+timeout -k 10 300 python3 "$B" --emulate-rank all/8 --steps 20 --warmup 3 > "$out/${tag}_bench_all8.log" 2> "$out/${tag}_bench_all8.err" || exit 10
+timeout -k 10 300 python3 "$B" --emulate-rank all/4 --steps 20 --warmup 3 > "$out/${tag}_bench_all4.log" 2> "$out/${tag}_bench_all4.err" || exit 11
+timeout -k 10 300 python3 "$B" --emulate-rank all/2 --steps 20 --warmup 3 > "$out/${tag}_bench_all2.log" 2> "$out/${tag}_bench_all2.err" || exit 12
 # keep only the summaries (the traces are large)
 find "$out" -name '*kernel_trace.csv' -size +20M -delete
 ls -R "$out" | head -50
