@@ -22,6 +22,9 @@ extern "C" {
 #define MGRIT_HIP_ABI_VERSION 3
 #define MGRIT_HIP_E 16            /* elements per lane (arithmetic spec) */
 #define MGRIT_HIP_MAX_N 16384     /* max DOFs per time point for the register-resident steppers */
+#define MGRIT_HIP_MAX_N_WIDE 65536 /* Heat1D levels above MGRIT_HIP_MAX_N: the same Phi as three launches over rows in HBM
+                                      (csrc/mgrit_hip_wide.inc): relaxations, residual / jump, the unfused FAS right-hand side,
+                                      transfers, exchange; no fused passes, no AT-MGRIT */
 #define MGRIT_HIP_MAX_N_2PTS 4096 /* two-point steppers: max DOFs per time point of a pair (two coefficient sets in LDS) */
 
 typedef struct mgrit_hip_engine mgrit_hip_engine;

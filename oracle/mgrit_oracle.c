@@ -36,6 +36,7 @@
 #define ORC_GROUP (ORC_E * ORC_LANES)
 #define ORC_MAX_LEVELS 16
 #define ORC_MAX_K 4
+#define ORC_MAX_G 64       /* groups of 1024 values per state the spec variant covers (n <= 65536) */
 
 /* ================================================================================================
  * Layout  (mgrit.py:742-838)
@@ -173,7 +174,8 @@ typedef struct {
     double pw[ORC_E + 1];   /* pw[k] = rho^k, pw[0] = 1, sequential products */
     double sc[6];           /* sc[s] = rho^(E*2^s), repeated squaring of pw[E] */
     double gc;              /* rho^(64E) = sc[5]^2 */
-    double gcp[4];          /* gc^(2^s): coefficients of the cross-group Kogge-Stone scans */
+    double gcp[6];          /* gc^(2^s): coefficients of the cross-group Kogge-Stone scans (4 stages cover 16 groups, 6 cover
+                               the 64 of a wide state: the stages beyond a state's groups add exact zeros) */
     double lp[ORC_LANES];   /* lp[l] = rho^(E*l), sequential products of pw[E] */
     double *tab;            /* heat: wg[j] (n) ; advection: rp[j] = r^(j+1) (n) */
     double pt_full[ORC_GROUP]; /* heat: local backward scan of rho^(j'+1) over a full group of 1024           */
@@ -201,7 +203,7 @@ static void cset_powers(orc_cset *c, double rho) {
     for (int s = 1; s < 6; ++s) c->sc[s] = c->sc[s - 1] * c->sc[s - 1];
     c->gc = c->sc[5] * c->sc[5];
     c->gcp[0] = c->gc;
-    for (int s = 1; s < 4; ++s) c->gcp[s] = c->gcp[s - 1] * c->gcp[s - 1];
+    for (int s = 1; s < 6; ++s) c->gcp[s] = c->gcp[s - 1] * c->gcp[s - 1];
     c->lp[0] = 1.0;
     for (int l = 1; l < ORC_LANES; ++l) c->lp[l] = c->lp[l - 1] * c->pw[ORC_E];
 }
@@ -234,9 +236,9 @@ static void cset_heat1d(orc_cset *c, int n, double fac, double dt) {
     double w0 = ((1.0 - ipow(rho, 2 * n)) * c->ik) / one_minus_r2;
     double gamma = kr2 / (1.0 + kr2 * w0);
     double gprime = (gamma * c->ik) / one_minus_r2;
-    double grp[16];                                  /* gc^g, sequential products */
+    double grp[ORC_MAX_G];                           /* gc^g, sequential products */
     grp[0] = 1.0;
-    for (int g = 1; g < 16; ++g) grp[g] = grp[g - 1] * c->gc;
+    for (int g = 1; g < ORC_MAX_G; ++g) grp[g] = grp[g - 1] * c->gc;
     int last_thread = (n - 1) / ORC_E;               /* thread that holds element n-1 */
     int g_last = last_thread / ORC_LANES, l_last = last_thread % ORC_LANES;
     int e_base = 2 * n - ORC_E * last_thread - (ORC_E - 1);   /* exponent of rho^(2n-j) at the last thread's element 15 */
@@ -445,15 +447,18 @@ static void heat1d_step_natural(orc_stepper *st, int nt, int i_stop, double dt, 
     heat1d_step_natural_ws(st, nt, i_stop, dt, u, out, st->w1, st->w2);
 }
 
-/* Cross-group carries: the <= 16 group totals sit in one row of 16 lanes; inclusive Kogge-Stone
- * scans with coefficients gc^(2^s). fwd: I_g = sum_{h<=g} gc^(g-h) A_h ; bwd: J_g = sum_{h>=g} gc^(h-g) A_h. */
+/* Cross-group carries: inclusive Kogge-Stone scans over the group totals with coefficients gc^(2^s):
+ * fwd: I_g = sum_{h<=g} gc^(g-h) A_h ; bwd: J_g = sum_{h>=g} gc^(h-g) A_h. The register-resident kernels hold <= 16 groups in
+ * one row of 16 lanes (4 stages); a wide state (17..64 groups, csrc/mgrit_hip_wide.inc) takes the same scan over 64 lanes
+ * (6 stages). The arrays are ORC_MAX_G wide with zeros beyond the state's groups, so for <= 16 groups the two extra stages and
+ * the entries beyond 16 only ever add fma(coefficient, 0, a) = a: one spec for both. */
 static void cross_scan(const orc_cset *c, double *a, int backward) {
-    double t[16];
-    for (int s = 0; s < 4; ++s) {
+    double t[ORC_MAX_G];
+    for (int s = 0; s < 6; ++s) {
         int off = 1 << s;
-        for (int g = 0; g < 16; ++g) {
+        for (int g = 0; g < ORC_MAX_G; ++g) {
             if (!backward) t[g] = (g >= off) ? fma(c->gcp[s], a[g - off], a[g]) : a[g];
-            else t[g] = (g + off < 16) ? fma(c->gcp[s], a[g + off], a[g]) : a[g];
+            else t[g] = (g + off < ORC_MAX_G) ? fma(c->gcp[s], a[g + off], a[g]) : a[g];
         }
         memcpy(a, t, sizeof(t));
     }
@@ -464,7 +469,7 @@ static void cross_scan(const orc_cset *c, double *a, int backward) {
 /* x = (I + dt*L)^{-1} d for the coefficient set c; d (padded work array, first n entries filled) is overwritten */
 static void heat_solve_spec(const orc_cset *c, int n, double *d, double *out) {
     int NP = padded(n), G = NP / ORC_GROUP;
-    double A[16] = {0}, B[16] = {0}, C[17] = {0}, Zf[17] = {0};
+    double A[ORC_MAX_G] = {0}, B[ORC_MAX_G] = {0}, C[ORC_MAX_G + 1] = {0}, Zf[ORC_MAX_G + 1] = {0};
     for (int j = n; j < NP; ++j) d[j] = 0.0;
     for (int g = 0; g < G; ++g) {
         double *dg = d + (size_t)g * ORC_GROUP;
@@ -474,11 +479,11 @@ static void heat_solve_spec(const orc_cset *c, int n, double *d, double *out) {
     }
     cross_scan(c, A, 0);                       /* A[g] := inclusive forward scan */
     C[0] = 0.0;
-    for (int g = 1; g < 16; ++g) C[g] = A[g - 1];
-    for (int g = 0; g < 16; ++g)
+    for (int g = 1; g < ORC_MAX_G; ++g) C[g] = A[g - 1];
+    for (int g = 0; g < ORC_MAX_G; ++g)
         Zf[g] = (g < G) ? fma(C[g], (g == G - 1) ? c->pt_last[0] : c->pt_full[0], B[g]) : 0.0;
     cross_scan(c, Zf, 1);                      /* Zf[g] := true z at the first element of group g */
-    Zf[16] = 0.0;
+    Zf[ORC_MAX_G] = 0.0;
     double z0 = Zf[0] * c->ik;
     for (int g = 0; g < G; ++g) {
         const double *pt = (g == G - 1) ? c->pt_last : c->pt_full;
@@ -596,13 +601,13 @@ static void advection1d_step_spec(orc_stepper *st, double dt, const double *u, d
     int n = st->n, NP = padded(n), G = NP / ORC_GROUP;
     orc_cset *c = get_cset(st, dt);
     double *d = st->w1;
-    double A[16] = {0}, C[17] = {0};
+    double A[ORC_MAX_G] = {0}, C[ORC_MAX_G + 1] = {0};
     for (int j = 0; j < n; ++j) d[j] = u[j] * c->ik;
     for (int j = n; j < NP; ++j) d[j] = 0.0;
     for (int g = 0; g < G; ++g) A[g] = group_scan_fwd(c, d + (size_t)g * ORC_GROUP);
     cross_scan(c, A, 0);
     C[0] = 0.0;
-    for (int g = 1; g < 16; ++g) C[g] = A[g - 1];
+    for (int g = 1; g < ORC_MAX_G; ++g) C[g] = A[g - 1];
     /* periodic closure from the last real element n-1 (lane l*, element k* of group G-1) */
     int jl = n - 1, gl = jl / ORC_GROUP, ll = (jl % ORC_GROUP) / ORC_E, kl = jl % ORC_E;
     double ylast = fma(c->pw[kl + 1], c->lp[ll] * C[gl], d[jl]);
@@ -1282,7 +1287,7 @@ static void cset_chain_tables(orc_cset *c, int n) {
 static int chain_overlapped(const orc_level *L, int lvl) {
     if (lvl == 0) return 0;   /* a one-level hierarchy is plain time stepping: its residual must vanish exactly */
     const orc_stepper *st = &L->st;
-    if (st->kind != ORC_HEAT1D || !st->variant || st->n <= ORC_GROUP || st->K > 1 || st->frows || L->nt < 2) return 0;
+    if (st->kind != ORC_HEAT1D || !st->variant || st->n <= ORC_GROUP || st->n > 16 * ORC_GROUP || st->K > 1 || st->frows || L->nt < 2) return 0;
     double dt0 = L->t[1] - L->t[0];
     for (int i = 2; i < L->nt; ++i) {
         double dt = L->t[i] - L->t[i - 1];
@@ -1321,7 +1326,7 @@ static void heat1d_chain_spec(orc_problem *p, int lvl) {
                 dg[j] = fma(-z0, v3[(size_t)g * ORC_GROUP + j], fma(zin[g + 1], v2[j], fma(cm[g], v1[j], dg[j])));
         }
         /* the one exchange of the step: carries from the totals of all groups (3.3 step 3) */
-        double I[16], Zf[17];
+        double I[ORC_MAX_G] = {0}, Zf[ORC_MAX_G + 1] = {0};   /* (the overlapped chain itself covers <= 16 groups) */
         for (int g = 0; g < 16; ++g) I[g] = (g < G) ? A[g] : 0.0;
         cross_scan(c, I, 0);
         cm[0] = 0.0;

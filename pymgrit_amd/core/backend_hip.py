@@ -205,7 +205,7 @@ class HipBackend:
         gt = np.asarray(mg.global_t[lvl], dtype=np.float64)
         dts = np.diff(gt)
         n_terms = np.asarray(d.get("forcing_space", np.zeros((0, n)))).reshape(-1, n).shape[0] if d["kind"] == "heat1d" else 0
-        wide = (lvl > 0 and d["kind"] == "heat1d" and n > 1024 and n_terms <= 1 and d.get("forcing_rows") is None and dts.size > 0
+        wide = (lvl > 0 and d["kind"] == "heat1d" and 1024 < n <= hip_lib.MAX_N and n_terms <= 1 and d.get("forcing_rows") is None and dts.size > 0
                 and bool(np.all(dts.view(np.int64) == dts.view(np.int64)[0])) and os.environ.get("MGRIT_HIP_CHAIN_PLAIN", "") != "1")
         check(self.lib.mgrit_hip_chain_enable(self.h, lvl, int(wide)))
         slen = C.c_int(0)
@@ -807,9 +807,16 @@ class HipBackend:
         check(self.lib.mgrit_hip_fas_rhs(self.h, lvl, self._pair_id(lvl, pairs)))
 
     # fused FAS residual (identity transfer, like steppers on both levels): see include/mgrit_hip.h
+    def _resident(self, lvl):
+        """both levels of the pair hold a state in one workgroup's registers (n <= 16384): the fused passes' precondition; wider
+        Heat1D states run sweep by sweep through the three-launch Phi (csrc/mgrit_hip_wide.inc)"""
+        return max(self.n[lvl], self.n[min(lvl + 1, len(self.n) - 1)]) <= hip_lib.MAX_N or self.desc[lvl]["kind"] == "heat2d"
+
     def can_fuse_fas(self, lvl):
         tr = self.mg.transfer_objects[lvl]
         da, db = self.desc[lvl], self.desc[lvl + 1]
+        if not self._resident(lvl):
+            return False
         same_forcing = len(da.get("forcing_time", [])) == len(db.get("forcing_time", []))
         return (self._device_transfer(lvl) and int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and
                 da["kind"] == db["kind"] and da["kind"] in ("heat1d", "advection1d") and
@@ -893,6 +900,8 @@ class HipBackend:
     def can_fuse_ec(self, lvl):
         tr = self.mg.transfer_objects[lvl]
         da, db = self.desc[lvl], self.desc[lvl + 1]
+        if not self._resident(lvl):
+            return False
         return (self._device_transfer(lvl) and int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and
                 da["kind"] == db["kind"] and da["kind"] in ("heat1d", "advection1d") and self.n[lvl] == self.n[lvl + 1])
 
@@ -916,7 +925,7 @@ class HipBackend:
         """level 0, Heat1D with a separable forcing on both levels, identity transfer (weight and layout: the caller)"""
         tr = self.mg.transfer_objects[lvl]
         da, db = self.desc[lvl], self.desc[lvl + 1]
-        return (lvl == 0 and os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and self._device_transfer(lvl) and
+        return (lvl == 0 and self._resident(lvl) and os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and self._device_transfer(lvl) and
                 int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and da["kind"] == db["kind"] == "heat1d" and
                 self.n[lvl] == self.n[lvl + 1] and da.get("forcing_rows") is None and db.get("forcing_rows") is None and
                 len(da.get("forcing_time", [])) == len(db.get("forcing_time", [])))
@@ -945,7 +954,7 @@ class HipBackend:
             # the next block, and the rank has few blocks to hide that behind)
             blocks = self.mg.plan_blocks()
             want = "1" if (blocks >= 5 or (blocks >= 2 and self.mg.comm_time_size > 1)) else "0"
-        return (want == "1" and
+        return (want == "1" and self._resident(lvl) and
                 os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and self._device_transfer(lvl) and
                 int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and da["kind"] == db["kind"] == "heat1d" and
                 self.n[lvl] == self.n[lvl + 1] and da.get("forcing_rows") is None and db.get("forcing_rows") is None and

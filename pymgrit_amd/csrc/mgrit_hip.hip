@@ -1305,6 +1305,8 @@ __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, c
 
 #include "mgrit_hip_heat2d.inc"
 
+#include "mgrit_hip_wide.inc"
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -1338,7 +1340,14 @@ struct H2DHost {
                                              // coarse half of the FAS right-hand side of another block of time points)
 };
 
+// Heat1D states of more than MGRIT_HIP_MAX_N values (mgrit_hip_wide.inc): work slabs of the three-launch Phi
+struct WideHost {
+    double *W = nullptr, *tot = nullptr, *car = nullptr, *z0 = nullptr, *red = nullptr;
+    size_t cap = 0;
+};
+
 struct Level {
+    WideHost *wide = nullptr;
     int order = 0;   // two-point steppers: BDF order (1 or 2)
     bool set = false;
     H2DHost *h2d = nullptr;
@@ -1533,21 +1542,23 @@ void build_cset_heat1d(CSet &c, std::vector<double> &tab, int n, double fac, dou
     const double kr2 = beta * rho;
     const double gamma = kr2 / (1.0 + kr2 * w0);
     const double gp = (gamma * c.ik) / om;
-    double Gp[MAX_G];
+    constexpr int GW = MGRIT_HIP_MAX_N_WIDE / GROUP;   // group factors for wide states too (their kernels read the table)
+    double Gp[GW], pg[GW], qg[GW], qg2[GW];
     Gp[0] = 1.0;
-    for (int g = 1; g < MAX_G; ++g) Gp[g] = Gp[g - 1] * c.gc;
+    for (int g = 1; g < GW; ++g) Gp[g] = Gp[g - 1] * c.gc;
     const int t_last = (n - 1) / E, gL = t_last / LANES, lL = t_last % LANES, e0 = 2 * n - E * t_last - (E - 1);
     const double qb = gp * (e0 >= 0 ? pow_int(rho, e0) : (rho >= 1e-12 ? 1.0 / pow_int(rho, -e0) : 0.0));
-    for (int g = 0; g < MAX_G; ++g) {
-        c.pg[g] = gp * Gp[g];
-        c.qg[g] = g <= gL ? qb * Gp[gL - g] : 0.0;
-        c.qg2[g] = g < gL ? qb * Gp[gL - g - 1] : 0.0;
+    for (int g = 0; g < GW; ++g) {
+        pg[g] = gp * Gp[g];
+        qg[g] = g <= gL ? qb * Gp[gL - g] : 0.0;
+        qg2[g] = g < gL ? qb * Gp[gL - g - 1] : 0.0;
     }
+    for (int g = 0; g < MAX_G; ++g) { c.pg[g] = pg[g]; c.qg[g] = qg[g]; c.qg2[g] = qg2[g]; }
     tab.assign(n, 0.0);
     for (int j = 0; j < n; ++j) {
         const int t = j / E, k = j % E, g = t / LANES, l = t % LANES;
-        const double P = c.pg[g] * c.lp[l];
-        const double Q = (l <= lL ? c.qg[g] : c.qg2[g]) * c.lp[(lL - l) & (LANES - 1)];
+        const double P = pg[g] * c.lp[l];
+        const double Q = (l <= lL ? qg[g] : qg2[g]) * c.lp[(lL - l) & (LANES - 1)];
         tab[j] = std::fma(-Q, c.pw[E - 1 - k], P * c.pw[k]);
     }
 }
@@ -1686,9 +1697,10 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
                  int K, const double *s, const double *tau) {
     int rc = check_level(e, lvl, false);
     if (rc) return rc;
-    if (n < 1 || n > MGRIT_HIP_MAX_N)
-        return fail(MGRIT_HIP_EUNSUPPORTED, "n=%d DOFs per time point outside [1,%d] (register-resident stepper)", n,
-                    MGRIT_HIP_MAX_N);
+    const int n_max = kind == MGRIT_HIP_STEPPER_HEAT1D ? MGRIT_HIP_MAX_N_WIDE : MGRIT_HIP_MAX_N;
+    if (n < 1 || n > n_max)
+        return fail(MGRIT_HIP_EUNSUPPORTED, "n=%d DOFs per time point outside [1,%d] (%s)", n, n_max,
+                    kind == MGRIT_HIP_STEPPER_HEAT1D ? "Heat1D: register-resident up to 16384, three-launch Phi above" : "register-resident stepper");
     if (ld != mgrit_hip_row_stride(n)) return fail(MGRIT_HIP_EINVAL, "ld=%d must equal mgrit_hip_row_stride(n=%d)=%d", ld, n, mgrit_hip_row_stride(n));
     if (n_pts < 0 || (n_pts > 0 && !t_local)) return fail(MGRIT_HIP_EINVAL, "bad local time grid");
     if (K < 0 || K > 8 || (K > 0 && (!s || (n_pts > 0 && !tau)))) return fail(MGRIT_HIP_EINVAL, "bad forcing description (K=%d)", K);
@@ -1726,7 +1738,8 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     std::vector<double> tabT(uniq.size() * (size_t)E * T, 0.0), tab;  // row storage order per coefficient set
     std::vector<double> ptT(uniq.size() * (size_t)2 * GROUP, 0.0), pt(GROUP), pt_last(GROUP), chT;
     // the overlapped chain (the oracle's chain_overlapped is the same rule on its one rank)
-    const bool overlapped = kind == MGRIT_HIP_STEPPER_HEAT1D && G >= 2 && uniq.size() == 1 && K <= 1;
+    const bool overlapped = kind == MGRIT_HIP_STEPPER_HEAT1D && G >= 2 && G <= MAX_G && uniq.size() == 1 && K <= 1;
+    if (n > MGRIT_HIP_MAX_N) lv.wide = new WideHost();
     for (size_t q = 0; q < uniq.size(); ++q) {
         std::memset(&cs[q], 0, sizeof(CSet));
         if (kind == MGRIT_HIP_STEPPER_HEAT1D) {
@@ -2153,6 +2166,176 @@ int force_mode(const Level &lv) {
     return lv.dev.K == 0 ? 0 : lv.dev.K == 1 ? 1 : 2;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wide Heat1D states (mgrit_hip_wide.inc): batch plans and the three-launch Phi, in the scheme of the Heat2D path
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int WIDE_MAX_BATCH = 2048;   // items per batch (work slab: 2048 rows of up to 512 KB)
+
+int wide_reserve(Level &lv, int count) {
+    WideHost &h = *lv.wide;
+    if ((size_t)count <= h.cap) return 0;
+    for (double **p : {&h.W, &h.tot, &h.car, &h.z0, &h.red}) {
+        if (*p) HIP_TRY(hipFree(*p));
+        *p = nullptr;
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.W), sizeof(double) * (size_t)count * lv.dev.ld));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.tot), sizeof(double) * (size_t)count * 2 * WIDE_MAX_G));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.car), sizeof(double) * (size_t)count * 2 * WIDE_MAX_G));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.z0), sizeof(double) * (size_t)count));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.red), sizeof(double) * (size_t)count * WIDE_MAX_G));
+    h.cap = count;
+    return 0;
+}
+
+int wide_make_plans(mgrit_hip_engine *e, Level &lv, const std::vector<H2DItem> &items, std::vector<H2DPlan> &plans) {
+    for (size_t off = 0; off < items.size(); off += WIDE_MAX_BATCH) {
+        const size_t cnt = std::min<size_t>(WIDE_MAX_BATCH, items.size() - off);
+        std::vector<int32_t> vin(cnt), vst(cnt), vds(cnt), va(cnt), vb(cnt);
+        for (size_t k = 0; k < cnt; ++k) {
+            const H2DItem &it = items[off + k];
+            vin[k] = it.in; vst[k] = it.step; vds[k] = it.dst; va[k] = it.a; vb[k] = it.b;
+        }
+        H2DPlan pl;
+        pl.count = (int)cnt;
+        int rc;
+        if ((rc = dev_upload_raw(lv, e->stream, vin.data(), cnt, &pl.d_in))) return rc;
+        if ((rc = dev_upload_raw(lv, e->stream, vst.data(), cnt, &pl.d_step))) return rc;
+        if ((rc = dev_upload_raw(lv, e->stream, vds.data(), cnt, &pl.d_dst))) return rc;
+        if ((rc = dev_upload_raw(lv, e->stream, va.data(), cnt, &pl.d_a))) return rc;
+        if ((rc = dev_upload_raw(lv, e->stream, vb.data(), cnt, &pl.d_b))) return rc;
+        plans.push_back(pl);
+    }
+    return 0;
+}
+
+// the scanned rows of Phi(in_slab[plan.d_in[b]]) for the steps plan.d_step[b] in the work slab, and their carries
+int wide_phi(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab) {
+    int rc;
+    if ((rc = wide_reserve(lv, std::min(WIDE_MAX_BATCH, std::max(pl.count, 1))))) return rc;
+    WideHost &h = *lv.wide;
+    const int G = lv.dev.T / LANES;
+    const dim3 grid((G + 15) / 16, pl.count), block(1024);
+    const int fm = force_mode(lv);
+    if (fm == 0) hipLaunchKernelGGL((wide_local_kernel<0>), grid, block, 0, e->stream, lv.dev, in_slab, pl.d_in, pl.d_step, h.W, h.tot);
+    else if (fm == 3) hipLaunchKernelGGL((wide_local_kernel<3>), grid, block, 0, e->stream, lv.dev, in_slab, pl.d_in, pl.d_step, h.W, h.tot);
+    else hipLaunchKernelGGL((wide_local_kernel<2>), grid, block, 0, e->stream, lv.dev, in_slab, pl.d_in, pl.d_step, h.W, h.tot);
+    hipLaunchKernelGGL(wide_carry_kernel, dim3(pl.count), dim3(64), 0, e->stream, lv.dev, pl.d_step, h.tot, h.car, h.z0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int wide_finish(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, double *dst_slab, int dst_ld, const double *a_slab,
+                const double *b_slab, int op, int use_g, double w) {
+    WideHost &h = *lv.wide;
+    const int G = lv.dev.T / LANES;
+    hipLaunchKernelGGL(wide_finish_kernel, dim3((G + 15) / 16, pl.count), dim3(1024), 0, e->stream, lv.dev, h.W, pl.d_step, h.car, h.z0,
+                       dst_slab, dst_ld, pl.d_dst, a_slab, pl.d_a, b_slab, pl.d_b, op, use_g, w, 1.0 - w, h.red);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int wide_relax(mgrit_hip_engine *e, int lvl, RunList *rl, int mode, double weight_c) {
+    Level &lv = e->L[lvl];
+    int rc;
+    if (mode == MGRIT_HIP_RELAX_FC) return fail(MGRIT_HIP_EUNSUPPORTED, "relax mode FC: states of at most %d values", MGRIT_HIP_MAX_N);
+    if (!rl->h2d_relax_built) {
+        int maxlen = 0;
+        for (int r = 0; r < rl->n; ++r) maxlen = std::max(maxlen, (int)rl->h_len[r]);
+        for (int k = 0; k < maxlen; ++k) {   // step k of every run that is long enough: one batch
+            std::vector<H2DItem> items;
+            for (int r = 0; r < rl->n; ++r)
+                if (rl->h_len[r] > k) {
+                    const int i = rl->h_start[r] + k;
+                    items.push_back({i - 1, i, i, i, i});
+                }
+            if ((rc = wide_make_plans(e, lv, items, rl->h2d_relax))) return rc;
+        }
+        rl->h2d_relax_built = true;
+    }
+    const int op = mode == MGRIT_HIP_RELAX_C ? WIDE_OP_C : WIDE_OP_F;
+    for (const H2DPlan &pl : rl->h2d_relax) {
+        if ((rc = wide_phi(e, lv, pl, lv.dev.u))) return rc;
+        if ((rc = wide_finish(e, lv, pl, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, op, lvl > 0 ? 1 : 0, weight_c))) return rc;
+    }
+    return 0;
+}
+
+int wide_points_sumsq(mgrit_hip_engine *e, int lvl, RunList *rl, const double *prev, double *out) {
+    Level &lv = e->L[lvl];
+    int rc;
+    if (!rl->h2d_points_built) {
+        std::vector<H2DItem> items;
+        for (int r = 0; r < rl->n; ++r) {
+            const int i = rl->h_start[r];
+            items.push_back({i - 1, i, i, i, i});
+        }
+        if ((rc = wide_make_plans(e, lv, items, rl->h2d_points))) return rc;
+        rl->h2d_points_built = true;
+    }
+    const int G = lv.dev.T / LANES;
+    int off = 0;
+    for (const H2DPlan &pl : rl->h2d_points) {
+        if ((rc = wide_reserve(lv, std::min(WIDE_MAX_BATCH, std::max(pl.count, 1))))) return rc;
+        if (!prev) {
+            if ((rc = wide_phi(e, lv, pl, lv.dev.u))) return rc;
+            if ((rc = wide_finish(e, lv, pl, lv.dev.u, lv.dev.ld, lv.dev.u, lv.dev.u, WIDE_OP_RESIDUAL, 0, 1.0))) return rc;
+        } else {
+            hipLaunchKernelGGL(wide_diffsq_kernel, dim3((G + 15) / 16, pl.count), dim3(1024), 0, e->stream, lv.dev, lv.dev.u, prev,
+                               pl.d_dst, lv.wide->red);
+        }
+        hipLaunchKernelGGL(wide_rowsum_kernel, dim3((pl.count + 63) / 64), dim3(64), 0, e->stream, lv.wide->red, G, pl.count, out + off);
+        HIP_TRY(hipGetLastError());
+        off += pl.count;
+    }
+    return 0;
+}
+
+// fine half of the FAS right-hand side for a wide fine level: rows into dst_slab (g^{l+1} itself for the copy transfer, the
+// level's scratch rows -- one per pair -- for a spatial transfer that follows)
+int wide_fas_fine(mgrit_hip_engine *e, int lvl, PairList *pl, double *dst_slab, int dst_ld, bool by_pair) {
+    Level &lf = e->L[lvl];
+    int rc;
+    if (pl->h2d_fine.empty()) {
+        std::vector<H2DItem> fine;
+        for (int p = 0; p < pl->n; ++p) {
+            const int i = pl->h_fine[p];
+            fine.push_back({i - 1, i, by_pair ? p : pl->h_coarse[p], i, i});
+        }
+        if ((rc = wide_make_plans(e, lf, fine, pl->h2d_fine))) return rc;
+    }
+    for (const H2DPlan &q : pl->h2d_fine) {
+        if ((rc = wide_phi(e, lf, q, lf.dev.u))) return rc;
+        if ((rc = wide_finish(e, lf, q, dst_slab, dst_ld, lf.dev.g, lf.dev.u, WIDE_OP_FAS_FINE, lvl > 0 ? 1 : 0, 1.0))) return rc;
+    }
+    return 0;
+}
+
+int wide_fas_coarse(mgrit_hip_engine *e, int lvl, PairList *pl) {
+    Level &lc = e->L[lvl + 1];
+    int rc;
+    if (pl->h2d_coarse.empty()) {
+        std::vector<H2DItem> coarse;
+        for (int p = 0; p < pl->n; ++p) {
+            const int j = pl->h_coarse[p];
+            coarse.push_back({j - 1, j, j, j, j});
+        }
+        if ((rc = wide_make_plans(e, lc, coarse, pl->h2d_coarse))) return rc;
+    }
+    for (const H2DPlan &q : pl->h2d_coarse) {
+        if ((rc = wide_phi(e, lc, q, lc.dev.v))) return rc;
+        if ((rc = wide_finish(e, lc, q, lc.dev.g, lc.dev.ld, lc.dev.g, lc.dev.v, WIDE_OP_FAS_COARSE, 1, 1.0))) return rc;
+    }
+    return 0;
+}
+
+// entry points that hold a state in one workgroup refuse wide levels
+int no_wide(const Level &a, const Level *b, const char *what) {
+    if (a.wide || (b && b->wide))
+        return fail(MGRIT_HIP_EUNSUPPORTED, "%s: states of at most %d values per time point (wider Heat1D states run sweep by sweep)", what, MGRIT_HIP_MAX_N);
+    return 0;
+}
+
 // two-point kernels: template space BDF order x forcing mode
 #define LAUNCH2_CASE(kernel, O_, F_, lv, grid, ...)                                                              \
     if ((lv).order == O_ && force_mode(lv) == F_)                                                                 \
@@ -2243,6 +2426,11 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
             if (lv.h2d->Wc0) (void)hipFree(lv.h2d->Wc0);
             if (lv.h2d->Wc1) (void)hipFree(lv.h2d->Wc1);
             delete lv.h2d;
+        }
+        if (lv.wide) {
+            for (double *p : {lv.wide->W, lv.wide->tot, lv.wide->car, lv.wide->z0, lv.wide->red})
+                if (p) (void)hipFree(p);
+            delete lv.wide;
         }
         for (void *p : lv.allocs) (void)hipFree(p);
         if (lv.scratch) (void)hipFree(lv.scratch);
@@ -2502,6 +2690,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     Timed timed(e, mode == MGRIT_HIP_RELAX_F ? MGRIT_HIP_T_RELAX_F : mode == MGRIT_HIP_RELAX_CHAIN ? MGRIT_HIP_T_CHAIN :
                    mode == MGRIT_HIP_RELAX_FC ? MGRIT_HIP_T_RELAX_FC : MGRIT_HIP_T_RELAX_C, lvl);
     if (lv.h2d) return h2d_relax(e, lvl, rl, mode, weight_c);
+    if (lv.wide) return wide_relax(e, lvl, rl, mode, weight_c);
     if (is_2pts(lv)) {
         const bool use_g = lvl > 0, weighted = mode == MGRIT_HIP_RELAX_C && weight_c != 1.0;
         const double w = weight_c, w1 = 1.0 - weight_c;
@@ -2602,6 +2791,7 @@ int mgrit_hip_residual(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_
     if (!sumsq_out) return fail(MGRIT_HIP_EINVAL, "null output");
     Timed timed(e, MGRIT_HIP_T_RESIDUAL, lvl);
     if (lv.h2d) return h2d_points_sumsq(e, lvl, rl, nullptr, sumsq_out);
+    if (lv.wide) return wide_points_sumsq(e, lvl, rl, nullptr, sumsq_out);
     if (is_2pts(lv)) LAUNCH2_BY_ORDER(residual2_kernel, lv, persistent_grid(lv, rl->n), lv.dev, rl->d_start, rl->n, sumsq_out);
     else LAUNCH_BY_KIND(residual_kernel, lv, persistent_grid(lv, rl->n), sched_dev(e, lv), rl->d_start, rl->n, sumsq_out);
     return 0;
@@ -2617,6 +2807,7 @@ int mgrit_hip_jump(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev
     if (!sumsq_out || !prev) return fail(MGRIT_HIP_EINVAL, "null argument");
     Timed timed(e, MGRIT_HIP_T_JUMP, lvl);
     if (lv.h2d) return h2d_points_sumsq(e, lvl, rl, prev, sumsq_out);
+    if (lv.wide) return wide_points_sumsq(e, lvl, rl, prev, sumsq_out);
     if (is_2pts(lv))
         hipLaunchKernelGGL(jump2_kernel, dim3(rl->n), dim3(lv.dev.T), smem2_bytes(lv.G), e->stream, lv.dev, rl->d_start, prev, sumsq_out);
     else
@@ -2666,6 +2857,7 @@ int mgrit_hip_fas_fine_rows(mgrit_hip_engine *e, int lvl, int pairs_id, double *
     if ((rc = check_bound(lf, lvl > 0))) return rc;
     if (lf.h2d || is_2pts(lf)) return fail(MGRIT_HIP_EUNSUPPORTED, "split FAS right-hand side: 1-D one-point steppers only");
     if (pl->n > 0 && (!rows || ld_rows < lf.dev.ld)) return fail(MGRIT_HIP_EINVAL, "rows buffer missing or narrower than the level's rows");
+    if ((rc = no_wide(e->L[lvl], &e->L[lvl + 1], "FAS right-hand side around a caller's transfer"))) return rc;
     if (pl->n == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_FAS_RHS, lvl);
     LAUNCH_BY_KIND(fas_fine_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_iota, rows, ld_rows, lvl > 0 ? 1 : 0);
@@ -2679,6 +2871,7 @@ int mgrit_hip_fas_coarse(mgrit_hip_engine *e, int lvl, int pairs_id) {
     Level &lc = e->L[lvl + 1];
     if ((rc = check_bound(lc, true))) return rc;
     if (lc.h2d || is_2pts(lc)) return fail(MGRIT_HIP_EUNSUPPORTED, "split FAS right-hand side: 1-D one-point steppers only");
+    if ((rc = no_wide(e->L[lvl], &e->L[lvl + 1], "FAS right-hand side around a caller's transfer"))) return rc;
     if (pl->n == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_FAS_RHS, lvl);
     LAUNCH_BY_KIND(fas_coarse_kernel, lc, pl->n, lc.dev, pl->d_coarse);
@@ -2707,7 +2900,8 @@ int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id) {
         return 0;
     }
     if (lf.transfer == MGRIT_HIP_TRANSFER_COPY) {
-        LAUNCH_BY_KIND(fas_fine_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_coarse, lc.dev.g, lc.dev.ld, lvl > 0 ? 1 : 0);
+        if (lf.wide) { if ((rc = wide_fas_fine(e, lvl, pl, lc.dev.g, lc.dev.ld, false))) return rc; }
+        else { LAUNCH_BY_KIND(fas_fine_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_coarse, lc.dev.g, lc.dev.ld, lvl > 0 ? 1 : 0); }
     } else {
         if (lf.scratch_rows < (size_t)pl->n) {
             if (lf.scratch) HIP_TRY(hipFree(lf.scratch));
@@ -2715,12 +2909,14 @@ int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id) {
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lf.scratch), sizeof(double) * (size_t)pl->n * lf.dev.ld));
             lf.scratch_rows = pl->n;
         }
-        LAUNCH_BY_KIND(fas_fine_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_iota, lf.scratch, lf.dev.ld, lvl > 0 ? 1 : 0);
+        if (lf.wide) { if ((rc = wide_fas_fine(e, lvl, pl, lf.scratch, lf.dev.ld, true))) return rc; }
+        else { LAUNCH_BY_KIND(fas_fine_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_iota, lf.scratch, lf.dev.ld, lvl > 0 ? 1 : 0); }
         dim3 grid(pl->n, (lc.dev.ld + 255) / 256);
         hipLaunchKernelGGL(restrict_rows_kernel, grid, dim3(256), 0, e->stream, lf.scratch, lf.dev.ld, lf.dev.T, pl->d_iota,
                            lc.dev.g, lc.dev.ld, lc.dev.T, pl->d_coarse, lc.dev.n, lf.transfer);
         HIP_TRY(hipGetLastError());
     }
+    if (lc.wide) return wide_fas_coarse(e, lvl, pl);
     LAUNCH_BY_KIND(fas_coarse_kernel, lc, pl->n, lc.dev, pl->d_coarse);
     return 0;
 }
@@ -2745,6 +2941,7 @@ int mgrit_hip_fas_fused_opts(mgrit_hip_engine *e, int lvl, int triples_id, int o
     if (rc) return rc;
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
+    if ((rc = no_wide(lf, &lc, "fused FAS residual"))) return rc;
     if (!pl->d_prev) return fail(MGRIT_HIP_EINVAL, "list %d was not created by mgrit_hip_triples_create", triples_id);
     if (lf.h2d || lc.h2d || is_2pts(lf) || is_2pts(lc) || lf.transfer != MGRIT_HIP_TRANSFER_COPY || lf.dev.kind != lc.dev.kind ||
         force_mode(lf) != force_mode(lc) || lf.dev.n != lc.dev.n)
@@ -2822,6 +3019,7 @@ int mgrit_hip_at_solve(mgrit_hip_engine *e, int lvl, int k) {
     if (lvl == 0) return fail(MGRIT_HIP_EINVAL, "the truncated solve runs on a coarse level (it uses g)");
     if ((rc = check_bound(lv, true))) return rc;
     if (lv.h2d || is_2pts(lv)) return fail(MGRIT_HIP_EUNSUPPORTED, "AT-MGRIT coarsest solve: 1-D single-point steppers only");
+    if ((rc = no_wide(lv, nullptr, "AT-MGRIT coarsest solve"))) return rc;
     if (lv.dev.n_pts < 2) return 0;
     Timed timed(e, MGRIT_HIP_T_AT, lvl);
     const size_t rows = (size_t)lv.dev.n_pts;
@@ -2859,6 +3057,7 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id) {
     if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
     if (lf.h2d || lc.h2d || is_2pts(lf) || is_2pts(lc) || lf.transfer != MGRIT_HIP_TRANSFER_COPY || lf.dev.n != lc.dev.n)
         return fail(MGRIT_HIP_EUNSUPPORTED, "fused correction + F-relaxation needs 1-D steppers and the copy transfer");
+    if ((rc = no_wide(lf, &lc, "fused correction + F-relaxation"))) return rc;
     if (rl->n == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_EC_RELAX, lvl);
     const bool use_g = lvl > 0;
@@ -3012,6 +3211,7 @@ static int fused_level_check(mgrit_hip_engine *e, int lvl, int ivals_id, const c
     if (lvl != 0 && level0_only) return fail(MGRIT_HIP_EUNSUPPORTED, "%s: level 0 only", what);
     if (lvl + 1 >= e->n_levels || !e->L[lvl + 1].set) return fail(MGRIT_HIP_EINVAL, "level %d has no coarser level", lvl);
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    if ((rc = no_wide(lf, &lc, what))) return rc;
     if (ivals_id < 0 || ivals_id >= (int)lf.ivals.size()) return fail(MGRIT_HIP_EINVAL, "bad interval-list id %d on level %d", ivals_id, lvl);
     if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
     if (lf.dev.kind != MGRIT_HIP_STEPPER_HEAT1D || lc.dev.kind != MGRIT_HIP_STEPPER_HEAT1D || lf.transfer != MGRIT_HIP_TRANSFER_COPY ||

@@ -302,10 +302,11 @@ def test_full_size_properties_config3(oracle):
 
 
 def test_unsupported_sizes_fail_loudly():
-    """states beyond the register-resident limit (n > 16384) are rejected with an error, never computed elsewhere"""
+    """states beyond the engine's limits (Heat1D: n > 65536; see tests/test_hip_wide.py for 16384 < n <= 65536) are rejected with
+    an error, never computed elsewhere"""
     _need_gpu()
     from pymgrit_amd import Mgrit
     from pymgrit_amd.core.hip_lib import MgritHipError
-    prob = heat_problem(20000, [cases.lin(2, 9), cases.lin(2, 3)])
+    prob = heat_problem(70000, [cases.lin(2, 9), cases.lin(2, 3)])
     with pytest.raises(MgritHipError):
         Mgrit(prob, logging_lvl=30)
