@@ -454,8 +454,19 @@ class HipBackend:
         return self._sumsq
 
     # -- sweeps ----------------------------------------------------------------------------------------
+    def _before_c_write(self, lvl):
+        """a sweep that WRITES level-0 C-points on its own (a C-relaxation, an error correction, an interpolation called by
+        hand) while the last cycle's F-points still await materialise(): they are a function of the C-points as they ARE, so
+        they are put in place first -- rebuilt afterwards they would follow the new C-points, which is not what the reference's
+        state holds (found by tests/test_hip_state_fuzz.py). Mgrit.iteration's own C-relaxations are followed by an F-relaxation
+        that rewrites every F-point anyway (f_relax_follows)."""
+        if lvl == 0 and self._f_stale and not getattr(self, "f_relax_follows", False):
+            self.materialise()
+
     def relax(self, lvl, runs, mode):
         self._settle(lvl)
+        if mode == 'C':
+            self._before_c_write(lvl)
         if lvl == 0:
             self._residual_cache = None
         if not runs:
@@ -556,10 +567,12 @@ class HipBackend:
                 gc.collect()
                 gc.disable()     # a collection inside the capture could run the destructor of an old engine (hipFree,
                                  # hipStreamSynchronize): calls that invalidate a capture in progress
-                try:
+                was, self._f_stale = self._f_stale, 0     # (as in the launch-by-launch executions the capture repeats: the plan's
+                try:                                      # nodes are the cycle's own sweeps, nothing is put in place in between)
                     with torch.cuda.graph(graph, stream=cap, capture_error_mode="thread_local"):
                         self._plan_issue(plan, cap)
                 finally:
+                    self._f_stale = was
                     if gc_was_on:
                         gc.enable()
                 state["graph"] = graph
@@ -908,6 +921,7 @@ class HipBackend:
     def ec_relax(self, lvl, triples):
         """error correction of the C-point in front of each run + the run's F-relaxation in one launch"""
         self._settle(lvl)
+        self._before_c_write(lvl)
         if lvl == 0:
             self._residual_cache = None
         if not triples:
@@ -1009,6 +1023,7 @@ class HipBackend:
         self._residual_cache = tuple(points) if not isinstance(points, tuple) else points
 
     def error_correction(self, lvl, pairs):
+        self._before_c_write(lvl)
         if lvl == 0:
             self._residual_cache = None
         if pairs and not self._device_transfer(lvl):     # mgrit.py:724-726 through the user's interpolation
@@ -1019,6 +1034,7 @@ class HipBackend:
             check(self.lib.mgrit_hip_error_correction(self.h, lvl, self._pair_id(lvl, pairs)))
 
     def interpolate(self, lvl, pairs):
+        self._before_c_write(lvl)
         if lvl == 0:
             self._residual_cache = None
         if pairs and not self._device_transfer(lvl):     # mgrit.py:559-563

@@ -550,7 +550,11 @@ class Mgrit:
             # the partial intervals at the two ends and every exchange point as in the sweep-by-sweep form
             intervals, c0_run, edge_runs = shard
             for _ in range(self.cf_iter[lvl] - 1):
-                self.c_relax(lvl=lvl)
+                self.backend.f_relax_follows = True
+                try:
+                    self.c_relax(lvl=lvl)
+                finally:
+                    self.backend.f_relax_follows = False
                 self.f_relax(lvl=lvl)
             self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
                            recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=2)
@@ -564,7 +568,11 @@ class Mgrit:
             return
         down = fused is not None and self.cf_iter[lvl] >= 1
         for _ in range(self.cf_iter[lvl] - (1 if down else 0)):
-            self.c_relax(lvl=lvl)
+            self.backend.f_relax_follows = True     # (the F-relaxation below rewrites every F-point: nothing to put in place first)
+            try:
+                self.c_relax(lvl=lvl)
+            finally:
+                self.backend.f_relax_follows = False
             self.f_relax(lvl=lvl)
         if down:      # the last C-relaxation + F-relaxation + the FAS residual: one pass
             head = self._cached(('pair_head_x', lvl), lambda: self._pairs(lvl, skip_first=False)[:1] if self.comm_time_rank == 0 else [])
