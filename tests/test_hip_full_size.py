@@ -49,3 +49,44 @@ def test_full_size_solve_sharded_equals_one_rank(tmp_path):
             assert r["conv"] == one["conv"], (world, r["conv"], one["conv"])
         assert sum(r["n"] for r in parts) == one["n"] and all(r["first"] == 1 for r in parts[1:])   # local slot 0 = ghost point
         assert parts[-1]["u_last"] == one["u_last"], world      # the state at the final time, bit for bit
+
+
+def test_full_size_planned_cycles_match_the_oracle(oracle):
+    """the path bench.py times -- config 3 at FULL size, the default planned cycle (6 blocks, replayed as one hipGraph from its
+    third execution on), whole-level passes, C-point storage, pre-relaxed C-points -- against the ORACLE running the same cycles
+    at the same size (its independent intervals spread over host threads: bit-identical to its serial sweeps): per-point
+    residual norms of every cycle and sampled level-0 states, bit for bit. (Needs ~20 GB of host memory for the oracle's slabs.)"""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    import cases
+    try:
+        free_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
+    except (ValueError, OSError):
+        free_gb = 0.0
+    if free_gb < 48:
+        pytest.skip(f"host has {free_gb:.0f} GB free: the full-size oracle needs its own 17 GB of slabs")
+    import bench
+    from pymgrit_amd import Heat1D, Mgrit
+    nx, nt0 = 16384, 65537
+    t0 = np.linspace(0, 2.0 * (nt0 - 1) / 65536, nt0)
+    grids = [t0, t0[::4], t0[::16]]
+    prob = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=bench.init_cond, rhs_separable=[(bench.rhs_space, bench.rhs_time)],
+                   t_interval=g) for g in grids]
+    mg = Mgrit(prob, cf_iter=1, cycle_type='V', nested_iteration=False, max_iter=8, tol=0.0, logging_lvl=30)
+    assert mg.plan_blocks() >= 4 and mg._level_intervals(0) is not None
+    op = oracle.OracleProblem([cases.heat_level_spec(nx, g) for g in grids], variant=1, cf_iter=1, nested_iteration=False, max_iter=8,
+                              tol=0.0)
+    op.set_threads(min(32, os.cpu_count() or 1))
+    sample = [1, 2, 3, 4, 16381, 16384, 32768, 40001, 65533, 65535, 65536]
+    for it in range(5):        # iteration 0, then four steady cycles: the last two are graph replays
+        mg.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True)
+        got = np.asarray(mg.compute_residual())
+        op.iteration(0, 'V', it, True)
+        want = op.residual_norms()
+        assert np.array_equal(got, want), (it, float(np.abs(got - want).max()))
+    assert any(p is not None and getattr(p, "_hip", {}).get("graph") is not None for p in mg._plans.values())
+    ref = op.state("u", 0)
+    for i in sample:
+        assert np.array_equal(np.asarray(mg.u[0][i].get_values()), ref[i]), i
