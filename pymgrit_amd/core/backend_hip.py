@@ -230,7 +230,7 @@ class HipBackend:
         for lvl in range(mg.lvl_max - 1):
             tr = mg.transfer_objects[lvl]
             kind = int(tr.device_transfer()) if self._device_transfer(lvl) else hip_lib.TRANSFER_CALLER
-            if kind == hip_lib.TRANSFER_CALLER and self.desc[lvl]["kind"] not in ("heat1d", "advection1d"):
+            if kind == hip_lib.TRANSFER_CALLER and self.desc[lvl]["kind"] not in ("heat1d", "advection1d", "heat2d"):
                 raise MgritHipError(f"transfer {type(tr).__name__} is applied through its Python methods, which the "
                                     f"{self.desc[lvl]['kind']} levels do not support (they take GridTransferCopy)")
             check(self.lib.mgrit_hip_level_transfer(self.h, lvl, kind))

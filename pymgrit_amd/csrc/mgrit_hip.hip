@@ -1322,7 +1322,7 @@ struct PairList {
     int n = 0;
     int32_t *d_fine = nullptr, *d_coarse = nullptr, *d_iota = nullptr, *d_prev = nullptr;
     std::vector<int32_t> h_fine, h_coarse;
-    std::vector<H2DPlan> h2d_fine, h2d_coarse;
+    std::vector<H2DPlan> h2d_fine, h2d_coarse, h2d_rows;   // (h2d_rows: the fine half into caller rows, mgrit_hip_fas_fine_rows)
     bool h2d_built = false;
 };
 
@@ -2623,7 +2623,7 @@ int mgrit_hip_level_transfer(mgrit_hip_engine *e, int lvl, int kind) {
         if (e->L[lvl].h2d || e->L[lvl + 1].h2d) return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D levels support the copy transfer only");
         if (nf != 2 * nc) return fail(MGRIT_HIP_EINVAL, "periodic transfer needs n_fine = 2*n_coarse (%d vs %d)", nf, nc);
     } else if (kind == MGRIT_HIP_TRANSFER_CALLER) {
-        if (e->L[lvl].h2d || e->L[lvl + 1].h2d) return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D levels support the copy transfer only");
+        if (!e->L[lvl].h2d != !e->L[lvl + 1].h2d) return fail(MGRIT_HIP_EUNSUPPORTED, "a caller's transfer joins two Heat2D levels or two 1-D levels");
     } else return fail(MGRIT_HIP_EINVAL, "unknown transfer kind %d", kind);
     e->L[lvl].transfer = kind;
     return 0;
@@ -2855,8 +2855,24 @@ int mgrit_hip_fas_fine_rows(mgrit_hip_engine *e, int lvl, int pairs_id, double *
     if (rc) return rc;
     Level &lf = e->L[lvl];
     if ((rc = check_bound(lf, lvl > 0))) return rc;
-    if (lf.h2d || is_2pts(lf)) return fail(MGRIT_HIP_EUNSUPPORTED, "split FAS right-hand side: 1-D one-point steppers only");
+    if (is_2pts(lf)) return fail(MGRIT_HIP_EUNSUPPORTED, "split FAS right-hand side: one-point steppers only");
     if (pl->n > 0 && (!rows || ld_rows < lf.dev.ld)) return fail(MGRIT_HIP_EINVAL, "rows buffer missing or narrower than the level's rows");
+    if (lf.h2d) {   // Heat2D: the batched Phi, the fine half written to the caller's rows (one per pair)
+        if (pl->n == 0) return 0;
+        Timed timed(e, MGRIT_HIP_T_FAS_RHS, lvl);
+        if (pl->h2d_rows.empty()) {
+            std::vector<H2DItem> fine;
+            for (int p = 0; p < pl->n; ++p) fine.push_back({pl->h_fine[p] - 1, pl->h_fine[p], p, pl->h_fine[p], pl->h_fine[p]});
+            if ((rc = h2d_make_plans(e, lf, fine, pl->h2d_rows))) return rc;
+            if (pl->h2d_rows.size() > (size_t)((pl->n + H2D_MAX_BATCH - 1) / H2D_MAX_BATCH))
+                return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D FAS rows for a caller's transfer: one time-step size per level");
+        }
+        for (const H2DPlan &q : pl->h2d_rows) {
+            if ((rc = h2d_phi_batch(e, lf, q, lf.dev.u))) return rc;
+            if ((rc = h2d_finish(e, lf, q, lf.dev.u, rows, ld_rows, lf.dev.g, lf.dev.u, H2D_OP_FAS_FINE, lvl > 0 ? 1 : 0, 1.0))) return rc;
+        }
+        return 0;
+    }
     if ((rc = no_wide(e->L[lvl], &e->L[lvl + 1], "FAS right-hand side around a caller's transfer"))) return rc;
     if (pl->n == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_FAS_RHS, lvl);
@@ -2870,7 +2886,21 @@ int mgrit_hip_fas_coarse(mgrit_hip_engine *e, int lvl, int pairs_id) {
     if (rc) return rc;
     Level &lc = e->L[lvl + 1];
     if ((rc = check_bound(lc, true))) return rc;
-    if (lc.h2d || is_2pts(lc)) return fail(MGRIT_HIP_EUNSUPPORTED, "split FAS right-hand side: 1-D one-point steppers only");
+    if (is_2pts(lc)) return fail(MGRIT_HIP_EUNSUPPORTED, "split FAS right-hand side: one-point steppers only");
+    if (lc.h2d) {
+        if (pl->n == 0) return 0;
+        Timed timed(e, MGRIT_HIP_T_FAS_RHS, lvl);
+        if (pl->h2d_coarse.empty()) {
+            std::vector<H2DItem> coarse;
+            for (int p = 0; p < pl->n; ++p) { const int j = pl->h_coarse[p]; coarse.push_back({j - 1, j, j, j, j}); }
+            if ((rc = h2d_make_plans(e, lc, coarse, pl->h2d_coarse))) return rc;
+        }
+        for (const H2DPlan &q : pl->h2d_coarse) {
+            if ((rc = h2d_phi_batch(e, lc, q, lc.dev.v))) return rc;
+            if ((rc = h2d_finish(e, lc, q, lc.dev.v, lc.dev.g, lc.dev.ld, lc.dev.g, lc.dev.v, H2D_OP_FAS_COARSE, 1, 1.0))) return rc;
+        }
+        return 0;
+    }
     if ((rc = no_wide(e->L[lvl], &e->L[lvl + 1], "FAS right-hand side around a caller's transfer"))) return rc;
     if (pl->n == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_FAS_RHS, lvl);

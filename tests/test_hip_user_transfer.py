@@ -64,3 +64,64 @@ def test_user_transfer_on_the_device_path(case):
     assert np.array_equal(conv0, conv1), (conv0, conv1)
     for a, b in zip(u0, u1):
         assert np.array_equal(a, b)
+
+
+def test_user_transfer_between_heat2d_levels():
+    """a user's 2-D GridTransfer (the reference's interface is open, core/grid_transfer.py:31-55; it ships no 2-D transfer class):
+    spatial coarsening 17 x 21 -> 9 x 11 by full weighting / bilinear interpolation written in Python. The device path applies it
+    row by row between the kernels (MGRIT_HIP_TRANSFER_CALLER: mgrit_hip_fas_fine_rows / mgrit_hip_fas_coarse for Heat2D) while
+    every Phi stays on the GPU; the yardstick is the same hierarchy on the plugin path (host steppers, the reference's semantics)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    import cases
+    from pymgrit_amd import GridTransfer, Mgrit
+    from pymgrit_amd.heat.heat_2d import Heat2D, VectorHeat2D
+    calls = {"R": 0, "P": 0}
+
+    class Coarsen2D(GridTransfer):
+        def restriction(self, u):
+            calls["R"] += 1
+            f = np.asarray(u.get_values())
+            nxc, nyc = (f.shape[0] + 1) // 2, (f.shape[1] + 1) // 2
+            c = f[::2, ::2].copy()        # boundary values by injection, the interior by full weighting
+            c[1:-1, 1:-1] = (4 * f[2:-2:2, 2:-2:2] + 2 * (f[1:-3:2, 2:-2:2] + f[3:-1:2, 2:-2:2] + f[2:-2:2, 1:-3:2] + f[2:-2:2, 3:-1:2]) +
+                             f[1:-3:2, 1:-3:2] + f[1:-3:2, 3:-1:2] + f[3:-1:2, 1:-3:2] + f[3:-1:2, 3:-1:2]) / 16
+            out = VectorHeat2D(nxc, nyc)
+            out.set_values(c)
+            return out
+
+        def interpolation(self, u):
+            calls["P"] += 1
+            c = np.asarray(u.get_values())
+            f = np.zeros((2 * c.shape[0] - 1, 2 * c.shape[1] - 1))
+            f[::2, ::2] = c
+            f[1::2, ::2] = (c[:-1, :] + c[1:, :]) / 2
+            f[::2, 1::2] = (c[:, :-1] + c[:, 1:]) / 2
+            f[1::2, 1::2] = (c[:-1, :-1] + c[1:, :-1] + c[:-1, 1:] + c[1:, 1:]) / 4
+            out = VectorHeat2D(*f.shape)
+            out.set_values(f)
+            return out
+
+    def hierarchy(host):
+        t0 = np.linspace(0, 1, 33)
+        prob = [Heat2D(x_start=0, x_end=cases.H2D_X_END, y_start=0, y_end=cases.H2D_Y_END, nx=nx, ny=ny, a=cases.H2D_A,
+                       rhs_separable=[(cases.h2d_s0, lambda t: 1.0)], t_interval=t)
+                for (nx, ny), t in (((17, 21), t0), ((9, 11), t0[::2]), ((9, 11), t0[::4]))]
+        if host:
+            for p in prob:
+                p.device_stepper = lambda: None
+        from pymgrit_amd import GridTransferCopy
+        return prob, [Coarsen2D(), GridTransferCopy()]
+
+    out = {}
+    for host in (True, False):
+        prob, tr = hierarchy(host)
+        mg = Mgrit(prob, transfer=tr, logging_lvl=30, tol=1e-9, max_iter=8)
+        assert (type(mg.backend).__name__ == "HipBackend") != host
+        conv = mg.solve()["conv"]
+        out[host] = (conv, np.array([np.asarray(mg.u[0][i].get_values()) for i in (5, 16, 32)]))
+    assert calls["R"] > 0 and calls["P"] > 0
+    (ch, uh), (cd, ud) = out[True], out[False]
+    # (host steppers = another arithmetic of the same Phi: the fixtures' tolerance, 1e-9 relative above the rounding floor)
+    assert len(ch) == len(cd) and np.all(np.abs(ch - cd) <= 1e-9 * ch + 2e-11), (ch, cd)
+    assert np.max(np.abs(uh - ud)) <= 1e-11 * max(1.0, np.max(np.abs(uh)))
