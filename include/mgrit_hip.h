@@ -307,6 +307,12 @@ int mgrit_hip_error_correction_to(mgrit_hip_engine *e, int lvl, int pairs_id, do
  * (device-accessible, e.g. pinned host memory) on the stream: a replayed cycle always writes the engine's buffer, a solver
  * that looks at its stopping values some cycles late (Mgrit._solve_pipelined) keeps each cycle's values in a slot of its own */
 int mgrit_hip_residual_stash(mgrit_hip_engine *e, int n, double *dst);
+/* A HIP stream whose kernels run on CUs [first_cu, first_cu + n_cus) only (hipExtStreamCreateWithCUMask); for mgrit_hip_set_stream.
+ * A planned cycle (pymgrit_amd/core/cycle_plan.py) of Heat2D levels gives the sequential coarsest-level solve -- six small
+ * launches per step -- a few CUs of its own and the batched sweeps the rest: side by side the sweeps' thousands of workgroups
+ * would otherwise sit in front of every one of its launches. No reference counterpart. */
+int mgrit_hip_stream_create_masked(void **stream_out, int first_cu, int n_cus);
+int mgrit_hip_stream_destroy(void *stream);
 /* C-point mirror: from the next level-0 mgrit_hip_ec_relax_res pass on (stream order), every corrected C-point u^0_i (mgrit.py:
  * 724-726) is ALSO stored to row row0 + res_pos of the device slab `rows` ([>= row0 + res_len][ld]); NULL switches it off. A
  * solver that examines its stopping value some cycles late keeps the level-0 C-points of every cycle it may have to return to

@@ -490,9 +490,11 @@ class HipBackend:
             return 1
         n_c = len(self.mg.t[-1])
         if any(d["kind"] == "heat2d" for d in self.desc):
-            # the coarsest-level solve (six launches per step) beside the batched sweeps of other blocks; measured on config 4
-            # (2049 coarsest points): one block 619 ms per cycle, two 593, four 578, eight 574
-            return int(os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS_HEAT2D", str(max(1, min(8, n_c // 256)))))
+            # the coarsest-level solve (six launches per step) beside the batched sweeps of other blocks, each on CUs of its own
+            # (_masked_streams: one XCD of 32 CUs for the solve). Measured on config 4 (2049 coarsest points), ms per cycle: one
+            # block 619; without the CU partition two 593, four 578, eight 574; with it eight 533, twelve 523, sixteen 520
+            # (16 CUs for the solve: 676-696, 24: 620, 40: 539-550, 48: 540-548, 64: 552-569)
+            return int(os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS_HEAT2D", str(max(1, min(16, n_c // 128)))))
         # measured on config 3 (4097 coarsest points, round 2): 4 blocks 12.2 ms, 5 11.3, 6 10.8, 7 11.9, 8 13.3 -- more blocks
         # shorten the fill and drain of the block pipeline, fewer keep the launches large (a level-0 pass of one block is
         # 16384 / blocks / 4 chunks for 240 workgroups: with 6 blocks 2.8 rounds, with 8 blocks 2.1)
@@ -602,7 +604,50 @@ class HipBackend:
         finally:
             self._f_stale = max(self._f_stale, was)   # (also when a launch failed: rows that awaited materialise() still do)
 
+    def _masked_streams(self):
+        """Heat2D planned cycle: (sweep stream, chain stream) on disjoint sets of CUs (mgrit_hip_stream_create_masked), or None.
+        PYMGRIT_AMD_H2D_CHAIN_CUS = CUs given to the coarsest-level solve (default 32; 0: no partition)."""
+        if not hasattr(self, "_masked"):
+            self._masked = None
+            n_chain = int(os.environ.get("PYMGRIT_AMD_H2D_CHAIN_CUS", "32"))
+            total = torch.cuda.get_device_properties(self.device).multi_processor_count
+            if any(d["kind"] == "heat2d" for d in self.desc) and 0 < n_chain < total:
+                a, b = C.c_void_p(), C.c_void_p()
+                if self.lib.mgrit_hip_stream_create_masked(C.byref(a), 0, total - n_chain) == 0 and \
+                        self.lib.mgrit_hip_stream_create_masked(C.byref(b), total - n_chain, n_chain) == 0:
+                    self._masked = (torch.cuda.ExternalStream(a.value, device=self.device), torch.cuda.ExternalStream(b.value, device=self.device))
+        return self._masked
+
     def _plan_issue(self, plan, main):
+        masked = self._masked_streams() if (plan.has_chain and plan.n_blocks > 1) else None
+        if masked is not None:
+            # sweeps and chain on CU partitions of their own: fork both from the caller's stream, join both at the end
+            sweep, side = masked
+            if not hasattr(self, "_fork"):
+                self._fork = torch.cuda.Event()
+            self._fork.record(main)
+            sweep.wait_event(self._fork)
+            side.wait_event(self._fork)
+            last = {}
+            try:
+                for node in plan.order:
+                    st = side if node.stream == "chain" else sweep
+                    for p in node.cross_preds:
+                        st.wait_event(p.event)
+                    self._use_stream(st)
+                    node.fn()
+                    if node.needs_event:
+                        if node.event is None:
+                            node.event = torch.cuda.Event()
+                        node.event.record(st)
+                    last[st] = node
+            finally:
+                self._use_stream(self.stream)
+            for st in (sweep, side):
+                ev = torch.cuda.Event()
+                ev.record(st)
+                main.wait_event(ev)
+            return
         if self._chain_stream is None:
             self._chain_stream = torch.cuda.Stream(device=self.device, priority=-1)
             self._fork = torch.cuda.Event()

@@ -93,6 +93,8 @@ EXPORTS = {
     "mgrit_hip_error_correction_to": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "mgrit_hip_residual_stash": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mgrit_hip_cpoint_mirror": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "mgrit_hip_stream_create_masked": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "mgrit_hip_stream_destroy": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None

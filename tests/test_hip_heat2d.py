@@ -196,3 +196,22 @@ def test_general_forcing_solves_match_oracle_and_reference(oracle):
         assert len(conv) == len(ref) and np.all(np.abs(conv - ref) <= 1e-9 * ref + 2e-11), (name, conv, ref)
         last = np.asarray(mg.u[0][len(prob[0].t) - 1].get_values())
         assert np.max(np.abs(last - arr["solve_" + name])) <= 1e-10 * max(1.0, np.max(np.abs(last))), name
+
+
+@pytest.mark.parametrize("name", ["be_3lvl_F_bc", "cn_2lvl", "example_small"])
+def test_planned_cycle_on_cu_partitions_is_bit_identical(name, monkeypatch):
+    """Heat2D planned cycle: blocks of time points, the coarsest-level solve of a block beside the sweeps of the others, each side
+    on CUs of its own (mgrit_hip_stream_create_masked; the solve has work buffers of its own) -- same bits as the program order"""
+    from pymgrit_amd import Mgrit
+    assert torch.cuda.is_available()
+    out = []
+    for blocks in (1, 3, 5):
+        monkeypatch.setenv("PYMGRIT_AMD_PLAN_BLOCKS_HEAT2D", str(blocks))
+        prob, opts = cases.h2d_solve_problem(name)
+        mg = Mgrit(prob, logging_lvl=30, **opts)
+        conv = mg.solve()["conv"]
+        if blocks > 1 and mg.plan_blocks() > 1:
+            assert any(p is not None for p in mg._plans.values()) and mg.backend._masked_streams() is not None
+        out.append((conv, mg.backend.natural("u", 0)))
+    for conv, u in out[1:]:
+        assert np.array_equal(conv, out[0][0]) and np.array_equal(u, out[0][1])
