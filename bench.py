@@ -242,7 +242,8 @@ def bench_advection(args):
     nxs = [8193, 4097, 2049, 2049]
     prob = [Advection1D(c=1, x_start=-1, x_end=1, nx=nx, t_interval=t0[::2 ** lvl]) for lvl, nx in enumerate(nxs)]
     transfer = [GridTransferAdvection(), GridTransferAdvection(), GridTransferCopy()]
-    mg = Mgrit(prob, transfer=transfer, cf_iter=1, cycle_type='F', nested_iteration=False, max_iter=1, tol=0.0, logging_lvl=30)
+    mg = Mgrit(prob, transfer=transfer, cf_iter=1, cycle_type='F', nested_iteration=False, max_iter=1, tol=0.0, logging_lvl=30,
+               plan_blocks=args.plan_blocks)
     be = mg.backend
 
     def cycle(it):

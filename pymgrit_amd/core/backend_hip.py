@@ -611,9 +611,12 @@ class HipBackend:
             self._masked = None
             n_chain = int(os.environ.get("PYMGRIT_AMD_H2D_CHAIN_CUS", "32"))
             total = torch.cuda.get_device_properties(self.device).multi_processor_count
+            # (Heat2D only: its plans run launch by launch -- capturing the two masked streams into one hipGraph crashed the host
+            # process; tried for config 5's F-cycle as well, launch by launch: 22.3-23.3 ms with 2-8 blocks against 20.2 with one)
             if any(d["kind"] == "heat2d" for d in self.desc) and 0 < n_chain < total:
                 a, b = C.c_void_p(), C.c_void_p()
-                if self.lib.mgrit_hip_stream_create_masked(C.byref(a), 0, total - n_chain) == 0 and \
+                n_sweep = total if os.environ.get("PYMGRIT_AMD_H2D_SWEEP_ALL", "") == "1" else total - n_chain   # (experiment)
+                if self.lib.mgrit_hip_stream_create_masked(C.byref(a), 0, n_sweep) == 0 and \
                         self.lib.mgrit_hip_stream_create_masked(C.byref(b), total - n_chain, n_chain) == 0:
                     self._masked = (torch.cuda.ExternalStream(a.value, device=self.device), torch.cuda.ExternalStream(b.value, device=self.device))
         return self._masked
