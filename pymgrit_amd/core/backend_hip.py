@@ -494,7 +494,9 @@ class HipBackend:
             # (_masked_streams: one XCD of 32 CUs for the solve). Measured on config 4 (2049 coarsest points), ms per cycle: one
             # block 619; without the CU partition two 593, four 578, eight 574; with it eight 533, twelve 523, sixteen 520
             # (16 CUs for the solve: 676-696, 24: 620, 40: 539-550, 48: 540-548, 64: 552-569)
-            return int(os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS_HEAT2D", str(max(1, min(16, n_c // 128)))))
+            # ... and since the sweeps apply their own arithmetic inside the last transform (h2d_inv_kernel<true>): sixteen 506,
+            # twenty-four 501, thirty-two 501 (40 CUs for the solve: 517-520, 64: 528-530)
+            return int(os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS_HEAT2D", str(max(1, min(24, n_c // 85)))))
         # measured on config 3 (4097 coarsest points, round 2): 4 blocks 12.2 ms, 5 11.3, 6 10.8, 7 11.9, 8 13.3 -- more blocks
         # shorten the fill and drain of the block pipeline, fewer keep the launches large (a level-0 pass of one block is
         # 16384 / blocks / 4 chunks for 240 workgroups: with 6 blocks 2.8 rounds, with 8 blocks 2.1)

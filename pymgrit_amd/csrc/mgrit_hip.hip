@@ -1974,7 +1974,10 @@ int h2d_dinv(mgrit_hip_engine *e, Level &lv, uint64_t dtbits, double **out) {
 }
 
 // U (in W0) = interior of Phi applied to the rows in_slab[plan.d_in[b]] for the steps plan.d_step[b]  (theta > 0)
-int h2d_phi_batch(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab, bool chain = false) {
+// fin: the sweep's arithmetic is applied by the last transform itself (h2d_inv_kernel<true> + h2d_rim_kernel): no epilogue
+// launch, and the interior of U is neither written to nor read from the work slab
+int h2d_phi_batch(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab, bool chain = false,
+                  const H2DFin *fin = nullptr) {
     H2DHost &h = *lv.h2d;
     const H2DDev &H = h.dev;
     if (H.theta == 0.0) return 0;  // explicit: evaluated inside the epilogue kernels
@@ -1996,14 +1999,40 @@ int h2d_phi_batch(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const doubl
     const dim3 ix(H.Mj / 64, h.HPx / 64, pl.count), iy(H.Mi / 64, h.HPy / 64, pl.count);      // (n tiles, i tiles, items)
     hipLaunchKernelGGL((h2d_fwd_kernel<false>), fx, dim3(256), 0, e->stream, h.Fxe, h.Fxo, H.mi, h.HPx, W0, H.Mj, W1, nullptr, per);
     hipLaunchKernelGGL((h2d_fwd_kernel<true>), fy, dim3(256), 0, e->stream, h.Fye, h.Fyo, H.mj, h.HPy, W1, H.Mi, W0, dinv, per);
-    hipLaunchKernelGGL(h2d_inv_kernel, ix, dim3(256), 0, e->stream, h.FxeT, h.FxoT, H.mi, h.HPx, W0, H.Mj, W1, per);
-    hipLaunchKernelGGL(h2d_inv_kernel, iy, dim3(256), 0, e->stream, h.FyeT, h.FyoT, H.mj, h.HPy, W1, H.Mi, W0, per);
+    const H2DFin none{};
+    hipLaunchKernelGGL((h2d_inv_kernel<false>), ix, dim3(256), 0, e->stream, h.FxeT, h.FxoT, H.mi, h.HPx, W0, H.Mj, W1, per, H, none);
+    if (fin) {
+        hipLaunchKernelGGL((h2d_inv_kernel<true>), iy, dim3(256), 0, e->stream, h.FyeT, h.FyoT, H.mj, h.HPy, W1, H.Mi, W0, per, H, *fin);
+        const int n_rim = 2 * H.ny + 2 * (H.nx - 2);
+        hipLaunchKernelGGL(h2d_rim_kernel, dim3((n_rim + 127) / 128, pl.count), dim3(128), 0, e->stream, H, *fin);
+    } else {
+        hipLaunchKernelGGL((h2d_inv_kernel<false>), iy, dim3(256), 0, e->stream, h.FyeT, h.FyoT, H.mj, h.HPy, W1, H.Mi, W0, per, H, none);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
+// Phi of the batch followed by the sweep's arithmetic: fused into the last transform for the implicit schemes, the epilogue
+// kernel (which evaluates the explicit stencil itself) for theta = 0. MGRIT_HIP_H2D_UNFUSED=1: always the epilogue (measurement).
 int h2d_finish(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab, double *dst_slab, int dst_ld,
+               const double *a_slab, const double *b_slab, int op, int use_g, double w, bool chain);
+
+int h2d_phi_op(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab, double *dst_slab, int dst_ld,
                const double *a_slab, const double *b_slab, int op, int use_g, double w, bool chain = false) {
+    static const bool unfused = [] { const char *s = std::getenv("MGRIT_HIP_H2D_UNFUSED"); return s && s[0] == '1'; }();
+    int rc;
+    // (the sequential coarsest-level solve keeps the epilogue kernel: fused, one step of one state took 107 instead of 92 us --
+    // the last transform's 64 tiles then also carry the sweep's loads and the rim is a launch of its own)
+    if (lv.h2d->dev.theta != 0.0 && !unfused && !chain) {
+        const H2DFin fin{dst_slab, dst_ld, pl.d_dst, a_slab, pl.d_a, b_slab, pl.d_b, op, use_g, w, 1.0 - w};
+        return h2d_phi_batch(e, lv, pl, in_slab, chain, &fin);
+    }
+    if ((rc = h2d_phi_batch(e, lv, pl, in_slab, chain))) return rc;
+    return h2d_finish(e, lv, pl, in_slab, dst_slab, dst_ld, a_slab, b_slab, op, use_g, w, chain);
+}
+
+int h2d_finish(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab, double *dst_slab, int dst_ld,
+               const double *a_slab, const double *b_slab, int op, int use_g, double w, bool chain) {
     const H2DDev &H = lv.h2d->dev;
     hipLaunchKernelGGL(h2d_finish_kernel, dim3((H.ny + 127) / 128, H.nx, pl.count), dim3(128), 0, e->stream, H,
                        (chain && pl.count == 1 && lv.h2d->Wc0) ? lv.h2d->Wc0 : lv.h2d->W0, in_slab,
@@ -2034,8 +2063,7 @@ int h2d_relax(mgrit_hip_engine *e, int lvl, RunList *rl, int mode, double weight
     const int op = mode == MGRIT_HIP_RELAX_C ? H2D_OP_C : H2D_OP_F;
     const bool chain = mode == MGRIT_HIP_RELAX_CHAIN && lv.h2d->dev.theta != 0.0;   // its own work buffers (H2DHost::Wc0)
     for (const H2DPlan &pl : rl->h2d_relax) {
-        if ((rc = h2d_phi_batch(e, lv, pl, lv.dev.u, chain))) return rc;
-        if ((rc = h2d_finish(e, lv, pl, lv.dev.u, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, op, lvl > 0 ? 1 : 0, weight_c, chain))) return rc;
+        if ((rc = h2d_phi_op(e, lv, pl, lv.dev.u, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, op, lvl > 0 ? 1 : 0, weight_c, chain))) return rc;
     }
     return 0;
 }
@@ -2091,12 +2119,10 @@ int h2d_fas_rhs(mgrit_hip_engine *e, int lvl, PairList *pl) {
         pl->h2d_built = true;
     }
     for (const H2DPlan &q : pl->h2d_fine) {
-        if ((rc = h2d_phi_batch(e, lf, q, lf.dev.u))) return rc;
-        if ((rc = h2d_finish(e, lf, q, lf.dev.u, lc.dev.g, lc.dev.ld, lf.dev.g, lf.dev.u, H2D_OP_FAS_FINE, lvl > 0 ? 1 : 0, 1.0))) return rc;
+        if ((rc = h2d_phi_op(e, lf, q, lf.dev.u, lc.dev.g, lc.dev.ld, lf.dev.g, lf.dev.u, H2D_OP_FAS_FINE, lvl > 0 ? 1 : 0, 1.0))) return rc;
     }
     for (const H2DPlan &q : pl->h2d_coarse) {
-        if ((rc = h2d_phi_batch(e, lc, q, lc.dev.v))) return rc;
-        if ((rc = h2d_finish(e, lc, q, lc.dev.v, lc.dev.g, lc.dev.ld, lc.dev.g, lc.dev.v, H2D_OP_FAS_COARSE, 1, 1.0))) return rc;
+        if ((rc = h2d_phi_op(e, lc, q, lc.dev.v, lc.dev.g, lc.dev.ld, lc.dev.g, lc.dev.v, H2D_OP_FAS_COARSE, 1, 1.0))) return rc;
     }
     return 0;
 }
@@ -2868,8 +2894,7 @@ int mgrit_hip_fas_fine_rows(mgrit_hip_engine *e, int lvl, int pairs_id, double *
                 return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D FAS rows for a caller's transfer: one time-step size per level");
         }
         for (const H2DPlan &q : pl->h2d_rows) {
-            if ((rc = h2d_phi_batch(e, lf, q, lf.dev.u))) return rc;
-            if ((rc = h2d_finish(e, lf, q, lf.dev.u, rows, ld_rows, lf.dev.g, lf.dev.u, H2D_OP_FAS_FINE, lvl > 0 ? 1 : 0, 1.0))) return rc;
+            if ((rc = h2d_phi_op(e, lf, q, lf.dev.u, rows, ld_rows, lf.dev.g, lf.dev.u, H2D_OP_FAS_FINE, lvl > 0 ? 1 : 0, 1.0))) return rc;
         }
         return 0;
     }
@@ -2896,8 +2921,7 @@ int mgrit_hip_fas_coarse(mgrit_hip_engine *e, int lvl, int pairs_id) {
             if ((rc = h2d_make_plans(e, lc, coarse, pl->h2d_coarse))) return rc;
         }
         for (const H2DPlan &q : pl->h2d_coarse) {
-            if ((rc = h2d_phi_batch(e, lc, q, lc.dev.v))) return rc;
-            if ((rc = h2d_finish(e, lc, q, lc.dev.v, lc.dev.g, lc.dev.ld, lc.dev.g, lc.dev.v, H2D_OP_FAS_COARSE, 1, 1.0))) return rc;
+            if ((rc = h2d_phi_op(e, lc, q, lc.dev.v, lc.dev.g, lc.dev.ld, lc.dev.g, lc.dev.v, H2D_OP_FAS_COARSE, 1, 1.0))) return rc;
         }
         return 0;
     }
