@@ -222,6 +222,24 @@ int mgrit_hip_ec_relax_res(mgrit_hip_engine *e, int lvl, int intervals_id, int s
 int mgrit_hip_ec_relax_res_to(mgrit_hip_engine *e, int lvl, int intervals_id, int store_all_f, double *sumsq_out);
 int mgrit_hip_residual_fetch(mgrit_hip_engine *e, int n, double *sumsq_host);
 
+/* The same two whole-level passes for ANY pair of register-resident 1-D steppers of one kind (Heat1D with any forcing,
+ * Advection1D) joined by ANY of the library's transfers (copy, MGRIT_HIP_TRANSFER_HEAT1D, MGRIT_HIP_TRANSFER_PERIODIC1D;
+ * examples/example_spatial_coarsening.py:33-82), on every level with a coarser one (BASELINE config 5: Advection1D, F-cycle,
+ * spatial coarsening):
+ *   mgrit_hip_gen_down:  Mgrit.c_relax, Mgrit.f_relax, Mgrit.fas_residual (mgrit.py:335-370, 292-333, 488-549 as in
+ *                        mgrit.py:277-281; weight_c = 1) for the C-points the intervals end on, as three launches: the sweeps
+ *                        of the fine level with the defect rows r_i = Phi(u_{i-1}) - u_i [+ g_i] left in a scratch slab (F-points
+ *                        not stored), ONE transfer launch (u^{l+1}_j = v^{l+1}_j = R(u_i), g^{l+1}_j = R(r_i)), and the coarse half
+ *                        g_j += v_j - Phi_c(v_{j-1}). keep[] of the list is not used: every row of lvl+1 is written.
+ *   mgrit_hip_gen_up:    Mgrit.error_correction with the interpolation P(u^{l+1}_j - v^{l+1}_j) evaluated in registers
+ *                        (mgrit.py:715-726), Mgrit.f_relax (every F-point stored) and, with_residual != 0 (level 0 only),
+ *                        Mgrit.compute_residual (mgrit.py:387-413) into the engine's buffer (mgrit_hip_residual_fetch) or
+ *                        sumsq_out when given: one launch. Needs the mgrit_hip_gen_down of the same list earlier in the cycle (it
+ *                        takes the uncorrected value of the C-point a chunk starts from out of that pass's side slab).
+ * Arithmetic: exactly that of the separate sweeps (same expressions, same order). */
+int mgrit_hip_gen_down(mgrit_hip_engine *e, int lvl, int intervals_id);
+int mgrit_hip_gen_up(mgrit_hip_engine *e, int lvl, int intervals_id, int with_residual, double *sumsq_out);
+
 /* Same two reductions with the result delivered to HOST memory (sumsq_host[r], r < n_runs) when the call returns: the
  * device->host leg of Mgrit.convergence_criterion (mgrit.py:425-432). */
 int mgrit_hip_residual_host(mgrit_hip_engine *e, int lvl, int runs_id, double *sumsq_host);
@@ -236,7 +254,7 @@ enum { MGRIT_HIP_T_RELAX_F = 0, MGRIT_HIP_T_RELAX_C = 1, MGRIT_HIP_T_CHAIN = 2, 
        MGRIT_HIP_T_RESTRICT = 5, MGRIT_HIP_T_COPY = 6, MGRIT_HIP_T_FAS_RHS = 7, MGRIT_HIP_T_FAS_FUSED = 8,
        MGRIT_HIP_T_ERROR_CORRECTION = 9, MGRIT_HIP_T_INTERPOLATE = 10, MGRIT_HIP_T_EC_RELAX = 11, MGRIT_HIP_T_AT = 12,
        MGRIT_HIP_T_CF_FAS = 13, MGRIT_HIP_T_EC_RELAX_RES = 14, MGRIT_HIP_T_RELAX_FC = 15, MGRIT_HIP_T_F_FAS = 16,
-       MGRIT_HIP_T_EXCHANGE = 17, MGRIT_HIP_T_KINDS = 18 };
+       MGRIT_HIP_T_EXCHANGE = 17, MGRIT_HIP_T_GEN_DOWN = 18, MGRIT_HIP_T_GEN_UP = 19, MGRIT_HIP_T_KINDS = 20 };
 int mgrit_hip_set_timing(mgrit_hip_engine *e, int enabled);
 int mgrit_hip_last_kernel_ms(mgrit_hip_engine *e, float *ms);
 int mgrit_hip_timing_drain(mgrit_hip_engine *e, int max_records, int *kind, int *lvl, float *ms, int *n_out);

@@ -1067,6 +1067,32 @@ class HipBackend:
             if lazy:
                 self._f_stale = max(self._f_stale, 2 if mode == 2 else 1)
 
+    # -- the same two passes for any 1-D stepper pair and any of the library's transfers (mgrit_hip_gen_down / mgrit_hip_gen_up) --
+    def can_gen_level(self, lvl):
+        """Heat1D (any forcing) or Advection1D on lvl and lvl+1, joined by a transfer the kernels apply (copy, full weighting with
+        Dirichlet ends, its periodic analogue), both states register-resident"""
+        if lvl + 1 >= len(self.desc) or os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") == "1" or \
+                os.environ.get("PYMGRIT_AMD_NO_GEN_PASSES", "") == "1":
+            return False
+        da, db = self.desc[lvl], self.desc[lvl + 1]
+        return (self._device_transfer(lvl) and da["kind"] == db["kind"] and da["kind"] in ("heat1d", "advection1d") and
+                max(self.n[lvl], self.n[lvl + 1]) <= hip_lib.MAX_N)
+
+    def gen_down(self, lvl, intervals):
+        """c_relax + f_relax + fas_residual of level lvl for the intervals (cstart, cend, cstart_coarse, cend_coarse, res_pos, keep)"""
+        self._settle(lvl)
+        if intervals:
+            if lvl == 0:
+                self._residual_cache = None
+            check(self.lib.mgrit_hip_gen_down(self.h, lvl, self._intervals_id(lvl, intervals)))
+
+    def gen_up(self, lvl, intervals, residual=False):
+        """error_correction + f_relax (+ compute_residual on level 0, values kept for residual_norms) of level lvl"""
+        if intervals:
+            if lvl == 0:
+                self._residual_cache = None
+            check(self.lib.mgrit_hip_gen_up(self.h, lvl, self._intervals_id(lvl, intervals), 1 if residual else 0, None))
+
     def residual_ready(self, points):
         """the residual of exactly these level-0 points has been produced by the last ec_relax_res sweep(s) and level 0 has not
         been touched since (Mgrit._ec_f_relax sets it, every other sweep on level 0 clears it)"""

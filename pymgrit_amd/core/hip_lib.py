@@ -10,7 +10,8 @@ RELAX_F, RELAX_C, RELAX_CHAIN, RELAX_FC = 0, 1, 2, 3
 FAS_WITH_F_RELAX, FAS_SKIP_COARSE_U = 1, 2
 # MGRIT_HIP_T_*: kinds of timed entry-point calls (mgrit_hip_timing_drain)
 TIMED_KINDS = ("relax_f", "relax_c", "chain", "residual", "jump", "restrict", "copy", "fas_rhs", "fas_fused",
-               "error_correction", "interpolate", "ec_relax", "at_solve", "cf_fas", "ec_relax_res", "relax_fc", "f_fas", "exchange")
+               "error_correction", "interpolate", "ec_relax", "at_solve", "cf_fas", "ec_relax_res", "relax_fc", "f_fas", "exchange",
+               "gen_down", "gen_up")
 STEPPER_HEAT1D, STEPPER_ADVECTION1D = 1, 2
 TRANSFER_COPY, TRANSFER_HEAT1D, TRANSFER_CALLER = 0, 1, 3
 MAX_N = 16384
@@ -75,6 +76,8 @@ EXPORTS = {
     "mgrit_hip_cf_fas": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgrit_hip_ec_relax_res": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgrit_hip_ec_relax_res_to": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mgrit_hip_gen_down": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_gen_up": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mgrit_hip_residual_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     # ghost exchange under the ABI (links: RCCL two-rank communicators / mailboxes)
     "mgrit_hip_comm_unique_id": (C.c_int, [C.c_void_p]),

@@ -567,7 +567,8 @@ class Mgrit:
             self._up(lvl, None)
             return
         down = fused is not None and self.cf_iter[lvl] >= 1
-        for _ in range(self.cf_iter[lvl] - (1 if down else 0)):
+        gen = self._gen_intervals(lvl) if (fused is None and self.cf_iter[lvl] >= 1) else None
+        for _ in range(self.cf_iter[lvl] - (1 if (down or gen is not None) else 0)):
             self.backend.f_relax_follows = True     # (the F-relaxation below rewrites every F-point: nothing to put in place first)
             try:
                 self.c_relax(lvl=lvl)
@@ -593,11 +594,16 @@ class Mgrit:
             self._head(lvl, head, 'v')
             if self.comm_time_size > 1:
                 self._x4(lvl)
+        elif gen is not None:      # any 1-D stepper pair, any of the library's transfers: the same sweeps as three launches
+            head = self._cached(('pair_head_x', lvl), lambda: self._pairs(lvl, skip_first=False)[:1] if self.comm_time_rank == 0 else [])
+            self._head(lvl, head, 'u')
+            self._head(lvl, head, 'v')      # (the coarse half of the first interval starts from v^{l+1}_0)
+            self.backend.gen_down(lvl, gen)
         else:
             self.fas_residual(lvl=lvl)
         self._fresh_level = lvl + 1      # the next level starts from what the FAS sweep has just written (u == v there)
         self.iteration(lvl=lvl + 1, cycle_type=cycle_type, iteration=iteration, first_f=True)
-        self._up(lvl, fused)
+        self._up(lvl, fused, gen)
         if lvl != 0 and cycle_type == 'F':
             self.iteration(lvl=lvl, cycle_type='V', iteration=iteration, first_f=False)
 
@@ -623,8 +629,14 @@ class Mgrit:
         if gen is not None:      # (while a cycle is being recorded: the recorded cycle runs right away and does it; the cycles
             done.add((lvl, which))   # recorded after it leave it out; _planned keys its plans by the write generation)
 
-    def _up(self, lvl, fused):
+    def _up(self, lvl, fused, gen=None):
         """error correction + F-relaxation of level lvl on the way up (mgrit.py:283-284), in the most fused form available"""
+        if gen is not None:     # (the way down of this cycle was mgrit_hip_gen_down over the same intervals)
+            res = lvl == 0 and self.conv_crit in (0, 2)
+            self.backend.gen_up(lvl, gen, residual=res)
+            if res:
+                self.backend.residual_ready(self._c_points(0))
+            return
         shard = self._rank_intervals_up(lvl) if (fused is None and lvl == 0 and self.comm_time_size > 1) else None
         if shard is not None:
             # several ranks: correction + F-relaxation + residual sums of the rank's complete intervals in one pass; the first
@@ -863,6 +875,32 @@ class Mgrit:
         if got is None:
             return None
         return self._cached(('intervals_list', lvl, up), lambda: got)
+
+    def _gen_intervals(self, lvl):
+        """[(cstart, cend, cstart_coarse, cend_coarse, res_pos, 3)] of level lvl when its sweeps can run as the general
+        whole-level passes (mgrit_hip_gen_down / mgrit_hip_gen_up: any 1-D stepper pair, any of the library's transfers), else
+        None: one rank, the library's own sweeps, weight 1, every F-point between two local C-points."""
+        def build():
+            be = self.backend
+            own = all(getattr(type(self), name) is getattr(Mgrit, name) for name in
+                      ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "compute_residual", "_exchange",
+                       "_ec_f_relax", "_fas_residual_fused", "_relax_f"))
+            can = getattr(be, "can_gen_level", None)
+            if not (own and self.comm_time_size == 1 and self.weight_c == 1.0 and lvl < self.lvl_max - 1 and self._dry is None and
+                    not getattr(self, "_sweep_timing", False) and can is not None and can(lvl)):
+                return [None]
+            pairs = self._pairs(lvl, skip_first=False)
+            if len(pairs) < 2 or pairs[0][0] != 0 or self._c_points(lvl) != [p[0] for p in pairs[1:]]:
+                return [None]
+            want = [(pairs[k][0] + 1, pairs[k + 1][0] - pairs[k][0] - 1) for k in range(len(pairs) - 1)]
+            if [tuple(r) for r in self._f_runs(lvl)] != want or any(ln < 1 for _, ln in want):
+                return [None]
+            return [[(pairs[k][0], pairs[k + 1][0], pairs[k][1] if k >= 1 else -1, pairs[k + 1][1], k, 3)
+                     for k in range(len(pairs) - 1)]]
+        got = self._cached(('gen_intervals', lvl), build)[0]
+        if got is None:
+            return None
+        return self._cached(('gen_intervals_list', lvl), lambda: got)
 
     def _can_fuse_ec(self, lvl):
         return (getattr(self.backend, "can_fuse_ec", None) is not None and self.backend.can_fuse_ec(lvl) and

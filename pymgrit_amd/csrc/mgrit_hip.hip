@@ -858,14 +858,15 @@ __global__ void __launch_bounds__(1024) fas_fine_kernel(LevelDev L, const int32_
 
 // fas_residual, coarse half (mgrit.py:533-536 / 544-547): g_j = (g_j + v_j) - Phi_{l+1}(v_{j-1})
 template <int KIND, int FORCE>
-__global__ void __launch_bounds__(1024) fas_coarse_kernel(LevelDev L, const int32_t *__restrict__ coarse_idx) {
+__global__ void __launch_bounds__(1024) fas_coarse_kernel(LevelDev L, const int32_t *__restrict__ coarse_idx, int have_sum) {
+    // have_sum: the row of g already holds g_j + v_j (gen_down_kernel adds the two in registers)
     WG_PROLOGUE;
     const int j = coarse_idx[blockIdx.x];
     double x[E], a[E];
     load_row(L.v + (size_t)(j - 1) * L.ld, sl, x);
-    {
+    load_row(L.g + (size_t)j * L.ld, sl, a);
+    if (!have_sum) {
         double b[E];
-        load_row(L.g + (size_t)j * L.ld, sl, a);
         load_row(L.v + (size_t)j * L.ld, sl, b);
 #pragma unroll
         for (int k = 0; k < E; ++k) a[k] = a[k] + b[k];
@@ -1307,6 +1308,8 @@ __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, c
 
 #include "mgrit_hip_wide.inc"
 
+#include "mgrit_hip_gen.inc"
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -1357,11 +1360,14 @@ struct Level {
     std::vector<RunList> runs;
     std::vector<PairList> pairs;
     std::vector<IntervalsDev> ivals;   // mgrit_hip_intervals_create (device arrays live in allocs)
-    std::vector<int> ivals_n;          // intervals per list
+    std::vector<int> ivals_n;          // residual positions of the level (res_len) per list
+    std::vector<int> ivals_cnt;        // intervals per list
     std::vector<double> s_host;        // forcing space factors as uploaded (row storage order): levels with equal factors share
                                        // the LDS copy of the kernels that keep the factor there (FORCE 4)
     double *scratch = nullptr;
     size_t scratch_rows = 0;
+    double *gen_rows = nullptr;      // mgrit_hip_gen_down / _up: [res_len][ld] uncorrected chunk-end C-points
+    size_t gen_len = 0;              // res_len they were sized for
     double *chain_state = nullptr;   // caller-owned [ld + CHAIN_STATE_TAIL]: carry-free part of the last point + carries
     bool chain_resume = false;
     bool chain_overlapped = true;    // mgrit_hip_chain_enable: the caller's (global) word on the overlapped chain
@@ -1651,7 +1657,12 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(fas_fused_kernel<K, F>))) return rc;                                                     \
     if ((rc = allow_big_lds(ecf_kernel<K, F, false>))) return rc;                                                    \
     if ((rc = allow_big_lds(ecf_kernel<K, F, true>))) return rc;                                                     \
-    if ((rc = allow_big_lds(at_kernel<K, F>))) return rc;
+    if ((rc = allow_big_lds(at_kernel<K, F>))) return rc;                                                           \
+    if ((rc = allow_big_lds(gen_down_kernel<K, F, false>))) return rc;                                               \
+    if ((rc = allow_big_lds(gen_down_kernel<K, F, true>))) return rc;                                                \
+    if ((rc = allow_big_lds(gen_up_kernel<K, F, false, false>))) return rc;                                          \
+    if ((rc = allow_big_lds(gen_up_kernel<K, F, false, true>))) return rc;                                           \
+    if ((rc = allow_big_lds(gen_up_kernel<K, F, true, false>))) return rc;
     FOR_EACH_STEPPER(ATTR_ALL)
 #define ATTR_CHAIN_LOCAL(K, F)                                                                                       \
     if ((rc = allow_big_lds(chain_local_kernel<K, F, false>, chain_local_lds(CHAIN_LOCAL_MAX_G)))) return rc;          \
@@ -2928,7 +2939,7 @@ int mgrit_hip_fas_coarse(mgrit_hip_engine *e, int lvl, int pairs_id) {
     if ((rc = no_wide(e->L[lvl], &e->L[lvl + 1], "FAS right-hand side around a caller's transfer"))) return rc;
     if (pl->n == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_FAS_RHS, lvl);
-    LAUNCH_BY_KIND(fas_coarse_kernel, lc, pl->n, lc.dev, pl->d_coarse);
+    LAUNCH_BY_KIND(fas_coarse_kernel, lc, pl->n, lc.dev, pl->d_coarse, 0);
     return 0;
 }
 
@@ -2971,7 +2982,7 @@ int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id) {
         HIP_TRY(hipGetLastError());
     }
     if (lc.wide) return wide_fas_coarse(e, lvl, pl);
-    LAUNCH_BY_KIND(fas_coarse_kernel, lc, pl->n, lc.dev, pl->d_coarse);
+    LAUNCH_BY_KIND(fas_coarse_kernel, lc, pl->n, lc.dev, pl->d_coarse, 0);
     return 0;
 }
 
@@ -3255,6 +3266,7 @@ int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_
     d.chunk_start_coarse = p[6]; d.keep = p[7]; d.n_chunks = (int)cf.size();
     lv.ivals.push_back(d);
     lv.ivals_n.push_back(res_len);
+    lv.ivals_cnt.push_back(n);
     *id_out = (int)lv.ivals.size() - 1;
     return 0;
 }
@@ -3323,6 +3335,89 @@ static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int sto
     if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
     else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
     else hipLaunchKernelGGL((ecfr_kernel<2, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int gen_check(mgrit_hip_engine *e, int lvl, int ivals_id, const char *what) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    if (lvl + 1 >= e->n_levels || !e->L[lvl + 1].set) return fail(MGRIT_HIP_EINVAL, "level %d has no coarser level", lvl);
+    Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    if (lf.h2d || lc.h2d || is_2pts(lf) || is_2pts(lc) || lf.dev.kind != lc.dev.kind)
+        return fail(MGRIT_HIP_EUNSUPPORTED, "%s needs the same 1-D single-point stepper on both levels", what);
+    if ((rc = no_wide(lf, &lc, what))) return rc;
+    if (ivals_id < 0 || ivals_id >= (int)lf.ivals.size()) return fail(MGRIT_HIP_EINVAL, "bad interval-list id %d on level %d", ivals_id, lvl);
+    if ((rc = check_bound(lf, lvl > 0)) || (rc = check_bound(lc, true))) return rc;
+    const int tk = lf.transfer;
+    const bool fits = tk == MGRIT_HIP_TRANSFER_COPY ? lf.dev.n == lc.dev.n : tk == MGRIT_HIP_TRANSFER_HEAT1D ? lf.dev.n == 2 * lc.dev.n + 1
+                    : tk == MGRIT_HIP_TRANSFER_PERIODIC1D ? lf.dev.n == 2 * lc.dev.n : false;
+    if (!fits) return fail(MGRIT_HIP_EUNSUPPORTED, "%s: transfer kind %d does not join n=%d and n=%d", what, tk, lf.dev.n, lc.dev.n);
+    return 0;
+}
+
+static int gen_reserve(mgrit_hip_engine *e, Level &lf, size_t res_len) {
+    if (lf.gen_rows && lf.gen_len >= res_len) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(e->stream, &cs);
+    if (cs != hipStreamCaptureStatusNone) return fail(MGRIT_HIP_EINVAL, "first whole-level pass of a level inside a stream capture");
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, res_len * (size_t)lf.dev.ld * sizeof(double)));
+    lf.allocs.push_back(d);      // (an earlier, smaller slab stays in the list until the engine goes)
+    lf.gen_rows = static_cast<double *>(d);
+    lf.gen_len = res_len;
+    return 0;
+}
+
+int mgrit_hip_gen_down(mgrit_hip_engine *e, int lvl, int ivals_id) {
+    int rc = gen_check(e, lvl, ivals_id, "whole-level way down");
+    if (rc) return rc;
+    Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    const IntervalsDev &I = lf.ivals[ivals_id];
+    const int n_iv = lf.ivals_cnt[ivals_id];
+    if (I.n_chunks == 0) return 0;
+    const size_t res_len = (size_t)lf.ivals_n[ivals_id];
+    if ((rc = gen_reserve(e, lf, res_len))) return rc;
+    double *Cb = lf.gen_rows;
+    const int tk = lf.transfer;
+    Timed timed(e, MGRIT_HIP_T_GEN_DOWN, lvl);
+    const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
+    const bool use_g = lvl > 0;
+    const int fm = force_mode(lf);
+#define GEN_DOWN_CASE(K, F, G_)                                                                                     \
+    if (lf.dev.kind == K && fm == F && use_g == G_)                                                                 \
+        hipLaunchKernelGGL((gen_down_kernel<K, F, G_>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, Cb, tk);
+#define GEN_DOWN_CASES(K, F) GEN_DOWN_CASE(K, F, false) GEN_DOWN_CASE(K, F, true)
+    FOR_EACH_STEPPER(GEN_DOWN_CASES)
+    HIP_TRY(hipGetLastError());
+    LAUNCH_BY_KIND(fas_coarse_kernel, lc, n_iv, lc.dev, I.cend_coarse, 1);
+    return 0;
+}
+
+int mgrit_hip_gen_up(mgrit_hip_engine *e, int lvl, int ivals_id, int with_residual, double *sumsq_out) {
+    int rc = gen_check(e, lvl, ivals_id, "whole-level way up");
+    if (rc) return rc;
+    if (with_residual && lvl != 0) return fail(MGRIT_HIP_EINVAL, "the residual check belongs to level 0");
+    Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
+    const IntervalsDev &I = lf.ivals[ivals_id];
+    if (I.n_chunks == 0) return 0;
+    const size_t res_len = (size_t)lf.ivals_n[ivals_id];
+    if (!lf.gen_rows || lf.gen_len < res_len) return fail(MGRIT_HIP_EINVAL, "mgrit_hip_gen_up before the mgrit_hip_gen_down of the cycle");
+    const double *Cb = lf.gen_rows;
+    double *out = nullptr;
+    if (with_residual) {
+        if (!sumsq_out && (rc = ensure_pinned(e, (int)res_len))) return rc;
+        out = sumsq_out ? sumsq_out : e->pinned;
+    }
+    Timed timed(e, MGRIT_HIP_T_GEN_UP, lvl);
+    const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
+    const bool use_g = lvl > 0, res = with_residual != 0;
+    const int fm = force_mode(lf), tk = lf.transfer;
+#define GEN_UP_CASE(K, F, G_, R_)                                                                                    \
+    if (lf.dev.kind == K && fm == F && use_g == G_ && res == R_)                                                      \
+        hipLaunchKernelGGL((gen_up_kernel<K, F, G_, R_>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, Cb, out, tk);
+#define GEN_UP_CASES(K, F) GEN_UP_CASE(K, F, false, false) GEN_UP_CASE(K, F, false, true) GEN_UP_CASE(K, F, true, false)
+    FOR_EACH_STEPPER(GEN_UP_CASES)
     HIP_TRY(hipGetLastError());
     return 0;
 }
