@@ -2780,7 +2780,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             if (lv.G >= 2 && lv.G <= chain_local_max_g()) {   // a few groups: all workers in one workgroup, totals through LDS
 #define CHAIN_LOCAL_CASE(K, F, G_)                                                                            \
     if (lv.dev.kind == K && fm == F && use_g == G_)                                                            \
-        hipLaunchKernelGGL((chain_local_kernel<K, F, G_>), dim3(1), dim3(2 * lv.G * LANES), chain_local_lds(lv.G), e->stream, lv.dev, st, ln, e->chain_err);
+        hipLaunchKernelGGL((chain_local_kernel<K, F, G_>), dim3(1), dim3((K == MGRIT_HIP_STEPPER_ADVECTION1D ? 3 : 2) * lv.G * LANES), chain_local_lds(lv.G), e->stream, lv.dev, st, ln, e->chain_err);
 #define CHAIN_LOCAL_CASES(K, F) CHAIN_LOCAL_CASE(K, F, false) CHAIN_LOCAL_CASE(K, F, true)
                 FOR_EACH_STEPPER(CHAIN_LOCAL_CASES)
                 HIP_TRY(hipGetLastError());
@@ -2788,7 +2788,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             }
 #define CHAIN_CASE(K, F, G_, S_)                                                                              \
     if (lv.dev.kind == K && fm == F && use_g == G_ && (lv.G == 1) == S_)                                       \
-        hipLaunchKernelGGL((chain_kernel<K, F, G_, S_>), grid, block, 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, e->sched, sel);
+        hipLaunchKernelGGL((chain_kernel<K, F, G_, S_>), grid, dim3(3 * LANES), 0, e->stream, lv.dev, st, ln, e->chain_gran, e->chain_err, e->sched, sel);
 #define CHAIN_CASES(K, F) CHAIN_CASE(K, F, false, false) CHAIN_CASE(K, F, true, false) CHAIN_CASE(K, F, false, true) \
     CHAIN_CASE(K, F, true, true)
             FOR_EACH_STEPPER(CHAIN_CASES)
