@@ -501,7 +501,10 @@ class HipBackend:
         # shorten the fill and drain of the block pipeline, fewer keep the launches large (a level-0 pass of one block is
         # 16384 / blocks / 4 chunks for 240 workgroups: with 6 blocks 2.8 rounds, with 8 blocks 2.1)
         # ... and only where the coarsest solve is long against the sweeps: Heat1D states wider than one group (config 3).
-        # Measured on config 5 (advection_1d, 4 levels, 2 groups per state): one block 26.3 ms per F-cycle, two 30.1, six 32.1.
+        # Measured on config 5 (advection_1d, 4 levels, 2 groups per state): one block 26.3 ms per F-cycle, two 30.1, six 32.1
+        # (round 2); with the general whole-level passes (round 3) one block 16.3, two 19.0, four 18.9, six 19.4: a chain part
+        # that runs beside sweeps shares its CU with their workgroups and finds its rows of g in HBM instead of the Infinity
+        # Cache (1.2-1.7 us per step instead of 0.89), which costs more than the overlap of an F-cycle's few sweeps hides.
         if any(d["kind"] != "heat1d" for d in self.desc) or max(self.n) <= 1024:
             return 1
         if self.mg.comm_time_size > 1:
