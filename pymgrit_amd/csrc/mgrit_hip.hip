@@ -1666,7 +1666,11 @@ int setup_kernel_attrs() {
     FOR_EACH_STEPPER(ATTR_ALL)
 #define ATTR_CHAIN_LOCAL(K, F)                                                                                       \
     if ((rc = allow_big_lds(chain_local_kernel<K, F, false>, chain_local_lds(CHAIN_LOCAL_MAX_G)))) return rc;          \
-    if ((rc = allow_big_lds(chain_local_kernel<K, F, true>, chain_local_lds(CHAIN_LOCAL_MAX_G)))) return rc;
+    if ((rc = allow_big_lds(chain_local_kernel<K, F, true>, chain_local_lds(CHAIN_LOCAL_MAX_G)))) return rc;           \
+    if (K == MGRIT_HIP_STEPPER_ADVECTION1D) {                                                                          \
+        if ((rc = allow_big_lds(chain_local_kernel<K, F, false, true>, chain_local_lds(CHAIN_LOCAL_MAX_G)))) return rc;  \
+        if ((rc = allow_big_lds(chain_local_kernel<K, F, true, true>, chain_local_lds(CHAIN_LOCAL_MAX_G)))) return rc;   \
+    }
     FOR_EACH_STEPPER(ATTR_CHAIN_LOCAL)
     if ((rc = allow_big_lds(cfas_kernel<0>))) return rc;
     if ((rc = allow_big_lds(cfas_kernel<2>))) return rc;
@@ -2780,7 +2784,12 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
             if (lv.G >= 2 && lv.G <= chain_local_max_g()) {   // a few groups: all workers in one workgroup, totals through LDS
 #define CHAIN_LOCAL_CASE(K, F, G_)                                                                            \
     if (lv.dev.kind == K && fm == F && use_g == G_)                                                            \
-        hipLaunchKernelGGL((chain_local_kernel<K, F, G_>), dim3(1), dim3((K == MGRIT_HIP_STEPPER_ADVECTION1D ? 3 : 2) * lv.G * LANES), chain_local_lds(lv.G), e->stream, lv.dev, st, ln, e->chain_err);
+    {                                                                                                          \
+        if (K == MGRIT_HIP_STEPPER_ADVECTION1D && lv.G <= CHAIN_SPLIT_MAX_G)                                   \
+            hipLaunchKernelGGL((chain_local_kernel<K, F, G_, true>), dim3(1), dim3(4 * lv.G * LANES), chain_local_lds(lv.G), e->stream, lv.dev, st, ln, e->chain_err); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((chain_local_kernel<K, F, G_, false>), dim3(1), dim3(2 * lv.G * LANES), chain_local_lds(lv.G), e->stream, lv.dev, st, ln, e->chain_err); \
+    }
 #define CHAIN_LOCAL_CASES(K, F) CHAIN_LOCAL_CASE(K, F, false) CHAIN_LOCAL_CASE(K, F, true)
                 FOR_EACH_STEPPER(CHAIN_LOCAL_CASES)
                 HIP_TRY(hipGetLastError());
