@@ -345,11 +345,13 @@ __device__ __forceinline__ double *ld_uniform_ptr(double *const *p) {
     return reinterpret_cast<double *>(((unsigned long long)hi << 32) | lo);
 }
 
-__device__ __forceinline__ Smem carve_smem(char *base, int T) {
+__device__ __forceinline__ Smem carve_smem(char *base, int T, bool with_pt = true) {
+    // with_pt = false (Advection1D: no backward scan, no Pt): 16 KB less, which at 8 groups is the difference between one and two
+    // workgroups per CU (83 KB against 67 of the CU's 160)
     Smem s;
     s.tab = reinterpret_cast<double2 *>(base);
     s.pt = s.tab + (size_t)8 * T;
-    double *tail = reinterpret_cast<double *>(s.pt + 2 * 512);
+    double *tail = reinterpret_cast<double *>(s.pt + (with_pt ? 2 * 512 : 0));
     s.ga = tail;
     s.gb = tail + 2 * MAX_G;
     s.lp = tail + 4 * MAX_G;
@@ -683,7 +685,7 @@ extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
 #define WG_PROLOGUE                                                                        \
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = blockDim.x >> 6;          \
-    const Smem sm = carve_smem(smem_raw, L.T);                                             \
+    const Smem sm = carve_smem(smem_raw, L.T, KIND != MGRIT_HIP_STEPPER_ADVECTION1D);      \
     const unsigned sl = slot0(t);                                                          \
     StepCtx ctx;                                                                           \
     __shared__ int wgq_slot[2];                                                            \
@@ -817,7 +819,7 @@ __global__ void __launch_bounds__(1024) residual_kernel(LevelDev L, const int32_
 __global__ void __launch_bounds__(1024) jump_kernel(LevelDev L, const int32_t *__restrict__ run_start,
                                                     const double *__restrict__ prev, double *__restrict__ out) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = blockDim.x >> 6;
-    const Smem sm = carve_smem(smem_raw, L.T);
+    const Smem sm = carve_smem(smem_raw, L.T, L.kind != MGRIT_HIP_STEPPER_ADVECTION1D);
     const unsigned sl = slot0(t);
     const int i = run_start[blockIdx.x];
     double x[E], p[E];
@@ -1624,7 +1626,9 @@ bool two_phase_fas() {
     return v;
 }
 
-size_t smem_bytes(int G) { return (size_t)(8 * G * LANES + 2 * 512) * sizeof(double2) + (8 * MAX_G + LANES) * sizeof(double); }
+size_t smem_bytes(int G, int kind = MGRIT_HIP_STEPPER_HEAT1D) {
+    return (size_t)(8 * G * LANES + (kind == MGRIT_HIP_STEPPER_ADVECTION1D ? 0 : 2 * 512)) * sizeof(double2) + (8 * MAX_G + LANES) * sizeof(double);
+}
 
 constexpr int MAX_G2 = MGRIT_HIP_MAX_N_2PTS / GROUP;  // two-point steppers: waves per half
 size_t smem2_bytes(int G) { return (size_t)2 * (8 * G * LANES + 2 * 512) * sizeof(double2) + (12 * MAX_G + 2 * LANES) * sizeof(double); }
@@ -2195,7 +2199,7 @@ int check_bound(const Level &lv, bool need_vg) {
 bool is_2pts(const Level &lv) { return lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D_2PTS; }
 
 int wgs_per_cu(const Level &lv) {
-    const size_t lds = is_2pts(lv) ? smem2_bytes(lv.G) : smem_bytes(lv.G);
+    const size_t lds = is_2pts(lv) ? smem2_bytes(lv.G) : smem_bytes(lv.G, lv.dev.kind);
     return std::max(1, std::min((int)(160 * 1024 / lds), 2048 / lv.dev.T));
 }
 
@@ -2391,7 +2395,7 @@ int no_wide(const Level &a, const Level *b, const char *what) {
 
 #define LAUNCH_CASE(kernel, K_, F_, lv, grid, ...)                                                               \
     if ((lv).dev.kind == K_ && force_mode(lv) == F_)                                                              \
-        hipLaunchKernelGGL((kernel<K_, F_>), dim3(grid), dim3((lv).dev.T), smem_bytes((lv).G), e->stream, __VA_ARGS__);
+        hipLaunchKernelGGL((kernel<K_, F_>), dim3(grid), dim3((lv).dev.T), smem_bytes((lv).G, (lv).dev.kind), e->stream, __VA_ARGS__);
 #define LAUNCH_BY_KIND(kernel, lv, grid, ...)                                                                    \
     do {                                                                                                         \
         LAUNCH_CASE(kernel, MGRIT_HIP_STEPPER_HEAT1D, 0, lv, grid, __VA_ARGS__)                                   \
@@ -2810,7 +2814,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
         const int role = mode == MGRIT_HIP_RELAX_F ? ROLE_F : mode == MGRIT_HIP_RELAX_FC ? ROLE_FC : (weight_c != 1.0) ? ROLE_C_WEIGHTED : ROLE_C;
         const double w = weight_c, w1 = 1.0 - weight_c;
         // persistent grid: as many workgroups as stay resident (LDS- and thread-limited), at most one per run
-        const size_t lds = smem_bytes(lv.G);
+        const size_t lds = smem_bytes(lv.G, lv.dev.kind);
         const dim3 grid(persistent_grid(lv, rl->n)), block(lv.dev.T);
         const int fm = force_mode(lv);
 #define RELAX_CASE(K, F, G_, R)                                                                                    \
@@ -2857,7 +2861,7 @@ int mgrit_hip_jump(mgrit_hip_engine *e, int lvl, int runs_id, const double *prev
     if (is_2pts(lv))
         hipLaunchKernelGGL(jump2_kernel, dim3(rl->n), dim3(lv.dev.T), smem2_bytes(lv.G), e->stream, lv.dev, rl->d_start, prev, sumsq_out);
     else
-        hipLaunchKernelGGL(jump_kernel, dim3(rl->n), dim3(lv.dev.T), smem_bytes(lv.G), e->stream, lv.dev, rl->d_start, prev, sumsq_out);
+        hipLaunchKernelGGL(jump_kernel, dim3(rl->n), dim3(lv.dev.T), smem_bytes(lv.G, lv.dev.kind), e->stream, lv.dev, rl->d_start, prev, sumsq_out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -3035,7 +3039,7 @@ int mgrit_hip_fas_fused_opts(mgrit_hip_engine *e, int lvl, int triples_id, int o
         const int kopts = opts | ((fm == 1 && lf.s_host == lc.s_host) ? 4 : 0);
 #define FAS1_CASE(F_, P_)                                                                                                  \
     if ((fm == 0 ? 0 : fm == 1 ? 4 : 2) == F_ && ((opts & MGRIT_HIP_FAS_WITH_F_RELAX) != 0) == P_)                          \
-        hipLaunchKernelGGL((fas_fused1_kernel<F_, P_>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, \
+        hipLaunchKernelGGL((fas_fused1_kernel<F_, P_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, \
                            pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g, kopts);
         FAS1_CASE(0, false) FAS1_CASE(2, false) FAS1_CASE(4, false) FAS1_CASE(0, true) FAS1_CASE(2, true) FAS1_CASE(4, true)
         HIP_TRY(hipGetLastError());
@@ -3044,7 +3048,7 @@ int mgrit_hip_fas_fused_opts(mgrit_hip_engine *e, int lvl, int triples_id, int o
     if (opts) return fail(MGRIT_HIP_EUNSUPPORTED, "fused FAS residual with options: Heat1D levels (one-pass form) only");
 #define FUSED_CASE(K_, F_)                                                                                         \
     if (lf.dev.kind == K_ && force_mode(lf) == F_)                                                                  \
-        hipLaunchKernelGGL((fas_fused_kernel<K_, F_>), dim3(persistent_grid(lf, pl->n)), dim3(lf.dev.T), smem_bytes(lf.G),  \
+        hipLaunchKernelGGL((fas_fused_kernel<K_, F_>), dim3(persistent_grid(lf, pl->n)), dim3(lf.dev.T), smem_bytes(lf.G, lf.dev.kind),  \
                            e->stream, lf.dev, lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);
     FOR_EACH_STEPPER(FUSED_CASE)
     HIP_TRY(hipGetLastError());
@@ -3139,7 +3143,7 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id) {
     const dim3 grid(persistent_grid(lf, rl->n)), block(lf.dev.T);
 #define ECF_CASE(K, F, G_)                                                                                          \
     if (lf.dev.kind == K && fm == F && use_g == G_)                                                                 \
-        hipLaunchKernelGGL((ecf_kernel<K, F, G_>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, rl->d_start,  \
+        hipLaunchKernelGGL((ecf_kernel<K, F, G_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, rl->d_start,  \
                            rl->d_len, rl->d_ec, rl->n);
 #define ECF_CASES(K, F) ECF_CASE(K, F, false) ECF_CASE(K, F, true)
     FOR_EACH_STEPPER(ECF_CASES)
@@ -3303,8 +3307,8 @@ int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id, int pre_relaxed
     if (I.n_chunks == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_CF_FAS, lvl);
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
-    if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
-    else hipLaunchKernelGGL((cfas_kernel<2>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    else hipLaunchKernelGGL((cfas_kernel<2>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -3329,9 +3333,9 @@ static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int sto
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
     if (lvl > 0) {   // coarser level: rows of g, every F-point stored (the finer level's correction reads them), no residual
         Timed timed(e, MGRIT_HIP_T_EC_RELAX, lvl);
-        if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);
-        else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);   // one term: its space factor in LDS
-        else hipLaunchKernelGGL((ecfr_kernel<2, true, false>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);
+        if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, true, false>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);
+        else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, true, false>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);   // one term: its space factor in LDS
+        else hipLaunchKernelGGL((ecfr_kernel<2, true, false>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -3341,9 +3345,9 @@ static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int sto
     Timed timed(e, MGRIT_HIP_T_EC_RELAX_RES, lvl);
     double *const *mirror = e->mirror_cur;   // null until mgrit_hip_cpoint_mirror has been called
     const int row0 = e->mirror_row0;
-    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
-    else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
-    else hipLaunchKernelGGL((ecfr_kernel<2, false, true>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
+    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, false, true>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
+    else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, false, true>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
+    else hipLaunchKernelGGL((ecfr_kernel<2, false, true>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -3395,7 +3399,7 @@ int mgrit_hip_gen_down(mgrit_hip_engine *e, int lvl, int ivals_id) {
     const int fm = force_mode(lf);
 #define GEN_DOWN_CASE(K, F, G_)                                                                                     \
     if (lf.dev.kind == K && fm == F && use_g == G_)                                                                 \
-        hipLaunchKernelGGL((gen_down_kernel<K, F, G_>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, Cb, tk);
+        hipLaunchKernelGGL((gen_down_kernel<K, F, G_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, Cb, tk);
 #define GEN_DOWN_CASES(K, F) GEN_DOWN_CASE(K, F, false) GEN_DOWN_CASE(K, F, true)
     FOR_EACH_STEPPER(GEN_DOWN_CASES)
     HIP_TRY(hipGetLastError());
@@ -3424,7 +3428,7 @@ int mgrit_hip_gen_up(mgrit_hip_engine *e, int lvl, int ivals_id, int with_residu
     const int fm = force_mode(lf), tk = lf.transfer;
 #define GEN_UP_CASE(K, F, G_, R_)                                                                                    \
     if (lf.dev.kind == K && fm == F && use_g == G_ && res == R_)                                                      \
-        hipLaunchKernelGGL((gen_up_kernel<K, F, G_, R_>), grid, block, smem_bytes(lf.G), e->stream, sched_dev(e, lf), lc.dev, I, Cb, out, tk);
+        hipLaunchKernelGGL((gen_up_kernel<K, F, G_, R_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, Cb, out, tk);
 #define GEN_UP_CASES(K, F) GEN_UP_CASE(K, F, false, false) GEN_UP_CASE(K, F, false, true) GEN_UP_CASE(K, F, true, false)
     FOR_EACH_STEPPER(GEN_UP_CASES)
     HIP_TRY(hipGetLastError());
