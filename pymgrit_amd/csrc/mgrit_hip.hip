@@ -2221,7 +2221,7 @@ int wide_reserve(Level &lv, int count) {
     WideHost &h = *lv.wide;
     if ((size_t)count <= h.cap) return 0;
     for (double **p : {&h.W, &h.tot, &h.car, &h.z0, &h.red}) {
-        if (*p) HIP_TRY(hipFree(*p));
+        if (*p) lv.allocs.push_back(*p);   // kept until the engine goes: a captured cycle may still launch with the old addresses
         *p = nullptr;
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.W), sizeof(double) * (size_t)count * lv.dev.ld));
@@ -2982,7 +2982,10 @@ int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id) {
         else { LAUNCH_BY_KIND(fas_fine_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_coarse, lc.dev.g, lc.dev.ld, lvl > 0 ? 1 : 0); }
     } else {
         if (lf.scratch_rows < (size_t)pl->n) {
-            if (lf.scratch) HIP_TRY(hipFree(lf.scratch));
+            // a bigger list than any before: a NEW slab; the old one stays alive until the engine goes (lf.allocs) -- a captured
+            // cycle that ran this sweep on a block's shorter list still launches with its address (found by the state fuzz: a
+            // whole-level fas_residual by hand between two replays of a two-block plan freed the slab under the graph)
+            if (lf.scratch) lf.allocs.push_back(lf.scratch);
             lf.scratch = nullptr;
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lf.scratch), sizeof(double) * (size_t)pl->n * lf.dev.ld));
             lf.scratch_rows = pl->n;
@@ -3102,7 +3105,7 @@ int mgrit_hip_at_solve(mgrit_hip_engine *e, int lvl, int k) {
     Timed timed(e, MGRIT_HIP_T_AT, lvl);
     const size_t rows = (size_t)lv.dev.n_pts;
     if (lv.scratch_rows < rows) {
-        if (lv.scratch) HIP_TRY(hipFree(lv.scratch));
+        if (lv.scratch) lv.allocs.push_back(lv.scratch);   // (kept until the engine goes: see mgrit_hip_fas_rhs)
         lv.scratch = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lv.scratch), sizeof(double) * rows * lv.dev.ld));
         lv.scratch_rows = rows;
