@@ -1409,6 +1409,7 @@ struct mgrit_hip_engine {
     unsigned *chain_err = nullptr;  // pinned, device-mapped: set by a worker whose bounded spin gave up
     double *pinned = nullptr;     // host staging buffer for small read-backs
     size_t pinned_len = 0;
+    std::vector<double *> pinned_old;   // smaller buffers it has outgrown
     hipEvent_t ev_read = nullptr;
     double **mirror_cur = nullptr;   // device word: the slab that mirrors the corrected level-0 C-points of the running cycle
     int mirror_row0 = 0;
@@ -2484,6 +2485,7 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
     if (e->sched) (void)hipFree(e->sched);
     if (e->chain_err) (void)hipHostFree(e->chain_err);
     if (e->pinned) (void)hipHostFree(e->pinned);
+    for (double *p : e->pinned_old) (void)hipHostFree(p);
     if (e->ev_read) (void)hipEventDestroy(e->ev_read);
     links_close(e, false);
     if (e->xscratch) (void)hipFree(e->xscratch);
@@ -3159,7 +3161,7 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id) {
 // idle stretch -- the single-workgroup coarsest-level chain -- was observed to start ~46 ms late on MI355X/ROCm 7.2.)
 static int ensure_pinned(mgrit_hip_engine *e, int n) {
     if (e->pinned_len < (size_t)n) {
-        if (e->pinned) HIP_TRY(hipHostFree(e->pinned));
+        if (e->pinned) e->pinned_old.push_back(e->pinned);   // kept until the engine goes: a captured cycle may still write there
         e->pinned = nullptr;
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->pinned), sizeof(double) * (size_t)n, hipHostMallocMapped));
         e->pinned_len = n;
