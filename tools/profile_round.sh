@@ -20,6 +20,8 @@ timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$out/${tag}_write" -- python3 "
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_config2" -- python3 "$B" --nx 1024 --nt 4097 --steps 100 --warmup 10 --no-cpu-baseline --no-ramp > "$out/${tag}_bench_config2.log" 2>&1 || exit 6
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_heat2d" -- python3 "$B" --workload heat2d --steps 2 --warmup 1 > "$out/${tag}_bench_heat2d.log" 2>&1 || exit 7
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_advection" -- python3 "$B" --workload advection --steps 10 --warmup 3 > "$out/${tag}_bench_advection.log" 2>&1 || exit 8
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_fetch_advection" -- python3 "$B" --workload advection --steps 3 --warmup 2 > "$out/${tag}_fetch_advection.log" 2>&1 || exit 13
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$out/${tag}_write_advection" -- python3 "$B" --workload advection --steps 3 --warmup 2 > "$out/${tag}_write_advection.log" 2>&1 || exit 14
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_rank3of8" -- python3 "$B" --emulate-rank 3/8 --steps 20 --warmup 3 > "$out/${tag}_bench_rank3of8.log" 2>&1 || exit 9
 timeout -k 10 300 python3 "$B" --emulate-rank all/8 --steps 20 --warmup 3 > "$out/${tag}_bench_all8.log" 2> "$out/${tag}_bench_all8.err" || exit 10
 timeout -k 10 300 python3 "$B" --emulate-rank all/4 --steps 20 --warmup 3 > "$out/${tag}_bench_all4.log" 2> "$out/${tag}_bench_all4.err" || exit 11

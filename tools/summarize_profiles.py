@@ -38,10 +38,32 @@ def stats_from_db(db, dest):
             w.writerow([name, calls, int(tot), f"{avg:.3f}", f"{100.0 * tot / total:.6f}", int(mn), int(mx)])
 
 
-def counters_from_db(db, counter):
+def counters_from_db(db, counter, by_workgroup=False):
     import sqlite3
     con = sqlite3.connect(db)
-    return con.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
+    rows = con.execute("select kernel_name, value, workgroup_size_x from counters_collection where counter_name = ?", (counter,)).fetchall()
+    # by_workgroup: one template instance serves several levels (the general whole-level passes of config 5): its launches differ
+    # in the workgroup size (64 threads per group of 1024 values), which keeps the levels apart
+    return [(f"{short(n)}@{wg}" if by_workgroup else n, v) for n, v, wg in rows]
+
+
+def traffic_summary(tag, suffix, by_workgroup):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        for db in newest(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{which}{suffix}", "*", "*.db"))):
+            for name, value in counters_from_db(db, counter, by_workgroup):
+                per[name if by_workgroup else short(name)][counter].append(float(value))
+    summary = {}
+    for k, d in per.items():
+        if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+            continue
+        f_kib = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"])
+        w_kib = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
+        summary[k] = {"launches_fetch_pass": len(d["FETCH_SIZE"]), "launches_write_pass": len(d["WRITE_SIZE"]),
+                      "FETCH_SIZE_KiB_avg": f_kib, "WRITE_SIZE_KiB_avg": w_kib,
+                      "read_bytes_per_launch_corrected": 2.0 * f_kib * 1024.0, "write_bytes_per_launch": w_kib * 1024.0,
+                      "hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0}
+    return summary
 
 
 def main(tag):
@@ -86,6 +108,13 @@ def main(tag):
                            "`python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ramp --plan-blocks 1` (tools/profile_round.sh); KiB units; read side doubled "
                            "(gfx950 FETCH_SIZE tallies 128-B requests at 64 B). Every kernel name of the headline cycle belongs to one (sweep, level): cfas/ecfr = level 0, the <.., true, ..> kernels and fas_fused1 = level 1, chain2 = level 2; relax_kernel<1, 1, false, 0|1> = the stand-alone level-0 F-/C-relax launches of the fcf_relax_level0 figure.",
                    "kernels": summary}, f, indent=1)
+    adv = traffic_summary(tag, "_advection", True)
+    if adv:
+        with open(os.path.join(out, f"{tag}_traffic_advection.json"), "w") as f:
+            json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around `python3 bench.py --workload advection "
+                               "--steps 3 --warmup 2` (tools/profile_round.sh); KiB units; read side doubled (gfx950 FETCH_SIZE tallies 128-B "
+                               "requests at 64 B). Keys: kernel@workgroup size -- 512 threads = level 0 (8192 values), 256 = level 1, "
+                               "128 = levels 2 and 3 (2048 values).", "kernels": adv}, f, indent=1)
     print("wrote", os.listdir(out))
 
 
