@@ -1027,7 +1027,7 @@ class HipBackend:
                 self.n[lvl] == self.n[lvl + 1] and da.get("forcing_rows") is None and db.get("forcing_rows") is None and
                 len(da.get("forcing_time", [])) == len(db.get("forcing_time", [])))
 
-    def _intervals_id(self, lvl, intervals):
+    def _intervals_id(self, lvl, intervals, chunk=None):
         def create():
             iid = C.c_int(-1)
             cols = [_i32([iv[k] for iv in intervals]) for k in range(6)]
@@ -1035,10 +1035,12 @@ class HipBackend:
             # a block of a planned cycle holds only a few hundred of their intervals, and 4 in a row would leave CUs idle
             # (0 = chosen by the library from the level's size: 4 on config 3, 1 where the level has fewer intervals than the chip
             # holds workgroups)
-            chunk = int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK", "0")) if lvl == 0 else int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK_COARSE", "1"))
+            ch = chunk
+            if ch is None:
+                ch = int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK", "0")) if lvl == 0 else int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK_COARSE", "1"))
             res_len = len(self.mg._c_points(lvl))
             check(self.lib.mgrit_hip_intervals_create(self.h, lvl, len(intervals), _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]),
-                                                      _ptr(cols[3]), _ptr(cols[4]), res_len, chunk, _ptr(cols[5]), C.byref(iid)))
+                                                      _ptr(cols[3]), _ptr(cols[4]), res_len, ch, _ptr(cols[5]), C.byref(iid)))
             return iid.value
         return self._handle(self._runs, lvl, intervals, "ivals", create)
 
@@ -1081,20 +1083,26 @@ class HipBackend:
         return (self._device_transfer(lvl) and da["kind"] == db["kind"] and da["kind"] in ("heat1d", "advection1d") and
                 max(self.n[lvl], self.n[lvl + 1]) <= hip_lib.MAX_N)
 
+    @staticmethod
+    def _gen_chunk():
+        """intervals a workgroup of the general passes walks in a row: 0 = the library's choice from the level's size (a chunk's
+        first C-point costs the way down a row and a Phi more, the way up a row of the side slab), on every level"""
+        return int(os.environ.get("PYMGRIT_AMD_GEN_CHUNK", "0"))
+
     def gen_down(self, lvl, intervals):
         """c_relax + f_relax + fas_residual of level lvl for the intervals (cstart, cend, cstart_coarse, cend_coarse, res_pos, keep)"""
         self._settle(lvl)
         if intervals:
             if lvl == 0:
                 self._residual_cache = None
-            check(self.lib.mgrit_hip_gen_down(self.h, lvl, self._intervals_id(lvl, intervals)))
+            check(self.lib.mgrit_hip_gen_down(self.h, lvl, self._intervals_id(lvl, intervals, chunk=self._gen_chunk())))
 
     def gen_up(self, lvl, intervals, residual=False):
         """error_correction + f_relax (+ compute_residual on level 0, values kept for residual_norms) of level lvl"""
         if intervals:
             if lvl == 0:
                 self._residual_cache = None
-            check(self.lib.mgrit_hip_gen_up(self.h, lvl, self._intervals_id(lvl, intervals), 1 if residual else 0, None))
+            check(self.lib.mgrit_hip_gen_up(self.h, lvl, self._intervals_id(lvl, intervals, chunk=self._gen_chunk()), 1 if residual else 0, None))
 
     def residual_ready(self, points):
         """the residual of exactly these level-0 points has been produced by the last ec_relax_res sweep(s) and level 0 has not
