@@ -217,36 +217,6 @@ def bench_heat2d(args):
             row["phi_per_launch"] = phi_per_launch[key]
             row["tflops"] = phi_per_launch[key] * flops_per_phi / (row["ms_per_launch"] * 1e-3) / 1e12
             row["mfma_frac"] = row["tflops"] / FP64_MFMA_PEAK_TFLOPS
-    # physical HBM bytes of the kernels that run, from the committed PMC passes of this workload (tools/profile_round.sh ->
-    # profiles/<tag>_traffic_advection.json, keys kernel@workgroup size: 512 threads = level 0, 256 = level 1, 128 = levels 2, 3)
-    tfile = os.path.join(ROOT, "profiles", "r03_traffic_advection.json")
-    if nt0 == 32769 and os.path.exists(tfile):
-        K = json.load(open(tfile))["kernels"]
-        per = lambda name: K.get(name, {}).get("hbm_bytes_per_launch")
-        cyc = K.get("gen_down_kernel<2, 0, false>@512", {}).get("launches_fetch_pass")     # once per cycle
-        if cyc:
-            extra = ("relax_kernel<2, 0, false, 0>@512",)      # the four stand-alone level-0 F-relaxations of the figure above
-            total = sum(v["hbm_bytes_per_launch"] * v["launches_fetch_pass"] for k, v in K.items() if k not in extra and "rocclr" not in k) / cyc
-            out["cycle"].update({"physical_bytes": total, "physical_GBps": total / (out["ms_per_step"] * 1e-3) / 1e9,
-                                 "physical_frac": total / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "physical_bytes_source": "profiles/r03_traffic_advection.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                                          "passes, KiB units, read side doubled per the guide's gfx950 note; committed with the "
-                                                          "round, not collected in this run)"})
-        wg = [512, 256, 128, 128]
-        for key, row in out["sweeps"].items():
-            kind, lv = key.split()[0], int(key.split()[1][1:])
-            g = "true" if lv > 0 else "false"
-            names = {"gen_down": [f"gen_down_kernel<2, 0, {g}>@{wg[lv]}"] + ([f"fas_coarse_kernel<2, 0>@{wg[lv + 1]}"] if lv + 1 < 4 else []),
-                     "gen_up": [f"gen_up_kernel<2, 0, {g}, {'true' if lv == 0 else 'false'}>@{wg[lv]}"],
-                     "relax_f": [f"relax_kernel<2, 0, {g}, 0>@{wg[lv]}"],
-                     "chain": ["chain_local_kernel<2, 0, true, true>@512"]}.get(kind, [])
-            got = [per(nm) for nm in names]
-            if got and all(b is not None for b in got):
-                # (fas_coarse_kernel@128 serves the level pairs 1 -> 2 and 2 -> 3 alike: its per-launch average is exact for neither)
-                row["kernels"] = names
-                row["physical_bytes_per_launch"] = sum(got)
-                row["physical_GBps"] = sum(got) / (row["ms_per_launch"] * 1e-3) / 1e9
-                row["physical_frac"] = row["physical_GBps"] / HBM_PEAK_GBS
     dominant = max(out["sweeps"], key=lambda k: out["sweeps"][k]["ms_per_cycle"])
     drow = out["sweeps"][dominant]
     out["roofline_level0_f_relax"] = out["roofline"]
@@ -334,12 +304,43 @@ def bench_advection(args):
             alg = (Ns[lv + 1] + 1 if lv + 1 < len(Ns) else N) * 16.0 * nc
         row["algorithmic_bytes_per_launch"] = alg
         row["algorithmic_GBps"] = alg / (row["ms_per_launch"] * 1e-3) / 1e9 if alg else None
+    # physical HBM bytes of the kernels that run, from the committed PMC passes of this workload (tools/profile_round.sh ->
+    # profiles/<tag>_traffic_advection.json, keys kernel@workgroup size: 512 threads = level 0, 256 = level 1, 128 = levels 2, 3)
+    tfile = os.path.join(ROOT, "profiles", "r03_traffic_advection.json")
+    if nt0 == 32769 and os.path.exists(tfile):
+        K = json.load(open(tfile))["kernels"]
+        per = lambda name: K.get(name, {}).get("hbm_bytes_per_launch")
+        cyc = K.get("gen_down_kernel<2, 0, false>@512", {}).get("launches_fetch_pass")     # once per cycle
+        if cyc:
+            extra = ("relax_kernel<2, 0, false, 0>@512",)      # the four stand-alone level-0 F-relaxations of the figure above
+            total = sum(v["hbm_bytes_per_launch"] * v["launches_fetch_pass"] for k, v in K.items() if k not in extra and "rocclr" not in k) / cyc
+            out["cycle"].update({"physical_bytes": total, "physical_GBps": total / (out["ms_per_step"] * 1e-3) / 1e9,
+                                 "physical_frac": total / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "physical_bytes_source": "profiles/r03_traffic_advection.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                                          "passes, KiB units, read side doubled per the guide's gfx950 note; committed with the "
+                                                          "round, not collected in this run)"})
+        wg = [512, 256, 128, 128]
+        for key, row in out["sweeps"].items():
+            kind, lv = key.split()[0], int(key.split()[1][1:])
+            g = "true" if lv > 0 else "false"
+            names = {"gen_down": [f"gen_down_kernel<2, 0, {g}>@{wg[lv]}"] + ([f"fas_coarse_kernel<2, 0>@{wg[lv + 1]}"] if lv + 1 < 4 else []),
+                     "gen_up": [f"gen_up_kernel<2, 0, {g}, {'true' if lv == 0 else 'false'}>@{wg[lv]}"],
+                     "relax_f": [f"relax_kernel<2, 0, {g}, 0>@{wg[lv]}"],
+                     "chain": ["chain_local_kernel<2, 0, true, true>@512"]}.get(kind, [])
+            got = [per(nm) for nm in names]
+            if got and all(b is not None for b in got):
+                # (fas_coarse_kernel@128 serves the level pairs 1 -> 2 and 2 -> 3 alike: its per-launch average is exact for neither)
+                row["kernels"] = names
+                row["physical_bytes_per_launch"] = sum(got)
+                row["physical_GBps"] = sum(got) / (row["ms_per_launch"] * 1e-3) / 1e9
+                row["physical_frac"] = row["physical_GBps"] / HBM_PEAK_GBS
     dominant = max(out["sweeps"], key=lambda k: out["sweeps"][k]["ms_per_cycle"])
     drow = out["sweeps"][dominant]
     out["roofline_level0_f_relax"] = out["roofline"]
     out["roofline"] = {"bound": "hbm", "achieved": drow["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": drow["algorithmic_GBps"] / HBM_PEAK_GBS if drow["algorithmic_GBps"] else None, "traffic": None,
-                       "kernel": f"{dominant} ({'chain_local_kernel<2, 0, true>' if dominant.startswith('chain') else 'gen_down_kernel / gen_up_kernel<2, 0, ...> and fas_coarse_kernel<2, 0>'})",
+                       "frac": drow["algorithmic_GBps"] / HBM_PEAK_GBS if drow["algorithmic_GBps"] else None,
+                       "traffic": drow.get("physical_bytes_per_launch"),
+                       "kernel": f"{dominant} ({'chain_local_kernel<2, 0, true, true>' if dominant.startswith('chain') else 'gen_down_kernel / gen_up_kernel<2, 0, ...> and fas_coarse_kernel<2, 0>'})",
                        "launch_ms": drow["ms_per_launch"], "launches_per_cycle": drow["launches_per_cycle"], "ms_per_cycle": drow["ms_per_cycle"],
                        "algorithmic_bytes_per_launch": drow["algorithmic_bytes_per_launch"],
                        "limited_by": "latency: sequential coarsest-level solve, one group exchange per step" if dominant.startswith("chain") else "HBM bandwidth"}
