@@ -34,7 +34,7 @@ def advection_problem(nx, grids, c=1.0):
 
 def make_pair(oracle, kind, nx, grids, transfer=None, x_end=1.0, forcing=True, **opts):
     """(product Mgrit on the GPU, oracle problem) for the same hierarchy; no nested iteration unless asked."""
-    from pymgrit_amd import GridTransferCopy, GridTransferHeat, Mgrit
+    from pymgrit_amd import GridTransferAdvection, GridTransferCopy, GridTransferHeat, Mgrit
     opts.setdefault("nested_iteration", False)
     nxs = nx if isinstance(nx, (list, tuple)) else [nx] * len(grids)
     if kind == "heat":
@@ -45,7 +45,7 @@ def make_pair(oracle, kind, nx, grids, transfer=None, x_end=1.0, forcing=True, *
         specs = [cases.advection_level_spec(n, t) for n, t in zip(nxs, grids)]
     tr = None
     if transfer is not None:
-        tr = [GridTransferHeat() if k == 1 else GridTransferCopy() for k in transfer]
+        tr = [GridTransferHeat() if k == 1 else GridTransferAdvection() if k == 2 else GridTransferCopy() for k in transfer]
     mg = Mgrit(prob, transfer=tr, logging_lvl=30, **opts)
     oopts = {k: v for k, v in opts.items() if k != "random_init_guess"}
     op = oracle.OracleProblem(specs, transfer=transfer, variant=1, **oopts)
