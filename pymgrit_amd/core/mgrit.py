@@ -542,6 +542,9 @@ class Mgrit:
                 self.iteration(lvl=lvl, cycle_type='V', iteration=iteration, first_f=False)
             return
         if first_f and (lvl > 0 or iteration == 0):
+            # (tried in round 3: this F-relaxation as part of the general way-down pass on a level the finer level's FAS sweep has
+            # just filled -- per interval the F-points from v, not stored. Bit-identical and slower: config 5's level-1 pass 0.44 ->
+            # 0.76 ms for the 0.17 ms launch it replaces; the extra Phi per interval costs more than the rows it saves.)
             self.f_relax(lvl=lvl)
         fused = self._level_intervals(lvl)     # whole-level sweeps in one pass (device backend, one rank), or None
         shard = self._rank_intervals(lvl) if (fused is None and self.comm_time_size > 1 and self.cf_iter[lvl] >= 1) else None
