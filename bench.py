@@ -872,7 +872,10 @@ def main():
                                device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(per, op=dist.ReduceOp.SUM)
             cycles_run = max(mg.solve_iter, 1) + 3
-            out["exchange"] = {"backend": args.backend, "messages_total": int(per[0].item()), "bytes_total": int(per[1].item()),
+            out["exchange"] = {"backend": args.backend,
+                               "path": ("mgrit_hip_exchange on RCCL links (ncclSend / ncclRecv under the C ABI)" if getattr(be, "device_links", False)
+                                        else "torch.distributed send / recv" + (f" (links failed: {be.link_error})" if getattr(be, "link_error", None) else "")),
+                               "messages_total": int(per[0].item()), "bytes_total": int(per[1].item()),
                                "device_resident_messages": int(per[2].item()),
                                "messages_per_cycle": per[0].item() / cycles_run, "bytes_per_cycle": per[1].item() / cycles_run,
                                "note": "point-to-point ghost rows of all ranks (ops 0-5, 7 of reference mgrit.py:693-713); "

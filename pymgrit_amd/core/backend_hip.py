@@ -241,8 +241,13 @@ class HipBackend:
         if mg.comm_time_size > 1 and getattr(comm, "device_exchange", False) and \
                 os.environ.get("PYMGRIT_AMD_EXCHANGE", "") != "torch":
             from pymgrit_amd.core.comm import links_needed
-            comm.open_links(self, links_needed(mg))
-            self.device_links = True
+            agreed = getattr(comm, "open_links_agreed", None)
+            self.link_error = agreed(self, links_needed(mg)) if agreed is not None else comm.open_links(self, links_needed(mg))
+            if self.link_error is None:
+                self.device_links = True
+            else:   # every rank has the same word: the ghost rows travel through torch.distributed instead (core/comm.py)
+                import warnings
+                warnings.warn(f"RCCL links could not be opened, exchange through torch.distributed: {self.link_error}")
 
     def _xlink(self, peer, direction, ch, ordinal):
         """((link handle, slot), done): a single message shakes hands with its peer now (LoopbackComm: the receiver enqueues

@@ -257,15 +257,22 @@ class RcclTimeComm(TorchTimeComm):
         all_need = sorted({tuple(k) for part in self.allgather_object(list(need)) for k in part})
         missing = [k for k in all_need if k not in self._comms]
         if missing:
-            mine = {}
-            for k in missing:
-                if k[0] == self.rank:
-                    buf = C.create_string_buffer(128)
-                    hip_lib.check(lib.mgrit_hip_comm_unique_id(buf))
-                    mine[k] = buf.raw
-            ids = {}
-            for part in self.allgather_object(mine):
+            mine, failed = {}, None
+            try:
+                for k in missing:
+                    if k[0] == self.rank:
+                        buf = C.create_string_buffer(128)
+                        hip_lib.check(lib.mgrit_hip_comm_unique_id(buf))
+                        mine[k] = buf.raw
+            except Exception as exc:      # noqa: BLE001 - told to every rank with the ids: nobody enters a rendezvous alone
+                failed = f"rank {self.rank}: {exc!r}"[:300]
+            ids, errs = {}, []
+            for part, err in self.allgather_object((mine, failed)):
                 ids.update(part)
+                if err:
+                    errs.append(err)
+            if errs:
+                raise RuntimeError(errs[0])
             for k in sorted(missing, key=lambda k: (k[0] % 2, k)):
                 if self.rank in k[:2]:
                     comm = C.c_void_p()
@@ -277,6 +284,29 @@ class RcclTimeComm(TorchTimeComm):
             send = k[0] == self.rank
             h = links.add((k[1] if send else k[0], 'send' if send else 'recv', k[2]))
             hip_lib.check(lib.mgrit_hip_link_attach(backend.h, h, self._comms[k], 1 if send else 0))
+
+    def open_links_agreed(self, backend, need):
+        """open_links, then ONE word from every rank: either all ranks have their links or none keeps any (the caller then runs
+        the exchange through torch.distributed). Returns None or the first error. A rank that fails while its peer is already
+        inside the communicator's rendezvous cannot be helped from here -- this covers the failures every rank sees (no librccl,
+        a transport that does not come up) and those in front of the first rendezvous."""
+        err = None
+        try:
+            self.open_links(backend, need)
+        except Exception as exc:      # noqa: BLE001 - reported to every rank below
+            err = f"rank {self.rank}: {exc!r}"[:300]
+        errs = [e for e in self.allgather_object(err) if e is not None]
+        if not errs:
+            return None
+        from pymgrit_amd.core import hip_lib
+        lib = hip_lib.load()
+        if getattr(backend, "h", None) is not None:
+            lib.mgrit_hip_links_close(backend.h, 1)
+        for comm in self._comms.values():
+            lib.mgrit_hip_comm_destroy(comm, 1)
+        self._comms = {}
+        self._engines.pop(id(backend), None)
+        return errs[0]
 
     def send_begin(self, backend, dest, channel):
         self.stats["messages"] += 1

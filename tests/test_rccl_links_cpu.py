@@ -24,6 +24,8 @@ log = []
 class FakeLib:
     n = 0
     def mgrit_hip_comm_unique_id(self, buf):
+        if FAIL_IDS == "all" or FAIL_IDS == str(rank):
+            return -4                                # MGRIT_HIP_EUNSUPPORTED: no librccl on this rank
         FakeLib.n += 1
         raw = (f"id-{rank}-{FakeLib.n}".encode()).ljust(128, b".")
         C.memmove(buf, raw, 128)
@@ -41,6 +43,13 @@ class FakeLib:
     def mgrit_hip_link_attach(self, h, handle, comm, peer):
         log.append(("attach", handle, peer))
         return 0
+    def mgrit_hip_links_close(self, h, abort):
+        log.append(("links_close", abort))
+        return 0
+    def mgrit_hip_comm_destroy(self, comm, abort):
+        log.append(("destroy", abort))
+        return 0
+FAIL_IDS = sys.argv[6] if len(sys.argv) > 6 else ""
 hip_lib._lib = FakeLib()
 hip_lib.check = lambda rc: None if rc == 0 else (_ for _ in ()).throw(RuntimeError(rc))
 
@@ -56,9 +65,13 @@ if world >= 4 and rank in (0, 2):
     need += [(0, 2, cm.CH_SWEEP)]
 tc = cm.RcclTimeComm()
 be = Backend()
-tc.open_links(be, need)
-links = tc._engines[id(be)].handle
-json.dump({"log": log, "links": {f"{k[0]}/{k[1]}/{k[2]}": v for k, v in links.items()}, "need": need}, open(os.path.join(out, f"r{rank}.json"), "w"))
+if FAIL_IDS:
+    err = tc.open_links_agreed(be, need)
+    json.dump({"log": log, "error": err, "comms": len(tc._comms), "engines": len(tc._engines)}, open(os.path.join(out, f"r{rank}.json"), "w"))
+else:
+    tc.open_links(be, need)
+    links = tc._engines[id(be)].handle
+    json.dump({"log": log, "links": {f"{k[0]}/{k[1]}/{k[2]}": v for k, v in links.items()}, "need": need}, open(os.path.join(out, f"r{rank}.json"), "w"))
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -92,3 +105,29 @@ def test_open_links_is_collective_and_crosswise_free(world):
         assert sorted(role for _, role in ends) == [0, 1], (uid, ends)
         sender = int(uid.split("-")[1])
         assert dict(ends)[sender] == 0, (uid, ends)
+
+
+@pytest.mark.parametrize("who", ["all", "1"])
+def test_links_that_cannot_be_made_are_given_up_by_every_rank(who):
+    """no librccl (every rank), or one rank whose id cannot be made: every rank learns it with the ids -- nobody enters a
+    communicator's rendezvous alone --, open_links_agreed returns the same error everywhere and leaves no link behind (the
+    backend then sends its ghost rows through torch.distributed)"""
+    import json
+    import socket
+    world = 3
+    out = tempfile.mkdtemp(prefix="rccl_links_fail_")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    script = os.path.join(out, "worker.py")
+    open(script, "w").write(WORKER)
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), out, os.path.dirname(HERE), who],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=120)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    res = [json.load(open(os.path.join(out, f"r{r}.json"))) for r in range(world)]
+    assert len({d["error"] for d in res}) == 1 and res[0]["error"] and "rank" in res[0]["error"], [d["error"] for d in res]
+    for d in res:
+        assert d["comms"] == 0 and d["engines"] == 0
+        assert not [e for e in d["log"] if e[0] == "init"]          # no rendezvous was entered
