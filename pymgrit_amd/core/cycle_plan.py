@@ -311,9 +311,9 @@ class Recorder:
             self._add("ec_relax_res", lvl, b, lambda p=part: real.ec_relax_res(lvl, p), reads,
                       own | {("res", lvl, m) for m in members} if lvl == 0 else own, 3 * len(part) + n_f * (2 if lvl > 0 else 1))
 
-    # the general whole-level passes (backend_hip.gen_down / gen_up): the way down leaves its defect rows and the uncorrected
-    # value of every chunk's last C-point in two scratch slabs of the level ("genR", "genC"); the way up of a block reads the
-    # latter for the C-point its first chunk starts from (an interval of the block before)
+    # the general whole-level passes (backend_hip.gen_down / gen_up): the way down leaves the uncorrected value of every chunk's last
+    # C-point in a side slab of the level ("genC"); the way up of a block reads it for the C-point its first chunk starts from (an
+    # interval of the block before)
     def gen_down(self, lvl, intervals):
         real = self.real
         for b, part in self._by_block(lvl, intervals, 1):
@@ -322,7 +322,7 @@ class Recorder:
                 self._cells("v", lvl + 1, np.maximum(jce - 1, 0))
             if lvl > 0:
                 reads |= {("g", lvl, b)} | self._cells("g", lvl, cs)
-            writes = {("u", lvl, b), ("genR", lvl, b), ("genC", lvl, b)} | self._cells("u", lvl + 1, jce) | \
+            writes = {("u", lvl, b), ("genC", lvl, b)} | self._cells("u", lvl + 1, jce) | \
                 self._cells("v", lvl + 1, jce) | self._cells("g", lvl + 1, jce)
             n_f = int(np.sum(ce - cs - 1))
             self._add("gen_down", lvl, b, lambda p=part: real.gen_down(lvl, p), reads, writes, 9 * len(part) + n_f * (1 if lvl > 0 else 0))
