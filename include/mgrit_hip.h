@@ -238,6 +238,10 @@ int mgrit_hip_residual_fetch(mgrit_hip_engine *e, int n, double *sumsq_host);
  *                        takes the uncorrected value of the C-point a chunk starts from out of that pass's side slab).
  * Arithmetic: exactly that of the separate sweeps (same expressions, same order). */
 int mgrit_hip_gen_down(mgrit_hip_engine *e, int lvl, int intervals_id);
+/* the two halves apart (parts: 1 = the fine level's pass with the restriction, 2 = the coarse half, 3 = both): a rank of a sharded
+ * run receives v^{l+1} of its ghost point -- the last point of the rank before -- between the two (op 4 of Mgrit.fas_residual,
+ * mgrit.py:511-520) */
+int mgrit_hip_gen_down_part(mgrit_hip_engine *e, int lvl, int intervals_id, int parts);
 int mgrit_hip_gen_up(mgrit_hip_engine *e, int lvl, int intervals_id, int with_residual, double *sumsq_out);
 
 /* Same two reductions with the result delivered to HOST memory (sumsq_host[r], r < n_runs) when the call returns: the

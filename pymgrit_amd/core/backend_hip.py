@@ -1094,13 +1094,14 @@ class HipBackend:
         first C-point costs the way down a row and a Phi more, the way up a row of the side slab), on every level"""
         return int(os.environ.get("PYMGRIT_AMD_GEN_CHUNK", "0"))
 
-    def gen_down(self, lvl, intervals):
-        """c_relax + f_relax + fas_residual of level lvl for the intervals (cstart, cend, cstart_coarse, cend_coarse, res_pos, keep)"""
+    def gen_down(self, lvl, intervals, parts=3):
+        """c_relax + f_relax + fas_residual of level lvl for the intervals (cstart, cend, cstart_coarse, cend_coarse, res_pos, keep);
+        parts: 1 = the fine level's pass with the restriction, 2 = the coarse half (a rank's op 4 sits between them), 3 = both"""
         self._settle(lvl)
         if intervals:
             if lvl == 0:
                 self._residual_cache = None
-            check(self.lib.mgrit_hip_gen_down(self.h, lvl, self._intervals_id(lvl, intervals, chunk=self._gen_chunk())))
+            check(self.lib.mgrit_hip_gen_down_part(self.h, lvl, self._intervals_id(lvl, intervals, chunk=self._gen_chunk()), int(parts)))
 
     def gen_up(self, lvl, intervals, residual=False):
         """error_correction + f_relax (+ compute_residual on level 0, values kept for residual_norms) of level lvl"""

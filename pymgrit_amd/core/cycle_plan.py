@@ -314,18 +314,23 @@ class Recorder:
     # the general whole-level passes (backend_hip.gen_down / gen_up): the way down leaves the uncorrected value of every chunk's last
     # C-point in a side slab of the level ("genC"); the way up of a block reads it for the C-point its first chunk starts from (an
     # interval of the block before)
-    def gen_down(self, lvl, intervals):
+    def gen_down(self, lvl, intervals, parts=3):
         real = self.real
         for b, part in self._by_block(lvl, intervals, 1):
             cs, ce, jcs, jce = _interval_cells(self, lvl, part)
-            reads = {("u", lvl, b)} | self._cells("u", lvl, cs) | self._cells("u", lvl, np.maximum(cs - 1, 0)) | \
-                self._cells("v", lvl + 1, np.maximum(jce - 1, 0))
-            if lvl > 0:
-                reads |= {("g", lvl, b)} | self._cells("g", lvl, cs)
-            writes = {("u", lvl, b), ("genC", lvl, b)} | self._cells("u", lvl + 1, jce) | \
-                self._cells("v", lvl + 1, jce) | self._cells("g", lvl + 1, jce)
+            reads, writes = set(), set()
+            if parts & 1:
+                reads |= {("u", lvl, b)} | self._cells("u", lvl, cs) | self._cells("u", lvl, np.maximum(cs - 1, 0))
+                if lvl > 0:
+                    reads |= {("g", lvl, b)} | self._cells("g", lvl, cs)
+                writes |= {("u", lvl, b), ("genC", lvl, b)} | self._cells("u", lvl + 1, jce) | \
+                    self._cells("v", lvl + 1, jce) | self._cells("g", lvl + 1, jce)
+            if parts & 2:
+                reads |= self._cells("v", lvl + 1, np.maximum(jce - 1, 0)) | self._cells("g", lvl + 1, jce)
+                writes |= self._cells("g", lvl + 1, jce)
             n_f = int(np.sum(ce - cs - 1))
-            self._add("gen_down", lvl, b, lambda p=part: real.gen_down(lvl, p), reads, writes, 9 * len(part) + n_f * (1 if lvl > 0 else 0))
+            self._add("gen_down" if parts & 1 else "gen_coarse", lvl, b, lambda p=part: real.gen_down(lvl, p, parts), reads, writes,
+                      (6 if parts & 1 else 0) * len(part) + (3 if parts & 2 else 0) * len(part) + (n_f * (1 if lvl > 0 else 0) if parts & 1 else 0))
 
     def gen_up(self, lvl, intervals, residual=False):
         real = self.real

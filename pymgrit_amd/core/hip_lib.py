@@ -77,6 +77,7 @@ EXPORTS = {
     "mgrit_hip_ec_relax_res": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgrit_hip_ec_relax_res_to": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mgrit_hip_gen_down": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_gen_down_part": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgrit_hip_gen_up": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mgrit_hip_residual_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     # ghost exchange under the ABI (links: RCCL two-rank communicators / mailboxes)

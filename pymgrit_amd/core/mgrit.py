@@ -599,9 +599,21 @@ class Mgrit:
                 self._x4(lvl)
         elif gen is not None:      # any 1-D stepper pair, any of the library's transfers: the same sweeps as three launches
             head = self._cached(('pair_head_x', lvl), lambda: self._pairs(lvl, skip_first=False)[:1] if self.comm_time_rank == 0 else [])
+            if self.comm_time_size > 1:
+                # aligned ranks: op 0 of the F-relaxation inside the pass (mgrit.py:306-310) carries the RELAXED last C-point: computed
+                # up front by a C-relaxation of that one point (the pass recomputes the same bits from the same F-point)
+                last = self._last_slot(lvl)
+                if self.last_is_c_point[lvl]:
+                    self.backend.relax(lvl, self._cached(('c_last', lvl), lambda: [(last, 1)]), 'C')
+                self._x0(lvl)
             self._head(lvl, head, 'u')
             self._head(lvl, head, 'v')      # (the coarse half of the first interval starts from v^{l+1}_0)
-            self.backend.gen_down(lvl, gen)
+            if self.comm_time_size > 1:     # op 4 (mgrit.py:511-520) between the restriction and the coarse half, which reads v of the ghost
+                self.backend.gen_down(lvl, gen, 1)
+                self._x4(lvl)
+                self.backend.gen_down(lvl, gen, 2)
+            else:
+                self.backend.gen_down(lvl, gen)
         else:
             self.fas_residual(lvl=lvl)
         self._fresh_level = lvl + 1      # the next level starts from what the FAS sweep has just written (u == v there)
@@ -636,6 +648,8 @@ class Mgrit:
         """error correction + F-relaxation of level lvl on the way up (mgrit.py:283-284), in the most fused form available"""
         if gen is not None:     # (the way down of this cycle was mgrit_hip_gen_down over the same intervals)
             res = lvl == 0 and self.conv_crit in (0, 2)
+            if self.comm_time_size > 1:     # aligned ranks: op 0 of the F-relaxation carries the CORRECTED last C-point (see below)
+                self._x0(lvl, staged=self._cached(('pair_last', lvl), lambda: [self._xpairs(lvl)[-1]]))
             self.backend.gen_up(lvl, gen, residual=res)
             if res:
                 self.backend.residual_ready(self._c_points(0))
@@ -889,10 +903,11 @@ class Mgrit:
                       ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "compute_residual", "_exchange",
                        "_ec_f_relax", "_fas_residual_fused", "_relax_f"))
             can = getattr(be, "can_gen_level", None)
-            if not (own and self.comm_time_size == 1 and self.weight_c == 1.0 and lvl < self.lvl_max - 1 and self._dry is None and
-                    not getattr(self, "_sweep_timing", False) and can is not None and can(lvl)):
+            if not (own and self._one_rank_like() and self.weight_c == 1.0 and lvl < self.lvl_max - 1 and self._dry is None and
+                    not getattr(self, "_sweep_timing", False) and can is not None and can(lvl) and
+                    (self.comm_time_size == 1 or os.environ.get("PYMGRIT_AMD_NO_RANK_GEN", "") != "1")):
                 return [None]
-            pairs = self._pairs(lvl, skip_first=False)
+            pairs = self._xpairs(lvl)
             if len(pairs) < 2 or pairs[0][0] != 0 or self._c_points(lvl) != [p[0] for p in pairs[1:]]:
                 return [None]
             want = [(pairs[k][0] + 1, pairs[k + 1][0] - pairs[k][0] - 1) for k in range(len(pairs) - 1)]

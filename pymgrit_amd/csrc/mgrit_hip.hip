@@ -3387,9 +3387,12 @@ static int gen_reserve(mgrit_hip_engine *e, Level &lf, size_t res_len) {
     return 0;
 }
 
-int mgrit_hip_gen_down(mgrit_hip_engine *e, int lvl, int ivals_id) {
+int mgrit_hip_gen_down(mgrit_hip_engine *e, int lvl, int ivals_id) { return mgrit_hip_gen_down_part(e, lvl, ivals_id, 3); }
+
+int mgrit_hip_gen_down_part(mgrit_hip_engine *e, int lvl, int ivals_id, int parts) {
     int rc = gen_check(e, lvl, ivals_id, "whole-level way down");
     if (rc) return rc;
+    if (parts < 1 || parts > 3) return fail(MGRIT_HIP_EINVAL, "parts %d: 1 = the fine level's pass, 2 = the coarse half, 3 = both", parts);
     Level &lf = e->L[lvl], &lc = e->L[lvl + 1];
     const IntervalsDev &I = lf.ivals[ivals_id];
     const int n_iv = lf.ivals_cnt[ivals_id];
@@ -3399,6 +3402,7 @@ int mgrit_hip_gen_down(mgrit_hip_engine *e, int lvl, int ivals_id) {
     double *Cb = lf.gen_rows;
     const int tk = lf.transfer;
     Timed timed(e, MGRIT_HIP_T_GEN_DOWN, lvl);
+    if (parts & 1) {
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
     const bool use_g = lvl > 0;
     const int fm = force_mode(lf);
@@ -3408,7 +3412,8 @@ int mgrit_hip_gen_down(mgrit_hip_engine *e, int lvl, int ivals_id) {
 #define GEN_DOWN_CASES(K, F) GEN_DOWN_CASE(K, F, false) GEN_DOWN_CASE(K, F, true)
     FOR_EACH_STEPPER(GEN_DOWN_CASES)
     HIP_TRY(hipGetLastError());
-    LAUNCH_BY_KIND(fas_coarse_kernel, lc, n_iv, lc.dev, I.cend_coarse, 1);
+    }
+    if (parts & 2) { LAUNCH_BY_KIND(fas_coarse_kernel, lc, n_iv, lc.dev, I.cend_coarse, 1); }
     return 0;
 }
 

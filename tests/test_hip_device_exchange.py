@@ -43,7 +43,8 @@ def solve_ranks(case, world, depth=None, plan_blocks=None):
         DIAG[(case, world, comm.rank)] = {
             "aligned": getattr(mg, "_aligned", False), "fused0": mg._level_intervals(0) is not None if mg.lvl_max > 1 else False,
             "graphs": sum(1 for p in mg._plans.values() if p is not None and getattr(p, "_hip", {}).get("graph") is not None),
-            "plans": sum(1 for p in mg._plans.values() if p is not None), "messages": comm.stats["device_messages"]}
+            "plans": sum(1 for p in mg._plans.values() if p is not None), "messages": comm.stats["device_messages"],
+            "gen": [lvl for lvl in range(mg.lvl_max - 1) if mg._level_intervals(lvl) is None and mg._gen_intervals(lvl) is not None]}
         return conv, vals, comm.stats["device_messages"]
     world_obj, res = run_loopback_ranks(world, target)
     world_obj.close()
@@ -87,7 +88,8 @@ ALIGNED = [("heat_nx33_V_nested", [2, 4]), ("heat_nx33_V_nonested", [2, 4]), ("h
            ("heat_nx33_V_jump", [4]), ("heat_nx33_V_weight13", [2]), ("heat_nx33_2lvl_m8", [2, 4]),
            ("heat_nx33_noforcing", [4]), ("heat_nx257_nt257", [4, 16]), ("heat_example_F5", [2, 4]), ("heat_config2", [2, 8]),
            ("heat_nx2050_wide", [2, 4]), ("heat_nx1500_wide_F", [2]), ("heat_nx3100_wide_2lvl", [2, 4]),
-           ("heat_spatial_coarsening_F", [2]), ("advection_3lvl_F", [4]), ("advection_nx2049_wide", [2, 4])]
+           ("heat_spatial_coarsening_F", [2]), ("advection_3lvl_F", [4]), ("advection_nx2049_wide", [2, 4]),
+           ("heat_spatial_coarsening", [2, 4]), ("advsc:adv_sc_F", [2, 4]), ("advsc:adv_sc_V", [2]), ("advection_example", [2, 4])]
 
 
 @pytest.mark.parametrize("case,sizes", ALIGNED, ids=[c for c, _ in ALIGNED])
@@ -107,6 +109,11 @@ def test_aligned_ranks_equal_single_rank(case, sizes, monkeypatch):
             assert d["aligned"] and d["fused0"] and d["plans"] >= 1 and (d["messages"] > 0 or r == sizes[-1] - 1), d
         if case == "heat_config2":      # enough cycles of one shape for the capture (third execution on)
             assert all(DIAG[(case, sizes[-1], r)]["graphs"] >= 1 for r in range(sizes[-1])), DIAG
+    if case in ("heat_spatial_coarsening_F", "advection_3lvl_F", "advsc:adv_sc_F", "advection_example"):
+        # ... with the GENERAL whole-level passes on the ranks (mgrit_hip_gen_down_part / mgrit_hip_gen_up between the exchange points)
+        for r in range(sizes[-1]):
+            d = DIAG[(case, sizes[-1], r)]
+            assert d["aligned"] and d["gen"], d
     monkeypatch.setenv("PYMGRIT_AMD_NO_ALIGNED", "1")     # the generic rank path on the same splits
     conv, u = solve_ranks(case, sizes[0])
     assert np.array_equal(conv, conv1) and np.array_equal(u, u1)
