@@ -494,19 +494,30 @@ def bench_emulated(args):
     which, P = args.emulate_rank.split("/")
     P = int(P)
     ranks = list(range(P)) if which == "all" else [int(which)]
-    nx, nt0 = args.nx, args.nt
-    nts = [nt0, (nt0 - 1) // 4 + 1, (nt0 - 1) // 16 + 1]
-    t0 = np.linspace(0, 2.0 * (nt0 - 1) / 65536, nt0)
-    grids = [t0, t0[::4], t0[::16]]
-    dof = nx - 2
-    counts = phi_counts(nts, [4, 4])
+    adv = args.workload == "advection"     # BASELINE configs[4] instead of configs[2]: advection_1d, 4 levels m = 2, F-cycle
+    if adv:
+        from pymgrit_amd import Advection1D, GridTransferAdvection, GridTransferCopy
+        nt0, nxs = args.nt_adv, [8193, 4097, 2049, 2049]
+        t0 = np.linspace(0, 2, nt0)
+        grids = [t0[::2 ** k] for k in range(4)]
+        nts, ctype = [len(g) for g in grids], 'F'
+        dofs = [n - 1 for n in nxs]
+        counts = cycle_phi_counts(nts, [2, 2, 2], 'F')
+    else:
+        nx, nt0 = args.nx, args.nt
+        nts, ctype = [nt0, (nt0 - 1) // 4 + 1, (nt0 - 1) // 16 + 1], 'V'
+        t0 = np.linspace(0, 2.0 * (nt0 - 1) / 65536, nt0)
+        grids = [t0, t0[::4], t0[::16]]
+        dofs = [nx - 2] * 3
+        counts = phi_counts(nts, [4, 4])
+    dof = dofs[0]
     world = LoopbackWorld(P)
     gate = threading.Barrier(P)
     out, err = {}, []
 
     def one_cycle(mg, it, pl):
         mg.backend.mirror_cpoints(it % 6, pl)
-        mg.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True)
+        mg.iteration(lvl=0, cycle_type=ctype, iteration=it, first_f=True)
         handle = mg.backend.residual_begin(mg._c_points(0))
         mg.backend.snapshot_cpoints(it % 6, pl)
         return handle
@@ -514,10 +525,15 @@ def bench_emulated(args):
     def work(q):
         try:
             comm = world.comm(q)
-            problem = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=init_cond, rhs_separable=[(rhs_space, rhs_time)],
-                              t_interval=g) for g in grids]
-            mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=False, max_iter=1000, tol=0.0, logging_lvl=30,
-                       comm_time=comm, plan_blocks=args.plan_blocks)
+            if adv:
+                problem = [Advection1D(c=1, x_start=-1, x_end=1, nx=n, t_interval=g) for n, g in zip(nxs, grids)]
+                transfer = [GridTransferAdvection(), GridTransferAdvection(), GridTransferCopy()]
+            else:
+                problem = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=init_cond, rhs_separable=[(rhs_space, rhs_time)],
+                                  t_interval=g) for g in grids]
+                transfer = None
+            mg = Mgrit(problem, transfer=transfer, cf_iter=1, cycle_type=ctype, nested_iteration=False, max_iter=1000, tol=0.0,
+                       logging_lvl=30, comm_time=comm, plan_blocks=args.plan_blocks)
             be = mg.backend
             pl = [int(i) for i in mg.index_local_c[0]]
             handles = [one_cycle(mg, 0, pl)]
@@ -583,15 +599,20 @@ def bench_emulated(args):
         row.update(lock)
         rows.append(row)
     worst = max(rows, key=lambda x: x["ms_per_cycle"])
-    updates = float(sum(c * dof for c in counts))
+    updates = float(sum(c * d for c, d in zip(counts, dofs)))
     res = {"metric": "time-point-DOF updates/sec per MGRIT V-cycle (EMULATED rank of a sharded run, one GPU)",
            "value": updates / P / (worst["ms_per_cycle"] * 1e-3), "unit": "time-point-DOF updates/s (this rank's share)",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": worst["ms_per_cycle"], "higher_is_better": True,
            "dtype": "f64", "data": "synthetic", "vs_baseline": None,
-           "config": {"workload": f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle + residual values + C-point snapshot: rank(s) "
-                                  f"{which} of {P} emulated on one GPU (loopback exchange)", "emulated_ranks": P,
+           "config": {"workload": (f"advection_1d nx=8193 nt={nt0} 4-level m=2 F-cycle with spatial coarsening" if adv else
+                                   f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle") +
+                                  f" + residual values + C-point snapshot: rank(s) {which} of {P} emulated on one GPU (loopback "
+                                  f"exchange)", "emulated_ranks": P,
                       "phi_per_cycle_by_level_whole_job": counts, "dof": dof},
            "ranks": rows}
+    for x in rows:
+        x["general_passes_on_levels"] = [lvl for lvl in range(out[x["rank"]][0].lvl_max - 1)
+                                         if out[x["rank"]][0]._level_intervals(lvl) is None and out[x["rank"]][0]._gen_intervals(lvl) is not None]
     if which == "all":
         res["all_ranks_on_one_gpu_ms_per_cycle"] = max(x.get("all_ranks_ms_per_cycle", 0.0) for x in rows)
         res["exchange"] = {"messages_per_cycle": sum(x["messages_sent_per_cycle"] for x in rows),

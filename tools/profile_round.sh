@@ -30,6 +30,7 @@ if [ "$from" -le 11 ]; then timeout -k 10 300 rocprofv3 --kernel-trace --stats -
 if [ "$from" -le 12 ]; then timeout -k 10 300 python3 "$B" --emulate-rank all/8 --steps 20 --warmup 3 > "$out/${tag}_bench_all8.log" 2> "$out/${tag}_bench_all8.err" || exit 10; fi
 if [ "$from" -le 13 ]; then timeout -k 10 300 python3 "$B" --emulate-rank all/4 --steps 20 --warmup 3 > "$out/${tag}_bench_all4.log" 2> "$out/${tag}_bench_all4.err" || exit 11; fi
 if [ "$from" -le 14 ]; then timeout -k 10 300 python3 "$B" --emulate-rank all/2 --steps 20 --warmup 3 > "$out/${tag}_bench_all2.log" 2> "$out/${tag}_bench_all2.err" || exit 12; fi
+if [ "$from" -le 15 ]; then for P in 2 4 8; do timeout -k 10 200 python3 "$B" --workload advection --emulate-rank all/$P --steps 10 --warmup 3 > "$out/${tag}_bench_advection_all$P.log" 2> "$out/${tag}_bench_advection_all$P.err" || exit 15; done; fi
 # keep only the summaries (the traces are large)
 find "$out" -name '*kernel_trace.csv' -size +20M -delete
 ls -R "$out" | head -50
