@@ -52,6 +52,24 @@ def test_bench_two_ranks_line():
     assert b["exchange"]["messages_per_cycle"] > 0 and b["exchange"]["backend"] == "gloo" and b["nccl_ranks"] == 0
 
 
+@pytest.mark.parametrize("extra,levels", [(["--nx", "1024", "--nt", "2049"], 3), (["--workload", "advection", "--nt-adv", "1025"], 4)])
+def test_bench_emulated_ranks_line(extra, levels):
+    """`--emulate-rank all/2`: both ranks of a two-rank run rehearsed on the one GPU (loopback exchange), configs[2] and configs[4]
+    shrunk: aligned ranks, the cycle of a rank replayed as a graph, rows sent through the device exchange"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emulate-rank", "all/2", "--steps", "4", "--warmup", "1"] + extra,
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    b = _last_json(r.stdout)
+    assert b["config"]["emulated_ranks"] == 2 and len(b["ranks"]) == 2 and b["all_ranks_on_one_gpu_ms_per_cycle"] > 0
+    assert b["exchange"]["messages_per_cycle"] > 0
+    for row in b["ranks"]:
+        assert row["aligned"] and row["ms_per_cycle"] > 0 and len(row["local_points_by_level"]) == levels
+    if levels == 4:      # spatial coarsening + Advection1D: the general whole-level passes on every level pair of every rank
+        assert all(row["general_passes_on_levels"] == [0, 1, 2] for row in b["ranks"])
+
+
 def test_bench_refuses_a_mismatched_launcher():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120,
