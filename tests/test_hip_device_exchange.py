@@ -9,6 +9,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import cases
+
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
@@ -119,6 +121,75 @@ def test_aligned_ranks_equal_single_rank(case, sizes, monkeypatch):
     assert np.array_equal(conv, conv1) and np.array_equal(u, u1)
 
 
+# random hierarchies whose shares end on C-points, with spatial coarsening: the general whole-level passes on aligned ranks
+# (`python tests/test_hip_device_exchange.py 0 300`: 300 of 300 bit-identical to one rank on the final build of round 3, the general
+# passes on every rank in 289 of them)
+def random_aligned_case(seed):
+    rng = np.random.default_rng(seed)
+    kind = "adv" if rng.random() < 0.5 else "heat"
+    L = int(rng.integers(2, 5))
+    m = int(rng.choice([2, 2, 4]))
+    P = int(rng.choice([2, 4]))
+    k = int(rng.integers(1, 4))
+    nt = P * m ** (L - 1) * k + 1
+    if nt > 600: L = 2; nt = P * m * k + 1
+    n0 = int(rng.choice([16, 64, 256, 2048] if kind == "adv" else [15, 63, 255, 2047]))
+    ns, tr = [n0], []
+    for _ in range(L - 1):
+        halve = ns[-1] >= 15 and rng.random() < 0.7
+        ns.append(((ns[-1] - 1) // 2 if kind == "heat" else ns[-1] // 2) if halve else ns[-1])
+        tr.append((1 if kind == "heat" else 2) if halve else 0)
+    opts = dict(cycle_type='F' if rng.random() < 0.4 else 'V', cf_iter=int(rng.choice([1, 1, 2])), nested_iteration=bool(rng.random() < 0.5),
+                max_iter=int(rng.integers(2, 5)), tol=0.0)
+    blocks = [None, 1, 2][int(rng.integers(3))]
+    depth = [None, 0, 2][int(rng.integers(3))]
+    return kind, ns, tr, nt, m, L, P, opts, blocks, depth
+
+def _build_random(kind, ns, tr, nt, m, L):
+    t0 = np.linspace(0, 1.0, nt)
+    grids = [t0[::m ** l] for l in range(L)]
+    if kind == "adv":
+        from pymgrit_amd import Advection1D, GridTransferAdvection, GridTransferCopy, GridTransferHeat, Heat1D
+        prob = [Advection1D(c=1, x_start=-1, x_end=1, nx=n + 1, t_interval=g) for n, g in zip(ns, grids)]
+        transfer = [GridTransferAdvection() if k == 2 else GridTransferCopy() for k in tr]
+    else:
+        from pymgrit_amd import GridTransferCopy, GridTransferHeat, Heat1D
+        prob = [Heat1D(x_start=0, x_end=2, nx=n + 2, a=1, init_cond=cases.init_cond, rhs_separable=[(cases.rhs_space, cases.rhs_time)], t_interval=g) for n, g in zip(ns, grids)]
+        transfer = [GridTransferHeat() if k == 1 else GridTransferCopy() for k in tr]
+    return prob, transfer
+
+def _solve_random(cfg, world):
+    kind, ns, tr, nt, m, L, P, opts, blocks, depth = cfg
+    info = {}
+    def target(comm):
+        prob, transfer = _build_random(kind, ns, tr, nt, m, L)
+        o = dict(opts)
+        if depth is not None: o["pipeline_depth"] = depth
+        if blocks is not None: o["plan_blocks"] = blocks
+        from pymgrit_amd import Mgrit
+        mg = Mgrit(prob, transfer=transfer, logging_lvl=30, comm_time=comm, **o)
+        conv = mg.solve()["conv"]
+        owned = [int(i) for i in mg.index_local[0]]
+        vals = np.array([np.asarray(mg.u[0][i].pack(), dtype=np.float64).ravel() for i in owned])
+        info[comm.rank] = (getattr(mg, "_aligned", False), [l for l in range(mg.lvl_max - 1) if mg._level_intervals(l) is None and mg._gen_intervals(l) is not None])
+        return conv, vals
+    from pymgrit_amd.core.comm import run_loopback_ranks
+    w, res = run_loopback_ranks(world, target)
+    w.close()
+    return res[0][0], np.concatenate([r[1] for r in res if r[1].size], axis=0), info
+
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_aligned_hierarchies_equal_single_rank(seed):
+    _gpu()
+    cfg = random_aligned_case(1000 + seed)
+    c1, u1, _ = _solve_random(cfg, 1)
+    cP, uP, info = _solve_random(cfg, cfg[6])
+    assert np.array_equal(c1, cP) and np.array_equal(u1, uP), (cfg, info)
+    assert all(v[0] for v in info.values()), (cfg, info)       # aligned ranks
+
+
 def _engine_with_rows(lib, n_rows, n=100):
     ld = lib.mgrit_hip_row_stride(n)
     eng = C.c_void_p()
@@ -226,3 +297,21 @@ def test_mailbox_link_and_bounded_sync():
     finally:
         lib.mgrit_hip_destroy(eng)
         lib.mgrit_hip_mailbox_destroy(mb)
+
+
+if __name__ == "__main__":
+    import sys
+    a, b = int(sys.argv[1]), int(sys.argv[2])
+    bad, n_gen = [], 0
+    for seed in range(a, b):
+        cfg = random_aligned_case(seed)
+        c1, u1, _ = _solve_random(cfg, 1)
+        cP, uP, info = _solve_random(cfg, cfg[6])
+        if all(v[0] and v[1] for v in info.values()):
+            n_gen += 1
+        if not (np.array_equal(c1, cP) and np.array_equal(u1, uP)):
+            bad.append(seed)
+            print("seed", seed, "FAILED", cfg, info, flush=True)
+        if seed % 20 == 0:
+            print("at", seed, "failures", bad, "with the general passes on every rank:", n_gen, flush=True)
+    print("done", a, b, "failures:", bad, "cases with the general passes on every rank:", n_gen)
