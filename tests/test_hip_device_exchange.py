@@ -123,7 +123,7 @@ def test_aligned_ranks_equal_single_rank(case, sizes, monkeypatch):
 
 # random hierarchies whose shares end on C-points, with spatial coarsening: the general whole-level passes on aligned ranks
 # (`python tests/test_hip_device_exchange.py 0 300`: 300 of 300 bit-identical to one rank on the final build of round 3, the general
-# passes on every rank in 289 of them)
+# passes on every rank in 289 of them; seeds 2000..2299 likewise, 283)
 def random_aligned_case(seed):
     rng = np.random.default_rng(seed)
     kind = "adv" if rng.random() < 0.5 else "heat"
@@ -300,7 +300,9 @@ def test_mailbox_link_and_bounded_sync():
 
 
 if __name__ == "__main__":
+    import os
     import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     a, b = int(sys.argv[1]), int(sys.argv[2])
     bad, n_gen = [], 0
     for seed in range(a, b):
