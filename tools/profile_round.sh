@@ -31,6 +31,11 @@ if [ "$from" -le 12 ]; then timeout -k 10 300 python3 "$B" --emulate-rank all/8 
 if [ "$from" -le 13 ]; then timeout -k 10 300 python3 "$B" --emulate-rank all/4 --steps 20 --warmup 3 > "$out/${tag}_bench_all4.log" 2> "$out/${tag}_bench_all4.err" || exit 11; fi
 if [ "$from" -le 14 ]; then timeout -k 10 300 python3 "$B" --emulate-rank all/2 --steps 20 --warmup 3 > "$out/${tag}_bench_all2.log" 2> "$out/${tag}_bench_all2.err" || exit 12; fi
 if [ "$from" -le 15 ]; then for P in 2 4 8; do timeout -k 10 200 python3 "$B" --workload advection --emulate-rank all/$P --steps 10 --warmup 3 > "$out/${tag}_bench_advection_all$P.log" 2> "$out/${tag}_bench_advection_all$P.err" || exit 15; done; fi
+W="$(dirname "$B")/tools/wide_bench.py"
+if [ "$from" -le 16 ]; then timeout -k 10 200 python3 "$W" > "$out/${tag}_bench_wide.log" 2> "$out/${tag}_bench_wide.err" || exit 16; fi
+if [ "$from" -le 17 ]; then timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_wide" -- python3 "$W" > "$out/${tag}_stats_wide.log" 2>&1 || exit 17; fi
+if [ "$from" -le 18 ]; then timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_fetch_wide" -- python3 "$W" > "$out/${tag}_fetch_wide.log" 2>&1 || exit 18; fi
+if [ "$from" -le 19 ]; then timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$out/${tag}_write_wide" -- python3 "$W" > "$out/${tag}_write_wide.log" 2>&1 || exit 19; fi
 # keep only the summaries (the traces are large)
 find "$out" -name '*kernel_trace.csv' -size +20M -delete
 ls -R "$out" | head -50

@@ -41,10 +41,13 @@ def stats_from_db(db, dest):
 def counters_from_db(db, counter, by_workgroup=False):
     import sqlite3
     con = sqlite3.connect(db)
-    rows = con.execute("select kernel_name, value, workgroup_size_x from counters_collection where counter_name = ?", (counter,)).fetchall()
+    rows = con.execute("select kernel_name, value, workgroup_size_x, grid_size from counters_collection where counter_name = ?", (counter,)).fetchall()
     # by_workgroup: one template instance serves several levels (the general whole-level passes of config 5): its launches differ
-    # in the workgroup size (64 threads per group of 1024 values), which keeps the levels apart
-    return [(f"{short(n)}@{wg}" if by_workgroup else n, v) for n, v, wg in rows]
+    # in the workgroup size (64 threads per group of 1024 values), which keeps the levels apart; "grid": by the launch's total size
+    # (wide states: the batches of a sweep against the small launches around them)
+    if by_workgroup == "grid":
+        return [(f"{short(n)}@grid{g}", v) for n, v, wg, g in rows]
+    return [(f"{short(n)}@{wg}" if by_workgroup else n, v) for n, v, wg, g in rows]
 
 
 def traffic_summary(tag, suffix, by_workgroup):
@@ -68,7 +71,7 @@ def traffic_summary(tag, suffix, by_workgroup):
 
 def main(tag):
     out = os.path.join(ROOT, "profiles")
-    for sub in ("stats", "stats_planned", "stats_config2", "stats_heat2d", "stats_advection", "stats_rank3of8"):
+    for sub in ("stats", "stats_planned", "stats_config2", "stats_heat2d", "stats_advection", "stats_rank3of8", "stats_wide"):
         dest = os.path.join(out, f"{tag}_kernel_{sub}.csv")
         stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*kernel_stats.csv"))
         dbs = newest(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*.db")))
@@ -115,6 +118,14 @@ def main(tag):
                                "--steps 3 --warmup 2` (tools/profile_round.sh); KiB units; read side doubled (gfx950 FETCH_SIZE tallies 128-B "
                                "requests at 64 B). Keys: kernel@workgroup size -- 512 threads = level 0 (8192 values), 256 = level 1, "
                                "128 = levels 2 and 3 (2048 values).", "kernels": adv}, f, indent=1)
+    wide = {k: v for k, v in traffic_summary(tag, "_wide", "grid").items() if k.startswith("wide_")}
+    if wide:
+        with open(os.path.join(out, f"{tag}_traffic_wide.json"), "w") as f:
+            json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around `python3 tools/wide_bench.py` (Heat1D nx=32770, "
+                               "nt=4097: wide states, three launches per Phi); KiB units; read side doubled (gfx950 FETCH_SIZE tallies 128-B "
+                               "requests at 64 B). Keys: kernel@grid<threads of the launch>. The level-0 F-relaxation of 3072 Phi = three batches of 1024 rows, each "
+                               "wide_local_kernel<2>@grid2097152 + wide_carry_kernel@grid65536 + wide_finish_kernel@grid2097152.",
+                       "kernels": wide}, f, indent=1)
     print("wrote", os.listdir(out))
 
 
