@@ -227,10 +227,11 @@ int mgrit_hip_residual_fetch(mgrit_hip_engine *e, int n, double *sumsq_host);
  * examples/example_spatial_coarsening.py:33-82), on every level with a coarser one (BASELINE config 5: Advection1D, F-cycle,
  * spatial coarsening):
  *   mgrit_hip_gen_down:  Mgrit.c_relax, Mgrit.f_relax, Mgrit.fas_residual (mgrit.py:335-370, 292-333, 488-549 as in
- *                        mgrit.py:277-281; weight_c = 1) for the C-points the intervals end on, as three launches: the sweeps
- *                        of the fine level with the defect rows r_i = Phi(u_{i-1}) - u_i [+ g_i] left in a scratch slab (F-points
- *                        not stored), ONE transfer launch (u^{l+1}_j = v^{l+1}_j = R(u_i), g^{l+1}_j = R(r_i)), and the coarse half
- *                        g_j += v_j - Phi_c(v_{j-1}). keep[] of the list is not used: every row of lvl+1 is written.
+ *                        mgrit.py:277-281; weight_c = 1) for the C-points the intervals end on, as two launches: the sweeps
+ *                        of the fine level (F-points not stored) with the restriction of the C-point and of the defect row
+ *                        r_i = Phi(u_{i-1}) - u_i [+ g_i] taken from the registers -- u^{l+1}_j = v^{l+1}_j = R(u_i),
+ *                        g^{l+1}_j = R(r_i) + v^{l+1}_j --, and the coarse half g_j -= Phi_c(v_{j-1}). keep[] of the list is not
+ *                        used: every row of lvl+1 is written.
  *   mgrit_hip_gen_up:    Mgrit.error_correction with the interpolation P(u^{l+1}_j - v^{l+1}_j) evaluated in registers
  *                        (mgrit.py:715-726), Mgrit.f_relax (every F-point stored) and, with_residual != 0 (level 0 only),
  *                        Mgrit.compute_residual (mgrit.py:387-413) into the engine's buffer (mgrit_hip_residual_fetch) or
