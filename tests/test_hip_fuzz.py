@@ -6,7 +6,8 @@ off, non-uniform time grids. A wider sweep of the same generator: `python tests/
 `python tests/test_hip_fuzz.py 40000 50000` -- 40000 of 40000 new seeds, 12000 of 12000 from seed 30000, and on the final build
 30000 of 30000 from seed 100000; round 3, final build -- general whole-level passes, three-wave chains, the generator with
 spatial coarsening on a third of the cases: 14000 of 14000 from seed 200000 before that extension, 8000 of 8000 from seed 300000
-with it, 2061 of them with full weighting or the periodic transfer on at least one level pair)."""
+with it, 2061 of them with full weighting or the periodic transfer on at least one level pair, and 30000 of 30000 from seed
+400000 at the very end of the round)."""
 import sys
 
 import numpy as np
