@@ -36,6 +36,10 @@ if [ "$from" -le 16 ]; then timeout -k 10 200 python3 "$W" > "$out/${tag}_bench_
 if [ "$from" -le 17 ]; then timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_wide" -- python3 "$W" > "$out/${tag}_stats_wide.log" 2>&1 || exit 17; fi
 if [ "$from" -le 18 ]; then timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_fetch_wide" -- python3 "$W" > "$out/${tag}_fetch_wide.log" 2>&1 || exit 18; fi
 if [ "$from" -le 19 ]; then timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$out/${tag}_write_wide" -- python3 "$W" > "$out/${tag}_write_wide.log" 2>&1 || exit 19; fi
-# keep only the summaries (the traces are large)
+# the summaries are made HERE, on the GPU box (gpurun copies at most 64 MiB back, the rocprofv3 databases are larger): they go to
+# gpurun_out/<tag>_profiles/, from where `cp gpurun_out/<tag>_profiles/* profiles/` takes them; then the databases are dropped
+cd "$(dirname "$B")" && python3 tools/summarize_profiles.py "$tag" > "$out/${tag}_summarize.log" 2>&1
+mkdir -p "$out/${tag}_profiles" && cp profiles/${tag}_* "$out/${tag}_profiles/"
+find "$out" -name '*_results.db' -delete
 find "$out" -name '*kernel_trace.csv' -size +20M -delete
 ls -R "$out" | head -50
