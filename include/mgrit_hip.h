@@ -26,6 +26,8 @@ extern "C" {
                                       (csrc/mgrit_hip_wide.inc): relaxations, residual / jump, the unfused FAS right-hand side,
                                       transfers, exchange; no fused passes, no AT-MGRIT */
 #define MGRIT_HIP_MAX_N_2PTS 4096 /* two-point steppers: max DOFs per time point of a pair (two coefficient sets in LDS) */
+#define MGRIT_HIP_BLOCK_K 16      /* time-parallel forward solve: steps per block */
+#define MGRIT_HIP_BLOCK_RMAX 64   /* ... and the most sine modes its recurrence over the blocks may need */
 
 typedef struct mgrit_hip_engine mgrit_hip_engine;
 
@@ -108,6 +110,31 @@ int mgrit_hip_chain_enable(mgrit_hip_engine *e, int lvl, int on);
 int mgrit_hip_chain_state_len(mgrit_hip_engine *e, int lvl, int *len_out);
 int mgrit_hip_chain_bind(mgrit_hip_engine *e, int lvl, double *state);
 int mgrit_hip_chain_resume(mgrit_hip_engine *e, int lvl, int on);
+/* Time-parallel form of Mgrit.forward_solve (mgrit.py:459-486) on a Heat1D level > 0 (csrc/mgrit_hip_blk.inc): the
+ * level's steps in blocks of MGRIT_HIP_BLOCK_K, every block stepped from a zero state, the block ends put right by a recurrence
+ * over the blocks in the r lowest sine modes (the steps share their eigenvectors; over one block all other modes decay below
+ * 2^-60), the block interiors stepped again from the corrected block starts. The same solve up to rounding; 2 Phi per step, all
+ * blocks at once, instead of 1 Phi per step one after the other.
+ *   mgrit_hip_block_solve_rank    the rule (pure host arithmetic): *r_out = modes needed for the time grid t[0..nt-1] (the level's
+ *                                 GLOBAL grid when it is sharded: every owner must take the same form), 0 = the level is solved
+ *                                 step by step (fewer than 4 blocks, or more than MGRIT_HIP_BLOCK_RMAX modes).
+ *   mgrit_hip_block_solve_config  r > 0: the level's CHAIN relax over all its steps takes this form with r modes; r = 0: never;
+ *                                 r = -1: the engine applies the rule to its local grid (one rank). first_real = 0: the rank has
+ *                                 a predecessor -- its first block starts from zero too, and the recurrence starts from the
+ *                                 amplitudes at the ghost point in uh_in; has_successor: the amplitudes at the last local point
+ *                                 go to uh_out. Both are device buffers of MGRIT_HIP_BLOCK_RMAX doubles owned by the caller
+ *                                 (the op-5 message of a sharded run carries them behind the point). A rank's share must be
+ *                                 whole blocks: its first local slot a multiple of MGRIT_HIP_BLOCK_K steps from the start.
+ *   mgrit_hip_block_solve         phases (bit mask) of the solve for callers that interleave them with the exchange:
+ *                                 1 = first pass (needs nothing from the predecessor), 2 = recurrence over the blocks (needs
+ *                                 uh_in) and, with a successor, the corrected last point, 4 = corrections + second pass (needs
+ *                                 the ghost point). mgrit_hip_relax(CHAIN) over all steps = the three phases in a row.
+ *   mgrit_hip_block_solve_state   *r_out = modes in effect on the level (0: step by step). */
+int mgrit_hip_block_solve_rank(int n, double fac, int nt, const double *t, int *r_out);
+int mgrit_hip_block_solve_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_successor, double *uh_in,
+                                 double *uh_out);
+int mgrit_hip_block_solve(mgrit_hip_engine *e, int lvl, int phases);
+int mgrit_hip_block_solve_state(mgrit_hip_engine *e, int lvl, int *r_out);
 /* Spatial transfer between lvl and lvl+1: GridTransferCopy (core/grid_transfer_copy.py:23-47) or the full-weighting
  * / linear-interpolation pair of examples/example_spatial_coarsening.py:33-82 (fine n = 2*coarse n + 1), or its periodic
  * analogue for Advection1D grids (fine n = 2*coarse n; no reference class exists, BASELINE config 5). */

@@ -822,6 +822,7 @@ typedef struct {
     double *tmp1, *tmp2, *tmp3;
     int64_t phi_count[ORC_MAX_LEVELS];
     int at_k;               /* > 0: AT-MGRIT (core/at_mgrit.py): truncated local solves of distance k on the coarsest level */
+    int no_block_solve;     /* 1: forward_solve never takes the time-parallel form */
     int threads;            /* > 1: the independent loops of the sweeps run on that many OpenMP threads (timing only; same
                                arithmetic, same results). Heat1D natural variant with copy transfers only. */
 } orc_problem;
@@ -1357,8 +1358,147 @@ static void heat1d_chain_spec(orc_problem *p, int lvl) {
     free(w); free(zh);
 }
 
+/* ================================================================================================
+ * Time-parallel forward solve of a Heat1D level (spec): the steps are cut into blocks of ORC_BLK_K; every block
+ * is stepped from a ZERO state (independent of all other blocks), the states at the block ends are then put right by a
+ * recurrence over the blocks in the r lowest sine modes -- all the steps of a block share the eigenvectors
+ * q_k(j) = sqrt(2/(n+1)) sin(pi (k+1)(j+1)/(n+1)), and the block's propagator prod_i (I + dt_i L)^{-1} has the eigenvalues
+ * D_b(k) = prod_i 1/(1 + dt_i fac 4 sin^2(theta_k/2)), which fall below 2^-60 from mode r on (the rule that makes a level
+ * eligible: r <= ORC_BLK_RMAX) --, and the interiors of the blocks are stepped again from the corrected block starts.
+ *   phase 1   block 0: u_i = g_i + Phi(u_{i-1}) from u_0 (final values). Blocks b >= 1: x = 0, x = g_i + Phi(x) over the block,
+ *             W_b = x stored in the row of the block's last point e_b
+ *   phase 2a  what_b(k) = <q_k, u[e_b]>, b = 0 .. B-2 (reduction tree of 3.4: lane-local fma chain, xor butterfly, groups in order)
+ *   phase 2b  Uh = what_0; for b = 1 .. B-1: c_b = D_b * Uh (product), Uh = what_b + c_b
+ *   phase 2c  u[e_b] = W_b + sum_k q_k c_b(k), b >= 1: x = fma(q_k(j), c_b(k), x) for k ascending
+ *   phase 3   blocks b >= 1: x = u[e_{b-1}]; u_i = g_i + Phi(x) for the points strictly inside the block
+ * The same solve as the sequential one up to rounding and the truncation (2^-60 relative per block); every Phi is the step
+ * of 3.3. The last block takes the remainder (K .. 2K-1 steps). A level with fewer than 4 K steps, a level 0 (a one-level
+ * hierarchy is plain time stepping) and a level whose decay is too slow for ORC_BLK_RMAX modes are solved step by step.
+ * ============================================================================================== */
+#define ORC_BLK_K 16
+#define ORC_BLK_RMAX 64
+#define ORC_BLK_THR 8.673617379884035e-19   /* 2^-60 */
+
+/* 4 sin^2(theta_k / 2), theta_k = pi (k+1)/(n+1) */
+static double blk_lam4(int n, int k) {
+    double h = sin(M_PI * (double)(k + 1) / (2.0 * (double)(n + 1)));
+    return 4.0 * h * h;
+}
+
+/* blocks of the level's steps 1 .. nt-1: block b = steps K b + 1 .. K (b+1), the last one up to nt-1. Returns B (0: too short) */
+static int blk_count(int nt) { int N = nt - 1; return N >= 4 * ORC_BLK_K ? N / ORC_BLK_K : 0; }
+static int blk_end(int nt, int B, int b) { return b == B - 1 ? nt - 1 : ORC_BLK_K * (b + 1); }
+
+/* D[b][k] for k < ORC_BLK_RMAX + 1 and the rank r (0: the level is not eligible); fac = a/dx^2, t = the level's time grid */
+int orc_block_solve_rank(int n, double fac, int nt, const double *t, double *D /* [B][ORC_BLK_RMAX + 1] or NULL */) {
+    int B = blk_count(nt), r = 0;
+    if (B == 0 || n < 2) return 0;
+    int KM = ORC_BLK_RMAX + 1 < n ? ORC_BLK_RMAX + 1 : n;
+    for (int b = 0; b < B; ++b) {
+        int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b), rb = -1;
+        for (int k = 0; k < KM; ++k) {
+            double lam = blk_lam4(n, k), d = 1.0;
+            for (int i = first; i <= last; ++i) d = d * (1.0 / (1.0 + ((t[i] - t[i - 1]) * fac) * lam));
+            if (D) D[(size_t)b * (ORC_BLK_RMAX + 1) + k] = d;
+            if (rb < 0 && d < ORC_BLK_THR) rb = k;
+        }
+        if (b >= 1) {   /* block 0 propagates nothing (its start value is given) */
+            if (rb < 0 || rb > ORC_BLK_RMAX) return 0;
+            if (rb > r) r = rb;
+        }
+    }
+    return r < 1 ? 1 : r;
+}
+
+static int block_solve_on(const orc_problem *p, const orc_level *L, int lvl) {
+    const orc_stepper *st = &L->st;
+    if (p->no_block_solve || lvl == 0 || st->kind != ORC_HEAT1D || !st->variant || st->n > 16 * ORC_GROUP) return 0;
+    return orc_block_solve_rank(st->n, st->fac, L->nt, L->t, NULL);
+}
+
+/* <q, x> with the reduction tree of 3.4 */
+static double blk_dot(const double *x, const double *q, int n) {
+    int G = (n + ORC_GROUP - 1) / ORC_GROUP;
+    double tot = 0.0;
+    for (int g = 0; g < G; ++g) {
+        double a[ORC_LANES], b[ORC_LANES];
+        for (int l = 0; l < ORC_LANES; ++l) {
+            double acc = 0.0;
+            for (int k = 0; k < ORC_E; ++k) {
+                int j = (g * ORC_LANES + l) * ORC_E + k;
+                if (j < n) acc = fma(x[j], q[j], acc);
+            }
+            a[l] = acc;
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            for (int l = 0; l < ORC_LANES; ++l) b[l] = a[l] + a[l ^ off];
+            memcpy(a, b, sizeof(a));
+        }
+        tot = tot + a[0];
+    }
+    return tot;
+}
+
+static void heat1d_block_solve_spec(orc_problem *p, int lvl, int r) {
+    orc_level *L = &p->L[lvl];
+    int n = L->n, nt = L->nt, B = blk_count(nt), RM = ORC_BLK_RMAX + 1;
+    double *D = (double *)malloc(sizeof(double) * (size_t)B * RM);
+    orc_block_solve_rank(n, L->st.fac, nt, L->t, D);
+    double *Q = (double *)malloc(sizeof(double) * (size_t)r * n);
+    double sc = sqrt(2.0 / (double)(n + 1));
+    for (int k = 0; k < r; ++k)
+        for (int j = 0; j < n; ++j) {
+            long m = ((long)(k + 1) * (long)(j + 1)) % (2L * (n + 1));
+            Q[(size_t)k * n + j] = sc * sin(M_PI * (double)m / (double)(n + 1));
+        }
+    double *x = (double *)calloc((size_t)n, sizeof(double)), *what = (double *)calloc((size_t)B * r, sizeof(double));
+    double *Uh = (double *)calloc((size_t)r, sizeof(double)), *c = (double *)calloc((size_t)r, sizeof(double));
+    /* phase 1 */
+    for (int b = 0; b < B; ++b) {
+        int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
+        if (b == 0) memcpy(x, ROW(L->u, L, 0), sizeof(double) * (size_t)n);
+        else memset(x, 0, sizeof(double) * (size_t)n);
+        for (int i = first; i <= last; ++i) {
+            phi(p, lvl, i, x, p->tmp1);
+            const double *gi = ROW(L->g, L, i);
+            for (int j = 0; j < n; ++j) x[j] = gi[j] + p->tmp1[j];
+            if (b == 0) memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
+        }
+        if (b > 0) memcpy(ROW(L->u, L, last), x, sizeof(double) * (size_t)n);
+        if (b < B - 1)
+            for (int k = 0; k < r; ++k) what[(size_t)b * r + k] = blk_dot(x, Q + (size_t)k * n, n);
+    }
+    /* phases 2b, 2c */
+    memcpy(Uh, what, sizeof(double) * (size_t)r);
+    for (int b = 1; b < B; ++b) {
+        for (int k = 0; k < r; ++k) c[k] = D[(size_t)b * RM + k] * Uh[k];
+        if (b < B - 1) for (int k = 0; k < r; ++k) Uh[k] = what[(size_t)b * r + k] + c[k];
+        double *ue = ROW(L->u, L, blk_end(nt, B, b));
+        for (int j = 0; j < n; ++j) {
+            double v = ue[j];
+            for (int k = 0; k < r; ++k) v = fma(Q[(size_t)k * n + j], c[k], v);
+            ue[j] = v;
+        }
+    }
+    /* phase 3 */
+    for (int b = 1; b < B; ++b) {
+        int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
+        memcpy(x, ROW(L->u, L, first - 1), sizeof(double) * (size_t)n);
+        for (int i = first; i < last; ++i) {
+            phi(p, lvl, i, x, p->tmp1);
+            const double *gi = ROW(L->g, L, i);
+            for (int j = 0; j < n; ++j) x[j] = gi[j] + p->tmp1[j];
+            memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
+        }
+    }
+    free(D); free(Q); free(x); free(what); free(Uh); free(c);
+}
+
+void orc_problem_set_block_solve(orc_problem *p, int on) { p->no_block_solve = !on; }
+
 void orc_forward_solve(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl];
+    { int r = block_solve_on(p, L, lvl); if (r > 0) { heat1d_block_solve_spec(p, lvl, r); return; } }
     if (chain_overlapped(L, lvl)) { heat1d_chain_spec(p, lvl); return; }
     for (int i = 1; i < L->nt; ++i) {
         if (lvl == 0) phi(p, lvl, i, ROW(L->u, L, i - 1), ROW(L->u, L, i));

@@ -58,6 +58,9 @@ def lib():
                                                       C.c_double]
         L.orc_problem_set_transfer.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_problem_set_at.argtypes = [C.c_void_p, C.c_int]
+        L.orc_problem_set_block_solve.argtypes = [C.c_void_p, C.c_int]
+        L.orc_block_solve_rank.restype = C.c_int
+        L.orc_block_solve_rank.argtypes = [C.c_int, C.c_double, C.c_int, dp, dp]
         L.orc_at_forward_solve.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_problem_set_threads.restype = C.c_int
         L.orc_problem_set_threads.argtypes = [C.c_void_p, C.c_int]
@@ -100,6 +103,12 @@ def _dp(a):
 
 def _f64(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def block_solve_rank(n, fac, t):
+    """modes kept by the time-parallel forward solve of a Heat1D level (0: the level is solved step by step), DESIGN.md 3.8"""
+    t = _f64(t)
+    return int(lib().orc_block_solve_rank(int(n), float(fac), t.size, _dp(t), None))
 
 
 def split_into(n_points, n_procs):
@@ -166,7 +175,7 @@ class OracleProblem:
     """
 
     def __init__(self, levels, transfer=None, variant=1, weight_c=1.0, cf_iter=1, cycle_type='V', nested_iteration=True,
-                 t_norm=2, conv_crit=0, max_iter=100, tol=1e-7, norm_spec=True):
+                 t_norm=2, conv_crit=0, max_iter=100, tol=1e-7, norm_spec=True, block_solve=True):
         L = lib()
         self.L = L
         self.n_levels = len(levels)
@@ -232,6 +241,7 @@ class OracleProblem:
         L.orc_problem_set_options(self.h, float(weight_c), cf.ctypes.data_as(C.POINTER(C.c_int32)),
                                   1 if cycle_type == 'F' else 0, int(bool(nested_iteration)), int(t_norm),
                                   int(conv_crit), int(max_iter), float(tol), int(bool(norm_spec)))
+        L.orc_problem_set_block_solve(self.h, int(bool(block_solve)))   # time-parallel forward solve where eligible
         L.orc_problem_init_state(self.h)
 
     def __del__(self):

@@ -216,6 +216,7 @@ class HipBackend:
             assert slen.value == self.chain_handover[lvl]
             self.chain_state[lvl] = torch.zeros(slen.value, dtype=torch.float64, device=self.device)
             check(self.lib.mgrit_hip_chain_bind(self.h, lvl, C.c_void_p(self.chain_state[lvl].data_ptr())))
+        self._config_block_solve(lvl, d, n, gt)
         mg.u.append(SlabVectorList(u, n, tmpl, self.perm[lvl], on_write=self._before_write if lvl == 0 else self._forget_residual,
                                    on_read=self.materialise if lvl == 0 else None))
         mg.v.append(SlabVectorList(v, n, tmpl, self.perm[lvl]) if v is not None else None)
@@ -223,6 +224,20 @@ class HipBackend:
         if mg.comm_time_rank == 0 and n_pts:
             mg.u[lvl][0] = mg.problem[lvl].vector_t_start
         self._described[lvl] = True
+
+    def _config_block_solve(self, lvl, d, n, gt):
+        """Time-parallel forward solve (csrc/mgrit_hip_blk.inc): the rule is applied to the level's GLOBAL time
+        grid, so every owner of a sharded level takes the same form. block_r[lvl] = sine modes in use (0: step by step)."""
+        from pymgrit_amd.core.options import options
+        self.block_r = getattr(self, "block_r", {})
+        r = C.c_int(0)
+        if (lvl > 0 and lvl == self.mg.lvl_max - 1 and d["kind"] == "heat1d" and n <= hip_lib.MAX_N and options.coarse_solve != "sequential"
+                and type(self.mg).forward_solve.__qualname__ == "Mgrit.forward_solve"):
+            check(self.lib.mgrit_hip_block_solve_rank(n, float(d["fac"]), gt.size, _ptr(np.ascontiguousarray(gt)), C.byref(r)))
+        if r.value and self.mg.comm_time_size > 1:
+            r = C.c_int(0)      # (several ranks: see _config_block_solve_ranks)
+        check(self.lib.mgrit_hip_block_solve_config(self.h, lvl, r.value, 1, 0, None, None))
+        self.block_r[lvl] = r.value
 
     def finalize(self):
         """after every level is described: register the spatial transfers"""
@@ -512,6 +527,8 @@ class HipBackend:
         # Cache (1.2-1.7 us per step instead of 0.89), which costs more than the overlap of an F-cycle's few sweeps hides.
         if any(d["kind"] != "heat1d" for d in self.desc) or max(self.n) <= 1024:
             return 1
+        if self.block_r.get(self.mg.lvl_max - 1):
+            return 1     # the coarsest-level solve is time-parallel: nothing sequential is left to run beside sweeps
         if self.mg.comm_time_size > 1:
             # a rank of a sharded run (bench.py --emulate-rank, config 3): its share of the coarsest level is short, and a launch
             # over a fraction of a rank's intervals costs nearly what the launch over all of them costs (a few rounds of

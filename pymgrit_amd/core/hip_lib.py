@@ -16,6 +16,7 @@ STEPPER_HEAT1D, STEPPER_ADVECTION1D = 1, 2
 TRANSFER_COPY, TRANSFER_HEAT1D, TRANSFER_CALLER = 0, 1, 3
 MAX_N = 16384
 MAX_LINKS = 16
+BLOCK_K, BLOCK_RMAX = 16, 64      # time-parallel forward solve
 
 EXPORTS = {
     # name: (restype, argtypes)
@@ -45,6 +46,10 @@ EXPORTS = {
     "mgrit_hip_chain_state_len": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "mgrit_hip_chain_bind": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mgrit_hip_chain_resume": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_block_solve_rank": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "mgrit_hip_block_solve_config": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mgrit_hip_block_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mgrit_hip_block_solve_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "mgrit_hip_level_transfer": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_runs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mgrit_hip_pairs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),

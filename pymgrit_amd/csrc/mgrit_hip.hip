@@ -1312,6 +1312,8 @@ __global__ void interp_rows_kernel(double *__restrict__ uf, int f_ld, int T_f, c
 
 #include "mgrit_hip_gen.inc"
 
+#include "mgrit_hip_blk.inc"
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -1373,6 +1375,10 @@ struct Level {
     double *chain_state = nullptr;   // caller-owned [ld + CHAIN_STATE_TAIL]: carry-free part of the last point + carries
     bool chain_resume = false;
     bool chain_overlapped = true;    // mgrit_hip_chain_enable: the caller's (global) word on the overlapped chain
+    double fac = 0.0;                // Heat1D: a / dx^2
+    std::vector<double> t_host;      // the local time grid as described
+    BlkDev blk{};                    // time-parallel forward solve (mgrit_hip_blk.inc); blk.r = 0: step by step
+    int blk_state = -1;              // -1: not configured yet (mgrit_hip_block_solve_config), else configured
 };
 
 // ghost exchange (mgrit_hip_comm.inc): one direction of one pair of ranks
@@ -1631,6 +1637,9 @@ size_t smem_bytes(int G, int kind = MGRIT_HIP_STEPPER_HEAT1D) {
     return (size_t)(8 * G * LANES + (kind == MGRIT_HIP_STEPPER_ADVECTION1D ? 0 : 2 * 512)) * sizeof(double2) + (8 * MAX_G + LANES) * sizeof(double);
 }
 
+// time-parallel forward solve: the regular carve-up + the per-wave partial sums of the projections (mgrit_hip_blk.inc)
+size_t blk_smem_bytes(int G) { return smem_bytes(G) + (size_t)BLK_RMAX * MAX_G * sizeof(double); }
+
 constexpr int MAX_G2 = MGRIT_HIP_MAX_N_2PTS / GROUP;  // two-point steppers: waves per half
 size_t smem2_bytes(int G) { return (size_t)2 * (8 * G * LANES + 2 * 512) * sizeof(double2) + (12 * MAX_G + 2 * LANES) * sizeof(double); }
 
@@ -1692,6 +1701,14 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(fas_fused1_kernel<4, false>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<4, true>))) return rc;
     if ((rc = allow_big_lds(jump_kernel))) return rc;
+    if ((rc = allow_big_lds(blk_local_kernel<0>, blk_smem_bytes(MAX_G)))) return rc;
+    if ((rc = allow_big_lds(blk_local_kernel<2>, blk_smem_bytes(MAX_G)))) return rc;
+    if ((rc = allow_big_lds(blk_local_kernel<3>, blk_smem_bytes(MAX_G)))) return rc;
+    if ((rc = allow_big_lds(blk_local_kernel<4>, blk_smem_bytes(MAX_G)))) return rc;
+    if ((rc = allow_big_lds(blk_finish_kernel<0>, blk_smem_bytes(MAX_G)))) return rc;
+    if ((rc = allow_big_lds(blk_finish_kernel<2>, blk_smem_bytes(MAX_G)))) return rc;
+    if ((rc = allow_big_lds(blk_finish_kernel<3>, blk_smem_bytes(MAX_G)))) return rc;
+    if ((rc = allow_big_lds(blk_finish_kernel<4>, blk_smem_bytes(MAX_G)))) return rc;
 #define ATTR_2PTS(O, F)                                                                                              \
     if ((rc = allow_big_lds(relax2_kernel<O, F, false, false>, smem2_bytes(MAX_G2)))) return rc;                     \
     if ((rc = allow_big_lds(relax2_kernel<O, F, true, false>, smem2_bytes(MAX_G2)))) return rc;                      \
@@ -1729,6 +1746,8 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     if (lv.set) return fail(MGRIT_HIP_EINVAL, "level %d already described", lvl);
     const int G = (n + GROUP - 1) / GROUP, T = G * LANES;
     lv.G = G;
+    lv.fac = fac;
+    if (n_pts > 0) lv.t_host.assign(t_local, t_local + n_pts);
     LevelDev &d = lv.dev;
     d.n = n; d.ld = ld; d.T = T; d.n_pts = n_pts; d.K = K; d.kind = kind;
     d.stream_rows = (size_t)n_pts * (size_t)ld * sizeof(double) > ((size_t)256 << 20) ? 1 : 0;
@@ -2427,6 +2446,122 @@ LevelDev sched_dev(const mgrit_hip_engine *e, const Level &lv) {
     return d;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Time-parallel forward solve (mgrit_hip_blk.inc): the rule and the tables. The oracle's
+// orc_block_solve_rank / heat1d_block_solve_spec state the same arithmetic independently.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr double BLK_THR = 8.673617379884035e-19;   // 2^-60
+
+double blk_lam4(int n, int k) {
+    const double h = std::sin(M_PI * (double)(k + 1) / (2.0 * (double)(n + 1)));
+    return 4.0 * h * h;
+}
+int blk_count(int nt) { const int N = nt - 1; return N >= 4 * BLK_K ? N / BLK_K : 0; }
+
+// D[b][k], k <= BLK_RMAX (row stride BLK_RMAX + 1), and the rank; 0: not eligible
+int blk_rank(int n, double fac, int nt, const double *t, std::vector<double> *D) {
+    const int B = blk_count(nt);
+    int r = 0;
+    if (B == 0 || n < 2) return 0;
+    const int KM = BLK_RMAX + 1 < n ? BLK_RMAX + 1 : n;
+    if (D) D->assign((size_t)B * (BLK_RMAX + 1), 0.0);
+    for (int b = 0; b < B; ++b) {
+        const int first = BLK_K * b + 1, last = b == B - 1 ? nt - 1 : BLK_K * (b + 1);
+        int rb = -1;
+        for (int k = 0; k < KM; ++k) {
+            const double lam = blk_lam4(n, k);
+            double d = 1.0;
+            for (int i = first; i <= last; ++i) d = d * (1.0 / (1.0 + ((t[i] - t[i - 1]) * fac) * lam));
+            if (D) (*D)[(size_t)b * (BLK_RMAX + 1) + k] = d;
+            if (rb < 0 && d < BLK_THR) rb = k;
+        }
+        if (b >= 1) {
+            if (rb < 0 || rb > BLK_RMAX) return 0;
+            if (rb > r) r = rb;
+        }
+    }
+    return r < 1 ? 1 : r;
+}
+
+int blk_wgs_per_cu(const Level &lv) { return std::max(1, std::min((int)(160 * 1024 / blk_smem_bytes(lv.G)), 2048 / lv.dev.T)); }
+
+int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
+    BlkDev &bk = lv.blk;
+    const int fm = force_mode(lv), F = fm == 1 ? 4 : fm;
+    const size_t lds = blk_smem_bytes(lv.G);
+    const int cap = 256 * blk_wgs_per_cu(lv);
+    const dim3 block(lv.dev.T);
+    if (phases & 1) {
+        const dim3 grid(std::min(bk.B, cap));
+        if (F == 0) hipLaunchKernelGGL((blk_local_kernel<0>), grid, block, lds, e->stream, lv.dev, bk);
+        if (F == 2) hipLaunchKernelGGL((blk_local_kernel<2>), grid, block, lds, e->stream, lv.dev, bk);
+        if (F == 3) hipLaunchKernelGGL((blk_local_kernel<3>), grid, block, lds, e->stream, lv.dev, bk);
+        if (F == 4) hipLaunchKernelGGL((blk_local_kernel<4>), grid, block, lds, e->stream, lv.dev, bk);
+    }
+    if (phases & 2) {
+        hipLaunchKernelGGL(blk_scan_kernel, dim3(1), dim3(BLK_RMAX), 0, e->stream, bk);
+        if (bk.project_last) hipLaunchKernelGGL(blk_last_kernel, dim3(1), block, 0, e->stream, lv.dev, bk);
+    }
+    if (phases & 4) {
+        const int items = bk.B + 1 - (bk.first_real ? 1 : 0);
+        const dim3 grid(std::min(items, cap));
+        BlkDev b2 = bk;
+        b2.skip_last_row = bk.project_last;
+        if (F == 0) hipLaunchKernelGGL((blk_finish_kernel<0>), grid, block, lds, e->stream, lv.dev, b2);
+        if (F == 2) hipLaunchKernelGGL((blk_finish_kernel<2>), grid, block, lds, e->stream, lv.dev, b2);
+        if (F == 3) hipLaunchKernelGGL((blk_finish_kernel<3>), grid, block, lds, e->stream, lv.dev, b2);
+        if (F == 4) hipLaunchKernelGGL((blk_finish_kernel<4>), grid, block, lds, e->stream, lv.dev, b2);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_successor, double *uh_in, double *uh_out) {
+    Level &lv = e->L[lvl];
+    lv.blk = BlkDev{};
+    lv.blk_state = 0;
+    if (r == 0) return 0;
+    const bool can = lvl > 0 && lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && !lv.wide && !lv.h2d && lv.dev.n_pts >= 2;
+    if (r < 0 && !can) return 0;
+    if (!can) return fail(MGRIT_HIP_EUNSUPPORTED, "time-parallel forward solve: a register-resident Heat1D level > 0");
+    const int n = lv.dev.n, ld = lv.dev.ld, nt = lv.dev.n_pts;
+    std::vector<double> D;
+    const int r_local = blk_rank(n, lv.fac, nt, lv.t_host.data(), &D);
+    if (r < 0) {
+        r = r_local;
+        if (r == 0) return 0;
+    }
+    const int B = blk_count(nt);
+    if (B == 0) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: %d local steps are fewer than %d", nt - 1, 4 * BLK_K);
+    if (r > BLK_RMAX || r > n) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: r = %d modes outside [1, %d]", r, std::min(BLK_RMAX, n));
+    if (!first_real && !uh_in) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: a rank with a predecessor needs uh_in");
+    if (has_successor && !uh_out) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: a rank with a successor needs uh_out");
+    std::vector<double> Dt((size_t)B * BLK_RMAX, 0.0), Q((size_t)r * ld, 0.0);
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < BLK_RMAX && k < n; ++k) Dt[(size_t)b * BLK_RMAX + k] = D[(size_t)b * (BLK_RMAX + 1) + k];
+    const double sc = std::sqrt(2.0 / (double)(n + 1));
+    for (int k = 0; k < r; ++k)
+        for (int j = 0; j < n; ++j) {
+            const long m = ((long)(k + 1) * (long)(j + 1)) % (2L * (n + 1));
+            Q[(size_t)k * ld + row_pos(j)] = sc * std::sin(M_PI * (double)m / (double)(n + 1));
+        }
+    std::vector<double> zeros((size_t)B * BLK_RMAX, 0.0);
+    double *dQ, *dD, *dW, *dC;
+    int rc;
+    if ((rc = dev_upload(lv, e->stream, Q, &dQ))) return rc;
+    if ((rc = dev_upload(lv, e->stream, Dt, &dD))) return rc;
+    if ((rc = dev_upload(lv, e->stream, zeros, &dW))) return rc;
+    if ((rc = dev_upload(lv, e->stream, zeros, &dC))) return rc;
+    BlkDev &bk = lv.blk;
+    bk.Q = dQ; bk.D = dD; bk.what = dW; bk.C = dC;
+    bk.uh_in = uh_in; bk.uh_out = has_successor ? uh_out : nullptr;
+    bk.r = r; bk.B = B; bk.n_steps = nt - 1;
+    bk.first_real = first_real ? 1 : 0;
+    bk.project_last = has_successor ? 1 : 0;
+    bk.skip_last_row = 0;
+    return 0;
+}
+
 }  // namespace
 
 // ===============================================================================================================
@@ -2654,6 +2789,41 @@ int mgrit_hip_chain_resume(mgrit_hip_engine *e, int lvl, int on) {
     return 0;
 }
 
+int mgrit_hip_block_solve_rank(int n, double fac, int nt, const double *t, int *r_out) {
+    if (!r_out || (nt > 0 && !t)) return fail(MGRIT_HIP_EINVAL, "null argument");
+    *r_out = (n >= 2 && n <= MGRIT_HIP_MAX_N && nt >= 2) ? blk_rank(n, fac, nt, t, nullptr) : 0;
+    return 0;
+}
+
+int mgrit_hip_block_solve_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_successor, double *uh_in,
+                                 double *uh_out) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(e->stream, &cs);
+    if (cs != hipStreamCaptureStatusNone) return fail(MGRIT_HIP_EINVAL, "mgrit_hip_block_solve_config inside a stream capture");
+    return blk_config(e, lvl, r, first_real, has_successor, uh_in, uh_out);
+}
+
+int mgrit_hip_block_solve_state(mgrit_hip_engine *e, int lvl, int *r_out) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    if (!r_out) return fail(MGRIT_HIP_EINVAL, "null output");
+    *r_out = e->L[lvl].blk_state < 0 ? 0 : e->L[lvl].blk.r;
+    return 0;
+}
+
+int mgrit_hip_block_solve(mgrit_hip_engine *e, int lvl, int phases) {
+    int rc = check_level(e, lvl);
+    if (rc) return rc;
+    Level &lv = e->L[lvl];
+    if (lv.blk_state < 0 || lv.blk.r == 0) return fail(MGRIT_HIP_EINVAL, "level %d has no time-parallel forward solve configured", lvl);
+    if (phases < 1 || phases > 7) return fail(MGRIT_HIP_EINVAL, "bad phase mask %d", phases);
+    if ((rc = check_bound(lv, true))) return rc;
+    Timed timed(e, MGRIT_HIP_T_CHAIN, lvl);
+    return blk_launch(e, lv, phases);
+}
+
 int mgrit_hip_level_transfer(mgrit_hip_engine *e, int lvl, int kind) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
@@ -2752,6 +2922,15 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
         FOR_EACH_2PTS(RELAX2_CASES)
         HIP_TRY(hipGetLastError());
         return 0;
+    }
+    if (mode == MGRIT_HIP_RELAX_CHAIN && lvl > 0 && rl->n == 1 && rl->h_start[0] == 1 && rl->h_len[0] == lv.dev.n_pts - 1) {
+        // the whole level: the time-parallel form where the level qualifies (r = -1: the engine's own rule, first use)
+        if (lv.blk_state < 0 && (rc = mgrit_hip_block_solve_config(e, lvl, -1, 1, 0, nullptr, nullptr))) return rc;
+        if (lv.blk.r > 0) {
+            if (!lv.blk.first_real || lv.blk.project_last)
+                return fail(MGRIT_HIP_EINVAL, "level %d is one rank's part of a sharded solve: call mgrit_hip_block_solve by phases", lvl);
+            return blk_launch(e, lv, 7);
+        }
     }
     if (mode == MGRIT_HIP_RELAX_CHAIN) {
         // sequential chain: one two-wave workgroup (compute + streamer) per group, exchange through global granules

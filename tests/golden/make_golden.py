@@ -296,6 +296,7 @@ def make_solve(big=True):
         rec = run(c2, cf_iter=1, nested_iteration=True, max_iter=4, tol=1e-30, sample_pts=(2048, 4096))
         out["heat_config2"] = rec
     out.update(make_solve_wide())
+    out.update(make_solve_block())
     return out
 
 
@@ -307,6 +308,20 @@ def make_solve_wide():
     out["heat_nx1500_wide_F"] = run(heat_levels(1500, [33, 9, 3], forcing=False), tol=1e-9, max_iter=6, cycle_type='F',
                                     nested_iteration=False, sample_pts=(16, 32))
     out["heat_nx3100_wide_2lvl"] = run(heat_levels(3100, [33, 9]), tol=1e-9, max_iter=2, cf_iter=2, sample_pts=(32,))
+    return out
+
+
+def make_solve_block():
+    """coarsest levels long enough for the time-parallel forward solve of the device path (inputs restated in
+    tests/cases.block_cases)"""
+    out = {}
+    out["heat_blk_nx257_3lvl"] = run(heat_levels(257, [1025, 257, 65]), tol=1e-9, max_iter=6, sample_pts=(1, 512, 1024))
+    out["heat_blk_nx2050_2lvl"] = run(heat_levels(2050, [513, 129]), tol=1e-9, max_iter=4, cf_iter=2, sample_pts=(256, 512))
+    t0 = 2 * np.linspace(0, 1, 401) ** 1.3
+    nu = [Heat1D(x_start=0, x_end=1, nx=129, a=1, init_cond=init_cond, rhs=rhs, t_interval=t0[::s]) for s in (1, 2, 4)]
+    out["heat_blk_nonuniform_F"] = run(nu, tol=1e-9, max_iter=6, cycle_type='F', sample_pts=(3, 200, 400))
+    out["heat_blk_noforcing_cf0"] = run(heat_levels(65, [513, 129], forcing=False), tol=1e-9, max_iter=6, cf_iter=0,
+                                        nested_iteration=False, sample_pts=(512,))
     return out
 
 
@@ -753,6 +768,13 @@ def main():
         with open(os.path.join(HERE, "solve.json")) as f:
             sol = json.load(f)
         sol.update(make_solve_wide())
+        with open(os.path.join(HERE, "solve.json"), "w") as f:
+            json.dump(sol, f, separators=(",", ":"))
+        return
+    if "--only-solve-block" in sys.argv:
+        with open(os.path.join(HERE, "solve.json")) as f:
+            sol = json.load(f)
+        sol.update(make_solve_block())
         with open(os.path.join(HERE, "solve.json"), "w") as f:
             json.dump(sol, f, separators=(",", ":"))
         return

@@ -1,0 +1,119 @@
+"""Time-parallel forward solve of the coarsest level (csrc/mgrit_hip_blk.inc; reference Mgrit.forward_solve,
+src/pymgrit/core/mgrit.py:459-486): the HIP path against the oracle's statement of the same arithmetic
+(oracle/mgrit_oracle.c heat1d_block_solve_spec) -- states bit for bit --, the rule that selects it (CPU: library against oracle),
+and both against the step-by-step form."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+
+torch = pytest.importorskip("torch")
+
+
+def _grids(nt0, strides):
+    ts = [cases.lin(2, nt0)]
+    for s in strides:
+        ts.append(ts[-1][::s])
+    return ts
+
+
+NONUNIFORM = [cases.BLK_T0, cases.BLK_T0[::2], cases.BLK_T0[::4]]
+
+SHAPES = [
+    ("nx33_4blocks", 33, _grids(1025, (4, 4)), True),             # one group, exactly 4 blocks
+    ("nx1024_2lvl", 1024, _grids(513, (4,)), True),               # 8 blocks
+    ("nx1027_rem", 1027, _grids(309, (4,)), False),               # 77 steps: 4 blocks, the last one of 29; two groups; no forcing
+    ("nx2050_nonuniform", 2050, NONUNIFORM, True),                # every step its own size, 100 steps = 5 x 16 + 20
+    ("nx4099", 4099, _grids(641, (2, 2)), True),                  # 160 steps, five groups
+    ("nx16384", 16384, _grids(129, (2,)), True),                  # the widest register-resident state, 64 steps
+]
+
+
+def test_rank_rule_library_equals_oracle(oracle):
+    """the rule (how many sine modes, or step by step) is host arithmetic on both sides: same answers on uniform, non-uniform and
+    short grids, small and stiff problems"""
+    from pymgrit_amd.core import hip_lib
+    lib = hip_lib.load()
+    rng = np.random.default_rng(5)
+    seen = set()
+    for trial in range(200):
+        nx = int(rng.choice([5, 17, 65, 257, 1024, 4099, 16384]))
+        nt = int(rng.integers(2, 400))
+        t = np.sort(rng.uniform(0, 2, nt)) if trial % 3 == 0 else np.linspace(0, float(rng.uniform(0.01, 50)), nt)
+        spec = cases.heat_level_spec(nx, t)
+        r = C.c_int(-7)
+        hip_lib.check(lib.mgrit_hip_block_solve_rank(spec["n"], spec["fac"], nt, np.ascontiguousarray(t).ctypes.data_as(C.c_void_p), C.byref(r)))
+        assert r.value == oracle.block_solve_rank(spec["n"], spec["fac"], t), (nx, nt)
+        seen.add(min(r.value, 1))
+    assert seen == {0, 1}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,nx,grids,forcing", SHAPES, ids=[s[0] for s in SHAPES])
+def test_forward_solve_bit_exact(oracle, name, nx, grids, forcing):
+    from test_hip_parity import _need_gpu, assert_state_equal, make_pair, randomize
+    _need_gpu()
+    mg, op = make_pair(oracle, "heat", nx, grids, forcing=forcing)
+    lvl = mg.lvl_max - 1
+    assert mg.backend.block_r[lvl] == oracle.block_solve_rank(op.n[lvl], cases.heat_level_spec(nx, grids[-1])["fac"], grids[-1]) > 0
+    randomize(mg, op, seed=nx)
+    for rep in range(2):     # (twice: the second solve starts from rows the first one has written)
+        mg.forward_solve(lvl); op.forward_solve(lvl)
+        assert_state_equal(mg, op, what=("u",))
+    # ... and the cycle around it
+    mg.iteration(lvl=0, cycle_type='V', iteration=0, first_f=True); op.iteration(0, 'V', 0, True)
+    mg.backend.materialise()
+    assert_state_equal(mg, op, what=("u",))
+    got, ref = np.array(mg.compute_residual()), op.residual_norms()
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
+
+
+@pytest.mark.gpu
+def test_sequential_form_on_request(oracle):
+    """options.coarse_solve = 'sequential' keeps the step-by-step chain: bit for bit the oracle's step-by-step result, and within
+    rounding of the time-parallel one"""
+    from pymgrit_amd.core.options import options
+    from test_hip_parity import _need_gpu, assert_state_equal, make_pair, randomize
+    _need_gpu()
+    grids = _grids(513, (4,))
+    was = options.coarse_solve
+    try:
+        options.coarse_solve = "sequential"
+        mg, _ = make_pair(oracle, "heat", 1027, grids)
+    finally:
+        options.coarse_solve = was
+    assert mg.backend.block_r[1] == 0
+    specs = [cases.heat_level_spec(1027, t) for t in grids]
+    op = oracle.OracleProblem(specs, variant=1, nested_iteration=False, block_solve=False)
+    randomize(mg, op, seed=11)
+    mg.forward_solve(1); op.forward_solve(1)
+    assert_state_equal(mg, op, what=("u",))
+    mg2, op2 = make_pair(oracle, "heat", 1027, grids)
+    assert mg2.backend.block_r[1] > 0
+    randomize(mg2, op2, seed=11)
+    mg2.forward_solve(1)
+    a, b = mg.backend.natural("u", 1), mg2.backend.natural("u", 1)
+    assert np.abs(a - b).max() <= 1e-11 * np.abs(a).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(cases.block_cases()))
+def test_solve_matches_oracle_and_reference(oracle, name):
+    """whole solves whose coarsest level takes the time-parallel form: residual history equal to the oracle's (bar 1e-10 relative)
+    and inside the reference fixture's tolerance (tests/golden/solve.json, make_golden.make_solve_block)"""
+    from pymgrit_amd import Mgrit
+    from test_hip_parity import _need_gpu, heat_problem
+    _need_gpu()
+    case = cases.block_cases()[name]
+    levels = case["levels"]
+    nx = levels[0]["n"] + 2
+    prob = heat_problem(nx, [lv["t"] for lv in levels], forcing=levels[0].get("s") is not None)
+    res = Mgrit(prob, logging_lvl=30, **case["opts"]).solve()
+    ref = oracle.OracleProblem(levels, variant=1, **case["opts"]).solve()
+    m = min(len(ref), len(res["conv"]))
+    assert m >= 1 and np.all(np.abs(res["conv"][:m] - ref[:m]) <= 1e-10 * ref[:m])
+    fix = np.array(cases.load_json("solve.json")[name]["conv"])
+    m = min(len(fix), len(res["conv"]))
+    assert np.all(np.abs(res["conv"][:m] - fix[:m]) <= 1e-9 * fix[:m] + 2e-11)
