@@ -115,14 +115,19 @@ int mgrit_hip_chain_resume(mgrit_hip_engine *e, int lvl, int on);
  * over the blocks in the r lowest sine modes (the steps share their eigenvectors; over one block all other modes decay below
  * 2^-60), the block interiors stepped again from the corrected block starts. The same solve up to rounding; 2 Phi per step, all
  * blocks at once, instead of 1 Phi per step one after the other.
- *   mgrit_hip_block_solve_rank    the rule (pure host arithmetic): *r_out = modes needed for the time grid t[0..nt-1] (the level's
+ * Advection1D levels (periodic upwind: circulant steps, Fourier modes, nothing decays) take the same scheme on ALL n modes through
+ * a radix-2 FFT of the block ends: n a power of two in [64, 8192]; r = n, and the hand-over buffers hold n complex amplitudes
+ * (2 n doubles).
+ *   mgrit_hip_block_solve_rank    the rule (pure host arithmetic) for a stepper kind MGRIT_HIP_STEPPER_HEAT1D / _ADVECTION1D:
+ *                                 *r_out = modes needed for the time grid t[0..nt-1] (the level's
  *                                 GLOBAL grid when it is sharded: every owner must take the same form), 0 = the level is solved
- *                                 step by step (fewer than 4 blocks, or more than MGRIT_HIP_BLOCK_RMAX modes).
+ *                                 step by step (fewer than 4 blocks; Heat1D: more than MGRIT_HIP_BLOCK_RMAX modes; Advection1D: n
+ *                                 not a power of two in [64, 8192]).
  *   mgrit_hip_block_solve_config  r > 0: the level's CHAIN relax over all its steps takes this form with r modes; r = 0: never;
  *                                 r = -1: the engine applies the rule to its local grid (one rank). first_real = 0: the rank has
  *                                 a predecessor -- its first block starts from zero too, and the recurrence starts from the
  *                                 amplitudes at the ghost point in uh_in; has_successor: the amplitudes at the last local point
- *                                 go to uh_out. Both are device buffers of MGRIT_HIP_BLOCK_RMAX doubles owned by the caller
+ *                                 go to uh_out. Both are device buffers of MGRIT_HIP_BLOCK_RMAX doubles (Advection1D: 2 n) owned by the caller
  *                                 (the op-5 message of a sharded run carries them behind the point). A rank's share must be
  *                                 whole blocks: its first local slot a multiple of MGRIT_HIP_BLOCK_K steps from the start.
  *   mgrit_hip_block_solve         phases (bit mask) of the solve for callers that interleave them with the exchange:
@@ -130,7 +135,7 @@ int mgrit_hip_chain_resume(mgrit_hip_engine *e, int lvl, int on);
  *                                 uh_in) and, with a successor, the corrected last point, 4 = corrections + second pass (needs
  *                                 the ghost point). mgrit_hip_relax(CHAIN) over all steps = the three phases in a row.
  *   mgrit_hip_block_solve_state   *r_out = modes in effect on the level (0: step by step). */
-int mgrit_hip_block_solve_rank(int n, double fac, int nt, const double *t, int *r_out);
+int mgrit_hip_block_solve_rank(int stepper, int n, double fac, int nt, const double *t, int *r_out);
 int mgrit_hip_block_solve_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_successor, double *uh_in,
                                  double *uh_out);
 int mgrit_hip_block_solve(mgrit_hip_engine *e, int lvl, int phases);

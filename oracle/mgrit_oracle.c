@@ -1494,11 +1494,236 @@ static void heat1d_block_solve_spec(orc_problem *p, int lvl, int r) {
     free(D); free(Q); free(x); free(what); free(Uh); free(c);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * The same scheme for Advection1D (periodic upwind, advection_1d.py:101-143): its steps are circulant, so their
+ * common eigenvectors are the Fourier modes and NO mode may be dropped (transport does not decay): the states at the block ends
+ * are transformed by a radix-2 FFT (n a power of two, 64 .. 8192), the recurrence over the blocks runs on all n complex
+ * amplitudes, the propagated part comes back through the inverse transform.
+ *   forward   X_k = sum_j x_j e^{-2 pi i jk/n}: bit-reversed input order, stages s = 1 .. log2 n on pairs (a, b) half = 2^(s-1)
+ *             apart with the twiddle w = W[j n / 2^s] of position j inside the pair's block: t = w b with
+ *             t.re = fma(-w.im, b.im, w.re * b.re), t.im = fma(w.im, b.re, w.re * b.im); a' = a + t, b' = a - t.
+ *             W[t] = (cos(2 pi t/n), -sin(2 pi t/n)); inverse: the conjugate twiddles, then the real parts times 1/n
+ *   step      (1 + alpha) x_j - alpha x_{j-1} = u_j has the eigenvalues mu_k = (1 + alpha - alpha cos th_k) + i alpha sin th_k,
+ *             th_k = 2 pi k/n; d = 1/mu = (mu.re / |mu|^2, -mu.im / |mu|^2); D_b(k) = the complex product of the block's d in
+ *             step order (plain products and sums)
+ *   recurrence c_b = D_b Uh with c.re = fma(-D.im, Uh.im, D.re * Uh.re), c.im = fma(D.im, Uh.re, D.re * Uh.im); Uh = what_b + c_b
+ *   block end u[e_b] = W_b + Re(IFFT(c_b)) / n
+ * ---------------------------------------------------------------------------------------------- */
+/* cos and sin of one angle as two separate libm calls: a compiler that merges them into sincos() gets, on glibc, a last bit
+ * that differs from cos() / sin() for a few arguments (9 of the 16320 twiddle angles up to n = 8192), and the engine's tables
+ * must hold the same bits as these */
+static double __attribute__((noinline)) sep_cos(double x) { return cos(x); }
+static double __attribute__((noinline)) sep_sin(double x) { return sin(x); }
+
+static int adv_block_solve_on(const orc_problem *p, const orc_level *L, int lvl) {
+    const orc_stepper *st = &L->st;
+    int n = st->n;
+    if (p->no_block_solve || lvl == 0 || st->kind != ORC_ADVECTION1D || !st->variant) return 0;
+    if (n < 64 || n > 8192 || (n & (n - 1)) != 0) return 0;
+    return blk_count(L->nt) > 0;
+}
+
+/* in-place radix-2 transform of n complex values (re, im interleaved); inverse: conjugate twiddles, no scaling */
+void orc_fft_spec(double *x, int n, const double *W, int inverse) {
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    for (int i = 0; i < n; ++i) {
+        int r = 0;
+        for (int b = 0; b < lg; ++b) r |= ((i >> b) & 1) << (lg - 1 - b);
+        if (r > i) {
+            double tr = x[2 * i], ti = x[2 * i + 1];
+            x[2 * i] = x[2 * r]; x[2 * i + 1] = x[2 * r + 1];
+            x[2 * r] = tr; x[2 * r + 1] = ti;
+        }
+    }
+    for (int s = 1; s <= lg; ++s) {
+        int m = 1 << s, half = m >> 1, stride = n / m;
+        for (int base = 0; base < n; base += m)
+            for (int j = 0; j < half; ++j) {
+                double wr = W[2 * (j * stride)], wi = inverse ? -W[2 * (j * stride) + 1] : W[2 * (j * stride) + 1];
+                double *a = x + 2 * (base + j), *b = x + 2 * (base + j + half);
+                double tr = fma(-wi, b[1], wr * b[0]), ti = fma(wi, b[0], wr * b[1]);
+                double ar = a[0], ai = a[1];
+                a[0] = ar + tr; a[1] = ai + ti;
+                b[0] = ar - tr; b[1] = ai - ti;
+            }
+    }
+}
+
+void orc_fft_twiddles(int n, double *W /* [n/2][2] */) {
+    for (int t = 0; t < n / 2; ++t) {
+        double ang = 2.0 * M_PI * (double)t / (double)n;
+        W[2 * t] = sep_cos(ang); W[2 * t + 1] = -sep_sin(ang);
+    }
+}
+
+/* D[b][k] complex, k < n, of block b (steps K b + 1 .. its end) */
+void orc_adv_block_propagators(int n, double fac, int nt, const double *t, double *D /* [B][n][2] */) {
+    int B = blk_count(nt);
+    for (int b = 0; b < B; ++b) {
+        int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
+        for (int k = 0; k < n; ++k) {
+            double th = 2.0 * M_PI * (double)k / (double)n, cs = sep_cos(th), sn = sep_sin(th);
+            double pr = 1.0, pi = 0.0;
+            for (int i = first; i <= last; ++i) {
+                double alpha = (t[i] - t[i - 1]) * fac;
+                double mr = (1.0 + alpha) - alpha * cs, mi = alpha * sn, den = mr * mr + mi * mi;
+                double dr = mr / den, di = -mi / den;
+                double qr = pr * dr - pi * di, qi = pr * di + pi * dr;
+                pr = qr; pi = qi;
+            }
+            D[((size_t)b * n + k) * 2] = pr; D[((size_t)b * n + k) * 2 + 1] = pi;
+        }
+    }
+}
+
+static void advection_block_solve_spec(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl];
+    int n = L->n, nt = L->nt, B = blk_count(nt);
+    double *W = (double *)malloc(sizeof(double) * (size_t)n), *D = (double *)malloc(sizeof(double) * (size_t)B * n * 2);
+    orc_fft_twiddles(n, W);
+    orc_adv_block_propagators(n, L->st.fac, nt, L->t, D);
+    double *x = (double *)calloc((size_t)n, sizeof(double)), *what = (double *)calloc((size_t)B * n * 2, sizeof(double));
+    double *Uh = (double *)calloc((size_t)2 * n, sizeof(double)), *c = (double *)calloc((size_t)2 * n, sizeof(double));
+    double inv_n = 1.0 / (double)n;
+    for (int b = 0; b < B; ++b) {   /* phase 1 */
+        int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
+        if (b == 0) memcpy(x, ROW(L->u, L, 0), sizeof(double) * (size_t)n);
+        else memset(x, 0, sizeof(double) * (size_t)n);
+        for (int i = first; i <= last; ++i) {
+            phi(p, lvl, i, x, p->tmp1);
+            const double *gi = ROW(L->g, L, i);
+            for (int j = 0; j < n; ++j) x[j] = gi[j] + p->tmp1[j];
+            if (b == 0) memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
+        }
+        if (b > 0) memcpy(ROW(L->u, L, last), x, sizeof(double) * (size_t)n);
+        if (b < B - 1) {
+            double *wb = what + (size_t)b * n * 2;
+            for (int j = 0; j < n; ++j) { wb[2 * j] = x[j]; wb[2 * j + 1] = 0.0; }
+            orc_fft_spec(wb, n, W, 0);
+        }
+    }
+    memcpy(Uh, what, sizeof(double) * (size_t)2 * n);
+    for (int b = 1; b < B; ++b) {   /* recurrence over the blocks + block ends */
+        const double *Db = D + (size_t)b * n * 2, *wb = what + (size_t)b * n * 2;
+        for (int k = 0; k < n; ++k) {
+            double dr = Db[2 * k], di = Db[2 * k + 1], ur = Uh[2 * k], ui = Uh[2 * k + 1];
+            c[2 * k] = fma(-di, ui, dr * ur);
+            c[2 * k + 1] = fma(di, ur, dr * ui);
+        }
+        if (b < B - 1) for (int k = 0; k < 2 * n; ++k) Uh[k] = wb[k] + c[k];
+        orc_fft_spec(c, n, W, 1);
+        double *ue = ROW(L->u, L, blk_end(nt, B, b));
+        for (int j = 0; j < n; ++j) ue[j] = ue[j] + c[2 * j] * inv_n;
+    }
+    for (int b = 1; b < B; ++b) {   /* phase 3 */
+        int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
+        memcpy(x, ROW(L->u, L, first - 1), sizeof(double) * (size_t)n);
+        for (int i = first; i < last; ++i) {
+            phi(p, lvl, i, x, p->tmp1);
+            const double *gi = ROW(L->g, L, i);
+            for (int j = 0; j < n; ++j) x[j] = gi[j] + p->tmp1[j];
+            memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
+        }
+    }
+    free(W); free(D); free(x); free(what); free(Uh); free(c);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ... and for Heat2D with backward Euler (theta = 1; heat_2d.py:322-366): the implicit solve of 3.5 IS a
+ * diagonalisation, U = Qx ((Qx B Qy) o D) Qy, so the propagator of a block is the elementwise product of the steps' D tables and
+ * the recurrence over the blocks runs on the FULL sine spectrum of the interior (the transforms are those of 3.5, unscaled):
+ *   what_b = fwd_y(fwd_x(interior of u[e_b]));  D_b = product of dinv(dt_i) over the block's steps in step order;
+ *   c_b = D_b o Uh, Uh = what_b + c_b;  interior of u[e_b] += inv_y(inv_x(c_b)).  The rim of every state holds the boundary values.
+ * (theta < 1 reads the old rim through the explicit half of the stencil: not covered, solved step by step.)
+ * ---------------------------------------------------------------------------------------------- */
+static int h2d_block_solve_on(const orc_problem *p, const orc_level *L, int lvl) {
+    const orc_stepper *st = &L->st;
+    if (p->no_block_solve || lvl == 0 || st->kind != ORC_HEAT2D || st->theta != 1.0) return 0;
+    return blk_count(L->nt) > 0;
+}
+
+static void h2d_dinv_table(const orc_stepper *st, double dt, double *tab) {
+    int mi = st->mi, mj = st->mj, Mi = st->Mi, Mj = st->Mj;
+    int hxe = (mi + 1) / 2, hxo = mi / 2, hye = (mj + 1) / 2, hyo = mj / 2;
+    double thdt = st->theta * dt;
+    memset(tab, 0, sizeof(double) * (size_t)Mi * Mj);
+    for (int a = 0; a < Mi; ++a) {
+        if (!((a < hxe) || (a >= st->HPx && a < st->HPx + hxo))) continue;
+        for (int b = 0; b < Mj; ++b)
+            if ((b < hye) || (b >= st->HPy && b < st->HPy + hyo))
+                tab[(size_t)a * Mj + b] = 1.0 / (1.0 + thdt * (st->lx[a] + st->ly[b]));
+    }
+}
+
+static void heat2d_block_solve_spec(orc_problem *p, int lvl) {
+    orc_level *L = &p->L[lvl];
+    orc_stepper *st = &L->st;
+    int n = L->n, nt = L->nt, B = blk_count(nt), ny = st->ny, mi = st->mi, mj = st->mj, Mi = st->Mi, Mj = st->Mj;
+    size_t per = (size_t)Mi * Mj;
+    double *x = (double *)calloc((size_t)n, sizeof(double)), *what = (double *)calloc((size_t)B * per, sizeof(double));
+    double *D = (double *)malloc(sizeof(double) * per), *dv = (double *)malloc(sizeof(double) * per);
+    double *Uh = (double *)calloc(per, sizeof(double)), *c = (double *)calloc(per, sizeof(double));
+    double *P = (double *)calloc(per, sizeof(double)), *X = (double *)calloc(per, sizeof(double));
+    for (int b = 0; b < B; ++b) {   /* phase 1 */
+        int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
+        if (b == 0) memcpy(x, ROW(L->u, L, 0), sizeof(double) * (size_t)n);
+        else memset(x, 0, sizeof(double) * (size_t)n);
+        for (int i = first; i <= last; ++i) {
+            phi(p, lvl, i, x, p->tmp1);
+            const double *gi = ROW(L->g, L, i);
+            for (int j = 0; j < n; ++j) x[j] = gi[j] + p->tmp1[j];
+            if (b == 0) memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
+        }
+        if (b > 0) memcpy(ROW(L->u, L, last), x, sizeof(double) * (size_t)n);
+        if (b < B - 1) {
+            memset(P, 0, sizeof(double) * per);
+            for (int a = 0; a < mi; ++a)
+                for (int q = 0; q < mj; ++q) P[(size_t)a * Mj + q] = x[(size_t)(a + 1) * ny + (q + 1)];
+            h2d_fwd(st->Fxe, st->Fxo, mi, st->HPx, P, Mj, X);
+            h2d_fwd(st->Fye, st->Fyo, mj, st->HPy, X, Mi, what + (size_t)b * per);
+        }
+    }
+    memcpy(Uh, what, sizeof(double) * per);
+    for (int b = 1; b < B; ++b) {   /* recurrence over the blocks + block ends */
+        int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
+        for (int i = first; i <= last; ++i) {
+            h2d_dinv_table(st, L->t[i] - L->t[i - 1], dv);
+            if (i == first) memcpy(D, dv, sizeof(double) * per);
+            else for (size_t q = 0; q < per; ++q) D[q] = D[q] * dv[q];
+        }
+        for (size_t q = 0; q < per; ++q) c[q] = D[q] * Uh[q];
+        if (b < B - 1) for (size_t q = 0; q < per; ++q) Uh[q] = what[(size_t)b * per + q] + c[q];
+        h2d_inv(st->Fxe, st->Fxo, mi, st->HPx, c, Mj, X);
+        h2d_inv(st->Fye, st->Fyo, mj, st->HPy, X, Mi, P);
+        double *ue = ROW(L->u, L, last);
+        for (int a = 0; a < mi; ++a)
+            for (int q = 0; q < mj; ++q) {
+                size_t g = (size_t)(a + 1) * ny + (q + 1);
+                ue[g] = ue[g] + P[(size_t)a * Mj + q];
+            }
+    }
+    for (int b = 1; b < B; ++b) {   /* phase 3 */
+        int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
+        memcpy(x, ROW(L->u, L, first - 1), sizeof(double) * (size_t)n);
+        for (int i = first; i < last; ++i) {
+            phi(p, lvl, i, x, p->tmp1);
+            const double *gi = ROW(L->g, L, i);
+            for (int j = 0; j < n; ++j) x[j] = gi[j] + p->tmp1[j];
+            memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
+        }
+    }
+    st->dinv_dt = -1.0;   /* (the step's own cached table is untouched, but be explicit) */
+    free(x); free(what); free(D); free(dv); free(Uh); free(c); free(P); free(X);
+}
+
 void orc_problem_set_block_solve(orc_problem *p, int on) { p->no_block_solve = !on; }
 
 void orc_forward_solve(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl];
     { int r = block_solve_on(p, L, lvl); if (r > 0) { heat1d_block_solve_spec(p, lvl, r); return; } }
+    if (adv_block_solve_on(p, L, lvl)) { advection_block_solve_spec(p, lvl); return; }
+    if (h2d_block_solve_on(p, L, lvl)) { heat2d_block_solve_spec(p, lvl); return; }
     if (chain_overlapped(L, lvl)) { heat1d_chain_spec(p, lvl); return; }
     for (int i = 1; i < L->nt; ++i) {
         if (lvl == 0) phi(p, lvl, i, ROW(L->u, L, i - 1), ROW(L->u, L, i));

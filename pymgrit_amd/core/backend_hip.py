@@ -227,17 +227,67 @@ class HipBackend:
 
     def _config_block_solve(self, lvl, d, n, gt):
         """Time-parallel forward solve (csrc/mgrit_hip_blk.inc): the rule is applied to the level's GLOBAL time
-        grid, so every owner of a sharded level takes the same form. block_r[lvl] = sine modes in use (0: step by step)."""
+        grid, so every owner of a sharded level takes the same form. block_r[lvl] = sine modes in use (0: step by step).
+        Several ranks: every rank's share of the level has to be whole blocks (its ghost point a multiple of BLOCK_K steps from
+        the start, every rank at least one block) -- decided from the global layout, the same on every rank; the op-5 message
+        then carries the BLOCK_RMAX mode amplitudes behind the point instead of a chain state."""
+        from pymgrit_amd.core.layout import compute_layout
         from pymgrit_amd.core.options import options
+        mg = self.mg
         self.block_r = getattr(self, "block_r", {})
+        self.block_sharded = getattr(self, "block_sharded", {})
+        self.block_uh = getattr(self, "block_uh", {})
         r = C.c_int(0)
-        if (lvl > 0 and lvl == self.mg.lvl_max - 1 and d["kind"] == "heat1d" and n <= hip_lib.MAX_N and options.coarse_solve != "sequential"
-                and type(self.mg).forward_solve.__qualname__ == "Mgrit.forward_solve"):
-            check(self.lib.mgrit_hip_block_solve_rank(n, float(d["fac"]), gt.size, _ptr(np.ascontiguousarray(gt)), C.byref(r)))
-        if r.value and self.mg.comm_time_size > 1:
-            r = C.c_int(0)      # (several ranks: see _config_block_solve_ranks)
-        check(self.lib.mgrit_hip_block_solve_config(self.h, lvl, r.value, 1, 0, None, None))
+        if d["kind"] == "heat2d":
+            # Heat2D (backward Euler, one rank): the engine's own rule (level > 0, theta = 1, >= 64 steps), full sine spectrum
+            want = (lvl > 0 and lvl == mg.lvl_max - 1 and options.coarse_solve != "sequential" and mg.comm_time_size == 1 and
+                    getattr(type(mg).forward_solve, "__qualname__", "") == "Mgrit.forward_solve")
+            check(self.lib.mgrit_hip_block_solve_config(self.h, lvl, -1 if want else 0, 1, 0, None, None))
+            check(self.lib.mgrit_hip_block_solve_state(self.h, lvl, C.byref(r)))
+            self.block_r[lvl], self.block_sharded[lvl] = r.value, False
+            return
+        kinds = {"heat1d": hip_lib.STEPPER_HEAT1D, "advection1d": hip_lib.STEPPER_ADVECTION1D}
+        if (lvl > 0 and lvl == mg.lvl_max - 1 and d["kind"] in kinds and n <= hip_lib.MAX_N and options.coarse_solve != "sequential"
+                and getattr(type(mg).forward_solve, "__qualname__", "") == "Mgrit.forward_solve" and mg.global_conv_crit):
+            check(self.lib.mgrit_hip_block_solve_rank(kinds[d["kind"]], n, float(d["fac"]), gt.size, _ptr(np.ascontiguousarray(gt)),
+                                                      C.byref(r)))
+        size, K = mg.comm_time_size, hip_lib.BLOCK_K
+        first_real, successor = 1, 0
+        uh_in = uh_out = None
+        if r.value and size > 1:
+            ok = True
+            for p in range(size):
+                lay = compute_layout(mg.global_t, lvl, p, size)
+                n_owned = len(lay.index_local)
+                a = lay.first_owned
+                z = a + n_owned - 1
+                # first rank: owns point 0; the others: ghost a-1 on a block border; every rank ends on a block border or on
+                # the last point, and has at least one block of its own
+                ok = ok and n_owned > 0 and (a == 0 if p == 0 else (a - 1) % K == 0) and (z == gt.size - 1 or z % K == 0) and \
+                    (z - max(a - 1, 0)) >= K
+            if not ok:
+                r = C.c_int(0)
+            else:
+                first_real = int(mg.get_from[lvl] == -99)
+                successor = int(mg.send_to[lvl] != -99)
+                hlen = hip_lib.BLOCK_RMAX if d["kind"] == "heat1d" else 2 * n     # sine-mode amplitudes / n complex Fourier amplitudes
+                uh_in = torch.zeros(hlen, dtype=torch.float64, device=self.device)
+                uh_out = torch.zeros(hlen, dtype=torch.float64, device=self.device)
+                self.block_uh[lvl] = (uh_in, uh_out)
+        check(self.lib.mgrit_hip_block_solve_config(self.h, lvl, r.value, first_real, successor,
+                                                    C.c_void_p(uh_in.data_ptr() if uh_in is not None else 0),
+                                                    C.c_void_p(uh_out.data_ptr() if uh_out is not None else 0)))
         self.block_r[lvl] = r.value
+        self.block_sharded[lvl] = bool(r.value and size > 1)
+        if self.block_sharded[lvl]:
+            self.chain_handover[lvl] = int(uh_in.numel())      # doubles behind the point in the op-5 message
+            self.chain_state[lvl] = None
+
+    def block_solve(self, lvl, phases):
+        """phases of the time-parallel forward solve on a rank of a sharded level (mgrit_hip_block_solve): 1 = first pass,
+        2 = recurrence over the blocks (+ the corrected last point when a successor waits for it), 4 = corrections + second pass"""
+        self._settle(lvl)
+        check(self.lib.mgrit_hip_block_solve(self.h, lvl, int(phases)))
 
     def finalize(self):
         """after every level is described: register the spatial transfers"""
@@ -401,6 +451,8 @@ class HipBackend:
     def payload(self, lvl, idx, op=None):
         if lvl == 0:
             self.materialise()
+        if op == 5 and self.block_sharded.get(lvl):    # time-parallel solve: the point and the mode amplitudes behind it
+            return torch.cat((self._U[lvl][idx], self.block_uh[lvl][1]))
         if op == 5 and self.chain_handover.get(lvl):   # forward-solve hand-over: the point and the chain's running state
             state = self.chain_state[lvl]
             if state is None:   # this rank has no step of its own on the level (it owns the first point only): a fresh start
@@ -418,7 +470,11 @@ class HipBackend:
 
     def commit(self, lvl, idx, got, op=None):
         self._residual_cache = None
-        if op == 5 and self.chain_handover.get(lvl):
+        if op == 5 and self.block_sharded.get(lvl):
+            ld = self._U[lvl].shape[1]
+            self._U[lvl][idx].copy_(got[:ld])
+            self.block_uh[lvl][0].copy_(got[ld:])
+        elif op == 5 and self.chain_handover.get(lvl):
             ld = self._U[lvl].shape[1]
             self._U[lvl][idx].copy_(got[:ld])
             if self.chain_state[lvl] is not None:
@@ -509,6 +565,8 @@ class HipBackend:
         if any(d["kind"] not in ("heat1d", "advection1d", "heat2d") for d in self.desc) or self.mg.lvl_max < 2 or self._host_transfers():
             return 1
         n_c = len(self.mg.t[-1])
+        if any(d["kind"] == "heat2d" for d in self.desc) and self.block_r.get(self.mg.lvl_max - 1):
+            return 1     # time-parallel coarsest-level solve: batches of its own, nothing sequential to overlap
         if any(d["kind"] == "heat2d" for d in self.desc):
             # the coarsest-level solve (six launches per step) beside the batched sweeps of other blocks, each on CUs of its own
             # (_masked_streams: one XCD of 32 CUs for the solve). Measured on config 4 (2049 coarsest points), ms per cycle: one
@@ -794,7 +852,10 @@ class HipBackend:
         t0 = time.perf_counter()
         while not ev.query():
             if time.perf_counter() - t0 > limit:
-                self.lib.mgrit_hip_links_close(self.h, 1)
+                self.lib.mgrit_hip_links_close(self.h, 1)      # ncclCommAbort: the waiting kernels end, the stream drains
+                abort_all = getattr(self.mg.comm_time, "abort_all", None)
+                if abort_all is not None:
+                    abort_all()                                 # ... and the communicator object holds none of them any longer
                 raise MgritHipError(f"rank {self.mg.comm_time_rank}: the cycle did not finish within {limit} s (a neighbouring rank "
                                     f"never sent or never received): exchange links aborted")
             time.sleep(2e-5)

@@ -301,12 +301,19 @@ class RcclTimeComm(TorchTimeComm):
         from pymgrit_amd.core import hip_lib
         lib = hip_lib.load()
         if getattr(backend, "h", None) is not None:
-            lib.mgrit_hip_links_close(backend.h, 1)
-        for comm in self._comms.values():
-            lib.mgrit_hip_comm_destroy(comm, 1)
-        self._comms = {}
+            lib.mgrit_hip_links_close(backend.h, 0)      # detach only: the communicators are this object's to end, once (below)
+        self.abort_all()
         self._engines.pop(id(backend), None)
         return errs[0]
+
+    def abort_all(self):
+        """end every communicator exactly once (ncclCommAbort; one that the engine has aborted already -- a bounded wait that
+        gave up -- is only forgotten: mgrit_hip_comm_destroy knows) and hold none afterwards"""
+        from pymgrit_amd.core import hip_lib
+        lib = hip_lib.load()
+        comms, self._comms = self._comms, {}
+        for comm in comms.values():
+            lib.mgrit_hip_comm_destroy(comm, 1)
 
     def send_begin(self, backend, dest, channel):
         self.stats["messages"] += 1
@@ -336,9 +343,9 @@ class RcclTimeComm(TorchTimeComm):
     def close(self):
         from pymgrit_amd.core import hip_lib
         lib = hip_lib.load()
-        for comm in self._comms.values():
+        comms, self._comms = self._comms, {}
+        for comm in comms.values():
             lib.mgrit_hip_comm_destroy(comm, 0)
-        self._comms = {}
 
 
 class _LoopLink:
@@ -603,24 +610,34 @@ _default_comm = {}   # id(process group) -> (the group, its time communicator): 
                      # never freed)
 
 
+def _drop_default_comms():
+    """the process group they were made for is gone: two-rank communicators are freed before the entries are forgotten"""
+    for _, comm in list(_default_comm.values()):
+        close = getattr(comm, "close", None)
+        if close is not None:
+            try:
+                close()
+            except Exception:      # noqa: BLE001 - a communicator of a destroyed process group may refuse; nothing to do about it
+                pass
+    _default_comm.clear()
+
+
 def resolve_comm(comm_time):
     """``comm_time=None`` -> the default process group when torch.distributed is initialised, else serial: RcclTimeComm
     (ghost rows under the C ABI) on the "nccl" backend, TorchTimeComm (rows through torch.distributed, staged through the host
     for device slabs) on "gloo"."""
     if comm_time is None:
         if not (dist.is_available() and dist.is_initialized()):
-            _default_comm.clear()
+            _drop_default_comms()
             return SerialComm()
         world = dist.group.WORLD
         held = _default_comm.get(id(world))
         # (the id of a destroyed group may be reused: the entry must hold THIS group object)
         if held is None or held[0] is not world or held[1].backend != dist.get_backend():
-            _default_comm.clear()
+            _drop_default_comms()
             device = dist.get_backend() == "nccl" and os.environ.get("PYMGRIT_AMD_EXCHANGE", "rccl") != "torch"
             held = _default_comm[id(world)] = (world, RcclTimeComm() if device else TorchTimeComm())
-        comm = held[1]
-        comm.stats = {"messages": 0, "bytes": 0, "device_messages": 0}    # counters per solver, not per process
-        return comm
+        return held[1]      # (its counters are per process; a solver reports the difference over its own run: Mgrit.solve)
     if hasattr(comm_time, "exchange") and hasattr(comm_time, "Get_rank"):
         return comm_time
     raise Exception("comm_time must be None or a pymgrit_amd TimeComm (mpi4py communicators are not used on MI355X: "

@@ -84,7 +84,8 @@ class Recorder:
     # anything that is not a sweep (capability queries like can_fuse_ec, plan_blocks; plain attributes) is answered by the real
     # backend; a SWEEP the recorder has no dependency rule for ends the recording (the cycle then runs in program order)
     PASS_THROUGH = ("can_", "plan_")
-    PASS_NAMES = frozenset(("device_links", "chain_handover", "chain_state", "_cycle_pre", "ld", "n", "desc", "name"))
+    PASS_NAMES = frozenset(("device_links", "chain_handover", "chain_state", "_cycle_pre", "ld", "n", "desc", "name", "block_r",
+                            "block_sharded", "block_uh"))
 
     def __getattr__(self, name):
         if name.startswith(self.PASS_THROUGH) or name in self.PASS_NAMES:
@@ -169,6 +170,15 @@ class Recorder:
             return
         real, mg = self.real, self.mg
         chain = mode == 'CHAIN'
+        if chain and getattr(real, "block_r", {}).get(lvl):
+            # the time-parallel forward solve takes the level as a whole: ONE node between the way down of the last
+            # block and the way up of the first
+            blocks = {int(b) for b in np.unique(self.block_of[lvl])}
+            n_pts = int(sum(r[1] for r in runs))
+            self._add("chain", lvl, 0, lambda: real.relax(lvl, runs, 'CHAIN'),
+                      {("u", lvl, b) for b in blocks} | {("g", lvl, b) for b in blocks},
+                      {("u", lvl, b) for b in blocks} | {("chain", lvl, 0)}, 4 * n_pts)
+            return
         parts = self._by_block(lvl, self._split_runs(lvl, runs), 0)
         first = True
         for b, part in parts:
@@ -190,6 +200,15 @@ class Recorder:
                 rows = len(part) + n_pts * (2 if lvl > 0 else 1)
                 self._add("relax_" + mode, lvl, b, lambda p=part: real.relax(lvl, p, mode), reads, {("u", lvl, b)}, rows)
             first = False
+
+    def block_solve(self, lvl, phases):
+        """a phase of the time-parallel forward solve on a rank of a sharded level (backend_hip.block_solve): the phases and the
+        hand-overs between them keep their recorded order (they all write the level's "chain" cell)"""
+        real = self.real
+        blocks = {int(b) for b in np.unique(self.block_of[lvl])}
+        cells = {("u", lvl, b) for b in blocks}
+        self._add("block_solve", lvl, 0, lambda: real.block_solve(lvl, phases), cells | {("g", lvl, b) for b in blocks},
+                  cells | {("chain", lvl, 0)}, 2 * len(self.block_of[lvl]), stream="chain")
 
     # ---- exchange points (several ranks; backend_hip.exchange: stream operations of the engine) ------------------------------
     # A send reads the row it sends, a receive writes the ghost row; the messages of one link keep their recorded order (the

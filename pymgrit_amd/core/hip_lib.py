@@ -46,7 +46,7 @@ EXPORTS = {
     "mgrit_hip_chain_state_len": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "mgrit_hip_chain_bind": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mgrit_hip_chain_resume": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
-    "mgrit_hip_block_solve_rank": (C.c_int, [C.c_int, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "mgrit_hip_block_solve_rank": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     "mgrit_hip_block_solve_config": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mgrit_hip_block_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_block_solve_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

@@ -992,6 +992,20 @@ class Mgrit:
     def forward_solve(self, lvl: int) -> None:
         """Sequential time stepping on level ``lvl`` (mgrit.py:459-486); op 5 = pipeline hand-off between owners."""
         t0 = time.time()
+        if self._dry is None and getattr(self.backend, "block_sharded", {}).get(lvl):
+            # time-parallel form on a sharded level (DESIGN.md 3.8): the first pass needs nothing from the rank before; what the
+            # hand-over carries is the point and the amplitudes of a few sine modes, and the next rank waits for no more than the
+            # recurrence over this rank's blocks (one tiny launch) -- not for a pipeline stage of hundreds of steps
+            be = self.backend
+            be.block_solve(lvl, 1)
+            if self.get_from[lvl] != -99:
+                self._exchange(lvl, recv_idx=0, src=self.get_from[lvl], op=5)
+            be.block_solve(lvl, 2)
+            if self.send_to[lvl] != -99:
+                self._exchange(lvl, send_idx=int(self.index_local[lvl][-1]), dest=self.send_to[lvl], op=5)
+            be.block_solve(lvl, 4)
+            self._log_sweep("Forward solve", t0)
+            return
         if self.get_from[lvl] != -99:
             self._exchange(lvl, recv_idx=0, src=self.get_from[lvl], op=5)
         n = len(self.t[lvl])

@@ -1342,6 +1342,16 @@ struct H2DHost {
     double *Fye = nullptr, *Fyo = nullptr, *FyeT = nullptr, *FyoT = nullptr;
     double *W0 = nullptr, *W1 = nullptr, *rowsq = nullptr;
     size_t cap_items = 0;
+    // time-parallel forward solve (h2d_block_solve): batch plans of the two passes, the spectra of the block ends, the blocks'
+    // propagator tables (one per distinct sequence of step sizes) and a row of zeros (the state every block but the first starts from)
+    struct Blk {
+        bool built = false;
+        int B = 0;
+        std::vector<H2DPlan> p1_zero;
+        std::vector<std::vector<H2DPlan>> p1, p3;
+        int32_t *d_end_all = nullptr, *d_end_tail = nullptr, *d_dsel = nullptr;   // rows e_0 .. e_{B-2}; rows e_1 .. e_{B-1}; table of block b
+        double *spec = nullptr, *Dtab = nullptr, *zero_row = nullptr;
+    } blk;
     double *Wc0 = nullptr, *Wc1 = nullptr;   // one item each: the work buffers of the coarsest-level chain, which in a planned
                                              // cycle steps on a second stream BESIDE sweeps that apply this level's Phi too (the
                                              // coarse half of the FAS right-hand side of another block of time points)
@@ -1701,14 +1711,13 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(fas_fused1_kernel<4, false>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<4, true>))) return rc;
     if ((rc = allow_big_lds(jump_kernel))) return rc;
-    if ((rc = allow_big_lds(blk_local_kernel<0>, blk_smem_bytes(MAX_G)))) return rc;
-    if ((rc = allow_big_lds(blk_local_kernel<2>, blk_smem_bytes(MAX_G)))) return rc;
-    if ((rc = allow_big_lds(blk_local_kernel<3>, blk_smem_bytes(MAX_G)))) return rc;
-    if ((rc = allow_big_lds(blk_local_kernel<4>, blk_smem_bytes(MAX_G)))) return rc;
-    if ((rc = allow_big_lds(blk_finish_kernel<0>, blk_smem_bytes(MAX_G)))) return rc;
-    if ((rc = allow_big_lds(blk_finish_kernel<2>, blk_smem_bytes(MAX_G)))) return rc;
-    if ((rc = allow_big_lds(blk_finish_kernel<3>, blk_smem_bytes(MAX_G)))) return rc;
-    if ((rc = allow_big_lds(blk_finish_kernel<4>, blk_smem_bytes(MAX_G)))) return rc;
+#define ATTR_BLK(F)                                                                                                   \
+    if ((rc = allow_big_lds(blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, F>, blk_smem_bytes(MAX_G)))) return rc;        \
+    if ((rc = allow_big_lds(blk_finish_kernel<MGRIT_HIP_STEPPER_HEAT1D, F>, blk_smem_bytes(MAX_G)))) return rc;
+    ATTR_BLK(0) ATTR_BLK(2) ATTR_BLK(3) ATTR_BLK(4)
+    if ((rc = allow_big_lds(blk_local_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>, blk_smem_bytes(MAX_G)))) return rc;
+    if ((rc = allow_big_lds(blk_finish_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>, blk_smem_bytes(MAX_G)))) return rc;
+    if ((rc = allow_big_lds(adv_fft_rows_kernel, (size_t)BLK_FOURIER_MAX_N * sizeof(double2)))) return rc;
 #define ATTR_2PTS(O, F)                                                                                              \
     if ((rc = allow_big_lds(relax2_kernel<O, F, false, false>, smem2_bytes(MAX_G2)))) return rc;                     \
     if ((rc = allow_big_lds(relax2_kernel<O, F, true, false>, smem2_bytes(MAX_G2)))) return rc;                      \
@@ -2107,6 +2116,124 @@ int h2d_relax(mgrit_hip_engine *e, int lvl, RunList *rl, int mode, double weight
     return 0;
 }
 
+// Time-parallel forward solve of a Heat2D level with backward Euler (the oracle's heat2d_block_solve_spec): the level's
+// steps in blocks of BLK_K; first pass: step k of every block as ONE batch (all blocks but the first from a row of zeros);
+// the block ends through the forward transforms, the recurrence over the blocks on the full spectrum, the propagated parts back
+// through the inverse transforms straight into the rows (h2d_inv_kernel<true>, H2D_OP_ADD); second pass: the block interiors
+// from the corrected block starts, again one batch per step index. ~2 K batches of B states instead of K B single-state steps.
+bool h2d_block_ok(const Level &lv, int lvl) {
+    if (!lv.h2d || lvl == 0 || lv.h2d->dev.theta != 1.0) return false;
+    const int N = lv.dev.n_pts - 1;
+    return N >= 4 * MGRIT_HIP_BLOCK_K && N / MGRIT_HIP_BLOCK_K <= H2D_MAX_BATCH;
+}
+
+int h2d_block_build(mgrit_hip_engine *e, Level &lv) {
+    H2DHost &h = *lv.h2d;
+    H2DHost::Blk &k = h.blk;
+    const H2DDev &H = h.dev;
+    const int K = MGRIT_HIP_BLOCK_K, N = lv.dev.n_pts - 1, B = N / K;
+    const size_t per = (size_t)H.Mi * H.Mj;
+    int rc;
+    auto first = [&](int b) { return K * b + 1; };
+    auto last = [&](int b) { return b == B - 1 ? N : K * (b + 1); };
+    int maxlen = 0;
+    for (int b = 0; b < B; ++b) maxlen = std::max(maxlen, last(b) - first(b) + 1);
+    k.p1.resize(maxlen); k.p3.resize(maxlen);
+    for (int s = 0; s < maxlen; ++s) {
+        std::vector<H2DItem> it1, itz, it3;
+        for (int b = 0; b < B; ++b) {
+            const int i = first(b) + s;
+            if (i > last(b)) continue;
+            if (s == 0 && b >= 1) itz.push_back({0, i, i, i, i});   // from the row of zeros
+            else it1.push_back({i - 1, i, i, i, i});
+            if (b >= 1 && i < last(b)) it3.push_back({i - 1, i, i, i, i});
+        }
+        if (!itz.empty() && (rc = h2d_make_plans(e, lv, itz, k.p1_zero))) return rc;
+        if (!it1.empty() && (rc = h2d_make_plans(e, lv, it1, k.p1[s]))) return rc;
+        if (!it3.empty() && (rc = h2d_make_plans(e, lv, it3, k.p3[s]))) return rc;
+    }
+    std::vector<int32_t> end_all, end_tail, dsel(B, 0);
+    for (int b = 0; b < B - 1; ++b) end_all.push_back(last(b));
+    for (int b = 1; b < B; ++b) end_tail.push_back(last(b));
+    // propagator tables: the elementwise product of the steps' D tables in step order; one table per distinct sequence of step sizes
+    std::map<std::vector<uint64_t>, int> seen;
+    std::vector<double> tabs, dv(per);
+    const int hxe = (H.mi + 1) / 2, hxo = H.mi / 2, hye = (H.mj + 1) / 2, hyo = H.mj / 2;
+    for (int b = 1; b < B; ++b) {
+        std::vector<uint64_t> key;
+        for (int i = first(b); i <= last(b); ++i) key.push_back(dbl_bits(h.dts[i]));
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+            const size_t off = tabs.size();
+            tabs.resize(off + per, 0.0);
+            for (int i = first(b); i <= last(b); ++i) {
+                const double thdt = H.theta * h.dts[i];
+                std::fill(dv.begin(), dv.end(), 0.0);
+                for (int a = 0; a < H.Mi; ++a) {
+                    if (!((a < hxe) || (a >= h.HPx && a < h.HPx + hxo))) continue;
+                    for (int c = 0; c < H.Mj; ++c)
+                        if ((c < hye) || (c >= h.HPy && c < h.HPy + hyo)) dv[(size_t)a * H.Mj + c] = 1.0 / (1.0 + thdt * (h.lx[a] + h.ly[c]));
+                }
+                if (i == first(b)) std::copy(dv.begin(), dv.end(), tabs.begin() + (long)off);
+                else for (size_t q = 0; q < per; ++q) tabs[off + q] = tabs[off + q] * dv[q];
+            }
+            it = seen.emplace(key, (int)seen.size()).first;
+        }
+        dsel[b] = it->second;
+    }
+    if ((rc = dev_upload(lv, e->stream, end_all, &k.d_end_all))) return rc;
+    if ((rc = dev_upload(lv, e->stream, end_tail, &k.d_end_tail))) return rc;
+    if ((rc = dev_upload(lv, e->stream, dsel, &k.d_dsel))) return rc;
+    if ((rc = dev_upload(lv, e->stream, tabs, &k.Dtab))) return rc;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&k.spec), sizeof(double) * per * (size_t)B));
+    lv.allocs.push_back(k.spec);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&k.zero_row), sizeof(double) * (size_t)lv.dev.ld));
+    lv.allocs.push_back(k.zero_row);
+    HIP_TRY(hipMemsetAsync(k.zero_row, 0, sizeof(double) * (size_t)lv.dev.ld, e->stream));
+    if ((rc = h2d_reserve(lv, std::min(H2D_MAX_BATCH, B)))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    k.B = B;
+    k.built = true;
+    return 0;
+}
+
+int h2d_block_solve(mgrit_hip_engine *e, int lvl) {
+    Level &lv = e->L[lvl];
+    H2DHost &h = *lv.h2d;
+    H2DHost::Blk &k = h.blk;
+    const H2DDev &H = h.dev;
+    int rc;
+    if (!k.built && (rc = h2d_block_build(e, lv))) return rc;
+    const int B = k.B;
+    const size_t per = (size_t)H.Mi * H.Mj;
+    // first pass
+    for (size_t s = 0; s < k.p1.size(); ++s) {
+        if (s == 0)
+            for (const H2DPlan &pl : k.p1_zero)
+                if ((rc = h2d_phi_op(e, lv, pl, k.zero_row, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, H2D_OP_F, 1, 1.0))) return rc;
+        for (const H2DPlan &pl : k.p1[s])
+            if ((rc = h2d_phi_op(e, lv, pl, lv.dev.u, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, H2D_OP_F, 1, 1.0))) return rc;
+    }
+    // spectra of the block ends e_0 .. e_{B-2}
+    const dim3 fx(H.Mj / 64, H.Mi / 64, B - 1), fy(H.Mi / 64, H.Mj / 64, B - 1);
+    hipLaunchKernelGGL(h2d_pack_kernel, dim3((H.Mj + 255) / 256, H.Mi, B - 1), dim3(256), 0, e->stream, H, lv.dev.u, k.d_end_all, h.W0);
+    hipLaunchKernelGGL((h2d_fwd_kernel<false>), fx, dim3(256), 0, e->stream, h.Fxe, h.Fxo, H.mi, h.HPx, h.W0, H.Mj, h.W1, nullptr, per);
+    hipLaunchKernelGGL((h2d_fwd_kernel<false>), fy, dim3(256), 0, e->stream, h.Fye, h.Fyo, H.mj, h.HPy, h.W1, H.Mi, k.spec, nullptr, per);
+    // recurrence over the blocks, then the propagated parts into the rows e_1 .. e_{B-1}
+    hipLaunchKernelGGL(h2d_blk_scan_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, e->stream, k.spec, k.Dtab, k.d_dsel, B, per);
+    const dim3 ix(H.Mj / 64, h.HPx / 64, B - 1), iy(H.Mi / 64, h.HPy / 64, B - 1);
+    const H2DFin none{};
+    const H2DFin add{lv.dev.u, lv.dev.ld, k.d_end_tail, nullptr, nullptr, nullptr, nullptr, H2D_OP_ADD, 0, 1.0, 0.0};
+    hipLaunchKernelGGL((h2d_inv_kernel<false>), ix, dim3(256), 0, e->stream, h.FxeT, h.FxoT, H.mi, h.HPx, k.spec + per, H.Mj, h.W1, per, H, none);
+    hipLaunchKernelGGL((h2d_inv_kernel<true>), iy, dim3(256), 0, e->stream, h.FyeT, h.FyoT, H.mj, h.HPy, h.W1, H.Mi, h.W0, per, H, add);
+    HIP_TRY(hipGetLastError());
+    // second pass
+    for (size_t s = 0; s < k.p3.size(); ++s)
+        for (const H2DPlan &pl : k.p3[s])
+            if ((rc = h2d_phi_op(e, lv, pl, lv.dev.u, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, H2D_OP_F, 1, 1.0))) return rc;
+    return 0;
+}
+
 // per-point sums of squares: Phi(u_{i-1}) - u_i (residual) or u_i - prev_i (jump)
 int h2d_points_sumsq(mgrit_hip_engine *e, int lvl, RunList *rl, const double *prev, double *out) {
     Level &lv = e->L[lvl];
@@ -2116,15 +2243,11 @@ int h2d_points_sumsq(mgrit_hip_engine *e, int lvl, RunList *rl, const double *pr
         std::vector<H2DItem> items;
         for (int r = 0; r < rl->n; ++r) {
             const int i = rl->h_start[r];
-            items.push_back({i - 1, i, i, i, i});
+            items.push_back({i - 1, i, i, i, r});   // (b: the point's position in the list = where its sum goes)
         }
         if ((rc = h2d_make_plans(e, lv, items, rl->h2d_points))) return rc;
         rl->h2d_points_built = true;
-        // out[] is written in plan order; plans keep list order only when a single time-step size is present
-        if (rl->h2d_points.size() > (size_t)((rl->n + H2D_MAX_BATCH - 1) / H2D_MAX_BATCH))
-            return fail(MGRIT_HIP_EUNSUPPORTED, "Heat2D residual over points with several distinct time-step sizes");
     }
-    int off = 0;
     for (const H2DPlan &pl : rl->h2d_points) {
         if ((rc = h2d_reserve(lv, std::min(H2D_MAX_BATCH, pl.count)))) return rc;
         if (!prev) {
@@ -2136,9 +2259,8 @@ int h2d_points_sumsq(mgrit_hip_engine *e, int lvl, RunList *rl, const double *pr
                                pl.d_dst, pl.d_step, prev, pl.d_dst, H2D_OP_JUMP, lv.h2d->rowsq);
         }
         hipLaunchKernelGGL(h2d_rowsum_kernel, dim3((pl.count + 63) / 64), dim3(64), 0, e->stream, lv.h2d->rowsq, H.nx, pl.count,
-                           out + off);
+                           out, pl.d_b);
         HIP_TRY(hipGetLastError());
-        off += pl.count;
     }
     return 0;
 }
@@ -2483,7 +2605,18 @@ int blk_rank(int n, double fac, int nt, const double *t, std::vector<double> *D)
     return r < 1 ? 1 : r;
 }
 
+// cos and sin of one angle as two separate libm calls (a compiler that merges them into sincos() gets another last bit for a
+// few arguments on glibc; the oracle's tables are built the same way)
+double __attribute__((noinline)) sep_cos(double x) { return std::cos(x); }
+double __attribute__((noinline)) sep_sin(double x) { return std::sin(x); }
+
 int blk_wgs_per_cu(const Level &lv) { return std::max(1, std::min((int)(160 * 1024 / blk_smem_bytes(lv.G)), 2048 / lv.dev.T)); }
+
+// doubles behind the point in the hand-over of a sharded solve: the amplitudes at the rank's last point
+int blk_handover_len(const Level &lv) { return lv.blk.r == 0 ? 0 : lv.blk.fourier ? 2 * lv.dev.n : BLK_RMAX; }
+
+// Advection1D: the Fourier form needs n = 2^p, 64 <= n <= BLK_FOURIER_MAX_N (one workgroup's LDS holds a row's n complex values)
+bool blk_fourier_ok(int n, int nt) { return n >= 64 && n <= BLK_FOURIER_MAX_N && (n & (n - 1)) == 0 && blk_count(nt) > 0; }
 
 int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     BlkDev &bk = lv.blk;
@@ -2491,26 +2624,43 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     const size_t lds = blk_smem_bytes(lv.G);
     const int cap = 256 * blk_wgs_per_cu(lv);
     const dim3 block(lv.dev.T);
+    const bool adv = bk.fourier != 0;
+    const int n = lv.dev.n, fft_threads = std::min(n / 2, 1024), b_lo = bk.first_real ? 1 : 0;
+    const size_t fft_lds = (size_t)n * sizeof(double2);
     if (phases & 1) {
         const dim3 grid(std::min(bk.B, cap));
-        if (F == 0) hipLaunchKernelGGL((blk_local_kernel<0>), grid, block, lds, e->stream, lv.dev, bk);
-        if (F == 2) hipLaunchKernelGGL((blk_local_kernel<2>), grid, block, lds, e->stream, lv.dev, bk);
-        if (F == 3) hipLaunchKernelGGL((blk_local_kernel<3>), grid, block, lds, e->stream, lv.dev, bk);
-        if (F == 4) hipLaunchKernelGGL((blk_local_kernel<4>), grid, block, lds, e->stream, lv.dev, bk);
+        if (adv) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>), grid, block, lds, e->stream, lv.dev, bk);
+        else if (F == 0) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 0>), grid, block, lds, e->stream, lv.dev, bk);
+        else if (F == 2) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 2>), grid, block, lds, e->stream, lv.dev, bk);
+        else if (F == 3) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 3>), grid, block, lds, e->stream, lv.dev, bk);
+        else hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 4>), grid, block, lds, e->stream, lv.dev, bk);
+        if (adv) {   // what_b = FFT(u[e_b]) for the block ends the recurrence reads
+            const int cnt = bk.B - 1 + (bk.project_last ? 1 : 0);
+            if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, 0, 0);
+        }
     }
     if (phases & 2) {
-        hipLaunchKernelGGL(blk_scan_kernel, dim3(1), dim3(BLK_RMAX), 0, e->stream, bk);
-        if (bk.project_last) hipLaunchKernelGGL(blk_last_kernel, dim3(1), block, 0, e->stream, lv.dev, bk);
+        if (adv) hipLaunchKernelGGL(adv_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, bk, n);
+        else hipLaunchKernelGGL(blk_scan_kernel, dim3(1), dim3(BLK_RMAX), 0, e->stream, bk);
+        if (bk.project_last) {   // the last point, which the next rank waits for
+            if (adv) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(1), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, bk.B - 1, 1);
+            else hipLaunchKernelGGL(blk_last_kernel, dim3(1), block, 0, e->stream, lv.dev, bk);
+        }
     }
     if (phases & 4) {
-        const int items = bk.B + 1 - (bk.first_real ? 1 : 0);
-        const dim3 grid(std::min(items, cap));
         BlkDev b2 = bk;
         b2.skip_last_row = bk.project_last;
-        if (F == 0) hipLaunchKernelGGL((blk_finish_kernel<0>), grid, block, lds, e->stream, lv.dev, b2);
-        if (F == 2) hipLaunchKernelGGL((blk_finish_kernel<2>), grid, block, lds, e->stream, lv.dev, b2);
-        if (F == 3) hipLaunchKernelGGL((blk_finish_kernel<3>), grid, block, lds, e->stream, lv.dev, b2);
-        if (F == 4) hipLaunchKernelGGL((blk_finish_kernel<4>), grid, block, lds, e->stream, lv.dev, b2);
+        if (adv) {   // u[e_b] += Re(IFFT(c_b)) / n for the block ends not yet corrected, then the second pass
+            const int cnt = bk.B - b_lo - (bk.project_last ? 1 : 0);
+            if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, b_lo, 1);
+        }
+        const int items = bk.B + 1 - b_lo;
+        const dim3 grid(std::min(items, cap));
+        if (adv) hipLaunchKernelGGL((blk_finish_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>), grid, block, lds, e->stream, lv.dev, b2);
+        else if (F == 0) hipLaunchKernelGGL((blk_finish_kernel<MGRIT_HIP_STEPPER_HEAT1D, 0>), grid, block, lds, e->stream, lv.dev, b2);
+        else if (F == 2) hipLaunchKernelGGL((blk_finish_kernel<MGRIT_HIP_STEPPER_HEAT1D, 2>), grid, block, lds, e->stream, lv.dev, b2);
+        else if (F == 3) hipLaunchKernelGGL((blk_finish_kernel<MGRIT_HIP_STEPPER_HEAT1D, 3>), grid, block, lds, e->stream, lv.dev, b2);
+        else hipLaunchKernelGGL((blk_finish_kernel<MGRIT_HIP_STEPPER_HEAT1D, 4>), grid, block, lds, e->stream, lv.dev, b2);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -2521,44 +2671,95 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
     lv.blk = BlkDev{};
     lv.blk_state = 0;
     if (r == 0) return 0;
-    const bool can = lvl > 0 && lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && !lv.wide && !lv.h2d && lv.dev.n_pts >= 2;
+    if (lv.h2d) {   // Heat2D (backward Euler, one rank): the full spectrum, no tables here (h2d_block_build on first use)
+        if (!first_real || has_successor) return fail(MGRIT_HIP_EUNSUPPORTED, "time-parallel forward solve of a Heat2D level: one rank");
+        if (h2d_block_ok(lv, lvl)) lv.blk_state = 1;
+        else if (r > 0) return fail(MGRIT_HIP_EUNSUPPORTED, "time-parallel forward solve of a Heat2D level: level > 0, backward Euler, 64 .. %d steps", H2D_MAX_BATCH * BLK_K);
+        return 0;
+    }
+    const bool heat = lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D, adv = lv.dev.kind == MGRIT_HIP_STEPPER_ADVECTION1D;
+    const bool can = lvl > 0 && (heat || adv) && !lv.wide && !lv.h2d && lv.dev.n_pts >= 2;
     if (r < 0 && !can) return 0;
-    if (!can) return fail(MGRIT_HIP_EUNSUPPORTED, "time-parallel forward solve: a register-resident Heat1D level > 0");
+    if (!can) return fail(MGRIT_HIP_EUNSUPPORTED, "time-parallel forward solve: a register-resident Heat1D / Advection1D level > 0");
     const int n = lv.dev.n, ld = lv.dev.ld, nt = lv.dev.n_pts;
     std::vector<double> D;
-    const int r_local = blk_rank(n, lv.fac, nt, lv.t_host.data(), &D);
-    if (r < 0) {
-        r = r_local;
+    if (r < 0) {   // one rank: the rule on the local (= global) grid
+        r = heat ? blk_rank(n, lv.fac, nt, lv.t_host.data(), nullptr) : (blk_fourier_ok(n, nt) ? n : 0);
         if (r == 0) return 0;
     }
-    const int B = blk_count(nt);
-    if (B == 0) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: %d local steps are fewer than %d", nt - 1, 4 * BLK_K);
-    if (r > BLK_RMAX || r > n) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: r = %d modes outside [1, %d]", r, std::min(BLK_RMAX, n));
+    const int B = (nt - 1) / BLK_K;   // whole blocks of the rank's share, the last one with the remainder (a rank of a sharded level may hold fewer than 4)
+    if (B < 1) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: %d local steps are fewer than one block of %d", nt - 1, BLK_K);
     if (!first_real && !uh_in) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: a rank with a predecessor needs uh_in");
     if (has_successor && !uh_out) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: a rank with a successor needs uh_out");
-    std::vector<double> Dt((size_t)B * BLK_RMAX, 0.0), Q((size_t)r * ld, 0.0);
-    for (int b = 0; b < B; ++b)
-        for (int k = 0; k < BLK_RMAX && k < n; ++k) Dt[(size_t)b * BLK_RMAX + k] = D[(size_t)b * (BLK_RMAX + 1) + k];
-    const double sc = std::sqrt(2.0 / (double)(n + 1));
-    for (int k = 0; k < r; ++k)
-        for (int j = 0; j < n; ++j) {
-            const long m = ((long)(k + 1) * (long)(j + 1)) % (2L * (n + 1));
-            Q[(size_t)k * ld + row_pos(j)] = sc * std::sin(M_PI * (double)m / (double)(n + 1));
-        }
-    std::vector<double> zeros((size_t)B * BLK_RMAX, 0.0);
-    double *dQ, *dD, *dW, *dC;
     int rc;
-    if ((rc = dev_upload(lv, e->stream, Q, &dQ))) return rc;
-    if ((rc = dev_upload(lv, e->stream, Dt, &dD))) return rc;
-    if ((rc = dev_upload(lv, e->stream, zeros, &dW))) return rc;
-    if ((rc = dev_upload(lv, e->stream, zeros, &dC))) return rc;
-    BlkDev &bk = lv.blk;
-    bk.Q = dQ; bk.D = dD; bk.what = dW; bk.C = dC;
+    BlkDev bk{};
+    if (heat) {
+        if (r > BLK_RMAX || r > n) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: r = %d modes outside [1, %d]", r, std::min(BLK_RMAX, n));
+        // D_b(k) = prod over the block's steps of 1 / (1 + dt_i fac 4 sin^2(theta_k / 2)), products in step order
+        std::vector<double> Dt((size_t)B * BLK_RMAX, 0.0), Q((size_t)r * ld, 0.0);
+        for (int b = 0; b < B; ++b) {
+            const int first = BLK_K * b + 1, last = b == B - 1 ? nt - 1 : BLK_K * (b + 1);
+            for (int k = 0; k < BLK_RMAX && k < n; ++k) {
+                const double lam = blk_lam4(n, k);
+                double d = 1.0;
+                for (int i = first; i <= last; ++i) d = d * (1.0 / (1.0 + ((lv.t_host[i] - lv.t_host[i - 1]) * lv.fac) * lam));
+                Dt[(size_t)b * BLK_RMAX + k] = d;
+            }
+        }
+        const double sc = std::sqrt(2.0 / (double)(n + 1));
+        for (int k = 0; k < r; ++k)
+            for (int j = 0; j < n; ++j) {
+                const long m = ((long)(k + 1) * (long)(j + 1)) % (2L * (n + 1));
+                Q[(size_t)k * ld + row_pos(j)] = sc * std::sin(M_PI * (double)m / (double)(n + 1));
+            }
+        std::vector<double> zeros((size_t)B * BLK_RMAX, 0.0);
+        double *dQ, *dD, *dW, *dC;
+        if ((rc = dev_upload(lv, e->stream, Q, &dQ))) return rc;
+        if ((rc = dev_upload(lv, e->stream, Dt, &dD))) return rc;
+        if ((rc = dev_upload(lv, e->stream, zeros, &dW))) return rc;
+        if ((rc = dev_upload(lv, e->stream, zeros, &dC))) return rc;
+        bk.Q = dQ; bk.D = dD; bk.what = dW; bk.C = dC;
+    } else {
+        if (r != n || !(n >= 64 && n <= BLK_FOURIER_MAX_N && (n & (n - 1)) == 0))
+            return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve of an Advection1D level: all n modes, n a power of two in [64, %d] (n = %d, r = %d)", BLK_FOURIER_MAX_N, n, r);
+        // twiddles and the blocks' complex propagators (the oracle's orc_fft_twiddles / orc_adv_block_propagators: same expressions)
+        std::vector<double> W((size_t)n, 0.0), Dt((size_t)B * n * 2, 0.0);
+        for (int t = 0; t < n / 2; ++t) {
+            const double ang = 2.0 * M_PI * (double)t / (double)n;
+            W[2 * (size_t)t] = sep_cos(ang); W[2 * (size_t)t + 1] = -sep_sin(ang);
+        }
+        for (int b = 0; b < B; ++b) {
+            const int first = BLK_K * b + 1, last = b == B - 1 ? nt - 1 : BLK_K * (b + 1);
+            for (int k = 0; k < n; ++k) {
+                const double th = 2.0 * M_PI * (double)k / (double)n, cs = sep_cos(th), sn = sep_sin(th);
+                double pr = 1.0, pi = 0.0;
+                for (int i = first; i <= last; ++i) {
+                    const double alpha = (lv.t_host[i] - lv.t_host[i - 1]) * lv.fac;
+                    const double mr = (1.0 + alpha) - alpha * cs, mi = alpha * sn, den = mr * mr + mi * mi;
+                    const double dr = mr / den, di = -mi / den;
+                    const double qr = pr * dr - pi * di, qi = pr * di + pi * dr;
+                    pr = qr; pi = qi;
+                }
+                Dt[((size_t)b * n + k) * 2] = pr; Dt[((size_t)b * n + k) * 2 + 1] = pi;
+            }
+        }
+        std::vector<double> zeros((size_t)B * n * 2, 0.0);
+        double *dT, *dD, *dW, *dC;
+        if ((rc = dev_upload(lv, e->stream, W, &dT))) return rc;
+        if ((rc = dev_upload(lv, e->stream, Dt, &dD))) return rc;
+        if ((rc = dev_upload(lv, e->stream, zeros, &dW))) return rc;
+        if ((rc = dev_upload(lv, e->stream, zeros, &dC))) return rc;
+        bk.tw = reinterpret_cast<const double2 *>(dT); bk.D = dD; bk.what = dW; bk.C = dC;
+        bk.fourier = 1;
+        bk.lg_n = 0;
+        while ((1 << bk.lg_n) < n) ++bk.lg_n;
+    }
     bk.uh_in = uh_in; bk.uh_out = has_successor ? uh_out : nullptr;
     bk.r = r; bk.B = B; bk.n_steps = nt - 1;
     bk.first_real = first_real ? 1 : 0;
     bk.project_last = has_successor ? 1 : 0;
     bk.skip_last_row = 0;
+    lv.blk = bk;
     return 0;
 }
 
@@ -2789,9 +2990,11 @@ int mgrit_hip_chain_resume(mgrit_hip_engine *e, int lvl, int on) {
     return 0;
 }
 
-int mgrit_hip_block_solve_rank(int n, double fac, int nt, const double *t, int *r_out) {
+int mgrit_hip_block_solve_rank(int stepper, int n, double fac, int nt, const double *t, int *r_out) {
     if (!r_out || (nt > 0 && !t)) return fail(MGRIT_HIP_EINVAL, "null argument");
-    *r_out = (n >= 2 && n <= MGRIT_HIP_MAX_N && nt >= 2) ? blk_rank(n, fac, nt, t, nullptr) : 0;
+    *r_out = 0;
+    if (stepper == MGRIT_HIP_STEPPER_HEAT1D) *r_out = (n >= 2 && n <= MGRIT_HIP_MAX_N && nt >= 2) ? blk_rank(n, fac, nt, t, nullptr) : 0;
+    else if (stepper == MGRIT_HIP_STEPPER_ADVECTION1D) *r_out = blk_fourier_ok(n, nt) ? n : 0;
     return 0;
 }
 
@@ -2809,7 +3012,8 @@ int mgrit_hip_block_solve_state(mgrit_hip_engine *e, int lvl, int *r_out) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
     if (!r_out) return fail(MGRIT_HIP_EINVAL, "null output");
-    *r_out = e->L[lvl].blk_state < 0 ? 0 : e->L[lvl].blk.r;
+    const Level &lv = e->L[lvl];
+    *r_out = lv.blk_state < 0 ? 0 : (lv.h2d ? (lv.blk_state > 0 ? lv.h2d->dev.mi * lv.h2d->dev.mj : 0) : lv.blk.r);
     return 0;
 }
 
@@ -2906,6 +3110,10 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     if (rl->n == 0) return 0;
     Timed timed(e, mode == MGRIT_HIP_RELAX_F ? MGRIT_HIP_T_RELAX_F : mode == MGRIT_HIP_RELAX_CHAIN ? MGRIT_HIP_T_CHAIN :
                    mode == MGRIT_HIP_RELAX_FC ? MGRIT_HIP_T_RELAX_FC : MGRIT_HIP_T_RELAX_C, lvl);
+    const bool whole_chain = mode == MGRIT_HIP_RELAX_CHAIN && lvl > 0 && rl->n == 1 && rl->h_start[0] == 1 && rl->h_len[0] == lv.dev.n_pts - 1;
+    // the whole level: the time-parallel form where the level qualifies (not configured yet: the engine's own rule)
+    if (whole_chain && lv.blk_state < 0 && (rc = mgrit_hip_block_solve_config(e, lvl, -1, 1, 0, nullptr, nullptr))) return rc;
+    if (lv.h2d && whole_chain && lv.blk_state > 0) return h2d_block_solve(e, lvl);
     if (lv.h2d) return h2d_relax(e, lvl, rl, mode, weight_c);
     if (lv.wide) return wide_relax(e, lvl, rl, mode, weight_c);
     if (is_2pts(lv)) {
@@ -2923,9 +3131,7 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    if (mode == MGRIT_HIP_RELAX_CHAIN && lvl > 0 && rl->n == 1 && rl->h_start[0] == 1 && rl->h_len[0] == lv.dev.n_pts - 1) {
-        // the whole level: the time-parallel form where the level qualifies (r = -1: the engine's own rule, first use)
-        if (lv.blk_state < 0 && (rc = mgrit_hip_block_solve_config(e, lvl, -1, 1, 0, nullptr, nullptr))) return rc;
+    if (whole_chain) {
         if (lv.blk.r > 0) {
             if (!lv.blk.first_real || lv.blk.project_last)
                 return fail(MGRIT_HIP_EINVAL, "level %d is one rank's part of a sharded solve: call mgrit_hip_block_solve by phases", lvl);

@@ -20,6 +20,17 @@ def oracle():
     return orc
 
 
+@pytest.fixture
+def sequential_coarse():
+    """forward_solve step by step (options.coarse_solve = 'sequential') for the tests of the chain kernels themselves: levels that
+    qualify for the time-parallel form would otherwise never reach them. The oracle side: block_solve=False."""
+    from pymgrit_amd.core.options import options
+    was = options.coarse_solve
+    options.coarse_solve = "sequential"
+    yield
+    options.coarse_solve = was
+
+
 # Order of the suite (matters under `pytest -x`): the C ABI and the single-process oracle comparisons first, every test
 # that starts other processes or rank threads last, so a fault of the multi-process harness can never hide a parity test.
 _ORDER = ["test_hip_abi", "test_hip_parity", "test_hip_heat2d", "test_hip_fuzz", "test_hip_bdf", "test_advection_sc",

@@ -322,6 +322,14 @@ def make_solve_block():
     out["heat_blk_nonuniform_F"] = run(nu, tol=1e-9, max_iter=6, cycle_type='F', sample_pts=(3, 200, 400))
     out["heat_blk_noforcing_cf0"] = run(heat_levels(65, [513, 129], forcing=False), tol=1e-9, max_iter=6, cf_iter=0,
                                         nested_iteration=False, sample_pts=(512,))
+
+    def adv(nx, ts):
+        return [Advection1D(c=1, x_start=-1, x_end=1, nx=nx, t_interval=t) for t in ts]
+    out["advection_blk_nx257_3lvl_F"] = run(adv(257, [np.linspace(0, 2, nt) for nt in (1025, 257, 65)]), cycle_type='F', max_iter=6,
+                                            sample_pts=(512, 1024))
+    out["advection_blk_nx1025_2lvl"] = run(adv(1025, [np.linspace(0, 2, nt) for nt in (513, 129)]), max_iter=4, sample_pts=(512,))
+    out["advection_blk_nonuniform"] = run(adv(129, [t0[::s] for s in (1, 2, 4)]), max_iter=6, nested_iteration=False,
+                                          sample_pts=(7, 400))
     return out
 
 
@@ -381,6 +389,9 @@ def make_heat2d():
     solve("cn_2lvl", levels(12, 10, [65, 33], method="CN", a=0.1), tol=1e-9, max_iter=8, nested_iteration=False)
     solve("be_weight_bc", levels(10, 14, [33, 9], with_bc=True), weight_c=1.2, tol=1e-9, max_iter=8, nested_iteration=False)
     solve("fe_2lvl", levels(8, 8, [257, 65], method="FE", a=0.05), tol=1e-9, max_iter=6, nested_iteration=False)
+    # coarsest levels of >= 64 steps: the device path's time-parallel forward solve (backward Euler)
+    solve("be_blk_2lvl_bc", levels(12, 10, [513, 65], with_bc=True), tol=1e-9, max_iter=6, nested_iteration=False)
+    solve("be_blk_3lvl_F", levels(9, 14, [641, 161, 81]), cycle_type='F', tol=1e-9, max_iter=5, nested_iteration=False)
     with open(os.path.join(HERE, "heat2d.json"), "w") as f:
         json.dump(meta, f, indent=1)
     np.savez_compressed(os.path.join(HERE, "heat2d.npz"), **arrays)

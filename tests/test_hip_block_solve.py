@@ -1,7 +1,8 @@
 """Time-parallel forward solve of the coarsest level (csrc/mgrit_hip_blk.inc; reference Mgrit.forward_solve,
 src/pymgrit/core/mgrit.py:459-486): the HIP path against the oracle's statement of the same arithmetic
 (oracle/mgrit_oracle.c heat1d_block_solve_spec) -- states bit for bit --, the rule that selects it (CPU: library against oracle),
-and both against the step-by-step form."""
+and both against the step-by-step form. Whole solves on such levels against the reference's fixtures: tests/test_hip_parity.py::
+test_solve_matches_oracle_and_reference[heat_blk_*]."""
 import ctypes as C
 
 import numpy as np
@@ -22,13 +23,29 @@ def _grids(nt0, strides):
 NONUNIFORM = [cases.BLK_T0, cases.BLK_T0[::2], cases.BLK_T0[::4]]
 
 SHAPES = [
-    ("nx33_4blocks", 33, _grids(1025, (4, 4)), True),             # one group, exactly 4 blocks
-    ("nx1024_2lvl", 1024, _grids(513, (4,)), True),               # 8 blocks
-    ("nx1027_rem", 1027, _grids(309, (4,)), False),               # 77 steps: 4 blocks, the last one of 29; two groups; no forcing
-    ("nx2050_nonuniform", 2050, NONUNIFORM, True),                # every step its own size, 100 steps = 5 x 16 + 20
-    ("nx4099", 4099, _grids(641, (2, 2)), True),                  # 160 steps, five groups
-    ("nx16384", 16384, _grids(129, (2,)), True),                  # the widest register-resident state, 64 steps
+    ("nx33_4blocks", "heat", 33, _grids(1025, (4, 4)), True),             # one group, exactly 4 blocks
+    ("nx1024_2lvl", "heat", 1024, _grids(513, (4,)), True),               # 8 blocks
+    ("nx1027_rem", "heat", 1027, _grids(309, (4,)), False),               # 77 steps: 4 blocks, the last one of 29; two groups; no forcing
+    ("nx2050_nonuniform", "heat", 2050, NONUNIFORM, True),                # every step its own size, 100 steps = 5 x 16 + 20
+    ("nx4099", "heat", 4099, _grids(641, (2, 2)), True),                  # 160 steps, five groups
+    ("nx16384", "heat", 16384, _grids(129, (2,)), True),                  # the widest register-resident state, 64 steps
+    # Advection1D: all n Fourier modes (n = nx - 1 a power of two)
+    ("adv_n64", "advection", 65, _grids(1025, (4, 4)), None),             # the smallest transform, 64 steps
+    ("adv_n1024_rem", "advection", 1025, _grids(309, (4,)), None),        # one group, last block of 29 steps
+    ("adv_n2048_nonuniform", "advection", 2049, NONUNIFORM, None),        # two groups (config 5's coarsest level), every step its own size
+    ("adv_n8192", "advection", 8193, _grids(129, (2,)), None),            # the largest transform: 128 KB of LDS
 ]
+
+
+def test_fourier_rule():
+    """Advection1D: all n modes when n is a power of two in [64, 8192] and the level has at least 64 steps, else step by step"""
+    from pymgrit_amd.core import hip_lib
+    lib = hip_lib.load()
+    t = np.linspace(0, 1, 200)
+    for n, nt, want in [(64, 200, 64), (2048, 65, 2048), (8192, 200, 8192), (16384, 200, 0), (32, 200, 0), (96, 200, 0), (1024, 64, 0)]:
+        r = C.c_int(-7)
+        hip_lib.check(lib.mgrit_hip_block_solve_rank(hip_lib.STEPPER_ADVECTION1D, n, 3.0, nt, np.ascontiguousarray(t[:nt]).ctypes.data_as(C.c_void_p), C.byref(r)))
+        assert r.value == want, (n, nt)
 
 
 def test_rank_rule_library_equals_oracle(oracle):
@@ -44,20 +61,23 @@ def test_rank_rule_library_equals_oracle(oracle):
         t = np.sort(rng.uniform(0, 2, nt)) if trial % 3 == 0 else np.linspace(0, float(rng.uniform(0.01, 50)), nt)
         spec = cases.heat_level_spec(nx, t)
         r = C.c_int(-7)
-        hip_lib.check(lib.mgrit_hip_block_solve_rank(spec["n"], spec["fac"], nt, np.ascontiguousarray(t).ctypes.data_as(C.c_void_p), C.byref(r)))
+        hip_lib.check(lib.mgrit_hip_block_solve_rank(hip_lib.STEPPER_HEAT1D, spec["n"], spec["fac"], nt, np.ascontiguousarray(t).ctypes.data_as(C.c_void_p), C.byref(r)))
         assert r.value == oracle.block_solve_rank(spec["n"], spec["fac"], t), (nx, nt)
         seen.add(min(r.value, 1))
     assert seen == {0, 1}
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,nx,grids,forcing", SHAPES, ids=[s[0] for s in SHAPES])
-def test_forward_solve_bit_exact(oracle, name, nx, grids, forcing):
+@pytest.mark.parametrize("name,kind,nx,grids,forcing", SHAPES, ids=[s[0] for s in SHAPES])
+def test_forward_solve_bit_exact(oracle, name, kind, nx, grids, forcing):
     from test_hip_parity import _need_gpu, assert_state_equal, make_pair, randomize
     _need_gpu()
-    mg, op = make_pair(oracle, "heat", nx, grids, forcing=forcing)
+    mg, op = make_pair(oracle, kind, nx, grids, **({"forcing": forcing} if kind == "heat" else {}))
     lvl = mg.lvl_max - 1
-    assert mg.backend.block_r[lvl] == oracle.block_solve_rank(op.n[lvl], cases.heat_level_spec(nx, grids[-1])["fac"], grids[-1]) > 0
+    if kind == "heat":
+        assert mg.backend.block_r[lvl] == oracle.block_solve_rank(op.n[lvl], cases.heat_level_spec(nx, grids[-1])["fac"], grids[-1]) > 0
+    else:
+        assert mg.backend.block_r[lvl] == op.n[lvl] == nx - 1
     randomize(mg, op, seed=nx)
     for rep in range(2):     # (twice: the second solve starts from rows the first one has written)
         mg.forward_solve(lvl); op.forward_solve(lvl)
@@ -96,24 +116,3 @@ def test_sequential_form_on_request(oracle):
     mg2.forward_solve(1)
     a, b = mg.backend.natural("u", 1), mg2.backend.natural("u", 1)
     assert np.abs(a - b).max() <= 1e-11 * np.abs(a).max()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(cases.block_cases()))
-def test_solve_matches_oracle_and_reference(oracle, name):
-    """whole solves whose coarsest level takes the time-parallel form: residual history equal to the oracle's (bar 1e-10 relative)
-    and inside the reference fixture's tolerance (tests/golden/solve.json, make_golden.make_solve_block)"""
-    from pymgrit_amd import Mgrit
-    from test_hip_parity import _need_gpu, heat_problem
-    _need_gpu()
-    case = cases.block_cases()[name]
-    levels = case["levels"]
-    nx = levels[0]["n"] + 2
-    prob = heat_problem(nx, [lv["t"] for lv in levels], forcing=levels[0].get("s") is not None)
-    res = Mgrit(prob, logging_lvl=30, **case["opts"]).solve()
-    ref = oracle.OracleProblem(levels, variant=1, **case["opts"]).solve()
-    m = min(len(ref), len(res["conv"]))
-    assert m >= 1 and np.all(np.abs(res["conv"][:m] - ref[:m]) <= 1e-10 * ref[:m])
-    fix = np.array(cases.load_json("solve.json")[name]["conv"])
-    m = min(len(fix), len(res["conv"]))
-    assert np.all(np.abs(res["conv"][:m] - fix[:m]) <= 1e-9 * fix[:m] + 2e-11)

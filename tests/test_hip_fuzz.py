@@ -45,10 +45,10 @@ def random_case(seed):
     # general whole-level passes apply in registers, at sizes on both sides of the lane, wave and group boundaries
     transfer = None
     if rng.random() < 0.3:
-        n = int(rng.choice([15, 31, 63, 127, 1023, 2047, 4095, 8191, 16383] if kind == "heat" else [16, 64, 128, 1024, 2048, 4096, 8192, 16384]))
+        n = int(rng.choice([15, 31, 63, 127, 1023, 2047, 4095, 8191, 16383] if kind == "heat" else [16, 20, 40, 64, 100, 128, 1000, 1024, 2048, 2064, 4000, 4096, 8192, 16384]))
         ns, transfer = [n], []
         for _ in range(len(grids) - 1):
-            halve = n >= 15 and rng.random() < 0.7
+            halve = n >= 15 and (kind == "heat" or n % 2 == 0) and rng.random() < 0.7   # (ragged periodic sizes: coarse counts off the lane size)
             n = ((n - 1) // 2 if kind == "heat" else n // 2) if halve else n
             ns.append(n)
             transfer.append((1 if kind == "heat" else 2) if halve else 0)

@@ -102,6 +102,25 @@ def test_config5_scale_passes_bit_exact(oracle):
     _by_hand(mg, op, [0, 1], 2)
 
 
+@pytest.mark.parametrize("nxs", [(101, 51), (21, 11), (4001, 2001, 1001, 501), (2065, 1033), (41, 21, 11)])
+def test_periodic_passes_with_ragged_coarse_sizes(oracle, nxs):
+    """periodic coarse grids whose size is NOT a multiple of 8 (a lane holds 8 coarse values): the last coarse value sits in the
+    middle of a lane and its right neighbour is value 0 (round-3 advisor finding: the interpolation of the way up took a masked
+    zero there). 100 -> 50, 20 -> 10, 4000 -> 2000 -> 1000 -> 500, 2064 -> 1032 (two groups), 40 -> 20 -> 10 unknowns"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from test_hip_parity import randomize
+    from pymgrit_amd import Advection1D, GridTransferAdvection, Mgrit
+    t0 = np.linspace(0, 0.05, 2 ** (len(nxs) + 2) + 1)
+    ts = [t0[::2 ** k] for k in range(len(nxs))]
+    prob = [Advection1D(c=1, x_start=-1, x_end=1, nx=nx, t_interval=t) for nx, t in zip(nxs, ts)]
+    mg = Mgrit(prob, transfer=[GridTransferAdvection() for _ in nxs[1:]], nested_iteration=False, logging_lvl=30)
+    op = oracle.OracleProblem([cases.advection_level_spec(nx, t) for nx, t in zip(nxs, ts)], transfer=[2] * (len(nxs) - 1), variant=1,
+                              nested_iteration=False)
+    randomize(mg, op, seed=nxs[0])
+    _by_hand(mg, op, list(range(len(nxs) - 1)), len(nxs) - 1)
+
+
 @pytest.mark.parametrize("nxs", [(4097, 2049, 1025), (131, 66), (37, 19, 10)])
 def test_heat_full_weighting_passes_bit_exact(oracle, nxs):
     """Heat1D with full weighting / linear interpolation (n_f = 2 n_c + 1): states of one group and of four, two, one (4095 -> 2047 -> 1023

@@ -69,6 +69,41 @@ def test_sweeps_bit_exact(oracle, method, with_bc, nx, ny):
         assert np.array_equal(got, ref), np.abs(got - ref).max()
 
 
+BLK_SHAPES = [("be_bc_66x67_uniform", True, 66, 67, None), ("be_130x131_nonuniform", False, 130, 131, 1.3), ("be_bc_20x17_rem", True, 20, 17, None)]
+
+
+@pytest.mark.parametrize("name,with_bc,nx,ny,power", BLK_SHAPES, ids=[s[0] for s in BLK_SHAPES])
+def test_time_parallel_forward_solve_bit_exact(oracle, name, with_bc, nx, ny, power):
+    """coarsest levels of >= 64 steps, backward Euler: the time-parallel forward solve (blocks of 16 steps from
+    zero states, the block ends through the full sine spectrum) against the oracle's statement of it, random states; uniform
+    steps, every step its own size, a last block that takes the remainder (77 steps = 3 x 16 + 29); and the step-by-step form
+    on request"""
+    from pymgrit_amd.core.options import options
+    assert torch.cuda.is_available()
+    t0 = np.linspace(0, 1, 309) if power is None else np.linspace(0, 1, 321) ** power
+    ts = [t0, t0[::4]]
+    prob = [cases.h2d_app(nx, ny, t, "BE", with_bc) for t in ts]
+    mg, op = _pair(oracle, prob)
+    assert mg.backend.block_r[1] == (nx - 2) * (ny - 2)
+    _randomize(mg, op, nx)
+    for rep in range(2):
+        mg.forward_solve(1); op.forward_solve(1)
+        _equal(mg, op)
+    mg.iteration(lvl=0, cycle_type='V', iteration=0, first_f=True); op.iteration(0, 'V', 0, True)
+    _equal(mg, op)
+    was = options.coarse_solve
+    try:
+        options.coarse_solve = "sequential"
+        mg2, _ = _pair(oracle, [cases.h2d_app(nx, ny, t, "BE", with_bc) for t in ts])
+    finally:
+        options.coarse_solve = was
+    op2 = oracle.OracleProblem([cases.h2d_level_spec(a) for a in prob], nested_iteration=False, block_solve=False)
+    assert mg2.backend.block_r[1] == 0
+    _randomize(mg2, op2, nx)
+    mg2.forward_solve(1); op2.forward_solve(1)
+    _equal(mg2, op2)
+
+
 @pytest.mark.parametrize("name", sorted(cases.H2D_SOLVE))
 def test_solve_matches_oracle_and_reference(oracle, name):
     from pymgrit_amd import Mgrit

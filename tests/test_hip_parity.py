@@ -173,6 +173,11 @@ def build_product(name):
         "heat_config2": ("heat", 1024, 1.0, True),
         "heat_nx2050_wide": ("heat", 2050, 1.0, True), "heat_nx1500_wide_F": ("heat", 1500, 1.0, False),
         "heat_nx3100_wide_2lvl": ("heat", 3100, 1.0, True),
+        # coarsest levels whose forward solve takes the time-parallel form
+        "heat_blk_nx257_3lvl": ("heat", 257, 1.0, True), "heat_blk_nx2050_2lvl": ("heat", 2050, 1.0, True),
+        "heat_blk_nonuniform_F": ("heat", 129, 1.0, True), "heat_blk_noforcing_cf0": ("heat", 65, 1.0, False),
+        "advection_blk_nx257_3lvl_F": ("advection", 257, None, None), "advection_blk_nx1025_2lvl": ("advection", 1025, None, None),
+        "advection_blk_nonuniform": ("advection", 129, None, None),
     }
     c = cases.solve_cases()[name]
     kind, nx, x_end, forcing = P.get(name, ("heat", 33, 1.0, True))

@@ -61,9 +61,9 @@ def test_merged_way_up_bit_identical(monkeypatch, merge):
         assert np.array_equal(a, b)
 
 
-def test_planned_wide_chain_against_oracle(oracle):
-    """wide states, many coarsest points: the chain parts continue each other through the hand-over state; residual history
-    equal to the oracle's (same arithmetic spec) and the state bit-exact"""
+def test_planned_wide_chain_against_oracle(oracle, sequential_coarse):
+    """wide states, many coarsest points, the step-by-step forward solve: the chain parts continue each other through the hand-over
+    state; residual history equal to the oracle's (same arithmetic spec) and the state bit-exact"""
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU visible")
     from pymgrit_amd import Heat1D, Mgrit
@@ -75,7 +75,7 @@ def test_planned_wide_chain_against_oracle(oracle):
     conv = mg.solve()["conv"]
     plan = next(p for p in mg._plans.values() if p is not None)
     assert sum(1 for n in plan.order if n.stream == "chain") == 8
-    op = oracle.OracleProblem([cases.heat_level_spec(nx, g) for g in grids], variant=1, max_iter=3, tol=0.0)
+    op = oracle.OracleProblem([cases.heat_level_spec(nx, g) for g in grids], variant=1, max_iter=3, tol=0.0, block_solve=False)
     ref = op.solve()
     assert np.max(np.abs(conv - ref) / ref) <= 1e-10, (conv, ref)
     assert np.array_equal(mg.backend.natural("u", 0), op.state("u", 0))
