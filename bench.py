@@ -121,7 +121,28 @@ def cpu_baseline(nx, nt=16385):
     vn, used, cn, en = tried[best] if tried else (v1, 1, c1, e1)
     if v1 > vn:
         vn, used, cn, en = v1, 1, c1, e1
+    # calibration of the port against the reference itself: BASELINE.md section 2 holds the unmodified reference's
+    # numbers on config 2 (heat_1d nx=1024 nt=4097, 3-level m=4; one Python process on the 8-core build container, no GPU); the port
+    # runs the same configuration here, single-threaded, steady-state V-cycles incl. the residual check
+    nts2 = (4097, 1025, 257)
+    lv2 = [cases.heat_level_spec(1024, cases.lin(2.0, n)) for n in nts2]
+    p2 = orc.OracleProblem(lv2, variant=0, nested_iteration=False, max_iter=1, tol=0.0, norm_spec=False)
+    p2.iteration(0, 'V', 0, True)
+    t2, c2 = time.perf_counter(), 0
+    while c2 < 3 or time.perf_counter() - t2 < 1.0:
+        p2.iteration(0, 'V', 1, True)
+        p2.residual_norms()
+        c2 += 1
+    e2 = time.perf_counter() - t2
+    port2 = sum(c * 1022 for c in phi_counts(nts2, [4, 4])) * c2 / e2
+    reference = {"config": "BASELINE configs[1]: heat_1d nx=1024 (1022 DOF) nt=4097, 3-level m=4, V-cycle FCF", "updates_per_s": 2.61e6,
+                 "s_per_v_cycle": 4.97, "s_per_residual_check": 0.55, "processes": 1,
+                 "provenance": "BASELINE.md section 2: the unmodified reference (PyMGRIT v1.0.6, scipy SuperLU per step) measured in the "
+                               "8-core build container during the survey; it cannot travel to the GPU box",
+                 "port_same_config_updates_per_s_1core": port2, "port_over_reference": port2 / 2.61e6,
+                 "port_sample": f"{c2} V-cycles incl. residual check in {e2:.2f} s on 1 core of this host"}
     return {"value": vn, "unit": "time-point-DOF updates/s", "cores": used, "kind": "port", "value_1core": v1,
+            "reference_python": reference,
             "host_cores": os.cpu_count(), "by_threads": {str(t): r[0] for t, r in tried.items()},
             "sample": f"port = parity oracle variant 0 (Thomas solves, reference operation order), {used} of {os.cpu_count()} "
                       f"cores: heat_1d nx={nx} nt={nts[0]} 3-level m=4 ({(nts[0] - 1) // 4} F-intervals per level-0 sweep), "
@@ -136,8 +157,18 @@ def iters_to_tol(problem, nx, tol=1e-10):
     import cases
     from oracle import oracle as orc
     from pymgrit_amd import Heat1D, Mgrit
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=True, max_iter=30, tol=tol, logging_lvl=30)
-    conv_full = mg.solve()["conv"]
+    res = mg.solve()
+    torch.cuda.synchronize()
+    tts = {"note": f"Mgrit(...).solve() of the full workload to {tol:g} on this GPU, slabs and tables already described once (warm "
+                   f"library): setup = constructor incl. nested iteration, solve = the iterations incl. every stopping test and the "
+                   f"final F-relaxation that puts all F-points in place",
+           "setup_ms": 1e3 * res["time_setup"], "solve_ms": 1e3 * res["time_solve"], "wall_ms": 1e3 * (time.perf_counter() - t0),
+           "iterations": int(len(res["conv"]))}
+    conv_full = res["conv"]
     del mg
     nts = (1025, 257, 65)
     grids = [cases.lin(2.0 * (nts[0] - 1) / 65536, nt) for nt in nts]
@@ -147,7 +178,7 @@ def iters_to_tol(problem, nx, tol=1e-10):
     conv_cpu = orc.OracleProblem([cases.heat_level_spec(nx, g) for g in grids], variant=1, cf_iter=1, nested_iteration=True,
                                  max_iter=30, tol=tol).solve()
     k = min(len(conv_gpu), len(conv_cpu))
-    return {"tol": tol, "full_workload": {"gpu_iters": int(len(conv_full)), "conv_last": float(conv_full[-1])},
+    return {"tol": tol, "time_to_solution_ms": tts, "full_workload": {"gpu_iters": int(len(conv_full)), "conv_last": float(conv_full[-1])},
             "sample_nt1025": {"gpu_iters": int(len(conv_gpu)), "cpu_iters": int(len(conv_cpu)),
                               "max_rel_conv_diff": float(np.max(np.abs(conv_gpu[:k] - conv_cpu[:k]) / np.abs(conv_cpu[:k])))}}
 
@@ -405,18 +436,38 @@ def timed_sweeps(mg, be, cycle, cycles=2):
             for key, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])}
 
 
-def pmc_traffic(nx, nt0, world):
+def build_stamp():
+    """what the kernels were built from: sha256 over csrc/*.hip, csrc/*.inc and include/*.h (sorted by name), and of the library
+    itself. profiles/<tag>_traffic.json carries the stamp of the build its counters were collected on (tools/summarize_profiles.py,
+    run on the GPU box by tools/profile_round.sh)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "pymgrit_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "pymgrit_amd", "csrc", "*.inc")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    lib = os.path.join(ROOT, "pymgrit_amd", "lib", "libmgrit_hip.so")
+    return {"source_sha256": h.hexdigest(), "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None}
+
+
+def pmc_traffic(nx, nt0, world, name="traffic"):
     """per-kernel HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload
-    (tools/profile_round.sh -> profiles/<tag>_traffic.json; program order, full-width launches), or ({}, None)"""
+    (tools/profile_round.sh -> profiles/<tag>_<name>.json; program order, full-width launches): (kernels, source, stale). The file
+    must carry the stamp of THIS build (build_stamp): counters collected on other kernels price nothing -- ({}, reason, True)."""
     if not (world == 1 and nx == 16384 and nt0 == 65537):
-        return {}, None
-    for tag in ("r03", "r02", "r01"):
-        tfile = os.path.join(ROOT, "profiles", f"{tag}_traffic.json")
+        return {}, None, False
+    for tag in ("r04",):
+        tfile = os.path.join(ROOT, "profiles", f"{tag}_{name}.json")
         if os.path.exists(tfile):
-            return json.load(open(tfile))["kernels"], (f"profiles/{tag}_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                                       f"passes, KiB units, read side doubled per the guide's gfx950 note; committed "
-                                                       f"with the round, not collected in this run)")
-    return {}, None
+            rec = json.load(open(tfile))
+            have, want = (rec.get("build") or {}).get("source_sha256"), build_stamp()["source_sha256"]
+            if have != want:
+                return {}, f"profiles/{tag}_{name}.json was collected on another build (sources {str(have)[:12]} there, {want[:12]} here): not used", True
+            return rec["kernels"], (f"profiles/{tag}_{name}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KiB units, read "
+                                    f"side doubled per the guide's gfx950 note; collected on this build, sources {want[:12]}; not "
+                                    f"collected in this run)"), False
+    return {}, None, False
 
 
 def sweep_table(mg, be, nts, m_list, dof, cycle, cycles=3):
@@ -444,7 +495,9 @@ def sweep_table(mg, be, nts, m_list, dof, cycle, cycles=3):
     for key, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         kind = key.split()[0]
         sym = KERNEL_OF.get(kind, kind).format(g="true" if not key.endswith("L0") else "false")
-        if kind == "chain" and dof <= 1024:
+        if kind == "chain" and getattr(be, "block_r", {}).get(len(nts) - 1):
+            sym = "blk_local_kernel + blk_scan_kernel + blk_finish_kernel"     # the time-parallel forward solve
+        elif kind == "chain" and dof <= 1024:
             sym = "chain_kernel<1, 1, true, true>"    # one group of values: the single-workgroup chain, no exchange
         table[key] = {"kernel_symbol": sym, "launches_per_cycle": n / cycles, "ms_per_launch": tot / n, "ms_per_cycle": tot / cycles,
                       "algorithmic_bytes_per_cycle": alg.get(key, 0.0),
@@ -799,14 +852,28 @@ def main():
     # these are the kernel times a rocprofv3 --kernel-trace --stats run of `bench.py --plan-blocks 1` shows per kernel)
     table = sweep_table(mg, be, nts, [4, 4], dof, cycle)
     local_share = 1.0 / world      # the table holds THIS rank's launches: its share of the job's bytes
-    pmc, pmc_src = pmc_traffic(nx, nt0, world)
+    pmc, pmc_src, pmc_stale = pmc_traffic(nx, nt0, world)
+
+    def pmc_bytes(sym):
+        """HBM bytes per launch of a table row's kernel(s) from the PMC file; a row of several kernels (the time-parallel solve): their sum"""
+        if not pmc:
+            return None
+        parts = [p.strip() for p in sym.split(" + ")]
+        tot, hit = 0.0, 0
+        for part in parts:
+            for name, rec in pmc.items():
+                if name == part or (len(parts) > 1 and name.startswith(part)):
+                    tot += rec["hbm_bytes_per_launch"]
+                    hit += 1
+        return tot if hit >= len(parts) else None
+
     for row in table.values():
         # algorithmic = SURVEY 8d's bytes of the SWEEPS a launch stands for (a whole-level pass stands for two or three of them
         # and keeps the state in registers between them, so it moves far fewer bytes than that); physical = what the HBM
         # counters saw. Only physical bytes are priced against the HBM roofline.
         row["algorithmic_bytes_per_cycle"] *= local_share
-        k = pmc.get(row["kernel_symbol"])
-        phys = k["hbm_bytes_per_launch"] * row["launches_per_cycle"] if k else None
+        per_launch = pmc_bytes(row["kernel_symbol"])
+        phys = per_launch * row["launches_per_cycle"] if per_launch else None
         row["physical_bytes_per_cycle"] = phys
         row["physical_GBps"] = phys / (row["ms_per_cycle"] * 1e-3) / 1e9 if (phys and row["ms_per_cycle"]) else None
         row["physical_frac"] = row["physical_GBps"] / HBM_PEAK_GBS if row["physical_GBps"] else None
@@ -837,19 +904,39 @@ def main():
     cycle_bytes = sum(r["algorithmic_bytes_per_cycle"] for r in table.values()) / local_share
     ms_step = 1e3 * elapsed / args.steps
 
-    k = pmc.get(dom["kernel_symbol"])
-    traffic, traffic_src = (k["hbm_bytes_per_launch"], pmc_src) if k else (None, None)
+    traffic = pmc_bytes(dom["kernel_symbol"])
+    traffic_src = pmc_src
     phys_cycle = sum(r["physical_bytes_per_cycle"] or 0.0 for r in table.values()) if pmc else None
     # Phi applications the ENGINE performs per cycle (the work model behind `value` counts the sweeps of the reference's cycle,
-    # SURVEY 3.5): with pre-relaxed C-points the level-0 C-relaxation's Phi is the residual check's of the cycle before
+    # SURVEY 3.5): with pre-relaxed C-points the level-0 C-relaxation's Phi is the residual check's of the cycle before;
+    # the time-parallel coarsest-level solve applies two Phi per step (less block 0's second pass and one per block)
     applied = list(counts)
     if not args.at_k and mg.cf_iter[0] == 1 and os.environ.get("PYMGRIT_AMD_NO_PRE_RELAX", "") != "1" and mg._level_intervals(0) is not None:
         applied[0] -= (nts[0] - 1) // 4
-    dom_alg = dom["algorithmic_bytes_per_cycle"] / max(dom["launches_per_cycle"], 1)
+    if getattr(be, "block_r", {}).get(len(nts) - 1):
+        n_c = nts[-1] - 1
+        applied[-1] += n_c - 16 - (n_c // 16 - 1)
+    # The roofline entry: the kernel with the largest share of the cycle's device time. For a whole-level pass the ALGORITHMIC bytes
+    # are the rows the pass itself has to move (it stands for three sweeps of the reference's cycle but keeps the state
+    # in registers between them -- the sweeps' own 8d bytes are listed beside it as `unfused_algorithmic_bytes_per_launch`)
+    dom_unfused = dom["algorithmic_bytes_per_cycle"] / max(dom["launches_per_cycle"], 1)
+    kind = dominant.split()[0]
+    n_int = ((nts[0] - 1) // 4) * local_share
+    row_b = 8.0 * dof
+    if kind == "cf_fas":       # per interval: 1 row read (the pre-relaxed C-point); written: the C-point, g^{l+1}, u^{l+1} at the coarse
+                               # level's C-points (1 in 4), v^{l+1} where a chunk of the way up starts (1 in 4)
+        dom_alg = n_int * 3.5 * row_b
+    elif kind == "ec_relax_res":   # per interval: u^{l+1} and the fine C-point read (+ v^{l+1} at chunk starts); the C-point and the last F-point written
+        dom_alg = n_int * 4.25 * row_b
+    else:
+        dom_alg = dom_unfused
     dom_gbs = dom_alg / (dom["ms_per_launch"] * 1e-3) / 1e9
+    applied_updates = float(sum(c * dof for c in applied))
 
     out = {
         "metric": "time-point-DOF updates/sec per MGRIT V-cycle", "value": updates_per_cycle * args.steps / elapsed,
+        # the same with the Phi applications the engine really executes (config.phi_applied_by_level)
+        "value_applied": applied_updates * args.steps / elapsed,
         "unit": "time-point-DOF updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
@@ -863,7 +950,8 @@ def main():
         # the kernel that takes the largest share of the cycle's device time (this rank), priced against the HBM roofline with
         # SURVEY 8d's algorithmic bytes; `limited_by` says what really bounds it
         "roofline": {"bound": "hbm", "achieved": dom_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "frac": dom_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "stale": bool(pmc_stale),
+                     "unfused_algorithmic_bytes_per_launch": dom_unfused,
                      "kernel": f"{dom['kernel_symbol']} ({dominant})", "launch_ms": dom["ms_per_launch"],
                      "launches_per_cycle": dom["launches_per_cycle"], "ms_per_cycle": dom["ms_per_cycle"],
                      "algorithmic_bytes_per_launch": dom_alg, "limited_by": dom["limited_by"]},
@@ -906,6 +994,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx)
             out["iters_to_tol"] = iters_to_tol(problem, nx)
+            out["time_to_solution_ms"] = out["iters_to_tol"].pop("time_to_solution_ms", None)
             if (nx, nt0) == (16384, 65537) and not args.all_configs and not args.at_k:
                 # the other GPU configurations of BASELINE.json, each measured in a child process of its own AFTER everything
                 # above, folded into this ONE line (the full lines: --all-configs); a failure there never touches the headline

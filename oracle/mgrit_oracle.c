@@ -1365,12 +1365,16 @@ static void heat1d_chain_spec(orc_problem *p, int lvl) {
  * q_k(j) = sqrt(2/(n+1)) sin(pi (k+1)(j+1)/(n+1)), and the block's propagator prod_i (I + dt_i L)^{-1} has the eigenvalues
  * D_b(k) = prod_i 1/(1 + dt_i fac 4 sin^2(theta_k/2)), which fall below 2^-60 from mode r on (the rule that makes a level
  * eligible: r <= ORC_BLK_RMAX) --, and the interiors of the blocks are stepped again from the corrected block starts.
- *   phase 1   block 0: u_i = g_i + Phi(u_{i-1}) from u_0 (final values). Blocks b >= 1: x = 0, x = g_i + Phi(x) over the block,
- *             W_b = x stored in the row of the block's last point e_b
- *   phase 2a  what_b(k) = <q_k, u[e_b]>, b = 0 .. B-2 (reduction tree of 3.4: lane-local fma chain, xor butterfly, groups in order)
+ * The scheme works on the DEFECT of the level's current values u (the injected fine values of the FAS cycle): with the error e of u,
+ * e_i = r_i + Phi_lin(e_{i-1}), r_i = g_i + Phi(u_{i-1}) - u_i, every block propagates its own defects from a zero error,
+ *   phase 1   every block: x = 0; over the block's steps x = (g_i + Phi(u_{i-1} + x)) - u_i  (= r_i + Phi_lin(x) up to rounding; the
+ *             first step takes u_{i-1} itself), W_b = x kept aside. Values u that already satisfy u_i = g_i + Phi(u_{i-1}) bit for
+ *             bit give x = 0 throughout: the solve then changes nothing -- the property that lets the MGRIT iteration converge to
+ *             rounding level (a solve that re-derived u from scratch would differ from it by eps cond(Phi) in every cycle)
+ *   phase 2a  what_b(k) = <q_k, W_b>, b = 0 .. B-2 (reduction tree of 3.4: lane-local fma chain, xor butterfly, groups in order)
  *   phase 2b  Uh = what_0; for b = 1 .. B-1: c_b = D_b * Uh (product), Uh = what_b + c_b
- *   phase 2c  u[e_b] = W_b + sum_k q_k c_b(k), b >= 1: x = fma(q_k(j), c_b(k), x) for k ascending
- *   phase 3   blocks b >= 1: x = u[e_{b-1}]; u_i = g_i + Phi(x) for the points strictly inside the block
+ *   phase 2c  u[e_b] = u[e_b] + E_b, E_0 = W_0, E_b = W_b + sum_k q_k c_b(k): x = fma(q_k(j), c_b(k), x) for k ascending from x = W_b
+ *   phase 3   every block: x = u[e_{b-1}] (u_0 for the first); u_i = g_i + Phi(x) for the points strictly inside the block
  * The same solve as the sequential one up to rounding and the truncation (2^-60 relative per block); every Phi is the step
  * of 3.3. The last block takes the remainder (K .. 2K-1 steps). A level with fewer than 4 K steps, a level 0 (a one-level
  * hierarchy is plain time stepping) and a level whose decay is too slow for ORC_BLK_RMAX modes are solved step by step.
@@ -1451,37 +1455,39 @@ static void heat1d_block_solve_spec(orc_problem *p, int lvl, int r) {
             long m = ((long)(k + 1) * (long)(j + 1)) % (2L * (n + 1));
             Q[(size_t)k * n + j] = sc * sin(M_PI * (double)m / (double)(n + 1));
         }
-    double *x = (double *)calloc((size_t)n, sizeof(double)), *what = (double *)calloc((size_t)B * r, sizeof(double));
+    double *x = (double *)calloc((size_t)n, sizeof(double)), *y = (double *)calloc((size_t)n, sizeof(double));
+    double *what = (double *)calloc((size_t)B * r, sizeof(double)), *Ws = (double *)calloc((size_t)B * n, sizeof(double));
     double *Uh = (double *)calloc((size_t)r, sizeof(double)), *c = (double *)calloc((size_t)r, sizeof(double));
-    /* phase 1 */
+    /* phase 1: the defect of the level's CURRENT values, propagated through every block from zero */
     for (int b = 0; b < B; ++b) {
         int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
-        if (b == 0) memcpy(x, ROW(L->u, L, 0), sizeof(double) * (size_t)n);
-        else memset(x, 0, sizeof(double) * (size_t)n);
         for (int i = first; i <= last; ++i) {
-            phi(p, lvl, i, x, p->tmp1);
-            const double *gi = ROW(L->g, L, i);
-            for (int j = 0; j < n; ++j) x[j] = gi[j] + p->tmp1[j];
-            if (b == 0) memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
+            const double *up = ROW(L->u, L, i - 1), *ui = ROW(L->u, L, i), *gi = ROW(L->g, L, i);
+            if (i == first) memcpy(y, up, sizeof(double) * (size_t)n);
+            else for (int j = 0; j < n; ++j) y[j] = up[j] + x[j];
+            phi(p, lvl, i, y, p->tmp1);
+            for (int j = 0; j < n; ++j) x[j] = (gi[j] + p->tmp1[j]) - ui[j];
         }
-        if (b > 0) memcpy(ROW(L->u, L, last), x, sizeof(double) * (size_t)n);
+        memcpy(Ws + (size_t)b * n, x, sizeof(double) * (size_t)n);
         if (b < B - 1)
             for (int k = 0; k < r; ++k) what[(size_t)b * r + k] = blk_dot(x, Q + (size_t)k * n, n);
     }
     /* phases 2b, 2c */
     memcpy(Uh, what, sizeof(double) * (size_t)r);
-    for (int b = 1; b < B; ++b) {
+    for (int b = 0; b < B; ++b) {
+        double *ue = ROW(L->u, L, blk_end(nt, B, b));
+        const double *wb = Ws + (size_t)b * n;
+        if (b == 0) { for (int j = 0; j < n; ++j) ue[j] = ue[j] + wb[j]; continue; }
         for (int k = 0; k < r; ++k) c[k] = D[(size_t)b * RM + k] * Uh[k];
         if (b < B - 1) for (int k = 0; k < r; ++k) Uh[k] = what[(size_t)b * r + k] + c[k];
-        double *ue = ROW(L->u, L, blk_end(nt, B, b));
         for (int j = 0; j < n; ++j) {
-            double v = ue[j];
+            double v = wb[j];
             for (int k = 0; k < r; ++k) v = fma(Q[(size_t)k * n + j], c[k], v);
-            ue[j] = v;
+            ue[j] = ue[j] + v;
         }
     }
     /* phase 3 */
-    for (int b = 1; b < B; ++b) {
+    for (int b = 0; b < B; ++b) {
         int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
         memcpy(x, ROW(L->u, L, first - 1), sizeof(double) * (size_t)n);
         for (int i = first; i < last; ++i) {
@@ -1491,7 +1497,7 @@ static void heat1d_block_solve_spec(orc_problem *p, int lvl, int r) {
             memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
         }
     }
-    free(D); free(Q); free(x); free(what); free(Uh); free(c);
+    free(D); free(Q); free(x); free(y); free(what); free(Ws); free(Uh); free(c);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1583,20 +1589,20 @@ static void advection_block_solve_spec(orc_problem *p, int lvl) {
     double *W = (double *)malloc(sizeof(double) * (size_t)n), *D = (double *)malloc(sizeof(double) * (size_t)B * n * 2);
     orc_fft_twiddles(n, W);
     orc_adv_block_propagators(n, L->st.fac, nt, L->t, D);
-    double *x = (double *)calloc((size_t)n, sizeof(double)), *what = (double *)calloc((size_t)B * n * 2, sizeof(double));
+    double *x = (double *)calloc((size_t)n, sizeof(double)), *y = (double *)calloc((size_t)n, sizeof(double));
+    double *what = (double *)calloc((size_t)B * n * 2, sizeof(double)), *Ws = (double *)calloc((size_t)B * n, sizeof(double));
     double *Uh = (double *)calloc((size_t)2 * n, sizeof(double)), *c = (double *)calloc((size_t)2 * n, sizeof(double));
     double inv_n = 1.0 / (double)n;
     for (int b = 0; b < B; ++b) {   /* phase 1 */
         int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
-        if (b == 0) memcpy(x, ROW(L->u, L, 0), sizeof(double) * (size_t)n);
-        else memset(x, 0, sizeof(double) * (size_t)n);
         for (int i = first; i <= last; ++i) {
-            phi(p, lvl, i, x, p->tmp1);
-            const double *gi = ROW(L->g, L, i);
-            for (int j = 0; j < n; ++j) x[j] = gi[j] + p->tmp1[j];
-            if (b == 0) memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
+            const double *up = ROW(L->u, L, i - 1), *ui = ROW(L->u, L, i), *gi = ROW(L->g, L, i);
+            if (i == first) memcpy(y, up, sizeof(double) * (size_t)n);
+            else for (int j = 0; j < n; ++j) y[j] = up[j] + x[j];
+            phi(p, lvl, i, y, p->tmp1);
+            for (int j = 0; j < n; ++j) x[j] = (gi[j] + p->tmp1[j]) - ui[j];
         }
-        if (b > 0) memcpy(ROW(L->u, L, last), x, sizeof(double) * (size_t)n);
+        memcpy(Ws + (size_t)b * n, x, sizeof(double) * (size_t)n);
         if (b < B - 1) {
             double *wb = what + (size_t)b * n * 2;
             for (int j = 0; j < n; ++j) { wb[2 * j] = x[j]; wb[2 * j + 1] = 0.0; }
@@ -1604,7 +1610,10 @@ static void advection_block_solve_spec(orc_problem *p, int lvl) {
         }
     }
     memcpy(Uh, what, sizeof(double) * (size_t)2 * n);
-    for (int b = 1; b < B; ++b) {   /* recurrence over the blocks + block ends */
+    for (int b = 0; b < B; ++b) {   /* recurrence over the blocks + block ends */
+        double *ue = ROW(L->u, L, blk_end(nt, B, b));
+        const double *ws = Ws + (size_t)b * n;
+        if (b == 0) { for (int j = 0; j < n; ++j) ue[j] = ue[j] + ws[j]; continue; }
         const double *Db = D + (size_t)b * n * 2, *wb = what + (size_t)b * n * 2;
         for (int k = 0; k < n; ++k) {
             double dr = Db[2 * k], di = Db[2 * k + 1], ur = Uh[2 * k], ui = Uh[2 * k + 1];
@@ -1613,10 +1622,9 @@ static void advection_block_solve_spec(orc_problem *p, int lvl) {
         }
         if (b < B - 1) for (int k = 0; k < 2 * n; ++k) Uh[k] = wb[k] + c[k];
         orc_fft_spec(c, n, W, 1);
-        double *ue = ROW(L->u, L, blk_end(nt, B, b));
-        for (int j = 0; j < n; ++j) ue[j] = ue[j] + c[2 * j] * inv_n;
+        for (int j = 0; j < n; ++j) ue[j] = ue[j] + (ws[j] + c[2 * j] * inv_n);
     }
-    for (int b = 1; b < B; ++b) {   /* phase 3 */
+    for (int b = 0; b < B; ++b) {   /* phase 3 */
         int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
         memcpy(x, ROW(L->u, L, first - 1), sizeof(double) * (size_t)n);
         for (int i = first; i < last; ++i) {
@@ -1626,7 +1634,7 @@ static void advection_block_solve_spec(orc_problem *p, int lvl) {
             memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
         }
     }
-    free(W); free(D); free(x); free(what); free(Uh); free(c);
+    free(W); free(D); free(x); free(y); free(what); free(Ws); free(Uh); free(c);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1661,21 +1669,21 @@ static void heat2d_block_solve_spec(orc_problem *p, int lvl) {
     orc_stepper *st = &L->st;
     int n = L->n, nt = L->nt, B = blk_count(nt), ny = st->ny, mi = st->mi, mj = st->mj, Mi = st->Mi, Mj = st->Mj;
     size_t per = (size_t)Mi * Mj;
-    double *x = (double *)calloc((size_t)n, sizeof(double)), *what = (double *)calloc((size_t)B * per, sizeof(double));
+    double *x = (double *)calloc((size_t)n, sizeof(double)), *y = (double *)calloc((size_t)n, sizeof(double));
+    double *what = (double *)calloc((size_t)B * per, sizeof(double)), *Ws = (double *)calloc((size_t)B * n, sizeof(double));
     double *D = (double *)malloc(sizeof(double) * per), *dv = (double *)malloc(sizeof(double) * per);
     double *Uh = (double *)calloc(per, sizeof(double)), *c = (double *)calloc(per, sizeof(double));
     double *P = (double *)calloc(per, sizeof(double)), *X = (double *)calloc(per, sizeof(double));
     for (int b = 0; b < B; ++b) {   /* phase 1 */
         int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
-        if (b == 0) memcpy(x, ROW(L->u, L, 0), sizeof(double) * (size_t)n);
-        else memset(x, 0, sizeof(double) * (size_t)n);
         for (int i = first; i <= last; ++i) {
-            phi(p, lvl, i, x, p->tmp1);
-            const double *gi = ROW(L->g, L, i);
-            for (int j = 0; j < n; ++j) x[j] = gi[j] + p->tmp1[j];
-            if (b == 0) memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
+            const double *up = ROW(L->u, L, i - 1), *ui = ROW(L->u, L, i), *gi = ROW(L->g, L, i);
+            if (i == first) memcpy(y, up, sizeof(double) * (size_t)n);
+            else for (int j = 0; j < n; ++j) y[j] = up[j] + x[j];
+            phi(p, lvl, i, y, p->tmp1);
+            for (int j = 0; j < n; ++j) x[j] = (gi[j] + p->tmp1[j]) - ui[j];
         }
-        if (b > 0) memcpy(ROW(L->u, L, last), x, sizeof(double) * (size_t)n);
+        memcpy(Ws + (size_t)b * n, x, sizeof(double) * (size_t)n);
         if (b < B - 1) {
             memset(P, 0, sizeof(double) * per);
             for (int a = 0; a < mi; ++a)
@@ -1685,8 +1693,12 @@ static void heat2d_block_solve_spec(orc_problem *p, int lvl) {
         }
     }
     memcpy(Uh, what, sizeof(double) * per);
-    for (int b = 1; b < B; ++b) {   /* recurrence over the blocks + block ends */
+    for (int b = 0; b < B; ++b) {   /* recurrence over the blocks + block ends: u[e_b] = (u[e_b] + W_b) + the propagated part (interior) */
         int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
+        double *ue = ROW(L->u, L, last);
+        const double *ws = Ws + (size_t)b * n;
+        for (int j = 0; j < n; ++j) ue[j] = ue[j] + ws[j];
+        if (b == 0) continue;
         for (int i = first; i <= last; ++i) {
             h2d_dinv_table(st, L->t[i] - L->t[i - 1], dv);
             if (i == first) memcpy(D, dv, sizeof(double) * per);
@@ -1696,14 +1708,13 @@ static void heat2d_block_solve_spec(orc_problem *p, int lvl) {
         if (b < B - 1) for (size_t q = 0; q < per; ++q) Uh[q] = what[(size_t)b * per + q] + c[q];
         h2d_inv(st->Fxe, st->Fxo, mi, st->HPx, c, Mj, X);
         h2d_inv(st->Fye, st->Fyo, mj, st->HPy, X, Mi, P);
-        double *ue = ROW(L->u, L, last);
         for (int a = 0; a < mi; ++a)
             for (int q = 0; q < mj; ++q) {
                 size_t g = (size_t)(a + 1) * ny + (q + 1);
                 ue[g] = ue[g] + P[(size_t)a * Mj + q];
             }
     }
-    for (int b = 1; b < B; ++b) {   /* phase 3 */
+    for (int b = 0; b < B; ++b) {   /* phase 3 */
         int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
         memcpy(x, ROW(L->u, L, first - 1), sizeof(double) * (size_t)n);
         for (int i = first; i < last; ++i) {
@@ -1713,8 +1724,8 @@ static void heat2d_block_solve_spec(orc_problem *p, int lvl) {
             memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
         }
     }
-    st->dinv_dt = -1.0;   /* (the step's own cached table is untouched, but be explicit) */
-    free(x); free(what); free(D); free(dv); free(Uh); free(c); free(P); free(X);
+    st->dinv_dt = -1.0;
+    free(x); free(y); free(what); free(Ws); free(D); free(dv); free(Uh); free(c); free(P); free(X);
 }
 
 void orc_problem_set_block_solve(orc_problem *p, int on) { p->no_block_solve = !on; }

@@ -315,6 +315,43 @@ class RcclTimeComm(TorchTimeComm):
         for comm in comms.values():
             lib.mgrit_hip_comm_destroy(comm, 1)
 
+    def ping_links(self, backend, buf_ptr, reps=5, timeout=20.0):
+        """collective pre-flight of every link of the job, one after the other in ONE global order (a barrier in front of each):
+        the sending rank enqueues `reps` messages of 8 doubles from buf_ptr (a device buffer of >= 8 doubles) and waits for its
+        stream, the receiving rank likewise; both waits are bounded. Returns {"src->dst/ch": microseconds per message (max of the
+        two ends)} on every rank, or raises the same RuntimeError on every rank naming the first pair that did not answer."""
+        import ctypes as C
+        import time
+        from pymgrit_amd.core import hip_lib
+        lib = hip_lib.load()
+        mine = self._engines[id(backend)].handle
+        every = sorted({tuple(k) for part in self.allgather_object([list(k) for k in self._comms]) for k in part})
+        res = {}
+        for src, dst, ch in every:
+            self.barrier()
+            us, err = None, None
+            role = 'send' if src == self.rank else 'recv' if dst == self.rank else None
+            if role is not None:
+                h = mine.get((dst if role == 'send' else src, role, ch))
+                if h is None:        # the link exists in the job but this engine has not attached it
+                    err = f"link {src}->{dst} channel {ch}: not attached on rank {self.rank}"
+                else:
+                    fn = lib.mgrit_hip_send if role == 'send' else lib.mgrit_hip_recv
+                    t0 = time.perf_counter()
+                    rc = 0
+                    for _ in range(reps):
+                        rc = rc or fn(backend.h, h, 0, C.c_void_p(buf_ptr), 8)
+                    rc = rc or lib.mgrit_hip_sync_bounded(backend.h, float(timeout))
+                    us = 1e6 * (time.perf_counter() - t0) / reps
+                    if rc != 0:
+                        err = f"link {src}->{dst} channel {ch}: rank {self.rank} ({role}) got no answer within {timeout} s"
+            got = self.allgather_object((us, err))
+            errs = [e for _, e in got if e]
+            if errs:
+                raise RuntimeError("exchange links: " + errs[0])
+            res[f"{src}->{dst}/{ch}"] = max(u for u, _ in got if u is not None)
+        return res
+
     def send_begin(self, backend, dest, channel):
         self.stats["messages"] += 1
         self.stats["device_messages"] += 1

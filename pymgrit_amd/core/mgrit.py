@@ -804,7 +804,7 @@ class Mgrit:
                 return [None]
             fc_runs = [(st, ln + 1) for st, ln in want]                       # the F-points and the C-point closing them
             triples = [(pairs[k][0], pairs[k - 1][0], pairs[k][1]) for k in range(1, len(pairs))]
-            skip_u = lvl + 1 == self.lvl_max - 1 and type(self).forward_solve is Mgrit.forward_solve
+            skip_u = lvl + 1 == self.lvl_max - 1 and self._coarsest_u_unread()
             return [(fc_runs, triples, pairs[:1] if self.comm_time_rank == 0 else [], skip_u)]
         return self._cached(('coarse_down', lvl), build)[0]
 
@@ -875,7 +875,7 @@ class Mgrit:
             # when the correction on the way up is not the pass that takes v from the fine C-point
             coarsest = lvl + 1 == self.lvl_max - 1
             if coarsest:
-                need_u = (lambda j: False) if type(self).forward_solve is Mgrit.forward_solve else (lambda j: True)
+                need_u = (lambda j: False) if self._coarsest_u_unread() else (lambda j: True)
             else:
                 c_next = {int(i) for i in self.index_local_c[lvl + 1]}
                 need_u = lambda j: j in c_next
@@ -988,6 +988,13 @@ class Mgrit:
                     self._announced_at = iteration
             self.conv[iteration] = time_norm(np.asarray(val, dtype=np.float64).ravel(), self.t_norm)
         self._log_sweep("Convergence criterion", t0)
+
+    def _coarsest_u_unread(self) -> bool:
+        """the step-by-step forward solve (mgrit.py:459-486) overwrites every point of the coarsest level but the first before
+        anything reads it, so the sweeps above need not store u there; the time-parallel form works on the defect
+        of the level's CURRENT values and reads them all"""
+        return (type(self).forward_solve is Mgrit.forward_solve and
+                not getattr(self.backend, "block_r", {}).get(self.lvl_max - 1))
 
     def forward_solve(self, lvl: int) -> None:
         """Sequential time stepping on level ``lvl`` (mgrit.py:459-486); op 5 = pipeline hand-off between owners."""

@@ -1347,10 +1347,9 @@ struct H2DHost {
     struct Blk {
         bool built = false;
         int B = 0;
-        std::vector<H2DPlan> p1_zero;
         std::vector<std::vector<H2DPlan>> p1, p3;
-        int32_t *d_end_all = nullptr, *d_end_tail = nullptr, *d_dsel = nullptr;   // rows e_0 .. e_{B-2}; rows e_1 .. e_{B-1}; table of block b
-        double *spec = nullptr, *Dtab = nullptr, *zero_row = nullptr;
+        int32_t *d_iota = nullptr, *d_end_all = nullptr, *d_end_tail = nullptr, *d_dsel = nullptr;   // 0 .. B-1; rows e_0 .. e_{B-1}; e_1 .. e_{B-1}; table of block b
+        double *spec = nullptr, *Dtab = nullptr, *X = nullptr, *Y = nullptr;   // spectra; propagator tables; the blocks' errors x and inputs u + x
     } blk;
     double *Wc0 = nullptr, *Wc1 = nullptr;   // one item each: the work buffers of the coarsest-level chain, which in a planned
                                              // cycle steps on a second stream BESIDE sweeps that apply this level's Phi too (the
@@ -2117,10 +2116,11 @@ int h2d_relax(mgrit_hip_engine *e, int lvl, RunList *rl, int mode, double weight
 }
 
 // Time-parallel forward solve of a Heat2D level with backward Euler (the oracle's heat2d_block_solve_spec): the level's
-// steps in blocks of BLK_K; first pass: step k of every block as ONE batch (all blocks but the first from a row of zeros);
-// the block ends through the forward transforms, the recurrence over the blocks on the full spectrum, the propagated parts back
-// through the inverse transforms straight into the rows (h2d_inv_kernel<true>, H2D_OP_ADD); second pass: the block interiors
-// from the corrected block starts, again one batch per step index. ~2 K batches of B states instead of K B single-state steps.
+// steps in blocks of BLK_K. First pass: step s of EVERY block as one batch -- the error x_b a block has accumulated,
+// x_b = (g_i + Phi(u_{i-1} + x_b)) - u_i from x_b = 0; the errors at the block ends through the forward transforms, the recurrence
+// over the blocks on the full spectrum, the propagated parts back through the inverse transforms straight into the rows
+// (h2d_inv_kernel<true>, H2D_OP_ADD); second pass: the block interiors from the corrected block starts, again one batch per step
+// index. ~2 K batches of B states instead of K B single-state steps.
 bool h2d_block_ok(const Level &lv, int lvl) {
     if (!lv.h2d || lvl == 0 || lv.h2d->dev.theta != 1.0) return false;
     const int N = lv.dev.n_pts - 1;
@@ -2140,20 +2140,19 @@ int h2d_block_build(mgrit_hip_engine *e, Level &lv) {
     for (int b = 0; b < B; ++b) maxlen = std::max(maxlen, last(b) - first(b) + 1);
     k.p1.resize(maxlen); k.p3.resize(maxlen);
     for (int s = 0; s < maxlen; ++s) {
-        std::vector<H2DItem> it1, itz, it3;
+        std::vector<H2DItem> it1, it3;
         for (int b = 0; b < B; ++b) {
             const int i = first(b) + s;
             if (i > last(b)) continue;
-            if (s == 0 && b >= 1) itz.push_back({0, i, i, i, i});   // from the row of zeros
-            else it1.push_back({i - 1, i, i, i, i});
-            if (b >= 1 && i < last(b)) it3.push_back({i - 1, i, i, i, i});
+            // first pass: input row = u_{i-1} (s = 0) or Y[b] = u_{i-1} + x_b; output x_b = (g_i + Phi) - u_i into X[b]
+            it1.push_back({s == 0 ? i - 1 : b, i, b, i, i});
+            if (i < last(b)) it3.push_back({i - 1, i, i, i, i});
         }
-        if (!itz.empty() && (rc = h2d_make_plans(e, lv, itz, k.p1_zero))) return rc;
         if (!it1.empty() && (rc = h2d_make_plans(e, lv, it1, k.p1[s]))) return rc;
         if (!it3.empty() && (rc = h2d_make_plans(e, lv, it3, k.p3[s]))) return rc;
     }
-    std::vector<int32_t> end_all, end_tail, dsel(B, 0);
-    for (int b = 0; b < B - 1; ++b) end_all.push_back(last(b));
+    std::vector<int32_t> iota(B), end_all, end_tail, dsel(B, 0);
+    for (int b = 0; b < B; ++b) { iota[b] = b; end_all.push_back(last(b)); }
     for (int b = 1; b < B; ++b) end_tail.push_back(last(b));
     // propagator tables: the elementwise product of the steps' D tables in step order; one table per distinct sequence of step sizes
     std::map<std::vector<uint64_t>, int> seen;
@@ -2181,15 +2180,17 @@ int h2d_block_build(mgrit_hip_engine *e, Level &lv) {
         }
         dsel[b] = it->second;
     }
+    if ((rc = dev_upload(lv, e->stream, iota, &k.d_iota))) return rc;
     if ((rc = dev_upload(lv, e->stream, end_all, &k.d_end_all))) return rc;
     if ((rc = dev_upload(lv, e->stream, end_tail, &k.d_end_tail))) return rc;
     if ((rc = dev_upload(lv, e->stream, dsel, &k.d_dsel))) return rc;
     if ((rc = dev_upload(lv, e->stream, tabs, &k.Dtab))) return rc;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&k.spec), sizeof(double) * per * (size_t)B));
-    lv.allocs.push_back(k.spec);
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&k.zero_row), sizeof(double) * (size_t)lv.dev.ld));
-    lv.allocs.push_back(k.zero_row);
-    HIP_TRY(hipMemsetAsync(k.zero_row, 0, sizeof(double) * (size_t)lv.dev.ld, e->stream));
+    for (double **buf : {&k.spec, &k.X, &k.Y}) {
+        const size_t doubles = (buf == &k.spec ? per : (size_t)lv.dev.ld) * (size_t)B;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(buf), sizeof(double) * doubles));
+        lv.allocs.push_back(*buf);
+        HIP_TRY(hipMemsetAsync(*buf, 0, sizeof(double) * doubles, e->stream));
+    }
     if ((rc = h2d_reserve(lv, std::min(H2D_MAX_BATCH, B)))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     k.B = B;
@@ -2204,33 +2205,35 @@ int h2d_block_solve(mgrit_hip_engine *e, int lvl) {
     const H2DDev &H = h.dev;
     int rc;
     if (!k.built && (rc = h2d_block_build(e, lv))) return rc;
-    const int B = k.B;
+    const int B = k.B, ld = lv.dev.ld, n = H.nx * H.ny;
     const size_t per = (size_t)H.Mi * H.Mj;
-    // first pass
-    for (size_t s = 0; s < k.p1.size(); ++s) {
-        if (s == 0)
-            for (const H2DPlan &pl : k.p1_zero)
-                if ((rc = h2d_phi_op(e, lv, pl, k.zero_row, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, H2D_OP_F, 1, 1.0))) return rc;
-        for (const H2DPlan &pl : k.p1[s])
-            if ((rc = h2d_phi_op(e, lv, pl, lv.dev.u, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, H2D_OP_F, 1, 1.0))) return rc;
-    }
-    // spectra of the block ends e_0 .. e_{B-2}
+    // first pass: x_b = (g_i + Phi(u_{i-1} + x_b)) - u_i, step s of every block as one batch
+    for (size_t s = 0; s < k.p1.size(); ++s)
+        for (const H2DPlan &pl : k.p1[s]) {
+            if (s > 0)   // Y[b] = u_{i-1} + X[b]  (d_in = b, d_a = i)
+                hipLaunchKernelGGL(h2d_sum_rows_kernel, dim3((n + 255) / 256, pl.count), dim3(256), 0, e->stream, ld, n, k.Y, pl.d_in,
+                                   lv.dev.u, pl.d_a, -1, k.X, pl.d_in);
+            if ((rc = h2d_phi_op(e, lv, pl, s == 0 ? lv.dev.u : k.Y, k.X, ld, lv.dev.g, lv.dev.u, H2D_OP_DEFECT, 1, 1.0))) return rc;
+        }
+    // spectra of the errors at the block ends e_0 .. e_{B-2}
     const dim3 fx(H.Mj / 64, H.Mi / 64, B - 1), fy(H.Mi / 64, H.Mj / 64, B - 1);
-    hipLaunchKernelGGL(h2d_pack_kernel, dim3((H.Mj + 255) / 256, H.Mi, B - 1), dim3(256), 0, e->stream, H, lv.dev.u, k.d_end_all, h.W0);
+    hipLaunchKernelGGL(h2d_pack_kernel, dim3((H.Mj + 255) / 256, H.Mi, B - 1), dim3(256), 0, e->stream, H, k.X, k.d_iota, h.W0);
     hipLaunchKernelGGL((h2d_fwd_kernel<false>), fx, dim3(256), 0, e->stream, h.Fxe, h.Fxo, H.mi, h.HPx, h.W0, H.Mj, h.W1, nullptr, per);
     hipLaunchKernelGGL((h2d_fwd_kernel<false>), fy, dim3(256), 0, e->stream, h.Fye, h.Fyo, H.mj, h.HPy, h.W1, H.Mi, k.spec, nullptr, per);
-    // recurrence over the blocks, then the propagated parts into the rows e_1 .. e_{B-1}
+    // recurrence over the blocks; block ends: u[e_b] = (u[e_b] + x_b) + the propagated part on the interior (b >= 1)
     hipLaunchKernelGGL(h2d_blk_scan_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, e->stream, k.spec, k.Dtab, k.d_dsel, B, per);
+    hipLaunchKernelGGL(h2d_sum_rows_kernel, dim3((n + 255) / 256, B), dim3(256), 0, e->stream, ld, n, lv.dev.u, k.d_end_all, lv.dev.u,
+                       k.d_end_all, 0, k.X, k.d_iota);
     const dim3 ix(H.Mj / 64, h.HPx / 64, B - 1), iy(H.Mi / 64, h.HPy / 64, B - 1);
     const H2DFin none{};
-    const H2DFin add{lv.dev.u, lv.dev.ld, k.d_end_tail, nullptr, nullptr, nullptr, nullptr, H2D_OP_ADD, 0, 1.0, 0.0};
+    const H2DFin add{lv.dev.u, ld, k.d_end_tail, nullptr, nullptr, nullptr, nullptr, H2D_OP_ADD, 0, 1.0, 0.0};
     hipLaunchKernelGGL((h2d_inv_kernel<false>), ix, dim3(256), 0, e->stream, h.FxeT, h.FxoT, H.mi, h.HPx, k.spec + per, H.Mj, h.W1, per, H, none);
     hipLaunchKernelGGL((h2d_inv_kernel<true>), iy, dim3(256), 0, e->stream, h.FyeT, h.FyoT, H.mj, h.HPy, h.W1, H.Mi, h.W0, per, H, add);
     HIP_TRY(hipGetLastError());
-    // second pass
+    // second pass: every block's interior from its (corrected) start
     for (size_t s = 0; s < k.p3.size(); ++s)
         for (const H2DPlan &pl : k.p3[s])
-            if ((rc = h2d_phi_op(e, lv, pl, lv.dev.u, lv.dev.u, lv.dev.ld, lv.dev.g, lv.dev.u, H2D_OP_F, 1, 1.0))) return rc;
+            if ((rc = h2d_phi_op(e, lv, pl, lv.dev.u, lv.dev.u, ld, lv.dev.g, lv.dev.u, H2D_OP_F, 1, 1.0))) return rc;
     return 0;
 }
 
@@ -2625,7 +2628,7 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     const int cap = 256 * blk_wgs_per_cu(lv);
     const dim3 block(lv.dev.T);
     const bool adv = bk.fourier != 0;
-    const int n = lv.dev.n, fft_threads = std::min(n / 2, 1024), b_lo = bk.first_real ? 1 : 0;
+    const int n = lv.dev.n, fft_threads = std::min(n / 2, 1024);
     const size_t fft_lds = (size_t)n * sizeof(double2);
     if (phases & 1) {
         const dim3 grid(std::min(bk.B, cap));
@@ -2634,7 +2637,7 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
         else if (F == 2) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 2>), grid, block, lds, e->stream, lv.dev, bk);
         else if (F == 3) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 3>), grid, block, lds, e->stream, lv.dev, bk);
         else hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 4>), grid, block, lds, e->stream, lv.dev, bk);
-        if (adv) {   // what_b = FFT(u[e_b]) for the block ends the recurrence reads
+        if (adv) {   // what_b = FFT(W_b) for the blocks the recurrence reads
             const int cnt = bk.B - 1 + (bk.project_last ? 1 : 0);
             if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, 0, 0);
         }
@@ -2650,11 +2653,11 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     if (phases & 4) {
         BlkDev b2 = bk;
         b2.skip_last_row = bk.project_last;
-        if (adv) {   // u[e_b] += Re(IFFT(c_b)) / n for the block ends not yet corrected, then the second pass
-            const int cnt = bk.B - b_lo - (bk.project_last ? 1 : 0);
-            if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, b_lo, 1);
+        if (adv) {   // u[e_b] += W_b + Re(IFFT(c_b)) / n for the block ends not yet corrected, then the second pass
+            const int cnt = bk.B - (bk.project_last ? 1 : 0);
+            if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, 0, 1);
         }
-        const int items = bk.B + 1 - b_lo;
+        const int items = bk.B + 1;
         const dim3 grid(std::min(items, cap));
         if (adv) hipLaunchKernelGGL((blk_finish_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>), grid, block, lds, e->stream, lv.dev, b2);
         else if (F == 0) hipLaunchKernelGGL((blk_finish_kernel<MGRIT_HIP_STEPPER_HEAT1D, 0>), grid, block, lds, e->stream, lv.dev, b2);
@@ -2753,6 +2756,12 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
         bk.fourier = 1;
         bk.lg_n = 0;
         while ((1 << bk.lg_n) < n) ++bk.lg_n;
+    }
+    {
+        std::vector<double> zrows((size_t)B * ld, 0.0);
+        double *dWs;
+        if ((rc = dev_upload(lv, e->stream, zrows, &dWs))) return rc;
+        bk.Ws = dWs;
     }
     bk.uh_in = uh_in; bk.uh_out = has_successor ? uh_out : nullptr;
     bk.r = r; bk.B = B; bk.n_steps = nt - 1;

@@ -43,6 +43,17 @@ class FakeLib:
     def mgrit_hip_link_attach(self, h, handle, comm, peer):
         log.append(("attach", handle, peer))
         return 0
+    def mgrit_hip_send(self, h, handle, slot, ptr, count):
+        log.append(("send", handle, count))
+        store.add(f"msg/{rank}/{handle}", 1)        # (one counter per sending end)
+        return 0
+    def mgrit_hip_recv(self, h, handle, slot, ptr, count):
+        log.append(("recv", handle, count))
+        if DEAD_LINK and handle == int(DEAD_LINK):
+            log.append(("dead", handle))
+        return 0
+    def mgrit_hip_sync_bounded(self, h, timeout):
+        return -2 if any(e[0] == "dead" for e in log[-8:]) else 0   # a receive nobody answers: the bounded wait gives up
     def mgrit_hip_links_close(self, h, abort):
         log.append(("links_close", abort))
         return 0
@@ -50,6 +61,7 @@ class FakeLib:
         log.append(("destroy", abort))
         return 0
 FAIL_IDS = sys.argv[6] if len(sys.argv) > 6 else ""
+DEAD_LINK = sys.argv[7] if len(sys.argv) > 7 and int(sys.argv[1]) == 1 else ""     # rank 1's receive on this handle never completes
 hip_lib._lib = FakeLib()
 hip_lib.check = lambda rc: None if rc == 0 else (_ for _ in ()).throw(RuntimeError(rc))
 
@@ -71,14 +83,22 @@ if FAIL_IDS:
 else:
     tc.open_links(be, need)
     links = tc._engines[id(be)].handle
-    json.dump({"log": log, "links": {f"{k[0]}/{k[1]}/{k[2]}": v for k, v in links.items()}, "need": need}, open(os.path.join(out, f"r{rank}.json"), "w"))
+    ping, ping_err = None, None
+    try:
+        ping = tc.ping_links(be, 0, reps=3, timeout=1.0)
+    except RuntimeError as exc:
+        ping_err = str(exc)
+    json.dump({"log": log, "links": {f"{k[0]}/{k[1]}/{k[2]}": v for k, v in links.items()}, "need": need, "ping": ping, "ping_error": ping_err},
+              open(os.path.join(out, f"r{rank}.json"), "w"))
 dist.barrier()
 dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_open_links_is_collective_and_crosswise_free(world):
+    """(8 ranks: the layout of BASELINE configs[2] on one node -- 7 neighbour pairs x 2 channels = 14 communicators, plus the link
+    that skips a rank)"""
     import json
     import socket
     out = tempfile.mkdtemp(prefix="rccl_links_")
@@ -105,6 +125,40 @@ def test_open_links_is_collective_and_crosswise_free(world):
         assert sorted(role for _, role in ends) == [0, 1], (uid, ends)
         sender = int(uid.split("-")[1])
         assert dict(ends)[sender] == 0, (uid, ends)
+    # the pre-flight ping: every rank holds the latency of EVERY link of the job, and on every link the sender's messages are
+    # matched one to one by the receiver's (same number, same size)
+    n_links = len(ids)
+    for d in res:
+        assert d["ping_error"] is None and len(d["ping"]) == n_links, (d["ping_error"], d["ping"])
+    assert len({json.dumps(d["ping"], sort_keys=True) for d in res}) == 1
+    sends = sum(1 for d in res for e in d["log"] if e[0] == "send")
+    recvs = sum(1 for d in res for e in d["log"] if e[0] == "recv")
+    assert sends == recvs == 3 * n_links
+    assert {e[2] for d in res for e in d["log"] if e[0] in ("send", "recv")} == {8}
+
+
+def test_a_dead_link_is_named_by_every_rank():
+    """a receive that is never answered: the bounded wait gives up on that rank, and EVERY rank ends the pre-flight with the same
+    error naming the pair (bench.py --gpus N turns it into a non-zero exit)"""
+    import json
+    import socket
+    world = 3
+    out = tempfile.mkdtemp(prefix="rccl_links_dead_")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    script = os.path.join(out, "worker.py")
+    open(script, "w").write(WORKER)
+    # handle numbering on rank 1: its engine attaches [1->2 sweep, 1->2 chain, 0->1 sweep, 0->1 chain] = handles 0..3: kill 0->1 sweep
+    procs = [subprocess.Popen([sys.executable, script, str(r), str(world), str(port), out, os.path.dirname(HERE), "", "2"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=120)[0].decode(errors="replace") for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    res = [json.load(open(os.path.join(out, f"r{r}.json"))) for r in range(world)]
+    errs = {d["ping_error"] for d in res}
+    assert len(errs) == 1 and None not in errs, errs
+    assert "0->1" in errs.pop()
 
 
 @pytest.mark.parametrize("who", ["all", "1"])

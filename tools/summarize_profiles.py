@@ -12,6 +12,14 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def stamp():
+    """the build the counters were collected on (bench.build_stamp: sources + library): bench.py prices physical bytes only from a
+    traffic file whose stamp is that of the running build"""
+    from bench import build_stamp
+    return build_stamp()
 
 
 def short(name):
@@ -107,21 +115,24 @@ def main(tag):
                       "read_bytes_per_launch_corrected": 2.0 * f_kib * 1024.0, "write_bytes_per_launch": w_kib * 1024.0,
                       "hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0}
     with open(os.path.join(out, f"{tag}_traffic.json"), "w") as f:
-        json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around "
+        json.dump({"build": stamp(),
+                   "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around "
                            "`python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-ramp --plan-blocks 1` (tools/profile_round.sh); KiB units; read side doubled "
                            "(gfx950 FETCH_SIZE tallies 128-B requests at 64 B). Every kernel name of the headline cycle belongs to one (sweep, level): cfas/ecfr = level 0, the <.., true, ..> kernels and fas_fused1 = level 1, chain2 = level 2; relax_kernel<1, 1, false, 0|1> = the stand-alone level-0 F-/C-relax launches of the fcf_relax_level0 figure.",
                    "kernels": summary}, f, indent=1)
     adv = traffic_summary(tag, "_advection", True)
     if adv:
         with open(os.path.join(out, f"{tag}_traffic_advection.json"), "w") as f:
-            json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around `python3 bench.py --workload advection "
+            json.dump({"build": stamp(),
+                       "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around `python3 bench.py --workload advection "
                                "--steps 3 --warmup 2` (tools/profile_round.sh); KiB units; read side doubled (gfx950 FETCH_SIZE tallies 128-B "
                                "requests at 64 B). Keys: kernel@workgroup size -- 512 threads = level 0 (8192 values), 256 = level 1, "
                                "128 = levels 2 and 3 (2048 values).", "kernels": adv}, f, indent=1)
     wide = {k: v for k, v in traffic_summary(tag, "_wide", "grid").items() if k.startswith("wide_")}
     if wide:
         with open(os.path.join(out, f"{tag}_traffic_wide.json"), "w") as f:
-            json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around `python3 tools/wide_bench.py` (Heat1D nx=32770, "
+            json.dump({"build": stamp(),
+                       "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around `python3 tools/wide_bench.py` (Heat1D nx=32770, "
                                "nt=4097: wide states, three launches per Phi); KiB units; read side doubled (gfx950 FETCH_SIZE tallies 128-B "
                                "requests at 64 B). Keys: kernel@grid<threads of the launch>. The level-0 F-relaxation of 3072 Phi = three batches of 1024 rows, each "
                                "wide_local_kernel<2>@grid2097152 + wide_carry_kernel@grid65536 + wide_finish_kernel@grid2097152.",
