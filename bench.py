@@ -793,6 +793,15 @@ def main():
         mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=False, max_iter=2 + args.warmup + args.steps, tol=0.0,
                    logging_lvl=30, pipeline_depth=args.pipeline_depth, plan_blocks=args.plan_blocks)
     be = mg.backend
+    # several ranks on RCCL links: every link of the job answers BEFORE anything is timed -- per-link latency into the line, a link
+    # that does not answer ends every rank with the same message naming the pair (exit code 1)
+    link_us = None
+    if world > 1 and getattr(be, "device_links", False) and hasattr(mg.comm_time, "ping_links"):
+        ping_buf = torch.zeros(8, dtype=torch.float64, device="cuda")
+        try:
+            link_us = mg.comm_time.ping_links(be, ping_buf.data_ptr())
+        except RuntimeError as exc:
+            raise SystemExit(f"bench.py --gpus {world}: {exc}")
     dof = nx - 2
     counts = phi_counts(nts, [4, 4])
     if args.at_k:   # coarsest level: point p is recomputed by min(p, k-1) steps instead of one step of the sequential solve
@@ -841,6 +850,18 @@ def main():
         getattr(be, "materialise", lambda: None)()
         fence()
     elapsed = time.perf_counter() - t_start
+    # several ranks: the same steps once more through the reference's own loop (mgrit.py:621-646: the stopping value examined after
+    # every cycle, a blocking gather) -- what a solve costs when nothing may lag; outside `value`
+    ms_checked = None
+    if pipelined:
+        cycle(1)
+        fence()
+        t_c = time.perf_counter()
+        for _ in range(args.steps):
+            cycle(1)
+        getattr(be, "materialise", lambda: None)()
+        fence()
+        ms_checked = 1e3 * (time.perf_counter() - t_c) / args.steps
     chain_clock = be.chain_clock() if hasattr(be, "chain_clock") else (0.0, 0.0)   # last chain launch of the timed region
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -987,6 +1008,8 @@ def main():
                                "messages_total": int(per[0].item()), "bytes_total": int(per[1].item()),
                                "device_resident_messages": int(per[2].item()),
                                "messages_per_cycle": per[0].item() / cycles_run, "bytes_per_cycle": per[1].item() / cycles_run,
+                               "link_latency_us": link_us, "ms_per_step_check_every_cycle": ms_checked,
+                               "ms_per_step_pipelined": ms_step if pipelined else None,
                                "note": "point-to-point ghost rows of all ranks (ops 0-5, 7 of reference mgrit.py:693-713); "
                                        "SURVEY 2b counts 24-27 per V-cycle at P=4"}
         out["nccl_ranks"] = dist.get_world_size() if args.backend == "nccl" else 0

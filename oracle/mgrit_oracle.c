@@ -1371,7 +1371,7 @@ static void heat1d_chain_spec(orc_problem *p, int lvl) {
  *             first step takes u_{i-1} itself), W_b = x kept aside. Values u that already satisfy u_i = g_i + Phi(u_{i-1}) bit for
  *             bit give x = 0 throughout: the solve then changes nothing -- the property that lets the MGRIT iteration converge to
  *             rounding level (a solve that re-derived u from scratch would differ from it by eps cond(Phi) in every cycle)
- *   phase 2a  what_b(k) = <q_k, W_b>, b = 0 .. B-2 (reduction tree of 3.4: lane-local fma chain, xor butterfly, groups in order)
+ *   phase 2a  what_b(k) = <q_k, W_b>, b = 0 .. B-2 (blk_dot: one fma chain per chunk of 1024 values in row storage order, chunks in order)
  *   phase 2b  Uh = what_0; for b = 1 .. B-1: c_b = D_b * Uh (product), Uh = what_b + c_b
  *   phase 2c  u[e_b] = u[e_b] + E_b, E_0 = W_0, E_b = W_b + sum_k q_k c_b(k): x = fma(q_k(j), c_b(k), x) for k ascending from x = W_b
  *   phase 3   every block: x = u[e_{b-1}] (u_0 for the first); u_i = g_i + Phi(x) for the points strictly inside the block
@@ -1420,25 +1420,21 @@ static int block_solve_on(const orc_problem *p, const orc_level *L, int lvl) {
     return orc_block_solve_rank(st->n, st->fac, L->nt, L->t, NULL);
 }
 
-/* <q, x> with the reduction tree of 3.4 */
+/* <q, x> as the device's matrix cores accumulate it: the vector in the engine's row storage order -- inside a
+ * chunk of 1024 values: for q = 0..7, for lane = 0..63, for r = 0..1 the value 16 lane + 2 q + r --, one fma chain per chunk in that
+ * order (a K loop of v_mfma_f64_16x16x4 accumulates its products sequentially), the chunks' sums added in chunk order */
 static double blk_dot(const double *x, const double *q, int n) {
     int G = (n + ORC_GROUP - 1) / ORC_GROUP;
     double tot = 0.0;
-    for (int g = 0; g < G; ++g) {
-        double a[ORC_LANES], b[ORC_LANES];
-        for (int l = 0; l < ORC_LANES; ++l) {
-            double acc = 0.0;
-            for (int k = 0; k < ORC_E; ++k) {
-                int j = (g * ORC_LANES + l) * ORC_E + k;
-                if (j < n) acc = fma(x[j], q[j], acc);
-            }
-            a[l] = acc;
-        }
-        for (int off = 32; off >= 1; off >>= 1) {
-            for (int l = 0; l < ORC_LANES; ++l) b[l] = a[l] + a[l ^ off];
-            memcpy(a, b, sizeof(a));
-        }
-        tot = tot + a[0];
+    for (int c = 0; c < G; ++c) {
+        double acc = 0.0;
+        for (int qq = 0; qq < 8; ++qq)
+            for (int l = 0; l < ORC_LANES; ++l)
+                for (int r = 0; r < 2; ++r) {
+                    int j = c * ORC_GROUP + 16 * l + 2 * qq + r;
+                    if (j < n) acc = fma(x[j], q[j], acc);
+                }
+        tot = tot + acc;
     }
     return tot;
 }

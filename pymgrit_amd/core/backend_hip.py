@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from pymgrit_amd.core import hip_lib
+from pymgrit_amd.core.options import options
 from pymgrit_amd.core.hip_lib import MgritHipError, check
 
 
@@ -206,7 +207,7 @@ class HipBackend:
         dts = np.diff(gt)
         n_terms = np.asarray(d.get("forcing_space", np.zeros((0, n)))).reshape(-1, n).shape[0] if d["kind"] == "heat1d" else 0
         wide = (lvl > 0 and d["kind"] == "heat1d" and 1024 < n <= hip_lib.MAX_N and n_terms <= 1 and d.get("forcing_rows") is None and dts.size > 0
-                and bool(np.all(dts.view(np.int64) == dts.view(np.int64)[0])) and os.environ.get("MGRIT_HIP_CHAIN_PLAIN", "") != "1")
+                and bool(np.all(dts.view(np.int64) == dts.view(np.int64)[0])) and not options.chain_plain)
         check(self.lib.mgrit_hip_chain_enable(self.h, lvl, int(wide)))
         slen = C.c_int(0)
         check(self.lib.mgrit_hip_chain_state_len(self.h, lvl, C.byref(slen)))
@@ -232,7 +233,6 @@ class HipBackend:
         the start, every rank at least one block) -- decided from the global layout, the same on every rank; the op-5 message
         then carries the BLOCK_RMAX mode amplitudes behind the point instead of a chain state."""
         from pymgrit_amd.core.layout import compute_layout
-        from pymgrit_amd.core.options import options
         mg = self.mg
         self.block_r = getattr(self, "block_r", {})
         self.block_sharded = getattr(self, "block_sharded", {})
@@ -304,7 +304,7 @@ class HipBackend:
         self.device_links = False
         comm = mg.comm_time
         if mg.comm_time_size > 1 and getattr(comm, "device_exchange", False) and \
-                os.environ.get("PYMGRIT_AMD_EXCHANGE", "") != "torch":
+                options.exchange != "torch":
             from pymgrit_amd.core.comm import links_needed
             agreed = getattr(comm, "open_links_agreed", None)
             self.link_error = agreed(self, links_needed(mg)) if agreed is not None else comm.open_links(self, links_needed(mg))
@@ -574,7 +574,7 @@ class HipBackend:
             # (16 CUs for the solve: 676-696, 24: 620, 40: 539-550, 48: 540-548, 64: 552-569)
             # ... and since the sweeps apply their own arithmetic inside the last transform (h2d_inv_kernel<true>): sixteen 506,
             # twenty-four 501, thirty-two 501 (40 CUs for the solve: 517-520, 64: 528-530)
-            return int(os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS_HEAT2D", str(max(1, min(24, n_c // 85)))))
+            return int(options.plan_blocks_heat2d if options.plan_blocks_heat2d is not None else max(1, min(24, n_c // 85)))
         # measured on config 3 (4097 coarsest points, round 2): 4 blocks 12.2 ms, 5 11.3, 6 10.8, 7 11.9, 8 13.3 -- more blocks
         # shorten the fill and drain of the block pipeline, fewer keep the launches large (a level-0 pass of one block is
         # 16384 / blocks / 4 chunks for 240 workgroups: with 6 blocks 2.8 rounds, with 8 blocks 2.1)
@@ -619,11 +619,11 @@ class HipBackend:
         captured from exactly those launches and replayed with a single call: a cycle of a small hierarchy is a dozen kernels
         of 5-20 us each, and without the graph their launch cost, not their run time, is what a cycle takes.
         PYMGRIT_AMD_PLAN_GRAPH=0 keeps the launch-by-launch form."""
-        graph_ok = os.environ.get("PYMGRIT_AMD_PLAN_GRAPH", "1") != "0" and not getattr(self, "_timing_on", False)
+        graph_ok = options.plan_graph != "0" and not getattr(self, "_timing_on", False)
         if any(d["kind"] == "heat2d" for d in self.desc):
             graph_ok = False     # (six launches per step of the coarsest-level solve: tens of thousands of nodes per cycle)
         comm = self.mg.comm_time if getattr(plan, "sends", None) or getattr(plan, "recvs", None) else None
-        if comm is not None and plan.n_blocks > 2 and os.environ.get("PYMGRIT_AMD_PLAN_GRAPH", "") != "1":
+        if comm is not None and plan.n_blocks > 2 and options.plan_graph != "1":
             # a rank's cycle of three and more blocks runs faster launch by launch than as one graph (measured, one rank of two
             # on config 3, four blocks: 5.27 against 6.13 ms; with two blocks the graph wins: 2.92 against 3.33 on one rank of four)
             graph_ok = False
@@ -676,7 +676,7 @@ class HipBackend:
                     torch.cuda.synchronize(self.device)   # surfaces (and clears) what the broken capture left behind
                 except Exception:   # noqa: BLE001
                     pass
-                if os.environ.get("PYMGRIT_AMD_PLAN_GRAPH") == "require":
+                if options.plan_graph == "require":
                     raise
                 import warnings
                 warnings.warn(f"pymgrit_amd: cycle graph capture failed ({exc!r}); launching the cycle kernel by kernel")
@@ -690,17 +690,18 @@ class HipBackend:
             self._f_stale = max(self._f_stale, was)   # (also when a launch failed: rows that awaited materialise() still do)
 
     def _masked_streams(self):
-        """Heat2D planned cycle: (sweep stream, chain stream) on disjoint sets of CUs (mgrit_hip_stream_create_masked), or None.
-        PYMGRIT_AMD_H2D_CHAIN_CUS = CUs given to the coarsest-level solve (default 32; 0: no partition)."""
+        """Heat2D planned cycle with a step-by-step coarsest-level solve (theta < 1, or fewer than 64 coarsest steps: DESIGN.md 3.8
+        covers the rest): (sweep stream, chain stream) on disjoint sets of CUs (mgrit_hip_stream_create_masked), or None. 32 CUs =
+        one XCD for the solve (measured in round 3 on config 4: 16 CUs 676-696 ms, 24 620, 32 501, 40 517-539, 64 528-569)."""
         if not hasattr(self, "_masked"):
             self._masked = None
-            n_chain = int(os.environ.get("PYMGRIT_AMD_H2D_CHAIN_CUS", "32"))
+            n_chain = 32
             total = torch.cuda.get_device_properties(self.device).multi_processor_count
             # (Heat2D only: its plans run launch by launch -- capturing the two masked streams into one hipGraph crashed the host
             # process; tried for config 5's F-cycle as well, launch by launch: 22.3-23.3 ms with 2-8 blocks against 20.2 with one)
             if any(d["kind"] == "heat2d" for d in self.desc) and 0 < n_chain < total:
                 a, b = C.c_void_p(), C.c_void_p()
-                n_sweep = total if os.environ.get("PYMGRIT_AMD_H2D_SWEEP_ALL", "") == "1" else total - n_chain   # (experiment)
+                n_sweep = total - n_chain
                 if self.lib.mgrit_hip_stream_create_masked(C.byref(a), 0, n_sweep) == 0 and \
                         self.lib.mgrit_hip_stream_create_masked(C.byref(b), total - n_chain, n_chain) == 0:
                     self._masked = (torch.cuda.ExternalStream(a.value, device=self.device), torch.cuda.ExternalStream(b.value, device=self.device))
@@ -746,7 +747,7 @@ class HipBackend:
             side.wait_event(self._fork)
             # the sweeps leave one CU of XCD 0 per chain worker (one worker per group of 1024 values) to the chain
             groups = max(self.ld[lvl] // 1024 for lvl in {n.lvl for n in plan.order if n.stream == "chain"})
-            reserve = int(os.environ.get("PYMGRIT_AMD_PLAN_RESERVE", min(32, max(1, groups))))
+            reserve = int(min(32, max(1, groups)))
         two = plan.has_chain and plan.n_blocks > 1
         last_side = None
         try:
@@ -892,7 +893,7 @@ class HipBackend:
                 check(self.lib.mgrit_hip_cpoint_mirror(self.h, None, self._mirror_row0))
             self._mirror_on, self._mirror_slot, self._mirror_hit = False, None, False
             return
-        if not len(points) or os.environ.get("PYMGRIT_AMD_NO_CPOINT_MIRROR", "") == "1":
+        if not len(points):
             return
         rows = self._snap_slot(slot, points)
         # row of a corrected C-point in the slot = its position among the relaxed C-points (res_pos) + the points in front of them
@@ -1075,7 +1076,7 @@ class HipBackend:
         """level 0, Heat1D with a separable forcing on both levels, identity transfer (weight and layout: the caller)"""
         tr = self.mg.transfer_objects[lvl]
         da, db = self.desc[lvl], self.desc[lvl + 1]
-        return (lvl == 0 and self._resident(lvl) and os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and self._device_transfer(lvl) and
+        return (lvl == 0 and self._resident(lvl) and not options.no_level_fusion and self._device_transfer(lvl) and
                 int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and da["kind"] == db["kind"] == "heat1d" and
                 self.n[lvl] == self.n[lvl + 1] and da.get("forcing_rows") is None and db.get("forcing_rows") is None and
                 len(da.get("forcing_time", [])) == len(db.get("forcing_time", [])))
@@ -1084,9 +1085,8 @@ class HipBackend:
         """lvl > 0, Heat1D with a separable forcing on lvl and lvl+1, identity transfer: the way down of the level as two
         passes -- F-relaxation + C-relaxation (relax mode FC), F-relaxation + FAS residual (fas_fused with_f_relax)"""
         da = self.desc[lvl]
-        return (lvl > 0 and os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and self.can_fuse_fas(lvl) and
-                da["kind"] == "heat1d" and da.get("forcing_rows") is None and self.desc[lvl + 1].get("forcing_rows") is None and
-                os.environ.get("MGRIT_HIP_FAS_TWO_PHASE", "") != "1")
+        return (lvl > 0 and not options.no_level_fusion and self.can_fuse_fas(lvl) and
+                da["kind"] == "heat1d" and da.get("forcing_rows") is None and self.desc[lvl + 1].get("forcing_rows") is None)
 
     def can_fuse_level_up(self, lvl):
         """any level pair of Heat1D with a separable forcing and the identity transfer: error correction + F-relaxation in one
@@ -1097,15 +1097,15 @@ class HipBackend:
         # only (ecf_kernel: of the next block too). The launch itself is slower than ecf_kernel (every interval reads its two
         # boundary corrections), so it pays only together with the merged launch of the first blocks' way up (cycle_plan.py,
         # Recorder.up_merge) that it makes possible: config 3, six blocks, 8.60 -> 8.24 ms; alone 8.46. On by default exactly
-        # there (a planned cycle of five or more blocks); PYMGRIT_AMD_FUSE_UP_COARSE=1 / 0 forces it on / off.
-        want = os.environ.get("PYMGRIT_AMD_FUSE_UP_COARSE", "")
+        # there (a planned cycle of five or more blocks); options.fuse_up_coarse = True / False forces it on / off.
+        want = {True: "1", False: "0"}.get(options.fuse_up_coarse, "")
         if want not in ("0", "1"):
             # (a rank of a sharded run: from two blocks on -- its way up of a block would otherwise wait for the chain part of
             # the next block, and the rank has few blocks to hide that behind)
             blocks = self.mg.plan_blocks()
             want = "1" if (blocks >= 5 or (blocks >= 2 and self.mg.comm_time_size > 1)) else "0"
         return (want == "1" and self._resident(lvl) and
-                os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") != "1" and self._device_transfer(lvl) and
+                not options.no_level_fusion and self._device_transfer(lvl) and
                 int(tr.device_transfer()) == hip_lib.TRANSFER_COPY and da["kind"] == db["kind"] == "heat1d" and
                 self.n[lvl] == self.n[lvl + 1] and da.get("forcing_rows") is None and db.get("forcing_rows") is None and
                 len(da.get("forcing_time", [])) == len(db.get("forcing_time", [])))
@@ -1120,7 +1120,7 @@ class HipBackend:
             # holds workgroups)
             ch = chunk
             if ch is None:
-                ch = int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK", "0")) if lvl == 0 else int(os.environ.get("PYMGRIT_AMD_FUSE_CHUNK_COARSE", "1"))
+                ch = 0 if lvl == 0 else 1
             res_len = len(self.mg._c_points(lvl))
             check(self.lib.mgrit_hip_intervals_create(self.h, lvl, len(intervals), _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]),
                                                       _ptr(cols[3]), _ptr(cols[4]), res_len, ch, _ptr(cols[5]), C.byref(iid)))
@@ -1145,10 +1145,10 @@ class HipBackend:
         residual_norms() asks for exactly these points. F-points: C-point storage (materialise()) unless
         PYMGRIT_AMD_STORE_ALL_F=1"""
         if intervals:
-            lazy = lvl == 0 and os.environ.get("PYMGRIT_AMD_STORE_ALL_F", "") != "1"
+            lazy = lvl == 0 and not options.store_all_f
             # 2: the last F-point's row gets Phi of it, which the next cycle's cf_fas takes as its C-relaxation -- when that pass
             # IS the next reader of the level (cf_iter = 1: no plain C-relaxation in front of it)
-            mode = 1 if not lazy else (2 if (self.mg.cf_iter[0] == 1 and os.environ.get("PYMGRIT_AMD_NO_PRE_RELAX", "") != "1") else 0)
+            mode = 1 if not lazy else (2 if (self.mg.cf_iter[0] == 1 and not options.no_pre_relax) else 0)
             check(self.lib.mgrit_hip_ec_relax_res(self.h, lvl, self._intervals_id(lvl, intervals), mode))
             if lvl == 0 and getattr(self, "_mirror_on", False):
                 self._mirror_hit = True
@@ -1159,8 +1159,7 @@ class HipBackend:
     def can_gen_level(self, lvl):
         """Heat1D (any forcing) or Advection1D on lvl and lvl+1, joined by a transfer the kernels apply (copy, full weighting with
         Dirichlet ends, its periodic analogue), both states register-resident"""
-        if lvl + 1 >= len(self.desc) or os.environ.get("PYMGRIT_AMD_NO_LEVEL_FUSION", "") == "1" or \
-                os.environ.get("PYMGRIT_AMD_NO_GEN_PASSES", "") == "1":
+        if lvl + 1 >= len(self.desc) or options.no_level_fusion or options.no_gen_passes:
             return False
         da, db = self.desc[lvl], self.desc[lvl + 1]
         return (self._device_transfer(lvl) and da["kind"] == db["kind"] and da["kind"] in ("heat1d", "advection1d") and
@@ -1170,7 +1169,7 @@ class HipBackend:
     def _gen_chunk():
         """intervals a workgroup of the general passes walks in a row: 0 = the library's choice from the level's size (a chunk's
         first C-point costs the way down a row and a Phi more, the way up a row of the side slab), on every level"""
-        return int(os.environ.get("PYMGRIT_AMD_GEN_CHUNK", "0"))
+        return 0
 
     def gen_down(self, lvl, intervals, parts=3):
         """c_relax + f_relax + fas_residual of level lvl for the intervals (cstart, cend, cstart_coarse, cend_coarse, res_pos, keep);

@@ -11,6 +11,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from pymgrit_amd.core.options import options
+
 
 class SerialComm:
     """A communicator of size 1 (no exchange ever happens)."""
@@ -120,7 +122,7 @@ class TorchTimeComm:
             return
         ok = True
         try:
-            if os.environ.get("PYMGRIT_AMD_NO_EXTRA_GROUPS"):   # switch (and test hook): main group only, on every rank
+            if options.no_extra_groups:   # switch (and test hook): main group only, on every rank
                 raise RuntimeError("extra communicators disabled by PYMGRIT_AMD_NO_EXTRA_GROUPS")
             self._link(0, 1)
             self._side_group()
@@ -245,7 +247,7 @@ class RcclTimeComm(TorchTimeComm):
         super().__init__(group)
         self._comms = {}       # (src, dst, channel) -> ncclComm_t (c_void_p), created once per process group
         self._engines = {}     # id(backend) -> _EngineLinks
-        self.timeout_s = float(os.environ.get("PYMGRIT_AMD_EXCHANGE_TIMEOUT", "120"))
+        self.timeout_s = float(options.exchange_timeout)
 
     def open_links(self, backend, need):
         """collective: every rank names the links it takes part in; the sending rank of a link makes the unique id, everybody
@@ -413,7 +415,7 @@ class LoopbackWorld:
         self.links, self.objects, self.gathers, self.queues = {}, {}, {}, {}
         self.frozen = False        # no hand-shake: a single rank against the slots' last contents
         self.stream = None
-        self.timeout = float(os.environ.get("PYMGRIT_AMD_LOOPBACK_TIMEOUT", "120"))
+        self.timeout = float(options.loopback_timeout)
 
     def comm(self, rank):
         return LoopbackComm(self, rank)
@@ -672,7 +674,7 @@ def resolve_comm(comm_time):
         # (the id of a destroyed group may be reused: the entry must hold THIS group object)
         if held is None or held[0] is not world or held[1].backend != dist.get_backend():
             _drop_default_comms()
-            device = dist.get_backend() == "nccl" and os.environ.get("PYMGRIT_AMD_EXCHANGE", "rccl") != "torch"
+            device = dist.get_backend() == "nccl" and options.exchange != "torch"
             held = _default_comm[id(world)] = (world, RcclTimeComm() if device else TorchTimeComm())
         return held[1]      # (its counters are per process; a solver reports the difference over its own run: Mgrit.solve)
     if hasattr(comm_time, "exchange") and hasattr(comm_time, "Get_rank"):

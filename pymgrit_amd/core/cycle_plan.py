@@ -17,9 +17,9 @@ The recorder works at the backend interface (``relax``, ``fas_fused``, ``ec_rela
 engine and for the plugin backend (on the CPU the plan is executed serially in its scheduled order: that is how the
 dependency rules are tested without a GPU, tests/test_cycle_plan.py).
 """
-import os
-
 import numpy as np
+
+from pymgrit_amd.core.options import options
 
 
 class PlanUnsupported(Exception):
@@ -55,11 +55,6 @@ def block_maps(t_levels, n_blocks):
         return 1, [np.zeros(len(t), dtype=np.int64) for t in t_levels]
     stride = max(1, -(-(n_c - 1) // n_blocks))
     cuts = tc[stride:n_c - 1:stride]
-    shape = os.environ.get("PYMGRIT_AMD_PLAN_SHAPE")   # relative block sizes, e.g. "1,1,2,4,4,2,1,1" (experiments)
-    if shape:
-        w = np.cumsum([float(x) for x in shape.split(",")])
-        idx = np.unique(np.clip(np.round(w[:-1] / w[-1] * (n_c - 1)).astype(int), 1, n_c - 2))
-        cuts = tc[idx]
     return len(cuts) + 1, [np.searchsorted(cuts, np.asarray(t, dtype=np.float64), side='left').astype(np.int64) for t in t_levels]
 
 
@@ -73,7 +68,7 @@ class Recorder:
         self.K, self.block_of = block_maps(mg.t, n_blocks)
         # blocks at the front of the time grid whose way up goes into one launch (0 / 1: none): half of them when the cycle has
         # five or more blocks (measured on config 3 with six: three 8.24 ms, two 8.35, four 9.2, none 8.46-8.60)
-        self.up_merge = int(os.environ.get("PYMGRIT_AMD_PLAN_UP_MERGE", str(self.K // 2 if self.K >= 5 else 0)))
+        self.up_merge = int(options.plan_up_merge if options.plan_up_merge is not None else (self.K // 2 if self.K >= 5 else 0))
         self.nodes = []
         self.sends, self.recvs = {}, {}     # (peer rank, channel) -> messages of the cycle on that link (several ranks)
         self.host_after = []        # host-only bookkeeping calls of the cycle: run after every execution of the plan
@@ -195,7 +190,7 @@ class Recorder:
                     (lambda p=part: real.relax(lvl, p, 'CHAIN'))
                 # ("chain", lvl): the parts of one forward solve share the engine's granules and hand-over state
                 self._add("chain", lvl, b, fn, reads, {("u", lvl, b), ("chain", lvl, 0)}, n_pts, stream="chain",
-                          cost=5e-6 + n_pts * float(os.environ.get('PYMGRIT_AMD_PLAN_CHAIN_US', '2.0')) * 1e-6)
+                          cost=5e-6 + n_pts * 2.0e-6)
             else:
                 rows = len(part) + n_pts * (2 if lvl > 0 else 1)
                 self._add("relax_" + mode, lvl, b, lambda p=part: real.relax(lvl, p, mode), reads, {("u", lvl, b)}, rows)

@@ -22,6 +22,7 @@ from typing import List, Tuple
 
 import numpy as np
 
+from pymgrit_amd.core.options import options
 from pymgrit_amd.core.application import Application
 from pymgrit_amd.core.comm import resolve_comm
 from pymgrit_amd.core.grid_transfer import GridTransfer
@@ -235,7 +236,7 @@ class Mgrit:
         the reference refreshing slot 0 (ops 0 / 4 / 5; ops 1 / 2 / 3 / 7 never fire). Decided by all ranks together."""
         size, rank = self.comm_time_size, self.comm_time_rank
         if size == 1 or not getattr(self.backend, "device_links", False) or not self.global_conv_crit or \
-                os.environ.get("PYMGRIT_AMD_NO_ALIGNED", "") == "1":
+                options.no_aligned:
             if size > 1 and getattr(self.backend, "device_links", False):
                 self.comm_time.allgather_object(False)
             return False
@@ -439,8 +440,8 @@ class Mgrit:
             return 0 if probe_usable else 1
         if self._plan_request is not None:
             want = int(self._plan_request)
-        elif os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS"):
-            want = int(os.environ["PYMGRIT_AMD_PLAN_BLOCKS"])
+        elif options.plan_blocks is not None:
+            want = int(options.plan_blocks)
         else:
             want = int(getattr(self.backend, "plan_blocks", lambda: 1)() or 1)
         own = all(getattr(type(self), name) is getattr(Mgrit, name) for name in
@@ -458,7 +459,7 @@ class Mgrit:
         blocks = self.plan_blocks()
         if blocks <= 1:
             # one block = program order; the device backend still replays it as one graph launch (small hierarchies)
-            single = (self._plan_request is None and not os.environ.get("PYMGRIT_AMD_PLAN_BLOCKS") and self._one_rank_like()
+            single = (self._plan_request is None and options.plan_blocks is None and self._one_rank_like()
                       and self.plan_blocks(probe_usable=True) and getattr(self.backend, "plan_single_block", lambda: False)())
             if not single:
                 return None
@@ -689,7 +690,7 @@ class Mgrit:
         point (1: the first local C-point on ranks > 0; 0 on rank 0)."""
         def build():
             down = self._rank_intervals(lvl)
-            if (down is None or self.conv_crit != 0 or os.environ.get("PYMGRIT_AMD_NO_RANK_FUSION_UP", "") == "1" or
+            if (down is None or self.conv_crit != 0 or
                     not self._can_fuse_ec(lvl) or getattr(self.backend, "residual_reserve", None) is None):
                 return [None]
             ivals, c0_run, edge = down
@@ -720,8 +721,7 @@ class Mgrit:
                       ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "_exchange", "_ec_f_relax",
                        "_fas_residual_fused", "_relax_f"))
             can = getattr(be, "can_fuse_coarse_down", None)
-            if not (os.environ.get("PYMGRIT_AMD_NO_RANK_FUSION", "") != "1" and
-                    os.environ.get("PYMGRIT_AMD_NO_RANK_FUSION_COARSE", "") != "1" and own and 0 < lvl < self.lvl_max - 1 and
+            if not (not options.no_rank_fusion and own and 0 < lvl < self.lvl_max - 1 and
                     self.weight_c == 1.0 and self.cf_iter[lvl] == 1 and self.global_conv_crit and
                     not getattr(self, "_sweep_timing", False) and can is not None and can(lvl)):
                 return [None]
@@ -755,7 +755,7 @@ class Mgrit:
                       ("iteration", "f_relax", "c_relax", "fas_residual", "error_correction", "_exchange", "_ec_f_relax",
                        "_fas_residual_fused", "_relax_f"))
             can = getattr(be, "can_fuse_level", None)
-            if not (os.environ.get("PYMGRIT_AMD_NO_RANK_FUSION", "") != "1" and own and lvl == 0 and self.lvl_max > 1 and
+            if not (not options.no_rank_fusion and own and lvl == 0 and self.lvl_max > 1 and
                     self.weight_c == 1.0 and self.global_conv_crit and not getattr(self, "_sweep_timing", False) and
                     can is not None and can(lvl) and getattr(be, "can_fuse_fas", lambda l: False)(lvl)):
                 return [None]
@@ -905,7 +905,7 @@ class Mgrit:
             can = getattr(be, "can_gen_level", None)
             if not (own and self._one_rank_like() and self.weight_c == 1.0 and lvl < self.lvl_max - 1 and self._dry is None and
                     not getattr(self, "_sweep_timing", False) and can is not None and can(lvl) and
-                    (self.comm_time_size == 1 or os.environ.get("PYMGRIT_AMD_NO_RANK_GEN", "") != "1")):
+                    True):
                 return [None]
             pairs = self._xpairs(lvl)
             if len(pairs) < 2 or pairs[0][0] != 0 or self._c_points(lvl) != [p[0] for p in pairs[1:]]:
@@ -1121,7 +1121,7 @@ class Mgrit:
         if self._pipeline_request is not None:
             want = int(self._pipeline_request)
         else:   # default 4 (the last of 8 ranks lags about two cycles, its values are posted one trip late); PYMGRIT_AMD_PIPELINE_DEPTH overrides it without touching the script
-            want = int(os.environ.get("PYMGRIT_AMD_PIPELINE_DEPTH", "4"))
+            want = int(options.pipeline_depth)
         usable = (self.comm_time_size > 1 and self.lvl_max > 1 and self.conv_crit == 0 and
                   hasattr(self.comm_time, "iallgather_floats") and getattr(self.comm_time, "async_gather", True) and
                   not (self.output_fcn is not None and self.output_lvl == 2) and

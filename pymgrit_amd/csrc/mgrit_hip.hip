@@ -1636,12 +1636,6 @@ int chain_local_max_g() {
     return v;
 }
 
-// MGRIT_HIP_FAS_TWO_PHASE=1: the two-phase fused FAS sweep for Heat1D as well (measurement switch)
-bool two_phase_fas() {
-    static const bool v = [] { const char *s = std::getenv("MGRIT_HIP_FAS_TWO_PHASE"); return s && s[0] == '1'; }();
-    return v;
-}
-
 size_t smem_bytes(int G, int kind = MGRIT_HIP_STEPPER_HEAT1D) {
     return (size_t)(8 * G * LANES + (kind == MGRIT_HIP_STEPPER_ADVECTION1D ? 0 : 2 * 512)) * sizeof(double2) + (8 * MAX_G + LANES) * sizeof(double);
 }
@@ -2060,17 +2054,16 @@ int h2d_phi_batch(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const doubl
 }
 
 // Phi of the batch followed by the sweep's arithmetic: fused into the last transform for the implicit schemes, the epilogue
-// kernel (which evaluates the explicit stencil itself) for theta = 0. MGRIT_HIP_H2D_UNFUSED=1: always the epilogue (measurement).
+// kernel (which evaluates the explicit stencil itself) for theta = 0.
 int h2d_finish(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab, double *dst_slab, int dst_ld,
                const double *a_slab, const double *b_slab, int op, int use_g, double w, bool chain);
 
 int h2d_phi_op(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in_slab, double *dst_slab, int dst_ld,
                const double *a_slab, const double *b_slab, int op, int use_g, double w, bool chain = false) {
-    static const bool unfused = [] { const char *s = std::getenv("MGRIT_HIP_H2D_UNFUSED"); return s && s[0] == '1'; }();
     int rc;
     // (the sequential coarsest-level solve keeps the epilogue kernel: fused, one step of one state took 107 instead of 92 us --
     // the last transform's 64 tiles then also carry the sweep's loads and the rim is a launch of its own)
-    if (lv.h2d->dev.theta != 0.0 && !unfused && !chain) {
+    if (lv.h2d->dev.theta != 0.0 && !chain) {
         const H2DFin fin{dst_slab, dst_ld, pl.d_dst, a_slab, pl.d_a, b_slab, pl.d_b, op, use_g, w, 1.0 - w};
         return h2d_phi_batch(e, lv, pl, in_slab, chain, &fin);
     }
@@ -3428,7 +3421,7 @@ int mgrit_hip_fas_fused_opts(mgrit_hip_engine *e, int lvl, int triples_id, int o
     if (pl->n == 0) return 0;
     Timed timed(e, (opts & MGRIT_HIP_FAS_WITH_F_RELAX) ? MGRIT_HIP_T_F_FAS : MGRIT_HIP_T_FAS_FUSED, lvl);
     const int use_g = lvl > 0 ? 1 : 0;
-    if (lf.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && !two_phase_fas() && force_mode(lf) != 3) {   // one pass per C-point, coarse tables from L2
+    if (lf.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && force_mode(lf) != 3) {   // one pass per C-point, coarse tables from L2
         const dim3 grid(persistent_grid(lf, pl->n)), block(lf.dev.T);
         const int fm = force_mode(lf);
         // forcing factors of both levels are streamed (FORCE 2, the same fma per term): one Phi per point does not pay for
@@ -3863,20 +3856,6 @@ int mgrit_hip_chain_clock(mgrit_hip_engine *e, double *mhz, double *us_per_step)
     if (w[2] == 0 || w[3] == 0) return 0;
     *mhz = 100.0 * (double)w[1] / (double)w[2];
     *us_per_step = (double)w[2] / 100.0 / (double)w[3];
-    if (std::getenv("MGRIT_HIP_CHAIN_DEBUG") && e->sched) {
-        int h[16];
-        if (hipMemcpy(h, e->sched + 160, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            std::fprintf(stderr, "chain workers (xcd.cu flags):");
-            for (int k = 0; k < 16; ++k) std::fprintf(stderr, " %d.%02x%s%s(%d)", h[k] & 15, (h[k] >> 4) & 0xff, (h[k] & 0x1000) ? "s" : "", (h[k] & 0x2000) ? "X" : "", h[k] >> 16);
-            std::fprintf(stderr, "\n");
-        }
-        int c[2];
-        if (hipMemcpy(c, e->sched + 10, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
-            std::fprintf(stderr, "chain workers drawn on another XCD so far: %d, second on a CU: %d\n", c[0], c[1]);
-        std::fprintf(stderr, "chain launches by us/step (<1.0, 1.0, 1.1, ...):");
-        for (int b = 0; b < 32; ++b) std::fprintf(stderr, " %u", e->chain_err[32 + b]);
-        std::fprintf(stderr, "\n");
-    }
     return 0;
 }
 

@@ -1,14 +1,13 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): the profiles a round commits under profiles/ (tools/summarize_profiles.py <tag> copies them).
 #   <tag>_stats          rocprofv3 --kernel-trace --stats, cycle in program order (one launch per sweep and level)
-#   <tag>_stats_planned  the same for the default planned cycle (blocks of time points on two streams, graph replay)
+#   <tag>_stats_graph    the same for the default cycle (round 4: program order replayed as one hipGraph)
 #   <tag>_fetch/_write   separate --pmc FETCH_SIZE / WRITE_SIZE passes (program order)
 #   <tag>_bench*.log     plain bench lines (default run with the CPU baseline; --all-configs)
-# The Heat2D pass runs its planned cycle WITHOUT the CU partition (PYMGRIT_AMD_H2D_CHAIN_CUS=0): with streams made by
-# hipExtStreamCreateWithCUMask a process under rocprofv3 crashes in its exit handlers. Per-kernel times are those of the
-# partitioned run's kernels; the cycle is slower (574 against 501 ms).
+# (Round 4: the coarsest-level solves are time-parallel -- DESIGN.md 3.8 --, so no workload's default cycle uses CU-masked streams
+# any more and the Heat2D profile is the path the bench times.)
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 from=${2:-1}     # first step to run (a rerun after a failed step: bash tools/profile_round.sh r03 7)
 out=$PWD/gpurun_out
 mkdir -p "$out"
@@ -17,12 +16,12 @@ B="$PWD/bench.py"
 cd /tmp
 if [ "$from" -le 1 ]; then timeout -k 10 500 python3 "$B" --all-configs > "$out/${tag}_bench_all.log" 2> "$out/${tag}_bench_all.err" || exit 1; fi
 if [ "$from" -le 2 ]; then timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_bench_program_order.log" 2>&1 || exit 2; fi
-if [ "$from" -le 3 ]; then timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_planned" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-ramp > "$out/${tag}_bench_planned.log" 2>&1 || exit 3; fi
+if [ "$from" -le 3 ]; then timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_graph" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-ramp > "$out/${tag}_bench_graph.log" 2>&1 || exit 3; fi
 if [ "$from" -le 4 ]; then timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_fetch" -- python3 "$B" --steps 4 --warmup 2 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_fetch.log" 2>&1 || exit 4; fi
 if [ "$from" -le 5 ]; then timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$out/${tag}_write" -- python3 "$B" --steps 4 --warmup 2 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_write.log" 2>&1 || exit 5; fi
 # the other BASELINE configurations and one emulated rank of the sharded run: kernel summaries
 if [ "$from" -le 6 ]; then timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_config2" -- python3 "$B" --nx 1024 --nt 4097 --steps 100 --warmup 10 --no-cpu-baseline --no-ramp > "$out/${tag}_bench_config2.log" 2>&1 || exit 6; fi
-if [ "$from" -le 7 ]; then PYMGRIT_AMD_H2D_CHAIN_CUS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_heat2d" -- python3 "$B" --workload heat2d --steps 2 --warmup 1 > "$out/${tag}_bench_heat2d.log" 2>&1 || exit 7; fi
+if [ "$from" -le 7 ]; then timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_heat2d" -- python3 "$B" --workload heat2d --steps 2 --warmup 1 > "$out/${tag}_bench_heat2d.log" 2>&1 || exit 7; fi
 if [ "$from" -le 8 ]; then timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_advection" -- python3 "$B" --workload advection --steps 10 --warmup 3 > "$out/${tag}_bench_advection.log" 2>&1 || exit 8; fi
 if [ "$from" -le 9 ]; then timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_fetch_advection" -- python3 "$B" --workload advection --steps 3 --warmup 2 > "$out/${tag}_fetch_advection.log" 2>&1 || exit 13; fi
 if [ "$from" -le 10 ]; then timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$out/${tag}_write_advection" -- python3 "$B" --workload advection --steps 3 --warmup 2 > "$out/${tag}_write_advection.log" 2>&1 || exit 14; fi

@@ -79,7 +79,7 @@ def traffic_summary(tag, suffix, by_workgroup):
 
 def main(tag):
     out = os.path.join(ROOT, "profiles")
-    for sub in ("stats", "stats_planned", "stats_config2", "stats_heat2d", "stats_advection", "stats_rank3of8", "stats_wide"):
+    for sub in ("stats", "stats_graph", "stats_config2", "stats_heat2d", "stats_advection", "stats_rank3of8", "stats_wide"):
         dest = os.path.join(out, f"{tag}_kernel_{sub}.csv")
         stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*kernel_stats.csv"))
         dbs = newest(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*.db")))
