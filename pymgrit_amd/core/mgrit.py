@@ -223,7 +223,12 @@ class Mgrit:
             from pymgrit_amd.core.backend_hip import HipBackend
             return HipBackend(self)
         if any(has_desc) and not custom:
-            raise Exception('Mixed hierarchy: every level must be a device application (device_stepper()) or none')
+            # the reference takes ANY Application per level (core/mgrit.py:79-99). A hierarchy that mixes library applications with
+            # a user's Python application runs where that application's code runs: every level through its step() on the plugin path
+            # (the library's applications carry host steppers for exactly this), not through the kernels
+            host = sorted({type(p).__name__ for p, d in zip(problem, has_desc) if not d})
+            logging.warning('pymgrit_amd: %s have no device description: the whole hierarchy runs through the applications\' step() '
+                            'methods (plugin path), not through the MI355X kernels', host)
         from pymgrit_amd.core.backend_plugin import PluginBackend
         return PluginBackend(self)
 

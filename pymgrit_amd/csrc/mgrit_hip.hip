@@ -1387,6 +1387,7 @@ struct Level {
     double fac = 0.0;                // Heat1D: a / dx^2
     std::vector<double> t_host;      // the local time grid as described
     BlkDev blk{};                    // time-parallel forward solve (mgrit_hip_blk.inc); blk.r = 0: step by step
+    double *blk_part = nullptr;      // [G chunks][B][BLK_RMAX] the chunks' sums of the inner products (blk_project_kernel)
     int blk_state = -1;              // -1: not configured yet (mgrit_hip_block_solve_config), else configured
 };
 
@@ -1640,8 +1641,8 @@ size_t smem_bytes(int G, int kind = MGRIT_HIP_STEPPER_HEAT1D) {
     return (size_t)(8 * G * LANES + (kind == MGRIT_HIP_STEPPER_ADVECTION1D ? 0 : 2 * 512)) * sizeof(double2) + (8 * MAX_G + LANES) * sizeof(double);
 }
 
-// time-parallel forward solve: the regular carve-up + the per-wave partial sums of the projections (mgrit_hip_blk.inc)
-size_t blk_smem_bytes(int G) { return smem_bytes(G) + (size_t)BLK_RMAX * MAX_G * sizeof(double); }
+// time-parallel forward solve (mgrit_hip_blk.inc): the regular carve-up
+size_t blk_smem_bytes(int G) { return smem_bytes(G); }
 
 constexpr int MAX_G2 = MGRIT_HIP_MAX_N_2PTS / GROUP;  // two-point steppers: waves per half
 size_t smem2_bytes(int G) { return (size_t)2 * (8 * G * LANES + 2 * 512) * sizeof(double2) + (12 * MAX_G + 2 * LANES) * sizeof(double); }
@@ -2630,9 +2631,12 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
         else if (F == 2) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 2>), grid, block, lds, e->stream, lv.dev, bk);
         else if (F == 3) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 3>), grid, block, lds, e->stream, lv.dev, bk);
         else hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 4>), grid, block, lds, e->stream, lv.dev, bk);
-        if (adv) {   // what_b = FFT(W_b) for the blocks the recurrence reads
-            const int cnt = bk.B - 1 + (bk.project_last ? 1 : 0);
+        const int cnt = bk.B - 1 + (bk.project_last ? 1 : 0);     // blocks whose amplitudes the recurrence reads
+        if (adv) {   // what_b = FFT(W_b)
             if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, 0, 0);
+        } else if (cnt > 0) {   // what_b(k) = <q_k, W_b> on the matrix cores, chunk by chunk, then the chunks in order
+            hipLaunchKernelGGL(blk_project_kernel, dim3((cnt + 15) / 16, (bk.r + 15) / 16, lv.G), dim3(64), 0, e->stream, bk, lv.dev.ld, lv.blk_part);
+            hipLaunchKernelGGL(blk_sum_chunks_kernel, dim3(cnt), dim3(BLK_RMAX), 0, e->stream, bk, lv.G, lv.blk_part);
         }
     }
     if (phases & 2) {
@@ -2650,7 +2654,9 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
             const int cnt = bk.B - (bk.project_last ? 1 : 0);
             if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, 0, 1);
         }
-        const int items = bk.B + 1;
+        else hipLaunchKernelGGL(blk_correct_kernel, dim3((bk.B + 15) / 16, lv.dev.ld / 64), dim3(64), 0, e->stream, lv.dev, bk,
+                                bk.B - (bk.project_last ? 1 : 0));
+        const int items = bk.B;
         const dim3 grid(std::min(items, cap));
         if (adv) hipLaunchKernelGGL((blk_finish_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>), grid, block, lds, e->stream, lv.dev, b2);
         else if (F == 0) hipLaunchKernelGGL((blk_finish_kernel<MGRIT_HIP_STEPPER_HEAT1D, 0>), grid, block, lds, e->stream, lv.dev, b2);
@@ -2692,7 +2698,7 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
     if (heat) {
         if (r > BLK_RMAX || r > n) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: r = %d modes outside [1, %d]", r, std::min(BLK_RMAX, n));
         // D_b(k) = prod over the block's steps of 1 / (1 + dt_i fac 4 sin^2(theta_k / 2)), products in step order
-        std::vector<double> Dt((size_t)B * BLK_RMAX, 0.0), Q((size_t)r * ld, 0.0);
+        std::vector<double> Dt((size_t)B * BLK_RMAX, 0.0), Q((size_t)((r + 15) / 16 * 16) * ld, 0.0);   // (zero rows up to a multiple of 16 modes)
         for (int b = 0; b < B; ++b) {
             const int first = BLK_K * b + 1, last = b == B - 1 ? nt - 1 : BLK_K * (b + 1);
             for (int k = 0; k < BLK_RMAX && k < n; ++k) {
@@ -2715,6 +2721,8 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
         if ((rc = dev_upload(lv, e->stream, zeros, &dW))) return rc;
         if ((rc = dev_upload(lv, e->stream, zeros, &dC))) return rc;
         bk.Q = dQ; bk.D = dD; bk.what = dW; bk.C = dC;
+        std::vector<double> pz((size_t)lv.G * B * BLK_RMAX, 0.0);
+        if ((rc = dev_upload(lv, e->stream, pz, &lv.blk_part))) return rc;
     } else {
         if (r != n || !(n >= 64 && n <= BLK_FOURIER_MAX_N && (n & (n - 1)) == 0))
             return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve of an Advection1D level: all n modes, n a power of two in [64, %d] (n = %d, r = %d)", BLK_FOURIER_MAX_N, n, r);

@@ -184,3 +184,38 @@ def test_advection_1d_constructor_and_host_step():
     a6 = Advection1D(c=1, x_start=0, x_end=1, nx=6, t_start=0, t_stop=1, nt=11)
     res = a6.step(u_start=a6.vector_t_start, t_start=0, t_stop=0.1)
     np.testing.assert_almost_equal(res.get_values(), np.array([0.868043, 0.92987396, 0.87805385, 0.75780217, 0.604129]))
+
+
+def test_mixed_hierarchy_runs_through_the_applications_own_steps(caplog):
+    """the reference takes ANY Application per level (core/mgrit.py:79-99): a library Heat1D on the fine level over a user's own
+    Application on the coarse one is not refused -- the whole hierarchy runs through the applications' step() methods (plugin
+    path), and gives what the same hierarchy gives when both levels are the user's class"""
+    import logging
+    from pymgrit_amd import Mgrit
+
+    class MyHeat(Application):
+        """a user's restatement of backward Euler for the 1-D heat equation (dense solve), vectors of the library's type"""
+        def __init__(self, nx, **kw):
+            super().__init__(**kw)
+            self.x = np.linspace(0, 1, nx)[1:-1]
+            self.n, dx = self.x.size, 1.0 / (nx - 1)
+            self.L = (np.diag(2 * np.ones(self.n)) - np.diag(np.ones(self.n - 1), 1) - np.diag(np.ones(self.n - 1), -1)) / dx ** 2
+            self.vector_template = VectorHeat1D(self.n)
+            self.vector_t_start = VectorHeat1D(self.n)
+            self.vector_t_start.set_values(np.sin(np.pi * self.x))
+
+        def step(self, u_start, t_start, t_stop):
+            out = VectorHeat1D(self.n)
+            out.set_values(np.linalg.solve(np.eye(self.n) + (t_stop - t_start) * self.L, u_start.get_values()))
+            return out
+
+    t0 = np.linspace(0, 1, 33)
+    lib = Heat1D(x_start=0, x_end=1, nx=17, a=1, init_cond=lambda x: np.sin(np.pi * x), t_interval=t0)
+    with caplog.at_level(logging.WARNING):
+        mixed = Mgrit([lib, MyHeat(17, t_interval=t0[::4])], tol=1e-9, max_iter=8, logging_lvl=30)
+    assert type(mixed.backend).__name__ == "PluginBackend"
+    assert any("no device description" in r.getMessage() for r in caplog.records)
+    conv = mixed.solve()["conv"]
+    own = Mgrit([MyHeat(17, t_interval=t0), MyHeat(17, t_interval=t0[::4])], tol=1e-9, max_iter=8, logging_lvl=30).solve()["conv"]
+    assert len(conv) == len(own) and np.max(np.abs(conv - own) / own) <= 1e-6
+    assert np.all(np.diff(conv) < 0)      # (later cycles give an exact zero: a two-level hierarchy is exact after N_c / 2 iterations)
