@@ -1737,10 +1737,9 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
                  int K, const double *s, const double *tau) {
     int rc = check_level(e, lvl, false);
     if (rc) return rc;
-    const int n_max = kind == MGRIT_HIP_STEPPER_HEAT1D ? MGRIT_HIP_MAX_N_WIDE : MGRIT_HIP_MAX_N;
+    const int n_max = MGRIT_HIP_MAX_N_WIDE;
     if (n < 1 || n > n_max)
-        return fail(MGRIT_HIP_EUNSUPPORTED, "n=%d DOFs per time point outside [1,%d] (%s)", n, n_max,
-                    kind == MGRIT_HIP_STEPPER_HEAT1D ? "Heat1D: register-resident up to 16384, three-launch Phi above" : "register-resident stepper");
+        return fail(MGRIT_HIP_EUNSUPPORTED, "n=%d DOFs per time point outside [1,%d] (register-resident up to 16384, three-launch Phi above)", n, n_max);
     if (ld != mgrit_hip_row_stride(n)) return fail(MGRIT_HIP_EINVAL, "ld=%d must equal mgrit_hip_row_stride(n=%d)=%d", ld, n, mgrit_hip_row_stride(n));
     if (n_pts < 0 || (n_pts > 0 && !t_local)) return fail(MGRIT_HIP_EINVAL, "bad local time grid");
     if (K < 0 || K > 8 || (K > 0 && (!s || (n_pts > 0 && !tau)))) return fail(MGRIT_HIP_EINVAL, "bad forcing description (K=%d)", K);

@@ -93,7 +93,7 @@ def test_abi_misuse_returns_error_codes(lib):
         assert lib.mgrit_hip_relax(eng, 0, 0, 0, 1.0) < 0 and "no stepper" in err()
         assert lib.mgrit_hip_level_heat1d(eng, 0, 9, _ptr(t), n, ld + 16, 1.0, 0, C.c_void_p(0), C.c_void_p(0)) < 0 and "row_stride" in err()
         assert lib.mgrit_hip_level_heat1d(eng, 0, 9, _ptr(t), 70000, 70656, 1.0, 0, C.c_void_p(0), C.c_void_p(0)) < 0      # above the wide limit
-        assert lib.mgrit_hip_level_advection1d(eng, 0, 9, _ptr(t), 20000, 20480, 1.0) < 0                                  # wide states: Heat1D only
+        assert lib.mgrit_hip_level_advection1d(eng, 0, 9, _ptr(t), 70000, 70656, 1.0) < 0                                  # likewise for Advection1D
         assert lib.mgrit_hip_level_heat1d(eng, 0, 9, _ptr(t), n, ld, 1.0, 3, C.c_void_p(0), C.c_void_p(0)) < 0 and "forcing" in err()
         assert lib.mgrit_hip_level_heat1d(eng, 0, 9, _ptr(t), n, ld, 1.0, 0, C.c_void_p(0), C.c_void_p(0)) == 0
         assert lib.mgrit_hip_level_heat1d(eng, 0, 9, _ptr(t), n, ld, 1.0, 0, C.c_void_p(0), C.c_void_p(0)) < 0 and "already" in err()

@@ -1,5 +1,5 @@
-"""Heat1D states wider than one workgroup's registers (16384 < n <= 65536 values per time point; the reference has no limit,
-heat/heat_1d.py:154-157): the same Phi as three launches over rows in HBM (csrc/mgrit_hip_wide.inc), every sweep against the
+"""Heat1D and Advection1D states wider than one workgroup's registers (16384 < n <= 65536 values per time point; the reference has no
+limit, heat/heat_1d.py:154-157, advection/advection_1d.py:84-89): the same Phi as three launches over rows in HBM (csrc/mgrit_hip_wide.inc), every sweep against the
 oracle's spec variant bit for bit, solves against the oracle (residual history 1e-10, solution bit for bit), on one rank and on
 loopback ranks."""
 import numpy as np
@@ -37,6 +37,44 @@ def test_wide_sweeps_bit_exact(oracle, name, nx, grids, forcing):
             assert_state_equal(mg, op)
         got, ref = np.array(mg.compute_residual()), op.residual_norms()
         assert np.array_equal(got, ref), np.abs(got - ref).max()
+
+
+ADV_SHAPES = [("adv_n16400", 16401, G3), ("adv_n32768", 32769, G3), ("adv_n40001_dts", 40002, [cases.lin(5, 21), cases.lin(5, 11), cases.lin(5, 6)]),
+              ("adv_n65536", 65537, [cases.lin(2, 9), cases.lin(2, 5), cases.lin(2, 3)])]
+
+
+@pytest.mark.parametrize("name,nx,grids", ADV_SHAPES, ids=[s[0] for s in ADV_SHAPES])
+def test_wide_advection_sweeps_bit_exact(oracle, name, nx, grids):
+    """Advection1D states of 16385 .. 65536 periodic values (the reference has no limit, advection/advection_1d.py:84-89): every
+    sweep through the three-launch Phi against the oracle, bit for bit"""
+    assert torch.cuda.is_available()
+    mg, op = make_pair(oracle, "advection", nx, grids)
+    assert mg.backend.n[0] > 16384
+    randomize(mg, op, seed=nx)
+    for lvl in range(mg.lvl_max - 1):
+        mg.f_relax(lvl); op.f_relax(lvl)
+        assert_state_equal(mg, op)
+        mg.c_relax(lvl); op.c_relax(lvl)
+        assert_state_equal(mg, op)
+        mg.fas_residual(lvl); op.fas_residual(lvl)
+        assert_state_equal(mg, op)
+    mg.forward_solve(mg.lvl_max - 1); op.forward_solve(mg.lvl_max - 1)
+    assert_state_equal(mg, op)
+    for lvl in range(mg.lvl_max - 2, -1, -1):
+        mg.error_correction(lvl); op.error_correction(lvl)
+        assert_state_equal(mg, op)
+    got, ref = np.array(mg.compute_residual()), op.residual_norms()
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
+
+
+def test_wide_advection_solve_with_spatial_coarsening(oracle):
+    """a wide periodic fine level over register-resident coarse ones (periodic full weighting), F-cycle: residual history and states"""
+    assert torch.cuda.is_available()
+    t0 = cases.lin(2, 33)
+    mg, op = make_pair(oracle, "advection", [32769, 16385, 8193], [t0, t0[::2], t0[::4]], transfer=[2, 2], cycle_type='F', max_iter=3, tol=0.0)
+    conv, oconv = mg.solve()["conv"], op.solve()
+    assert len(conv) == len(oconv) and np.max(np.abs(conv - oconv) / oconv) <= 1e-10, (conv, oconv)
+    assert_state_equal(mg, op, what=("u",))
 
 
 def test_wide_spatial_coarsening_and_jump(oracle):
