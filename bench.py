@@ -158,16 +158,21 @@ def iters_to_tol(problem, nx, tol=1e-10):
     from oracle import oracle as orc
     from pymgrit_amd import Heat1D, Mgrit
     import torch
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=True, max_iter=30, tol=tol, logging_lvl=30)
-    res = mg.solve()
-    torch.cuda.synchronize()
-    tts = {"note": f"Mgrit(...).solve() of the full workload to {tol:g} on this GPU, slabs and tables already described once (warm "
-                   f"library): setup = constructor incl. nested iteration, solve = the iterations incl. every stopping test and the "
-                   f"final F-relaxation that puts all F-points in place",
-           "setup_ms": 1e3 * res["time_setup"], "solve_ms": 1e3 * res["time_solve"], "wall_ms": 1e3 * (time.perf_counter() - t0),
-           "iterations": int(len(res["conv"]))}
+    runs = []
+    for _ in range(2):   # the first constructor of a process also pays for fresh hipMalloc of the slabs (the timed Mgrit above is
+        torch.cuda.synchronize()   # still alive); the second finds them in the allocator's cache, as a long-lived service would
+        t0 = time.perf_counter()
+        mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=True, max_iter=30, tol=tol, logging_lvl=30)
+        res = mg.solve()
+        torch.cuda.synchronize()
+        runs.append((1e3 * res["time_setup"], 1e3 * res["time_solve"], 1e3 * (time.perf_counter() - t0)))
+        if len(runs) < 2:
+            del mg
+    tts = {"note": f"Mgrit(...).solve() of the full workload to {tol:g} on this GPU: setup = constructor incl. tables, slabs and the "
+                   f"nested iteration, solve = the iterations incl. every stopping test and the final F-relaxation that puts all "
+                   f"F-points in place; second of two runs (slabs from the allocator's cache), the first is setup_ms_cold",
+           "setup_ms": runs[1][0], "solve_ms": runs[1][1], "wall_ms": runs[1][2], "setup_ms_cold": runs[0][0],
+           "solve_ms_cold": runs[0][1], "iterations": int(len(res["conv"]))}
     conv_full = res["conv"]
     del mg
     nts = (1025, 257, 65)
@@ -326,20 +331,23 @@ def bench_advection(args):
         alg = {"relax_f": F * phi * n, "relax_c": C * phi * n, "chain": N * 24.0 * n, "residual": C * 16.0 * n,
                "fas_rhs": C * (phi * n + 32.0 * nc), "fas_fused": C * (phi * n + 32.0 * nc), "ec_relax": C * 32.0 * n + F * phi * n,
                "error_correction": C * (16.0 * n + 16.0 * nc), "restrict": C * (8.0 * n + 8.0 * nc), "copy": None,
-               # the whole-level passes stand for the reference's sweeps they replace: way down = C-relaxation + F-relaxation +
-               # FAS right-hand side (with its restrictions of u and of the defect and the clone into v), way up = error
-               # correction + F-relaxation (+ the residual check on level 0)
-               "gen_down": C * phi * n + F * phi * n + C * (phi * n + 32.0 * nc) + 2 * C * (8.0 * n + 8.0 * nc) + C * 16.0 * nc,
-               "gen_up": C * (16.0 * n + 16.0 * nc) + F * phi * n + (C * 16.0 * n if lv == 0 else 0.0)}.get(kind)
+               # the whole-level passes are priced by the rows ONE pass over the level has to move, not by the
+               # sum of the reference's sweeps they replace (that sum exceeds what any fused pass moves and would read as more
+               # than the peak). Way down, per coarse interval: the C-point row read [+ g rows of the interval], the relaxed
+               # C-point written, u, v, g of the coarse level written, then fas_coarse: v and g read, g written. Way up: the fine
+               # C-point and the two coarse rows read [+ g], the m rows of the interval written
+               "gen_down": C * ((16.0 + (16.0 if lv else 0.0)) * n + 48.0 * nc),
+               "gen_up": C * ((8.0 + (16.0 if lv else 0.0)) * n + 16.0 * nc + 16.0 * n)}.get(kind)
         if kind == "copy":
             alg = (Ns[lv + 1] + 1 if lv + 1 < len(Ns) else N) * 16.0 * nc
         row["algorithmic_bytes_per_launch"] = alg
         row["algorithmic_GBps"] = alg / (row["ms_per_launch"] * 1e-3) / 1e9 if alg else None
     # physical HBM bytes of the kernels that run, from the committed PMC passes of this workload (tools/profile_round.sh ->
     # profiles/<tag>_traffic_advection.json, keys kernel@workgroup size: 512 threads = level 0, 256 = level 1, 128 = levels 2, 3)
-    tfile = os.path.join(ROOT, "profiles", "r03_traffic_advection.json")
-    if nt0 == 32769 and os.path.exists(tfile):
-        K = json.load(open(tfile))["kernels"]
+    K, src, stale = pmc_traffic(16384, 65537, 1, name="traffic_advection") if nt0 == 32769 else ({}, None, False)
+    if stale:
+        out["cycle"]["physical_bytes_source"] = src
+    if K:
         per = lambda name: K.get(name, {}).get("hbm_bytes_per_launch")
         cyc = K.get("gen_down_kernel<2, 0, false>@512", {}).get("launches_fetch_pass")     # once per cycle
         if cyc:
@@ -347,9 +355,7 @@ def bench_advection(args):
             total = sum(v["hbm_bytes_per_launch"] * v["launches_fetch_pass"] for k, v in K.items() if k not in extra and "rocclr" not in k) / cyc
             out["cycle"].update({"physical_bytes": total, "physical_GBps": total / (out["ms_per_step"] * 1e-3) / 1e9,
                                  "physical_frac": total / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "physical_bytes_source": "profiles/r03_traffic_advection.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                                          "passes, KiB units, read side doubled per the guide's gfx950 note; committed with the "
-                                                          "round, not collected in this run)"})
+                                 "physical_bytes_source": src})
         wg = [512, 256, 128, 128]
         for key, row in out["sweeps"].items():
             kind, lv = key.split()[0], int(key.split()[1][1:])
@@ -357,7 +363,9 @@ def bench_advection(args):
             names = {"gen_down": [f"gen_down_kernel<2, 0, {g}>@{wg[lv]}"] + ([f"fas_coarse_kernel<2, 0>@{wg[lv + 1]}"] if lv + 1 < 4 else []),
                      "gen_up": [f"gen_up_kernel<2, 0, {g}, {'true' if lv == 0 else 'false'}>@{wg[lv]}"],
                      "relax_f": [f"relax_kernel<2, 0, {g}, 0>@{wg[lv]}"],
-                     "chain": ["chain_local_kernel<2, 0, true, true>@512"]}.get(kind, [])
+                     # the time-parallel coarsest-level solve: local pass, two FFT launches, scan, finish
+                     "chain": ["blk_local_kernel<2, 0>@128", "adv_fft_rows_kernel@1024", "adv_fft_rows_kernel@1024", "adv_scan_kernel@256",
+                               "blk_finish_kernel<2, 0>@128"]}.get(kind, [])
             got = [per(nm) for nm in names]
             if got and all(b is not None for b in got):
                 # (fas_coarse_kernel@128 serves the level pairs 1 -> 2 and 2 -> 3 alike: its per-launch average is exact for neither)
@@ -371,10 +379,10 @@ def bench_advection(args):
     out["roofline"] = {"bound": "hbm", "achieved": drow["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": drow["algorithmic_GBps"] / HBM_PEAK_GBS if drow["algorithmic_GBps"] else None,
                        "traffic": drow.get("physical_bytes_per_launch"),
-                       "kernel": f"{dominant} ({'chain_local_kernel<2, 0, true, true>' if dominant.startswith('chain') else 'gen_down_kernel / gen_up_kernel<2, 0, ...> and fas_coarse_kernel<2, 0>'})",
+                       "kernel": f"{dominant} ({'blk_local_kernel / adv_fft_rows_kernel / adv_scan_kernel / blk_finish_kernel' if dominant.startswith('chain') else 'gen_down_kernel / gen_up_kernel<2, 0, ...> and fas_coarse_kernel<2, 0>'})",
                        "launch_ms": drow["ms_per_launch"], "launches_per_cycle": drow["launches_per_cycle"], "ms_per_cycle": drow["ms_per_cycle"],
                        "algorithmic_bytes_per_launch": drow["algorithmic_bytes_per_launch"],
-                       "limited_by": "latency: sequential coarsest-level solve, one group exchange per step" if dominant.startswith("chain") else "HBM bandwidth"}
+                       "limited_by": "launch latency of the five small kernels of the time-parallel coarsest-level solve" if dominant.startswith("chain") else "HBM bandwidth"}
     print(json.dumps(out), flush=True)
 
 
@@ -1023,6 +1031,11 @@ def main():
                 # above, folded into this ONE line (the full lines: --all-configs); a failure there never touches the headline
                 out["other_configs"] = other_configs()
                 out["sharded_rank_emulation"] = sharded_emulation(ms_step)
+                iters = out["iters_to_tol"]["full_workload"]["gpu_iters"]
+                for row in out["sharded_rank_emulation"]:
+                    if "ms_per_cycle" in row:   # the solve's iterations on that rank when it never waits for a neighbour: a lower
+                        row["cycles_to_tol"] = iters       # bound of the sharded time to solution (one GPU: iterations x ms_per_step)
+                        row["iterations_ms_if_never_waiting"] = iters * row["ms_per_cycle"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

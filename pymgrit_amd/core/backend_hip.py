@@ -22,6 +22,14 @@ def _i32(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
 
 
+def _cols(items, k):
+    """the k columns of a list of equal-length int tuples as contiguous int32 arrays (one conversion, not k list walks)"""
+    if not len(items):
+        return [np.zeros(0, dtype=np.int32) for _ in range(k)]
+    arr = np.asarray(items, dtype=np.int32).reshape(len(items), -1)
+    return [np.ascontiguousarray(arr[:, c]) for c in range(k)]
+
+
 def _ptr(a):
     return C.c_void_p(a.ctypes.data) if a.size else C.c_void_p(0)
 
@@ -503,7 +511,7 @@ class HipBackend:
     def _run_id(self, lvl, runs):
         def create():
             rid = C.c_int(-1)
-            st, ln = _i32([r[0] for r in runs]), _i32([r[1] for r in runs])
+            st, ln = _cols(runs, 2)
             check(self.lib.mgrit_hip_runs_create(self.h, lvl, len(runs), _ptr(st), _ptr(ln), C.byref(rid)))
             return rid.value
         return self._handle(self._runs, lvl, runs, "runs", create)
@@ -519,7 +527,7 @@ class HipBackend:
     def _pair_id(self, lvl, pairs):
         def create():
             pid = C.c_int(-1)
-            fi, co = _i32([p[0] for p in pairs]), _i32([p[1] for p in pairs])
+            fi, co = _cols(pairs, 2)
             check(self.lib.mgrit_hip_pairs_create(self.h, lvl, len(pairs), _ptr(fi), _ptr(co), C.byref(pid)))
             return pid.value
         return self._handle(self._pairs, lvl, pairs, "pairs", create)
@@ -981,7 +989,7 @@ class HipBackend:
 
         def create():
             tid = C.c_int(-1)
-            fi, pr, co = (_i32([tr[k] for tr in triples]) for k in range(3))
+            fi, pr, co = _cols(triples, 3)
             check(self.lib.mgrit_hip_triples_create(self.h, lvl, len(triples), _ptr(fi), _ptr(pr), _ptr(co), C.byref(tid)))
             return tid.value
         opts = (hip_lib.FAS_WITH_F_RELAX if with_f_relax else 0) | (hip_lib.FAS_SKIP_COARSE_U if skip_coarse_u else 0)
@@ -1113,7 +1121,7 @@ class HipBackend:
     def _intervals_id(self, lvl, intervals, chunk=None):
         def create():
             iid = C.c_int(-1)
-            cols = [_i32([iv[k] for iv in intervals]) for k in range(6)]
+            cols = _cols(intervals, 6)
             # level 0: chunks of 4 intervals (one extra row + Phi per chunk start); coarser levels: one interval per item --
             # a block of a planned cycle holds only a few hundred of their intervals, and 4 in a row would leave CUs idle
             # (0 = chosen by the library from the level's size: 4 on config 3, 1 where the level has fewer intervals than the chip

@@ -117,10 +117,21 @@ class Recorder:
             return set()
         return {(arr, lvl, int(b)) for b in np.unique(self.block_of[lvl][slots])}
 
+    def _one_block(self, lvl):
+        """the whole level is one block of the plan (the default since the coarsest-level solves are time-parallel): nothing to
+        cut, the index lists of the sweeps go through as they are"""
+        memo = self.__dict__.setdefault("_one_block_memo", {})
+        if lvl not in memo:
+            bo = self.block_of[lvl]
+            memo[lvl] = bool(bo.size) and bool((bo == bo[0]).all())
+        return memo[lvl]
+
     def _by_block(self, lvl, items, key_slot):
         """items grouped by the block of item[key_slot] on level lvl, ascending block order; [(block, IndexList)]"""
         if not items:
             return []
+        if self._one_block(lvl):
+            return [(int(self.block_of[lvl][0]), items if hasattr(items, "__dict__") else IndexList(items))]
         blocks = self.block_of[lvl][np.asarray([it[key_slot] for it in items], dtype=np.int64)]
         out = []
         for b in np.unique(blocks):
@@ -146,6 +157,8 @@ class Recorder:
 
     def _split_runs(self, lvl, runs):
         """runs cut at block borders (a run continued in the next block reads the last point of its first part)"""
+        if self._one_block(lvl):
+            return runs
         out = []
         bo = self.block_of[lvl]
         for st, ln in runs:

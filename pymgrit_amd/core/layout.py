@@ -123,4 +123,6 @@ def consecutive_runs(slots: np.ndarray):
     if slots.size == 0:
         return []
     cuts = np.nonzero(np.diff(slots) != 1)[0] + 1
-    return [(int(r[0]), int(r.size)) for r in np.split(slots, cuts)]
+    first = np.concatenate(([0], cuts))
+    length = np.diff(np.concatenate((first, [slots.size])))
+    return list(zip(slots[first].tolist(), length.tolist()))

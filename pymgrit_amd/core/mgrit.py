@@ -378,7 +378,7 @@ class Mgrit:
         """(fine slot of the i-th local C-point, coarse slot index_local[lvl+1][i]) (mgrit.py:498-500,528,722-726)."""
         def build():
             fine, coarse = self.index_local_c[lvl], self.index_local[lvl + 1]
-            out = [(int(fine[i]), int(coarse[i])) for i in range(len(fine))]
+            out = list(zip(np.asarray(fine, dtype=np.int64).tolist(), np.asarray(coarse, dtype=np.int64)[:len(fine)].tolist()))
             if skip_first and self.comm_time_rank == 0:
                 out = out[1:]
             return out
@@ -879,20 +879,24 @@ class Mgrit:
             # mgrit.py:270-271), nothing on a coarsest level that forward_solve overwrites from its first point on --, v only
             # when the correction on the way up is not the pass that takes v from the fine C-point
             coarsest = lvl + 1 == self.lvl_max - 1
+            P = np.asarray(pairs, dtype=np.int64)
+            jce = P[1:, 1]                                   # coarse slot of the C-point an interval ends on
+            c_next = np.asarray(self.index_local_c[lvl + 1], dtype=np.int64)
             if coarsest:
-                need_u = (lambda j: False) if self._coarsest_u_unread() else (lambda j: True)
+                need_u = np.zeros(jce.size, dtype=bool) if self._coarsest_u_unread() else np.ones(jce.size, dtype=bool)
             else:
-                c_next = {int(i) for i in self.index_local_c[lvl + 1]}
-                need_u = lambda j: j in c_next
+                need_u = np.isin(jce, c_next)
             need_v = 0 if (lvl == 0 and self.conv_crit in (0, 2)) else 2
             # ... and where the coarse level's first pass (relax mode FC, _coarse_down) starts its runs from v: its C-points
-            v_starts = {int(i) for i in self.index_local_c[lvl + 1]} if (not coarsest and self._coarse_down(lvl + 1) is not None) else set()
+            v_start = np.isin(jce, c_next) if (not coarsest and self._coarse_down(lvl + 1) is not None) else np.zeros(jce.size, dtype=bool)
+            keep = need_u.astype(np.int64) | need_v | (2 * v_start.astype(np.int64))
             # aligned ranks: the last local point travels to the next owner (op 4: u^{l+1}) and its corrected value is staged for
             # op 0 of the way up from u^{l+1} and v^{l+1} (Mgrit._x0): both rows are kept there
-            last = len(pairs) - 2 if (self.comm_time_size > 1 and self.send_to[lvl + 1] >= 0) else -1
-            return [[(pairs[k][0], pairs[k + 1][0], pairs[k][1] if k >= 1 else -1, pairs[k + 1][1], k,
-                      (3 if k == last else 0) | (1 if need_u(pairs[k + 1][1]) else 0) | need_v | (2 if pairs[k + 1][1] in v_starts else 0))
-                     for k in range(len(pairs) - 1)]]
+            if self.comm_time_size > 1 and self.send_to[lvl + 1] >= 0:
+                keep[-1] |= 3
+            jcs = P[:-1, 1].copy()
+            jcs[0] = -1
+            return [list(zip(P[:-1, 0].tolist(), P[1:, 0].tolist(), jcs.tolist(), jce.tolist(), range(len(pairs) - 1), keep.tolist()))]
         got = self._cached(('intervals', lvl, up), build)[0]
         if got is None:
             return None
