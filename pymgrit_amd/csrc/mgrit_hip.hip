@@ -23,6 +23,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -92,6 +93,7 @@ struct LevelDev {
     const double *chT;    // overlapped chain, null when the level does not qualify: V3 row [ld], then
                           // Q1, V1, V2 as [2][1024] each (full / last group), then a1 b1 a2 b2 [2] each, a3[16], b3[16]
     int n, ld, T, n_pts, K, kind;
+    int one_cset;         // every step of the level has the same size: coefficient set 0, cidx is not read
     int stream_rows;      // the level's slabs are far larger than the caches (n_pts * ld * 8 B > 256 MB): rows written by the
                           // whole-level passes are stored with the non-temporal hint (store_row_nt)
     // launch-time fields (set per launch by the host, not part of the level description):
@@ -280,6 +282,7 @@ struct Smem {
     double *lp;     // [LANES] rho^(E*l) of the current coefficient set
     double *red;    // [MAX_G] per-wave partial sums of block_sumsq (own slots: persistent kernels reuse the others)
     double *wf;     // [3][MAX_G] heat: per-group factors pg | qg | qg2 of the rank-one correction (CSet, build_cset_heat1d)
+    double *lp2, *wf2;   // lp and wf of ANOTHER level's (only) coefficient set, staged once by kernels that also step that level
 };
 
 // wave-uniform scalar coefficients of the current coefficient set, forced into SGPRs (readfirstlane)
@@ -357,6 +360,8 @@ __device__ __forceinline__ Smem carve_smem(char *base, int T, bool with_pt = tru
     s.lp = tail + 4 * MAX_G;
     s.red = tail + 4 * MAX_G + LANES;
     s.wf = tail + 5 * MAX_G + LANES;
+    s.lp2 = tail + 8 * MAX_G + LANES;
+    s.wf2 = tail + 8 * MAX_G + 2 * LANES;
     return s;
 }
 
@@ -434,17 +439,53 @@ __device__ __forceinline__ void ctx_init(StepCtx &ctx, const LevelDev &L, int t)
 template <bool SGPR>
 __device__ __forceinline__ double uni(double v) { return SGPR ? to_sgpr(v) : v; }
 
+// SGPR = true: the scalars of the set through the SCALAR cache, six s_load of up to 64 B and ONE wait (measured inside
+// cfas_kernel with wall-clock stamps: the same values as ~30 wave-uniform vector loads + readfirstlane took 3.3 us per call --
+// a vector load's result retires in order behind every row load and store the wave has in flight --, twice per interval).
+typedef int sgpr4 __attribute__((ext_vector_type(4)));
+typedef int sgpr8 __attribute__((ext_vector_type(8)));
+typedef int sgpr16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ double sgpr_pair(int lo, int hi) { return __hiloint2double(hi, lo); }
+
 template <bool SGPR = true>
 __device__ __forceinline__ void load_coef(Coef &c, const CSet *g) {
-    c.rho = uni<SGPR>(g->rho); c.ik = uni<SGPR>(g->ik); c.scal = uni<SGPR>(g->scal);
-    c.pi_full = uni<SGPR>(g->pi_full); c.pi_last = uni<SGPR>(g->pi_last);
-    c.gcp[0] = uni<SGPR>(g->gc);
+    if (SGPR) {
+        static_assert(offsetof(CSet, pi_full) == 32 && offsetof(CSet, pw) == 48 + 3 * MAX_G * 8 && offsetof(CSet, sc) == offsetof(CSet, pw) + (E + 1) * 8 &&
+                      E == 16, "load_coef reads CSet by byte offsets");
+        sgpr8 a;      // rho ik scal gc
+        sgpr4 b;      // pi_full pi_last
+        sgpr16 p0, p1;   // pw[0..7], pw[8..15]
+        sgpr8 q;      // sc[0..3]
+        double p16;
+        asm volatile("s_load_dwordx8 %0, %6, 0x0\n\t"
+                     "s_load_dwordx4 %1, %6, 0x20\n\t"
+                     "s_load_dwordx16 %2, %6, %7\n\t"
+                     "s_load_dwordx16 %3, %6, %8\n\t"
+                     "s_load_dwordx2 %4, %6, %9\n\t"
+                     "s_load_dwordx8 %5, %6, %10\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(a), "=&s"(b), "=&s"(p0), "=&s"(p1), "=&s"(p16), "=&s"(q)
+                     : "s"(uniform_ptr(g)), "n"(offsetof(CSet, pw)), "n"(offsetof(CSet, pw) + 64), "n"(offsetof(CSet, pw) + 128),
+                       "n"(offsetof(CSet, sc)));
+        c.rho = sgpr_pair(a[0], a[1]); c.ik = sgpr_pair(a[2], a[3]); c.scal = sgpr_pair(a[4], a[5]);
+        c.gcp[0] = sgpr_pair(a[6], a[7]);
+        c.pi_full = sgpr_pair(b[0], b[1]); c.pi_last = sgpr_pair(b[2], b[3]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { c.pw[k] = sgpr_pair(p0[2 * k], p0[2 * k + 1]); c.pw[8 + k] = sgpr_pair(p1[2 * k], p1[2 * k + 1]); }
+        c.pw[16] = p16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c.sc[k] = sgpr_pair(q[2 * k], q[2 * k + 1]);
+    } else {
+        c.rho = g->rho; c.ik = g->ik; c.scal = g->scal;
+        c.pi_full = g->pi_full; c.pi_last = g->pi_last;
+        c.gcp[0] = g->gc;
+#pragma unroll
+        for (int k = 0; k <= E; ++k) c.pw[k] = g->pw[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c.sc[k] = g->sc[k];
+    }
 #pragma unroll
     for (int k = 1; k < 4; ++k) c.gcp[k] = c.gcp[k - 1] * c.gcp[k - 1];
-#pragma unroll
-    for (int k = 0; k <= E; ++k) c.pw[k] = uni<SGPR>(g->pw[k]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) c.sc[k] = uni<SGPR>(g->sc[k]);
 }
 
 // d <- u + dt*b(x, t_i), forcing folded as fma(s_k, tau_k*dt, .)  (L.tc[k][i] = tau_k(t_i)*dt_i)
@@ -588,10 +629,12 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
 
 // x <- Phi(x) for the step (i-1 -> i) of level L, one workgroup holding the whole vector (heat_1d.py:198-217 /
 // advection_1d.py:129-143; arithmetic: DESIGN.md section 3). One workgroup barrier per application.
-template <int KIND, int FORCE, bool CLOSED = false>
+// PART (Heat1D): 0 = the whole step; 1 = only the coefficient set and the forcing term d = u + dt*b; 2 = only the solve, for a
+// caller that puts work of its own between the two (cfas_kernel: its row stores)
+template <int KIND, int FORCE, bool CLOSED = false, int PART = 0>
 __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const LevelDev &L, int i, const Smem &sm, int t,
                                           int lane, int wave, int G) {
-    const int ci = ld_uniform(L.cidx + i);
+    const int ci = (PART == 2 || L.one_cset) ? (PART == 2 ? ctx.cur : 0) : ld_uniform(L.cidx + i);
     if (ci != ctx.cur) {  // (re)load this coefficient set: tables + lane powers -> LDS, scalars -> SGPRs; uniform branch
         __syncthreads();
         const CSet *g = L.cs + ci;
@@ -617,7 +660,8 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const Le
     double *ga = sm.ga + par * MAX_G, *gb = sm.gb + par * MAX_G;
     if (KIND == MGRIT_HIP_STEPPER_HEAT1D) {
         static_assert(FORCE != 4 || CLOSED, "FORCE 4 keeps the forcing factor where the correction table would be");
-        add_forcing<FORCE>(x, ctx, L, i, t, sm);
+        if (PART != 2) add_forcing<FORCE>(x, ctx, L, i, t, sm);
+        if (PART == 1) { ctx.parity ^= 1; return; }   // (the solve of PART 2 flips the parity back to this step's)
         heat_solve<CLOSED>(x, c, lc, sm, ga, gb, L.n, t, lane, wave, G);
     } else {
 #pragma unroll
@@ -941,11 +985,13 @@ __global__ void __launch_bounds__(1024) fas_fused_kernel(LevelDev L, LevelDev Lc
 template <int FORCE>
 __device__ __forceinline__ void phi_other_level(double (&w)[E], StepCtx &ctx, const LevelDev &Lc, int j, const Smem &sm, unsigned sl,
                                                 int t, int lane, int wave, int G) {
-    const int cj = ld_uniform(Lc.cidx + j);
+    const int cj = Lc.one_cset ? 0 : ld_uniform(Lc.cidx + j);
     const CSet *gc = Lc.cs + cj;
     Smem smc = sm;
-    smc.wf = const_cast<double *>(gc->pg);
-    smc.lp = const_cast<double *>(gc->lp);
+    // (a level with ONE coefficient set: the caller has staged its lane powers and group factors in LDS, stage_other_level --
+    // read from global memory they are vector loads, which retire behind every row store the wave still has in flight)
+    smc.wf = Lc.one_cset ? sm.wf2 : const_cast<double *>(gc->pg);
+    smc.lp = Lc.one_cset ? sm.lp2 : const_cast<double *>(gc->lp);
     smc.pt = const_cast<double2 *>(Lc.ptP) + (size_t)cj * 1024;
     if (FORCE != 0) {
         for (int kk = 0; kk < Lc.K; ++kk) {
@@ -962,10 +1008,18 @@ __device__ __forceinline__ void phi_other_level(double (&w)[E], StepCtx &ctx, co
     // would be live at once, more than the SGPR file holds. The caller reloads its own set afterwards, unconditionally, so
     // that the compiler sees ctx.c dead across this call.
     load_coef(ctx.c, gc);
-    const LaneCoef lcc = lane_coef(gc->lp, lane);
+    const LaneCoef lcc = lane_coef(smc.lp, lane);
     const int par = ctx.parity;
     ctx.parity ^= 1;
     heat_solve<true>(w, ctx.c, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
+}
+
+__device__ __forceinline__ void stage_other_level(const Smem &sm, const LevelDev &Lc, int t) {
+    if (Lc.one_cset) {
+        if (t < LANES) sm.lp2[t] = Lc.cs->lp[t];
+        if (t < 3 * MAX_G) sm.wf2[t] = (&Lc.cs->pg[0])[t];   // pg | qg | qg2 are consecutive members
+        __syncthreads();
+    }
 }
 
 // Interval list of the fused level sweeps below: item = the interval from one C-point to the next,
@@ -1002,6 +1056,7 @@ template <int FORCE>
 __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, int pre) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
     WG_PROLOGUE;
+    stage_other_level(sm, Lc, t);
     for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < I.n_chunks; wq.advance(t)) {
         const int k = wq.cur;
         wq.prefetch(t);
@@ -1019,8 +1074,10 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
                 load_row_nt(L.u + (size_t)cs * L.ld, sl, x, L.stream_rows);
             }
         }
+        /*STAMP 6*/
         for (int it = i0; it < i0 + cnt; ++it) {
             const int cs = I.cstart[it], ce = I.cend[it], jc = I.cend_coarse[it];
+            /*DRAIN*/ /*STAMP 8*/
             {   // q = Phi_{l+1}(v_j), v_j = C'_j
                 double w[E];
 #pragma unroll
@@ -1029,16 +1086,26 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
 #pragma unroll
                 for (int q = 0; q < 8; ++q) sm.tab[sl + q * 64] = make_double2(w[2 * q], w[2 * q + 1]);   // parked in LDS
             }
+            /*STAMP 0*/
             load_coef(ctx.c, L.cs + (ctx.cur >= 0 ? ctx.cur : 0));   // back to this level's set (ctx.cur < 0: any set, phi_apply loads the right one)
+            /*STAMP 9*/
             for (int i = cs + 1; i < ce; ++i) phi_apply<KIND, FORCE, true>(x, ctx, L, i, sm, t, lane, wave, G);
+            /*STAMP 1*/
             double b[E];
             load_row_nt(L.u + (size_t)(ce - 1) * L.ld, sl, b, L.stream_rows);   // (requested one Phi earlier it costs more in spills than it hides)
+            /*STAMP 2*/
             if (!pre) phi_apply<KIND, FORCE, true>(b, ctx, L, ce, sm, t, lane, wave, G);
+            // the residual Phi in two parts around the row stores: its forcing term (vector loads of the space factor) AHEAD of
+            // them -- a load issued behind stores retires behind them (vmcnt counts in order), and the Phi would wait for their
+            // round trip to HBM --, its solve (LDS and registers only) behind them
+            phi_apply<KIND, FORCE, true, 1>(x, ctx, L, ce, sm, t, lane, wave, G);
             store_row_nt(L.u + (size_t)ce * L.ld, sl, b, L.stream_rows);
             const int keep = __builtin_amdgcn_readfirstlane(I.keep[it]);
             if (keep & 1) store_row_nt(Lc.u + (size_t)jc * Lc.ld, sl, b, Lc.stream_rows);
             if (keep & 2) store_row_nt(Lc.v + (size_t)jc * Lc.ld, sl, b, Lc.stream_rows);
-            phi_apply<KIND, FORCE, true>(x, ctx, L, ce, sm, t, lane, wave, G);
+            /*STAMP 3*/
+            phi_apply<KIND, FORCE, true, 2>(x, ctx, L, ce, sm, t, lane, wave, G);
+            /*STAMP 4*/
 #pragma unroll
             for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
 #pragma unroll
@@ -1052,9 +1119,11 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
             store_row_nt(Lc.g + (size_t)jc * Lc.ld, sl, x, Lc.stream_rows);
 #pragma unroll
             for (int e = 0; e < E; ++e) x[e] = b[e];
+            /*STAMP 5*/
         }
     }
     wq.end(t);
+    /*STAMP 7*/
 }
 
 // (USE_G, !RES: the same pass on a coarser level -- error_correction + f_relax with the rows of g, every F-point stored, no
@@ -1206,7 +1275,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         for (int k = 0; k < E; ++k) x[k] = x[k] + w[k];   // + v_j : the partial g of the coarse level
         // ---- coarse Phi on v_{j-1} = u^l_{ip}
         load_row_nt(L.u + (size_t)ip * L.ld, sl, w, L.stream_rows);
-        const int cj = ld_uniform(Lc.cidx + j);
+        const int cj = Lc.one_cset ? 0 : ld_uniform(Lc.cidx + j);
         const CSet *gc = Lc.cs + cj;
         smc.wf = const_cast<double *>(gc->pg);
         smc.lp = const_cast<double *>(gc->lp);
@@ -1638,7 +1707,7 @@ int chain_local_max_g() {
 }
 
 size_t smem_bytes(int G, int kind = MGRIT_HIP_STEPPER_HEAT1D) {
-    return (size_t)(8 * G * LANES + (kind == MGRIT_HIP_STEPPER_ADVECTION1D ? 0 : 2 * 512)) * sizeof(double2) + (8 * MAX_G + LANES) * sizeof(double);
+    return (size_t)(8 * G * LANES + (kind == MGRIT_HIP_STEPPER_ADVECTION1D ? 0 : 2 * 512)) * sizeof(double2) + (11 * MAX_G + 2 * LANES) * sizeof(double);
 }
 
 // time-parallel forward solve (mgrit_hip_blk.inc): the regular carve-up
@@ -1775,6 +1844,7 @@ int level_common(mgrit_hip_engine *e, int lvl, int kind, int n_pts, const double
     }
     if (n_pts > 0) cidx[0] = 0;
     lv.n_csets = (int)uniq.size();
+    d.one_cset = uniq.size() == 1 ? 1 : 0;
     std::vector<CSet> cs(uniq.size());
     std::vector<double> tabT(uniq.size() * (size_t)E * T, 0.0), tab;  // row storage order per coefficient set
     std::vector<double> ptT(uniq.size() * (size_t)2 * GROUP, 0.0), pt(GROUP), pt_last(GROUP), chT;
