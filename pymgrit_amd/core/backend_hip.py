@@ -611,9 +611,12 @@ class HipBackend:
         return all(d["kind"] in ("heat1d", "advection1d", "heat2d") for d in self.desc)
 
     def plan_single_block(self):
-        """a cycle too small to be cut into blocks is still planned (as one block, program order): what pays there is the
-        replay of the whole cycle as one hipGraph (plan_run)"""
-        return (all(d["kind"] in ("heat1d", "advection1d") for d in self.desc) and self.mg.lvl_max >= 2 and
+        """a cycle that is not cut into blocks may still be planned (as one block, program order) and replayed as one hipGraph
+        (plan_run) -- on request only (options.plan_graph = "1" / "require"): measured in round 4 on configs 2, 3 and 5, the
+        replay of a one-block cycle is no faster than its launches issued one by one (0.266 against 0.244 ms, 6.78 against
+        6.71 ms, 5.18 against 5.17 ms), and recording the plan costs a solve 27 ms of host time"""
+        return (options.plan_graph in ("1", "require") and
+                all(d["kind"] in ("heat1d", "advection1d") for d in self.desc) and self.mg.lvl_max >= 2 and
                 not self._host_transfers())      # host round trips cannot be part of a captured graph
 
     def _use_stream(self, stream):

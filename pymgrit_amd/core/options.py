@@ -76,8 +76,9 @@ class Options:
                        "wherever the coarsest-level solve is time-parallel)")
     plan_blocks_heat2d = _Opt("PYMGRIT_AMD_PLAN_BLOCKS_HEAT2D", None, _opt_int, "the same for Heat2D hierarchies solved step by step")
     plan_graph = _Opt("PYMGRIT_AMD_PLAN_GRAPH", "auto", str,
-                      "'auto' = a cycle is replayed as one hipGraph from its third execution on where that pays, '0' = launch by "
-                      "launch, '1' = always, 'require' = a failed capture raises")
+                      "'auto' = a cycle cut into blocks (two streams) is replayed as one hipGraph from its third execution on, a one-block "
+                      "cycle is issued launch by launch (round 4: its replay measured no faster); '0' = always launch by launch, "
+                      "'1' = one-block cycles are planned and replayed too, 'require' = likewise and a failed capture raises")
     plan_up_merge = _Opt("PYMGRIT_AMD_PLAN_UP_MERGE", None, _opt_int,
                          "blocks at the front of the time grid whose way up goes into one launch (None = half of them from 5 on)")
     pipeline_depth = _Opt("PYMGRIT_AMD_PIPELINE_DEPTH", 4, _opt_int,

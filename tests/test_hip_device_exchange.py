@@ -100,6 +100,10 @@ def test_aligned_ranks_equal_single_rank(case, sizes, monkeypatch):
     the sweeps of the other), and with the stopping value examined late"""
     _gpu()
     conv1, u1 = solve_ranks(case, 1)
+    for world in sizes:       # the default: a rank's cycle issued launch by launch between its exchange points
+        conv, u = solve_ranks(case, world)
+        assert np.array_equal(conv, conv1) and np.array_equal(u, u1), (case, world, "launch by launch")
+    monkeypatch.setenv("PYMGRIT_AMD_PLAN_GRAPH", "1")   # one-block cycles planned and replayed as graphs (opt-in since round 4)
     for world in sizes:
         for blocks, depth in ((None, None), (2, 0), (None, 3)):
             conv, u = solve_ranks(case, world, depth=depth, plan_blocks=blocks)

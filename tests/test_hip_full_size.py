@@ -52,7 +52,7 @@ def test_full_size_solve_sharded_equals_one_rank(tmp_path):
         assert parts[-1]["u_last"] == one["u_last"], world      # the state at the final time, bit for bit
 
 
-def test_full_size_planned_cycles_match_the_oracle(oracle):
+def test_full_size_planned_cycles_match_the_oracle(oracle, monkeypatch):
     """the path bench.py times -- config 3 at FULL size, the default cycle (program order, replayed as one hipGraph from its third
     execution on), whole-level passes, C-point storage, pre-relaxed C-points, the time-parallel coarsest-level solve (DESIGN.md
     3.8: 256 blocks of 16 steps, 50 sine modes) -- against the ORACLE running the same cycles at the same size: per-point
@@ -62,6 +62,7 @@ def test_full_size_planned_cycles_match_the_oracle(oracle):
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU visible")
+    monkeypatch.setenv("PYMGRIT_AMD_PLAN_GRAPH", "1")   # the one-block cycle replayed as a hipGraph (opt-in since round 4) must give the same bits
     import cases
     try:
         free_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2 ** 30
@@ -94,7 +95,7 @@ def test_full_size_planned_cycles_match_the_oracle(oracle):
         assert np.array_equal(np.asarray(mg.u[0][i].get_values()), ref[i]), i
 
 
-def test_full_size_config5_cycles_match_the_oracle(oracle):
+def test_full_size_config5_cycles_match_the_oracle(oracle, monkeypatch):
     """BASELINE configs[4] at FULL size -- advection_1d 8192 DOF, nt = 32769, 4 levels m = 2, periodic spatial coarsening on the first
     two level pairs, F-cycle -- as bench.py --workload advection times it: the general whole-level passes on all three level
     pairs, one graph per cycle, the time-parallel coarsest-level solves (all 2048 Fourier modes, 256 blocks) against the oracle at
@@ -103,6 +104,7 @@ def test_full_size_config5_cycles_match_the_oracle(oracle):
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU visible")
+    monkeypatch.setenv("PYMGRIT_AMD_PLAN_GRAPH", "1")   # the one-block cycle replayed as a hipGraph (opt-in since round 4) must give the same bits
     import cases
     from pymgrit_amd import Advection1D, GridTransferAdvection, GridTransferCopy, Mgrit
     nt0, nxs = 32769, [8193, 4097, 2049, 2049]

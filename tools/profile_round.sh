@@ -1,7 +1,8 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): the profiles a round commits under profiles/ (tools/summarize_profiles.py <tag> copies them).
 #   <tag>_stats          rocprofv3 --kernel-trace --stats, cycle in program order (one launch per sweep and level)
-#   <tag>_stats_graph    the same for the default cycle (round 4: program order replayed as one hipGraph)
+#   <tag>_stats_graph    the same cycle planned as one block and replayed as ONE hipGraph (PYMGRIT_AMD_PLAN_GRAPH=1: opt-in since round 4,
+#                        where the replay measured no faster than the launches issued one by one)
 #   <tag>_fetch/_write   separate --pmc FETCH_SIZE / WRITE_SIZE passes (program order)
 #   <tag>_bench*.log     plain bench lines (default run with the CPU baseline; --all-configs)
 # (Round 4: the coarsest-level solves are time-parallel -- DESIGN.md 3.8 --, so no workload's default cycle uses CU-masked streams
@@ -14,9 +15,8 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="$PWD/bench.py"
 cd /tmp
-if [ "$from" -le 1 ]; then timeout -k 10 500 python3 "$B" --all-configs > "$out/${tag}_bench_all.log" 2> "$out/${tag}_bench_all.err" || exit 1; fi
 if [ "$from" -le 2 ]; then timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_bench_program_order.log" 2>&1 || exit 2; fi
-if [ "$from" -le 3 ]; then timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_graph" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-ramp > "$out/${tag}_bench_graph.log" 2>&1 || exit 3; fi
+if [ "$from" -le 3 ]; then PYMGRIT_AMD_PLAN_GRAPH=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$out/${tag}_stats_graph" -- python3 "$B" --steps 10 --warmup 3 --no-cpu-baseline --no-ramp > "$out/${tag}_bench_graph.log" 2>&1 || exit 3; fi
 if [ "$from" -le 4 ]; then timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d "$out/${tag}_fetch" -- python3 "$B" --steps 4 --warmup 2 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_fetch.log" 2>&1 || exit 4; fi
 if [ "$from" -le 5 ]; then timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$out/${tag}_write" -- python3 "$B" --steps 4 --warmup 2 --no-cpu-baseline --no-ramp --plan-blocks 1 > "$out/${tag}_write.log" 2>&1 || exit 5; fi
 # the other BASELINE configurations and one emulated rank of the sharded run: kernel summaries
@@ -38,6 +38,12 @@ if [ "$from" -le 19 ]; then timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d "$ou
 # the summaries are made HERE, on the GPU box (gpurun copies at most 64 MiB back, the rocprofv3 databases are larger): they go to
 # gpurun_out/<tag>_profiles/, from where `cp gpurun_out/<tag>_profiles/* profiles/` takes them; then the databases are dropped
 cd "$(dirname "$B")" && python3 tools/summarize_profiles.py "$tag" > "$out/${tag}_summarize.log" 2>&1
+# the bench lines that price PHYSICAL bytes come last: they read profiles/<tag>_traffic*.json, which the summary above has just made
+# from the counter passes of this very build (made first, the lines would find the file of an older build and say "stale")
+cd /tmp
+if [ "$from" -le 20 ]; then timeout -k 10 500 python3 "$B" --all-configs > "$out/${tag}_bench_all.log" 2> "$out/${tag}_bench_all.err" || exit 1; fi
+if [ "$from" -le 21 ]; then timeout -k 10 200 python3 "$B" --workload advection --steps 10 --warmup 3 > "$out/${tag}_bench_advection.log" 2> "$out/${tag}_bench_advection.err" || exit 21; fi
+cd "$(dirname "$B")" && python3 tools/summarize_profiles.py "$tag" > "$out/${tag}_summarize2.log" 2>&1
 mkdir -p "$out/${tag}_profiles" && cp profiles/${tag}_* "$out/${tag}_profiles/"
 find "$out" -name '*_results.db' -delete
 find "$out" -name '*kernel_trace.csv' -size +20M -delete
