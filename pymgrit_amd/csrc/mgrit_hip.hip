@@ -1052,6 +1052,10 @@ struct IntervalsDev {
 //                                                   mgrit.py:401-405) and ecfr_kernel (store_f = 2) left it there
 //   u^{l+1}_{j+1} = v^{l+1}_{j+1} = C'_{j+1},   g^{l+1}_{j+1} = ((Phi_l(F'_last) - C'_{j+1}) + C'_{j+1}) - q
 // Rows through HBM per interval: 1 read + 3..5 written (IntervalsDev::keep) instead of 12 (C-relax 2, F-relax m, fused FAS 6). A chunk's first C-point is recomputed from its old F-point (one more Phi per chunk), not waited for.
+// (The /*STAMP n*/ and /*DRAIN*/ comments mark the phases for tools/cfas_timeline.py, which turns them into wall-clock stamps in an
+// experiment build of its own: profiles/r04_cfas_timeline.txt. Per interval of config 3: five Phi at ~2.1 us of solve each plus
+// ~1.7 us each for streaming the forcing factor from L2 -- LDS, where ecfr_kernel keeps it, holds q here --, 4.4 us of row
+// traffic that the wave waits for, 2 us until the stores of the interval before have drained.)
 template <int FORCE>
 __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, int pre) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
@@ -1223,6 +1227,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
     constexpr bool CF = FORCE == 4;   // forcing factor in LDS, so every Phi in closed form
     WG_PROLOGUE;
     stage_forcing<FORCE>(sm, L, sl);
+    stage_other_level(sm, Lc, t);
     Smem smc = sm;
     for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < n_items; wq.advance(t)) {
         const int p = wq.cur;
@@ -1277,8 +1282,8 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         load_row_nt(L.u + (size_t)ip * L.ld, sl, w, L.stream_rows);
         const int cj = Lc.one_cset ? 0 : ld_uniform(Lc.cidx + j);
         const CSet *gc = Lc.cs + cj;
-        smc.wf = const_cast<double *>(gc->pg);
-        smc.lp = const_cast<double *>(gc->lp);
+        smc.wf = Lc.one_cset ? sm.wf2 : const_cast<double *>(gc->pg);   // (staged in LDS: stage_other_level)
+        smc.lp = Lc.one_cset ? sm.lp2 : const_cast<double *>(gc->lp);
         smc.pt = const_cast<double2 *>(Lc.ptP) + (size_t)cj * 1024;
         if (FORCE == 4 && (opts & 4)) {   // the coarse level's space factor is the fine level's, bit for bit: the LDS copy
             const double ck = ld_uniform(Lc.tc + j);
@@ -1302,7 +1307,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         {   // (a set of its own here: in the place of ctx.c, as in phi_other_level, this kernel measured 3 % slower)
             Coef cc;
             load_coef(cc, gc);
-            const LaneCoef lcc = lane_coef(gc->lp, lane);
+            const LaneCoef lcc = lane_coef(smc.lp, lane);
             const int par = ctx.parity;
             ctx.parity ^= 1;
             heat_solve<true>(w, cc, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
@@ -1444,6 +1449,7 @@ struct Level {
     std::vector<IntervalsDev> ivals;   // mgrit_hip_intervals_create (device arrays live in allocs)
     std::vector<int> ivals_n;          // residual positions of the level (res_len) per list
     std::vector<int> ivals_cnt;        // intervals per list
+    int same_factor_below = -1;        // the next coarser level has the same (one) forcing space factor, bit for bit; -1: not looked at yet
     std::vector<double> s_host;        // forcing space factors as uploaded (row storage order): levels with equal factors share
                                        // the LDS copy of the kernels that keep the factor there (FORCE 4)
     double *scratch = nullptr;
@@ -3505,7 +3511,8 @@ int mgrit_hip_fas_fused_opts(mgrit_hip_engine *e, int lvl, int triples_id, int o
         // keeping them in registers, and the registers are needed for the partial g that stays live across the coarse Phi
         // one forcing term: its space factor lives in LDS (FORCE 4, closed-form Phi); bit 2 tells the kernel that the coarse
         // level's factor is the same vector (same spatial grid, same rhs), so the coarse Phi takes it from there too
-        const int kopts = opts | ((fm == 1 && lf.s_host == lc.s_host) ? 4 : 0);
+        if (lf.same_factor_below < 0) lf.same_factor_below = (fm == 1 && lf.s_host == lc.s_host) ? 1 : 0;   // (131 KB compared once)
+        const int kopts = opts | (lf.same_factor_below ? 4 : 0);
 #define FAS1_CASE(F_, P_)                                                                                                  \
     if ((fm == 0 ? 0 : fm == 1 ? 4 : 2) == F_ && ((opts & MGRIT_HIP_FAS_WITH_F_RELAX) != 0) == P_)                          \
         hipLaunchKernelGGL((fas_fused1_kernel<F_, P_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, \
