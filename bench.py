@@ -168,6 +168,8 @@ def iters_to_tol(problem, nx, tol=1e-10):
         runs.append((1e3 * res["time_setup"], 1e3 * res["time_solve"], 1e3 * (time.perf_counter() - t0)))
         if len(runs) < 2:
             del mg
+            import gc
+            gc.collect()      # (the solver object holds reference cycles: only now do its slabs go back to the allocator's cache)
     tts = {"note": f"Mgrit(...).solve() of the full workload to {tol:g} on this GPU: setup = constructor incl. tables, slabs and the "
                    f"nested iteration, solve = the iterations incl. every stopping test and the final F-relaxation that puts all "
                    f"F-points in place; second of two runs (slabs from the allocator's cache), the first is setup_ms_cold",

@@ -30,6 +30,25 @@ def _cols(items, k):
     return [np.ascontiguousarray(arr[:, c]) for c in range(k)]
 
 
+def _time_factor(f, t):
+    """tau(t_i) of a separable forcing term at every point of a level. The user's callable is written for ONE time (heat_1d.py's
+    rhs is called per step); evaluated point by point a level of BASELINE config 3 costs 65537 Python calls (70 ms of a 115 ms
+    setup). It is tried on the whole array first and the result taken only if it has the right shape AND agrees bit for bit with
+    the point-by-point calls at 48 sampled points and both ends (numpy's elementwise functions are position-independent);
+    anything else -- an exception, a scalar, a different bit anywhere in the sample -- falls back to the loop."""
+    t = np.asarray(t, dtype=np.float64)
+    if t.size > 256:
+        try:
+            v = np.asarray(f(t), dtype=np.float64)
+            if v.shape == t.shape:
+                idx = np.unique(np.concatenate(([0, 1, t.size - 2, t.size - 1], np.random.default_rng(t.size).integers(0, t.size, 48))))
+                if all(np.float64(f(t[i])).tobytes() == v[i].tobytes() for i in idx):
+                    return v
+        except Exception:       # noqa: BLE001 -- whatever the callable does with an array is its business: ask it point by point
+            pass
+    return np.asarray([f(tt) for tt in t], dtype=np.float64)
+
+
 def _ptr(a):
     return C.c_void_p(a.ctypes.data) if a.size else C.c_void_p(0)
 
@@ -127,7 +146,7 @@ class HipBackend:
         K = s.shape[0]
         tau = np.zeros((K, n_pts))
         for k in range(K):
-            tau[k] = [d["forcing_time"][k](tt) for tt in t_local]
+            tau[k] = _time_factor(d["forcing_time"][k], t_local)
         tau = np.ascontiguousarray(tau)
         check(self.lib.mgrit_hip_level_heat1d(self.h, engine_lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"]), K,
                                               _ptr(s), _ptr(tau)))
@@ -157,7 +176,7 @@ class HipBackend:
             K = s.shape[0]
             tau, tau2 = np.zeros((K, n_pts)), np.zeros((K, n_pts))
             for k in range(K):
-                tau[k] = [d["forcing_time"][k](tt) for tt in t_local]
+                tau[k] = _time_factor(d["forcing_time"][k], t_local)
                 tau2[k] = [d["forcing_time"][k](tt + d["dtau"]) for tt in t_local]
             check(self.lib.mgrit_hip_level_heat1d_2pts(self.h, lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"]),
                                                        float(d["dtau"]), int(d["order"]), K, _ptr(s),
@@ -170,7 +189,7 @@ class HipBackend:
             K = S.shape[0]
             tau = np.zeros((K, n_pts))
             for k in range(K):
-                tau[k] = [d["forcing_time"][k](tt) for tt in t_local]
+                tau[k] = _time_factor(d["forcing_time"][k], t_local)
             tau = np.ascontiguousarray(tau)
             bc = np.ascontiguousarray(np.asarray(d["bc"], dtype=np.float64).ravel())
             check(self.lib.mgrit_hip_level_heat2d(self.h, lvl, n_pts, _ptr(t_local), nx, ny, ld, float(d["fx"]), float(d["fy"]),

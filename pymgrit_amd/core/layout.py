@@ -81,7 +81,14 @@ def compute_layout(global_t, lvl: int, rank: int, size: int) -> LevelLayout:
     f_slots = index_local[~own_c]
     if f_slots.size:
         cuts = np.nonzero(np.diff(f_slots) != 1)[0] + 1
-        index_local_f = np.concatenate(np.split(f_slots, cuts)[::-1])
+        # runs in reversed order, ascending inside a run -- np.concatenate(np.split(f_slots, cuts)[::-1]) without its Python
+        # list of 16384 pieces: every element goes to (start of its run in the reversed sequence) + (its place in the run)
+        first = np.concatenate(([0], cuts))
+        length = np.diff(np.concatenate((first, [f_slots.size])))
+        run = np.repeat(np.arange(first.size), length)
+        start_rev = np.concatenate((np.cumsum(length[::-1])[::-1][1:], [0]))     # elements of the runs AFTER run r
+        index_local_f = np.empty_like(f_slots)
+        index_local_f[start_rev[run] + (np.arange(f_slots.size) - first[run])] = f_slots
     else:
         index_local_f = np.zeros(0)  # the reference yields an empty float array here
 
