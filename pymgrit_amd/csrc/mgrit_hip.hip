@@ -2719,7 +2719,7 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
         else hipLaunchKernelGGL(blk_scan_kernel, dim3(1), dim3(BLK_RMAX), 0, e->stream, bk);
         if (bk.project_last) {   // the last point, which the next rank waits for
             if (adv) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(1), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, bk.B - 1, 1);
-            else hipLaunchKernelGGL(blk_last_kernel, dim3(1), block, 0, e->stream, lv.dev, bk);
+            else hipLaunchKernelGGL(blk_last_kernel, dim3(8, lv.G), dim3(LANES), 0, e->stream, lv.dev, bk);
         }
     }
     if (phases & 4) {
