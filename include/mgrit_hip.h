@@ -25,7 +25,9 @@ extern "C" {
 #define MGRIT_HIP_MAX_N_WIDE 65536 /* Heat1D levels above MGRIT_HIP_MAX_N: the same Phi as three launches over rows in HBM
                                       (csrc/mgrit_hip_wide.inc): relaxations, residual / jump, the unfused FAS right-hand side,
                                       transfers, exchange; no fused passes, no AT-MGRIT */
-#define MGRIT_HIP_MAX_N_2PTS 4096 /* two-point steppers: max DOFs per time point of a pair (two coefficient sets in LDS) */
+#define MGRIT_HIP_MAX_N_2PTS 4096 /* two-point steppers: values per half of a pair that ONE workgroup holds (two coefficient sets in
+                                      LDS); wider pairs, up to MGRIT_HIP_MAX_N_WIDE per half, take every half-solve as three
+                                      launches over rows in HBM like wide Heat1D states (round 4; csrc/mgrit_hip_wide.inc, wide2_*) */
 #define MGRIT_HIP_BLOCK_K 16      /* time-parallel forward solve: steps per block */
 #define MGRIT_HIP_BLOCK_RMAX 64   /* ... and the most sine modes its recurrence over the blocks may need */
 

@@ -1433,6 +1433,7 @@ struct H2DHost {
 // Heat1D states of more than MGRIT_HIP_MAX_N values (mgrit_hip_wide.inc): work slabs of the three-launch Phi
 struct WideHost {
     double *W = nullptr, *tot = nullptr, *car = nullptr, *z0 = nullptr, *red = nullptr;
+    double *T0 = nullptr;   // two-point levels: the new first values of a batch (half rows)
     size_t cap = 0;
 };
 
@@ -1920,8 +1921,8 @@ int level_heat1d_2pts(mgrit_hip_engine *e, int lvl, int n_pts, const double *t_l
                       int order, int K, const double *s, const double *tau, const double *tau2) {
     int rc = check_level(e, lvl, false);
     if (rc) return rc;
-    if (n < 1 || n > MGRIT_HIP_MAX_N_2PTS)
-        return fail(MGRIT_HIP_EUNSUPPORTED, "n=%d DOFs per time point outside [1,%d] (two-point stepper)", n, MGRIT_HIP_MAX_N_2PTS);
+    if (n < 1 || n > MGRIT_HIP_MAX_N_WIDE)
+        return fail(MGRIT_HIP_EUNSUPPORTED, "n=%d DOFs per time point outside [1,%d] (two-point stepper)", n, MGRIT_HIP_MAX_N_WIDE);
     if (ld != 2 * mgrit_hip_row_stride(n)) return fail(MGRIT_HIP_EINVAL, "ld=%d must equal 2*mgrit_hip_row_stride(n=%d)=%d", ld, n, 2 * mgrit_hip_row_stride(n));
     if (order != 1 && order != 2) return fail(MGRIT_HIP_EINVAL, "BDF order must be 1 or 2");
     if (n_pts < 0 || (n_pts > 0 && !t_local)) return fail(MGRIT_HIP_EINVAL, "bad local time grid");
@@ -1932,6 +1933,7 @@ int level_heat1d_2pts(mgrit_hip_engine *e, int lvl, int n_pts, const double *t_l
     const int G = (n + GROUP - 1) / GROUP, T = G * LANES;
     lv.G = G;
     lv.order = order;
+    if (n > MGRIT_HIP_MAX_N_2PTS) lv.wide = new WideHost();   // wider than a workgroup holds: every half-solve as three launches (mgrit_hip_wide.inc)
     LevelDev &d = lv.dev;
     d.n = n; d.ld = ld; d.T = T; d.n_pts = n_pts; d.K = K; d.kind = MGRIT_HIP_STEPPER_HEAT1D_2PTS;
     d.stream_rows = 0;
@@ -2434,15 +2436,17 @@ constexpr int WIDE_MAX_BATCH = 2048;   // items per batch (work slab: 2048 rows 
 int wide_reserve(Level &lv, int count) {
     WideHost &h = *lv.wide;
     if ((size_t)count <= h.cap) return 0;
-    for (double **p : {&h.W, &h.tot, &h.car, &h.z0, &h.red}) {
+    for (double **p : {&h.W, &h.tot, &h.car, &h.z0, &h.red, &h.T0}) {
         if (*p) lv.allocs.push_back(*p);   // kept until the engine goes: a captured cycle may still launch with the old addresses
         *p = nullptr;
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.W), sizeof(double) * (size_t)count * lv.dev.ld));
+    if (lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D_2PTS)
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.T0), sizeof(double) * (size_t)count * (lv.dev.ld / 2)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.tot), sizeof(double) * (size_t)count * 2 * WIDE_MAX_G));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.car), sizeof(double) * (size_t)count * 2 * WIDE_MAX_G));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.z0), sizeof(double) * (size_t)count));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.red), sizeof(double) * (size_t)count * WIDE_MAX_G));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h.red), sizeof(double) * (size_t)count * 2 * WIDE_MAX_G));   // (two-point: both halves)
     h.cap = count;
     return 0;
 }
@@ -2476,10 +2480,25 @@ int wide_phi(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const double *in
     const int G = lv.dev.T / LANES;
     const dim3 grid((G + 15) / 16, pl.count), block(1024);
     const int fm = force_mode(lv);
+    if (lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D_2PTS) {   // two half-solves; the second one's scanned rows and carries are what wide_finish takes
+        for (int hf = 0; hf < 2; ++hf) {
+#define WIDE2_LOCAL(O_, F_)                                                                                                         \
+    if (lv.order == O_ && (fm != 0) == (F_ != 0))                                                                                  \
+        hipLaunchKernelGGL((wide2_local_kernel<O_, F_>), grid, block, 0, e->stream, lv.dev, hf, in_slab, pl.d_in, pl.d_step, h.T0, h.W, h.tot);
+            WIDE2_LOCAL(1, 0) WIDE2_LOCAL(1, 2) WIDE2_LOCAL(2, 0) WIDE2_LOCAL(2, 2)
+            hipLaunchKernelGGL(wide_carry_kernel, dim3(pl.count), dim3(64), 0, e->stream, lv.dev, pl.d_step, h.tot, h.car, h.z0, hf);
+            if (hf == 0)
+                hipLaunchKernelGGL(wide2_finish_kernel, grid, block, 0, e->stream, lv.dev, 0, h.W, pl.d_step, h.car, h.z0, h.T0, (double *)nullptr, 0,
+                                   (const int32_t *)nullptr, (const double *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
+                                   (const int32_t *)nullptr, 0, 0, 1.0, 0.0, (double *)nullptr);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (fm == 0) hipLaunchKernelGGL((wide_local_kernel<0>), grid, block, 0, e->stream, lv.dev, in_slab, pl.d_in, pl.d_step, h.W, h.tot);
     else if (fm == 3) hipLaunchKernelGGL((wide_local_kernel<3>), grid, block, 0, e->stream, lv.dev, in_slab, pl.d_in, pl.d_step, h.W, h.tot);
     else hipLaunchKernelGGL((wide_local_kernel<2>), grid, block, 0, e->stream, lv.dev, in_slab, pl.d_in, pl.d_step, h.W, h.tot);
-    hipLaunchKernelGGL(wide_carry_kernel, dim3(pl.count), dim3(64), 0, e->stream, lv.dev, pl.d_step, h.tot, h.car, h.z0);
+    hipLaunchKernelGGL(wide_carry_kernel, dim3(pl.count), dim3(64), 0, e->stream, lv.dev, pl.d_step, h.tot, h.car, h.z0, -1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2488,6 +2507,10 @@ int wide_finish(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, double *dst_s
                 const double *b_slab, int op, int use_g, double w) {
     WideHost &h = *lv.wide;
     const int G = lv.dev.T / LANES;
+    if (lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D_2PTS)
+        hipLaunchKernelGGL(wide2_finish_kernel, dim3((G + 15) / 16, pl.count), dim3(1024), 0, e->stream, lv.dev, 1, h.W, pl.d_step, h.car, h.z0,
+                           h.T0, dst_slab, dst_ld, pl.d_dst, a_slab, pl.d_a, b_slab, pl.d_b, op, use_g, w, 1.0 - w, h.red);
+    else
     hipLaunchKernelGGL(wide_finish_kernel, dim3((G + 15) / 16, pl.count), dim3(1024), 0, e->stream, lv.dev, h.W, pl.d_step, h.car, h.z0,
                        dst_slab, dst_ld, pl.d_dst, a_slab, pl.d_a, b_slab, pl.d_b, op, use_g, w, 1.0 - w, h.red);
     HIP_TRY(hipGetLastError());
@@ -2532,7 +2555,7 @@ int wide_points_sumsq(mgrit_hip_engine *e, int lvl, RunList *rl, const double *p
         if ((rc = wide_make_plans(e, lv, items, rl->h2d_points))) return rc;
         rl->h2d_points_built = true;
     }
-    const int G = lv.dev.T / LANES;
+    const int G = lv.dev.T / LANES, halves = lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D_2PTS ? 2 : 1;
     int off = 0;
     for (const H2DPlan &pl : rl->h2d_points) {
         if ((rc = wide_reserve(lv, std::min(WIDE_MAX_BATCH, std::max(pl.count, 1))))) return rc;
@@ -2541,9 +2564,10 @@ int wide_points_sumsq(mgrit_hip_engine *e, int lvl, RunList *rl, const double *p
             if ((rc = wide_finish(e, lv, pl, lv.dev.u, lv.dev.ld, lv.dev.u, lv.dev.u, WIDE_OP_RESIDUAL, 0, 1.0))) return rc;
         } else {
             hipLaunchKernelGGL(wide_diffsq_kernel, dim3((G + 15) / 16, pl.count), dim3(1024), 0, e->stream, lv.dev, lv.dev.u, prev,
-                               pl.d_dst, lv.wide->red);
+                               pl.d_dst, lv.wide->red, halves);
         }
-        hipLaunchKernelGGL(wide_rowsum_kernel, dim3((pl.count + 63) / 64), dim3(64), 0, e->stream, lv.wide->red, G, pl.count, out + off);
+        hipLaunchKernelGGL(wide_rowsum_kernel, dim3((pl.count + 63) / 64), dim3(64), 0, e->stream, lv.wide->red, halves * G, pl.count, out + off,
+                           halves * WIDE_MAX_G);
         HIP_TRY(hipGetLastError());
         off += pl.count;
     }
@@ -2895,7 +2919,7 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
             delete lv.h2d;
         }
         if (lv.wide) {
-            for (double *p : {lv.wide->W, lv.wide->tot, lv.wide->car, lv.wide->z0, lv.wide->red})
+            for (double *p : {lv.wide->W, lv.wide->tot, lv.wide->car, lv.wide->z0, lv.wide->red, lv.wide->T0})
                 if (p) (void)hipFree(p);
             delete lv.wide;
         }
@@ -3445,7 +3469,9 @@ int mgrit_hip_fas_rhs(mgrit_hip_engine *e, int lvl, int pairs_id) {
     if (is_2pts(lf) || is_2pts(lc)) {
         if (!is_2pts(lf) || !is_2pts(lc) || lf.transfer != MGRIT_HIP_TRANSFER_COPY)
             return fail(MGRIT_HIP_EUNSUPPORTED, "two-point levels pair with two-point levels through the copy transfer only");
-        LAUNCH2_BY_ORDER(fas_fine2_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_coarse, lc.dev.g, lc.dev.ld, lvl > 0 ? 1 : 0);
+        if (lf.wide) { if ((rc = wide_fas_fine(e, lvl, pl, lc.dev.g, lc.dev.ld, false))) return rc; }
+        else { LAUNCH2_BY_ORDER(fas_fine2_kernel, lf, pl->n, lf.dev, pl->d_fine, pl->d_coarse, lc.dev.g, lc.dev.ld, lvl > 0 ? 1 : 0); }
+        if (lc.wide) return wide_fas_coarse(e, lvl, pl);
         LAUNCH2_BY_ORDER(fas_coarse2_kernel, lc, pl->n, lc.dev, pl->d_coarse);
         return 0;
     }

@@ -27,7 +27,9 @@ def make_pair(oracle, nx, n_pairs, orders, coarsening, forcing, **opts):
 SHAPES = [  # nx (incl. boundary points), pairs, BDF order per level, coarsening, forcing
     (11, 33, [2, 1, 1], 2, "one"), (35, 33, [1, 1, 1], 2, "one"), (35, 33, [2, 2, 2], 2, "two"), (35, 17, [2, 1], 4, "zero"),
     (1026, 17, [2, 1, 1], 2, "one"), (1027, 17, [2, 2, 1], 2, "two"), (3000, 9, [1, 1], 2, "one"),
-    (4098, 9, [2, 1, 1], 2, "one"),   # 4096 values per time point of the pair: the largest supported state
+    (4098, 9, [2, 1, 1], 2, "one"),   # 4096 values per half of the pair: the largest state one workgroup holds
+    # wider pairs (round 4): every half-solve as three launches over rows in HBM (csrc/mgrit_hip_wide.inc, wide2_*)
+    (4099, 9, [2, 1], 2, "one"), (5002, 9, [2, 1, 1], 2, "one"), (5003, 9, [1, 1], 2, "two"), (20002, 5, [2, 2], 2, "one"),
 ]
 
 
@@ -99,6 +101,27 @@ def test_two_point_limits_fail_loudly():
     _need_gpu()
     from pymgrit_amd import Mgrit
     from pymgrit_amd.core.hip_lib import MgritHipError
-    prob = cases.bdf_levels(4100, 5, [1, 1], 2, "zero")
+    prob = cases.bdf_levels(65540, 3, [1, 1], 2, "zero")      # 65538 values per half: beyond the wide path's 64 groups
     with pytest.raises(MgritHipError, match="two-point"):
         Mgrit(prob, logging_lvl=30)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(conv_crit=1), dict(weight_c=1.3, cycle_type='F'), dict(nested_iteration=True)],
+                         ids=["residual", "jump", "weighted_F", "nested"])
+def test_two_point_wide_solve_matches_oracle(oracle, kw):
+    """pairs of 5000 values per half (five groups: beyond one workgroup's registers, csrc/mgrit_hip_wide.inc wide2_*): whole solves --
+    residual and jump criterion (both halves' groups in the spec's order), weighted C-relaxation, F-cycle, nested iteration --
+    against the oracle: the same history, the same states"""
+    _need_gpu()
+    from pymgrit_amd import Mgrit
+    prob = cases.bdf_levels(5002, 17, [2, 1, 1], 2, "one")
+    opts = dict(nested_iteration=False, max_iter=4, tol=1e-14)
+    opts.update(kw)
+    mg = Mgrit(prob, logging_lvl=30, **opts)
+    assert mg.backend.name == "hip"
+    conv = mg.solve()["conv"]
+    op = oracle.OracleProblem([cases.bdf_level_spec(p) for p in prob], variant=1, **opts)
+    ref = op.solve()
+    assert len(conv) == len(ref) and np.all(np.abs(conv - ref) <= 1e-10 * np.abs(ref)), (conv, ref)
+    for lvl in range(mg.lvl_max):
+        assert np.array_equal(mg.backend.natural("u", lvl), op.state("u", lvl)), lvl
