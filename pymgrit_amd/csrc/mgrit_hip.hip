@@ -2808,11 +2808,21 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
             }
         }
         const double sc = std::sqrt(2.0 / (double)(n + 1));
-        for (int k = 0; k < r; ++k)
-            for (int j = 0; j < n; ++j) {
-                const long m = ((long)(k + 1) * (long)(j + 1)) % (2L * (n + 1));
-                Q[(size_t)k * ld + row_pos(j)] = sc * std::sin(M_PI * (double)m / (double)(n + 1));
-            }
+        {   // the r mode rows are independent: on a few host threads (r n calls of sin -- 0.8 M at config 3 -- were 15 ms of a solve's setup)
+            auto rows = [&](int k0, int k1) {
+                for (int k = k0; k < k1; ++k)
+                    for (int j = 0; j < n; ++j) {
+                        const long m = ((long)(k + 1) * (long)(j + 1)) % (2L * (n + 1));
+                        Q[(size_t)k * ld + row_pos(j)] = sc * std::sin(M_PI * (double)m / (double)(n + 1));
+                    }
+            };
+            const unsigned hw = std::thread::hardware_concurrency();
+            const int nth = (size_t)r * n < 65536 ? 1 : std::max(1, std::min({8, (int)(hw ? hw : 1), r}));
+            std::vector<std::thread> pool;
+            for (int w = 1; w < nth; ++w) pool.emplace_back(rows, (int)((long)r * w / nth), (int)((long)r * (w + 1) / nth));
+            rows(0, r / nth);
+            for (std::thread &th : pool) th.join();
+        }
         std::vector<double> zeros((size_t)B * BLK_RMAX, 0.0);
         double *dQ, *dD, *dW, *dC;
         if ((rc = dev_upload(lv, e->stream, Q, &dQ))) return rc;
@@ -2858,9 +2868,10 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
         while ((1 << bk.lg_n) < n) ++bk.lg_n;
     }
     {
-        std::vector<double> zrows((size_t)B * ld, 0.0);
-        double *dWs;
-        if ((rc = dev_upload(lv, e->stream, zrows, &dWs))) return rc;
+        double *dWs = nullptr;   // (zeroed on the device: as a host vector of B rows it was 33 MB allocated, cleared and copied at config 3)
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dWs), sizeof(double) * (size_t)B * ld));
+        lv.allocs.push_back(dWs);
+        HIP_TRY(hipMemsetAsync(dWs, 0, sizeof(double) * (size_t)B * ld, e->stream));
         bk.Ws = dWs;
     }
     bk.uh_in = uh_in; bk.uh_out = has_successor ? uh_out : nullptr;
