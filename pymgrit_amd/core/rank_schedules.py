@@ -280,18 +280,20 @@ class RankSchedules:
                     can is not None and can(lvl) and (not up or self._can_fuse_ec(lvl))):
                 return [None]
             pairs = self._xpairs(lvl)
-            if len(pairs) < 2 or pairs[0][0] != 0 or self._c_points(lvl) != [p[0] for p in pairs[1:]]:
+            P = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+            if len(pairs) < 2 or pairs[0][0] != 0 or not np.array_equal(np.asarray(self._c_points(lvl), dtype=np.int64), P[1:, 0]):
                 return [None]
-            runs = self._f_runs(lvl)
-            want = [(pairs[k][0] + 1, pairs[k + 1][0] - pairs[k][0] - 1) for k in range(len(pairs) - 1)]
-            if [tuple(r) for r in runs] != want or any(ln < 1 for _, ln in want):
+            # every interval between two C-points is one run of F-points, at least one (compared as arrays: 16384 of them at config 3)
+            R = np.asarray(self._f_runs(lvl), dtype=np.int64).reshape(-1, 2)
+            want_len = P[1:, 0] - P[:-1, 0] - 1
+            if R.shape[0] != P.shape[0] - 1 or not np.array_equal(R[:, 0], P[:-1, 0] + 1) or not np.array_equal(R[:, 1], want_len) or \
+                    (want_len < 1).any():
                 return [None]
             # rows of lvl+1 that the down pass must really store for the closing C-point (include/mgrit_hip.h, keep): u only
             # where the coarse level reads it before writing it -- its C-points when it starts with an F-relaxation (always,
             # mgrit.py:270-271), nothing on a coarsest level that forward_solve overwrites from its first point on --, v only
             # when the correction on the way up is not the pass that takes v from the fine C-point
             coarsest = lvl + 1 == self.lvl_max - 1
-            P = np.asarray(pairs, dtype=np.int64)
             jce = P[1:, 1]                                   # coarse slot of the C-point an interval ends on
             c_next = np.asarray(self.index_local_c[lvl + 1], dtype=np.int64)
             if coarsest:
