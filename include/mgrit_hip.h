@@ -205,7 +205,9 @@ int mgrit_hip_error_correction(mgrit_hip_engine *e, int lvl, int pairs_id);
 /* Mgrit.nested_iteration interpolation (mgrit.py:559-563): u^l_i = P(u^{l+1}_j) */
 int mgrit_hip_interpolate(mgrit_hip_engine *e, int lvl, int pairs_id);
 /* AtMgrit.forward_solve on one rank (core/at_mgrit.py:79-87): every point p >= 1 of coarse level lvl becomes the value
- * obtained from the OLD u at point max(0, p-k+1) by the steps up to p, u_i = g_i + Phi(u_{i-1}); points are independent. */
+ * obtained from the OLD u at point max(0, p-k+1) by the steps up to p, u_i = g_i + Phi(u_{i-1}); points are independent. Every
+ * stepper: register-resident 1-D states and two-point pairs in one launch, Heat2D and the wide states as one batch of their Phi
+ * launches per step distance (round 4). */
 int mgrit_hip_at_solve(mgrit_hip_engine *e, int lvl, int k);
 /* Mgrit.error_correction followed by Mgrit.f_relax (mgrit.py:715-726, then 292-333, as Mgrit.iteration calls them,
  * mgrit.py:283-284) in one pass, for 1-D steppers and the identity transfer: a run list whose run r additionally names the

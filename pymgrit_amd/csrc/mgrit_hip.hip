@@ -1455,6 +1455,8 @@ struct Level {
                                        // the LDS copy of the kernels that keep the factor there (FORCE 4)
     double *scratch = nullptr;
     size_t scratch_rows = 0;
+    struct AtPlans { int32_t *d_src = nullptr, *d_own = nullptr; int count = 0; std::vector<std::vector<H2DPlan>> steps; };
+    std::map<int, AtPlans> at_plans;   // batched truncated solves (mgrit_hip_at_solve on Heat2D / wide levels), by distance k
     double *gen_rows = nullptr;      // mgrit_hip_gen_down / _up: [res_len][ld] uncorrected chunk-end C-points
     size_t gen_len = 0;              // res_len they were sized for
     double *chain_state = nullptr;   // caller-owned [ld + CHAIN_STATE_TAIL]: carry-free part of the last point + carries
@@ -1795,7 +1797,8 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(relax2_kernel<O, F, true, true>, smem2_bytes(MAX_G2)))) return rc;                       \
     if ((rc = allow_big_lds(residual2_kernel<O, F>, smem2_bytes(MAX_G2)))) return rc;                                \
     if ((rc = allow_big_lds(fas_fine2_kernel<O, F>, smem2_bytes(MAX_G2)))) return rc;                                \
-    if ((rc = allow_big_lds(fas_coarse2_kernel<O, F>, smem2_bytes(MAX_G2)))) return rc;
+    if ((rc = allow_big_lds(fas_coarse2_kernel<O, F>, smem2_bytes(MAX_G2)))) return rc;                              \
+    if ((rc = allow_big_lds(at2_kernel<O, F>, smem2_bytes(MAX_G2)))) return rc;
     FOR_EACH_2PTS(ATTR_2PTS)
     if ((rc = allow_big_lds(jump2_kernel, smem2_bytes(MAX_G2)))) return rc;
     g_attr_done = true;
@@ -3602,6 +3605,50 @@ static int interp_common(mgrit_hip_engine *e, int lvl, int pairs_id, int mode) {
 int mgrit_hip_error_correction(mgrit_hip_engine *e, int lvl, int pairs_id) { return interp_common(e, lvl, pairs_id, 1); }
 int mgrit_hip_interpolate(mgrit_hip_engine *e, int lvl, int pairs_id) { return interp_common(e, lvl, pairs_id, 0); }
 
+// the truncated solves of a level whose Phi is a batch of launches over rows (Heat2D, wide 1-D states, wide two-point pairs; round 4):
+// row p of a work slab starts as the OLD u of the point k-1 back (or the first point) and takes the steps up to p one batch per
+// step distance -- every point at once, x = g_i + Phi(x) --; then the rows go back into u. The arithmetic of every point is the
+// kernel at_kernel's: the same steps on the same values.
+static int at_batched(mgrit_hip_engine *e, int lvl, int k) {
+    Level &lv = e->L[lvl];
+    int rc;
+    const int n_pts = lv.dev.n_pts, ld = lv.dev.ld;
+    Level::AtPlans &ap = lv.at_plans[k];
+    if (ap.steps.empty() && ap.count == 0) {
+        std::vector<int32_t> src, own;
+        for (int p = 1; p < n_pts; ++p) { src.push_back(p - k + 1 > 0 ? p - k + 1 : 0); own.push_back(p); }
+        ap.count = (int)own.size();
+        if ((rc = dev_upload(lv, e->stream, src, &ap.d_src)) || (rc = dev_upload(lv, e->stream, own, &ap.d_own))) return rc;
+        for (int d = 1; d < k; ++d) {
+            std::vector<H2DItem> items;
+            for (int p = 1; p < n_pts; ++p) {
+                const int i = (p - k + 1 > 0 ? p - k + 1 : 0) + d;
+                if (i <= p) items.push_back({p, i, p, i, i});
+            }
+            std::vector<H2DPlan> plans;
+            if (!items.empty() && (rc = lv.h2d ? h2d_make_plans(e, lv, items, plans) : wide_make_plans(e, lv, items, plans))) return rc;
+            ap.steps.push_back(plans);
+        }
+    }
+    double *X = lv.scratch;
+    const dim3 grid(ap.count, (ld + 255) / 256);
+    hipLaunchKernelGGL(restrict_rows_kernel, grid, dim3(256), 0, e->stream, lv.dev.u, ld, lv.dev.T, ap.d_src, X, ld, lv.dev.T, ap.d_own,
+                       lv.dev.n, MGRIT_HIP_TRANSFER_COPY);
+    for (const std::vector<H2DPlan> &plans : ap.steps)
+        for (const H2DPlan &pl : plans) {
+            if (lv.h2d) {
+                if ((rc = h2d_phi_op(e, lv, pl, X, X, ld, lv.dev.g, X, H2D_OP_F, 1, 1.0))) return rc;
+            } else {
+                if ((rc = wide_phi(e, lv, pl, X))) return rc;
+                if ((rc = wide_finish(e, lv, pl, X, ld, lv.dev.g, X, WIDE_OP_F, 1, 1.0))) return rc;
+            }
+        }
+    hipLaunchKernelGGL(restrict_rows_kernel, grid, dim3(256), 0, e->stream, X, ld, lv.dev.T, ap.d_own, lv.dev.u, ld, lv.dev.T, ap.d_own,
+                       lv.dev.n, MGRIT_HIP_TRANSFER_COPY);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int mgrit_hip_at_solve(mgrit_hip_engine *e, int lvl, int k) {
     int rc = check_level(e, lvl);
     if (rc) return rc;
@@ -3609,8 +3656,6 @@ int mgrit_hip_at_solve(mgrit_hip_engine *e, int lvl, int k) {
     if (k < 1) return fail(MGRIT_HIP_EINVAL, "distance k=%d must be at least 1", k);
     if (lvl == 0) return fail(MGRIT_HIP_EINVAL, "the truncated solve runs on a coarse level (it uses g)");
     if ((rc = check_bound(lv, true))) return rc;
-    if (lv.h2d || is_2pts(lv)) return fail(MGRIT_HIP_EUNSUPPORTED, "AT-MGRIT coarsest solve: 1-D single-point steppers only");
-    if ((rc = no_wide(lv, nullptr, "AT-MGRIT coarsest solve"))) return rc;
     if (lv.dev.n_pts < 2) return 0;
     Timed timed(e, MGRIT_HIP_T_AT, lvl);
     const size_t rows = (size_t)lv.dev.n_pts;
@@ -3620,8 +3665,10 @@ int mgrit_hip_at_solve(mgrit_hip_engine *e, int lvl, int k) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lv.scratch), sizeof(double) * rows * lv.dev.ld));
         lv.scratch_rows = rows;
     }
+    if (lv.h2d || lv.wide) return at_batched(e, lvl, k);
     HIP_TRY(hipMemcpyAsync(lv.scratch, lv.dev.u, sizeof(double) * rows * lv.dev.ld, hipMemcpyDeviceToDevice, e->stream));
-    LAUNCH_BY_KIND(at_kernel, lv, persistent_grid(lv, lv.dev.n_pts - 1), lv.dev, lv.scratch, k);
+    if (is_2pts(lv)) { LAUNCH2_BY_ORDER(at2_kernel, lv, persistent_grid(lv, lv.dev.n_pts - 1), lv.dev, lv.scratch, k); }
+    else { LAUNCH_BY_KIND(at_kernel, lv, persistent_grid(lv, lv.dev.n_pts - 1), lv.dev, lv.scratch, k); }
     return 0;
 }
 

@@ -178,3 +178,38 @@ def test_several_processes_equal_one_on_the_host_path(name, world):
     conv1, u1 = launch(1, "at:" + name)
     conv, u = launch(world, "at:" + name)
     assert np.array_equal(conv, conv1) and np.array_equal(u, u1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["heat2d_BE", "heat2d_CN", "bdf_narrow", "bdf_wide", "heat_wide", "advection_wide"])
+def test_hip_truncated_solve_on_every_device_stepper(oracle, what):
+    """round 4: mgrit_hip_at_solve beyond the register-resident 1-D steppers -- Heat2D and the wide 1-D states as batches of the
+    level's own Phi launches (one batch per step distance, every point at once), two-point pairs in one workgroup by a kernel of
+    their own -- against the oracle's AtMgrit.forward_solve (core/at_mgrit.py:79-87) on random u and g: bit for bit"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    from pymgrit_amd import Advection1D
+    from test_hip_parity import assert_state_equal, randomize
+    for k in (1, 3, 6):
+        if what.startswith("heat2d"):
+            prob = [cases.h2d_app(19, 23, t, what[-2:], True, cases.H2D_A) for t in cases.h2d_grids([33, 9])]
+            specs = [cases.h2d_level_spec(a) for a in prob]
+            op = oracle.OracleProblem(specs, nested_iteration=False)
+        elif what.startswith("bdf"):
+            prob = cases.bdf_levels(35 if what == "bdf_narrow" else 5002, 17, [2, 1], 2, "one")
+            op = oracle.OracleProblem([cases.bdf_level_spec(p) for p in prob], variant=1, nested_iteration=False)
+        elif what == "heat_wide":
+            grids = [cases.lin(2, 17), cases.lin(2, 9)]
+            prob = heat(20002, [17, 9], False)
+            op = oracle.OracleProblem([cases.heat_level_spec(20002, t) for t in grids], variant=1, nested_iteration=False)
+        else:
+            grids = [cases.lin(2, 17), cases.lin(2, 9)]
+            prob = [Advection1D(c=1, x_start=-1, x_end=1, nx=20001, t_interval=t) for t in grids]
+            op = oracle.OracleProblem([cases.advection_level_spec(20001, t) for t in grids], variant=1, nested_iteration=False)
+        mg = AtMgrit(problem=prob, k=k, logging_lvl=30, nested_iteration=False)
+        assert mg.backend.name == "hip"
+        randomize(mg, op, seed=7 + k)
+        mg.forward_solve(1)
+        op.at_forward_solve(1, k)
+        assert_state_equal(mg, op)
