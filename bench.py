@@ -157,6 +157,7 @@ def iters_to_tol(problem, nx, tol=1e-10):
     import cases
     from oracle import oracle as orc
     from pymgrit_amd import Heat1D, Mgrit
+    from pymgrit_amd.core.options import options
     import torch
     runs = []
     for _ in range(2):   # the first constructor of a process also pays for fresh hipMalloc of the slabs (the timed Mgrit above is
@@ -552,6 +553,7 @@ def bench_emulated(args):
     import threading
     import torch
     from pymgrit_amd import Heat1D, Mgrit
+    from pymgrit_amd.core.options import options
     from pymgrit_amd.core.comm import LoopbackWorld
     torch.cuda.set_device(0)
     which, P = args.emulate_rank.split("/")
@@ -774,6 +776,7 @@ def main():
     import torch
     import torch.distributed as dist
     from pymgrit_amd import Heat1D, Mgrit
+    from pymgrit_amd.core.options import options
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -837,12 +840,15 @@ def main():
             be.relax(0, mg._f_runs(0), 'F')
         be.sync()
     pipelined = mg.pipeline_depth() > 0   # several ranks: the solver's own pipelined loop (Mgrit._solve_pipelined)
+    comm_stats = getattr(mg.comm_time, "stats", None)      # per-process counters: only the timed steps' share is reported
+    stats0 = None
     if pipelined:
         # the same steps through the solver's pipelined loop: every step still is one cycle + its stopping value; the values
         # are gathered asynchronously and ALL of them are resolved inside the timed region (_pl_finish)
         mg._pl_advance(1 + args.warmup, stop_on_tol=False)
         mg._pl_finish(stop_on_tol=False)
         fence()
+        stats0 = dict(comm_stats) if comm_stats is not None else None
         t_start = time.perf_counter()
         mg._pl_advance(args.steps, stop_on_tol=False)
         mg._pl_finish(stop_on_tol=False)
@@ -852,6 +858,7 @@ def main():
         for _ in range(args.warmup):
             cycle(1)
         fence()
+        stats0 = dict(comm_stats) if comm_stats is not None else None
         t_start = time.perf_counter()
         for _ in range(args.steps):
             cycle(1)
@@ -860,6 +867,7 @@ def main():
         getattr(be, "materialise", lambda: None)()
         fence()
     elapsed = time.perf_counter() - t_start
+    stats_timed = {k: comm_stats[k] - stats0[k] for k in comm_stats} if comm_stats is not None and stats0 is not None else None
     # several ranks: the same steps once more through the reference's own loop (mgrit.py:621-646: the stopping value examined after
     # every cycle, a blocking gather) -- what a solve costs when nothing may lag; outside `value`
     ms_checked = None
@@ -942,7 +950,7 @@ def main():
     # SURVEY 3.5): with pre-relaxed C-points the level-0 C-relaxation's Phi is the residual check's of the cycle before;
     # the time-parallel coarsest-level solve applies two Phi per step (less block 0's second pass and one per block)
     applied = list(counts)
-    if not args.at_k and mg.cf_iter[0] == 1 and os.environ.get("PYMGRIT_AMD_NO_PRE_RELAX", "") != "1" and mg._level_intervals(0) is not None:
+    if not args.at_k and mg.cf_iter[0] == 1 and not options.no_pre_relax and mg._level_intervals(0) is not None:
         applied[0] -= (nts[0] - 1) // 4
     if getattr(be, "block_r", {}).get(len(nts) - 1):
         n_c = nts[-1] - 1
@@ -1006,12 +1014,12 @@ def main():
     }
     if world > 1:
         comm = mg.comm_time
-        st = getattr(comm, "stats", None)
+        st = stats_timed
         if st is not None:
             per = torch.tensor([float(st["messages"]), float(st["bytes"]), float(st["device_messages"])], dtype=torch.float64,
                                device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(per, op=dist.ReduceOp.SUM)
-            cycles_run = max(mg.solve_iter, 1) + 3
+            cycles_run = args.steps      # the counters' difference over the timed steps alone
             out["exchange"] = {"backend": args.backend,
                                "path": ("mgrit_hip_exchange on RCCL links (ncclSend / ncclRecv under the C ABI)" if getattr(be, "device_links", False)
                                         else "torch.distributed send / recv" + (f" (links failed: {be.link_error})" if getattr(be, "link_error", None) else "")),

@@ -21,5 +21,15 @@ from pymgrit_amd.heat.grid_transfer_heat import GridTransferHeat
 from pymgrit_amd.advection.advection_1d import Advection1D
 from pymgrit_amd.advection.grid_transfer_advection import GridTransferAdvection
 
-__all__ = ["Application", "Vector", "GridTransfer", "GridTransferCopy", "simple_setup_problem", "Mgrit", "AtMgrit", "Dahlquist",
+
+
+def elementwise(f):
+    """Declare a forcing time factor tau(t) elementwise: called with an array of times it returns, entry by entry, exactly what
+    it returns for each time alone (no dependence on position, length, other entries or earlier calls). The device path then
+    evaluates it once per level instead of once per time point (core/backend_hip._time_factor)."""
+    f.elementwise = True
+    return f
+
+
+__all__ = ["elementwise", "Application", "Vector", "GridTransfer", "GridTransferCopy", "simple_setup_problem", "Mgrit", "AtMgrit", "Dahlquist",
            "Heat1D", "Heat1DBDF1", "Heat1DBDF2", "Heat2D", "GridTransferHeat", "Advection1D", "GridTransferAdvection"]

@@ -33,15 +33,32 @@ def _cols(items, k):
 def _time_factor(f, t):
     """tau(t_i) of a separable forcing term at every point of a level. The user's callable is written for ONE time (heat_1d.py's
     rhs is called per step); evaluated point by point a level of BASELINE config 3 costs 65537 Python calls (70 ms of a 115 ms
-    setup). It is tried on the whole array first and the result taken only if it has the right shape AND agrees bit for bit with
-    the point-by-point calls at 48 sampled points and both ends (numpy's elementwise functions are position-independent);
-    anything else -- an exception, a scalar, a different bit anywhere in the sample -- falls back to the loop."""
+    setup). options.time_factor: 'pointwise' = always the loop (the reference's calls, no question asked); 'auto' (default) =
+    the callable is tried on the whole array and its result taken only if
+      * it has the right shape and a second call returns the same bits (no state),
+      * the calls on t[1:] and on the first half of t return the same bits for the same times (an elementwise function must not
+        depend on a value's position in the array -- SIMD lane or tail --, on the array's length or on its other entries),
+      * it agrees bit for bit with the point-by-point calls at EVERY point of a level of <= 4096 points, and at both ends + 256
+        sampled points of a longer one;
+    anything else -- an exception, a scalar, a different bit anywhere -- falls back to the loop. A callable carrying the
+    attribute `elementwise = True` (pymgrit_amd.elementwise(f)) declares the property itself and skips the shifted calls.
+    INTEGRATION.md states the contract."""
     t = np.asarray(t, dtype=np.float64)
-    if t.size > 256:
+    mode = options.time_factor
+    if t.size > 256 and mode != "pointwise":
         try:
             v = np.asarray(f(t), dtype=np.float64)
-            if v.shape == t.shape:
-                idx = np.unique(np.concatenate(([0, 1, t.size - 2, t.size - 1], np.random.default_rng(t.size).integers(0, t.size, 48))))
+            ok = v.shape == t.shape
+            if ok and not getattr(f, "elementwise", False):
+                h = t.size // 2
+                ok = (np.asarray(f(t), dtype=np.float64).tobytes() == v.tobytes()
+                      and np.asarray(f(t[1:]), dtype=np.float64).tobytes() == v[1:].tobytes()
+                      and np.asarray(f(t[:h]), dtype=np.float64).tobytes() == v[:h].tobytes())
+            if ok:
+                if t.size <= 4096:
+                    idx = range(t.size)
+                else:
+                    idx = np.unique(np.concatenate(([0, 1, t.size - 2, t.size - 1], np.random.default_rng(t.size).integers(0, t.size, 256))))
                 if all(np.float64(f(t[i])).tobytes() == v[i].tobytes() for i in idx):
                     return v
         except Exception:       # noqa: BLE001 -- whatever the callable does with an array is its business: ask it point by point
@@ -177,7 +194,7 @@ class HipBackend:
             tau, tau2 = np.zeros((K, n_pts)), np.zeros((K, n_pts))
             for k in range(K):
                 tau[k] = _time_factor(d["forcing_time"][k], t_local)
-                tau2[k] = [d["forcing_time"][k](tt + d["dtau"]) for tt in t_local]
+                tau2[k] = _time_factor(d["forcing_time"][k], t_local + d["dtau"])      # (t + dtau elementwise: the same sums)
             check(self.lib.mgrit_hip_level_heat1d_2pts(self.h, lvl, n_pts, _ptr(t_local), n, ld, float(d["fac"]),
                                                        float(d["dtau"]), int(d["order"]), K, _ptr(s),
                                                        _ptr(np.ascontiguousarray(tau)), _ptr(np.ascontiguousarray(tau2))))
@@ -308,6 +325,9 @@ class HipBackend:
         self.block_sharded[lvl] = bool(r.value and size > 1)
         if self.block_sharded[lvl]:
             self.chain_handover[lvl] = int(uh_in.numel())      # doubles behind the point in the op-5 message
+            # no chain on this level any more: the engine must not keep the address of a state tensor that goes back to the allocator
+            check(self.lib.mgrit_hip_chain_enable(self.h, lvl, 0))
+            check(self.lib.mgrit_hip_chain_bind(self.h, lvl, None))
             self.chain_state[lvl] = None
 
     def block_solve(self, lvl, phases):
@@ -1246,7 +1266,12 @@ class HipBackend:
 
     def sync(self):
         if getattr(self, "device_links", False):   # a neighbour that never sends or never receives must end in an error here
-            check(self.lib.mgrit_hip_sync_bounded(self.h, float(getattr(self.mg.comm_time, "timeout_s", 120.0))))
+            rc = self.lib.mgrit_hip_sync_bounded(self.h, float(getattr(self.mg.comm_time, "timeout_s", 120.0)))
+            if rc != 0:     # the library has aborted this engine's links: the communicator object must not keep their handles
+                abort_all = getattr(self.mg.comm_time, "abort_all", None)
+                if abort_all is not None:
+                    abort_all()
+            check(rc)
         else:
             check(self.lib.mgrit_hip_sync(self.h))
 

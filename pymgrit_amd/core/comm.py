@@ -350,6 +350,7 @@ class RcclTimeComm(TorchTimeComm):
             got = self.allgather_object((us, err))
             errs = [e for _, e in got if e]
             if errs:
+                self.abort_all()     # a bounded wait that gave up has aborted links inside the library: hold no handle of them
                 raise RuntimeError("exchange links: " + errs[0])
             res[f"{src}->{dst}/{ch}"] = max(u for u, _ in got if u is not None)
         return res
@@ -676,7 +677,7 @@ def resolve_comm(comm_time):
             _drop_default_comms()
             device = dist.get_backend() == "nccl" and options.exchange != "torch"
             held = _default_comm[id(world)] = (world, RcclTimeComm() if device else TorchTimeComm())
-        return held[1]      # (its counters are per process; a solver reports the difference over its own run: Mgrit.solve)
+        return held[1]      # (its counters are per process; Mgrit.solve() reports its own share as mg.exchange_stats)
     if hasattr(comm_time, "exchange") and hasattr(comm_time, "Get_rank"):
         return comm_time
     raise Exception("comm_time must be None or a pymgrit_amd TimeComm (mpi4py communicators are not used on MI355X: "

@@ -780,7 +780,19 @@ class Mgrit(RankSchedules, PipelinedLoop):
                 ('convergence criterion', str(self.conv_crit))]
         self.log_info('\n'.join(['Run parameter overview'] + ['  ' + '{0: <25}'.format(k) + ' : ' + v for k, v in rows]))
 
+    def _exchange_stats_begin(self):
+        """the time communicator's counters are per process (several solvers may share it): a solve reports its own share"""
+        st = getattr(self.comm_time, "stats", None)
+        self._stats0 = dict(st) if st is not None else None
+        self.exchange_stats = None
+
+    def _exchange_stats_end(self):
+        st = getattr(self.comm_time, "stats", None)
+        if st is not None and getattr(self, "_stats0", None) is not None:
+            self.exchange_stats = {k: v - self._stats0.get(k, 0) for k, v in st.items()}
+
     def solve(self) -> dict:
+        self._exchange_stats_begin()
         if self.pipeline_depth() > 0:
             return self._solve_pipelined()
         self.log_info("Start solve")
@@ -811,6 +823,7 @@ class Mgrit(RankSchedules, PipelinedLoop):
         getattr(self.comm_time, 'drain', lambda: None)()
         self.comm_time.barrier()
         self.runtime_solve = time.time() - solve_start
+        self._exchange_stats_end()
         self.log_info(f"Solve took {self.runtime_solve} s")
         if self.output_fcn is not None and self.output_lvl == 1:
             self.output_fcn(self)

@@ -70,6 +70,9 @@ class Options:
                           "several ranks: no whole-level passes over a rank's complete intervals")
     no_aligned = _Opt("PYMGRIT_AMD_NO_ALIGNED", False, _flag,
                       "several ranks whose shares end on C-points: the generic rank path instead of the one-rank machinery")
+    time_factor = _Opt("PYMGRIT_AMD_TIME_FACTOR", "auto", str,
+                       "forcing time factors tau(t_i) of a level: 'auto' = the callable evaluated on the whole time grid where that "
+                       "provably equals the point-by-point calls (backend_hip._time_factor), 'pointwise' = always one call per point")
     # ---- how a cycle is issued -------------------------------------------------------------------------------------------------
     plan_blocks = _Opt("PYMGRIT_AMD_PLAN_BLOCKS", None, _opt_int,
                        "blocks of time points of a planned cycle (core/cycle_plan.py); None = the backend's choice (1 = program order "

@@ -139,6 +139,7 @@ class PipelinedLoop:
         getattr(self.comm_time, 'drain', lambda: None)()
         self.comm_time.barrier()
         self.runtime_solve = time.time() - solve_start
+        self._exchange_stats_end()
         self.log_info(f"Solve took {self.runtime_solve} s")
         if self.output_fcn is not None and self.output_lvl == 1:
             self.output_fcn(self)

@@ -25,10 +25,11 @@ def sequential_coarse():
     """forward_solve step by step (options.coarse_solve = 'sequential') for the tests of the chain kernels themselves: levels that
     qualify for the time-parallel form would otherwise never reach them. The oracle side: block_solve=False."""
     from pymgrit_amd.core.options import options
-    was = options.coarse_solve
     options.coarse_solve = "sequential"
-    yield
-    options.coarse_solve = was
+    try:
+        yield
+    finally:
+        options.reset("coarse_solve")      # back to environment / default (an assignment would pin the value for later tests)
 
 
 # Order of the suite (matters under `pytest -x`): the C ABI and the single-process oracle comparisons first, every test

@@ -751,6 +751,95 @@ def make_restated():
     print("solve_restated.json:", {k: len(v["conv"]) for k, v in out.items()})
 
 
+# --------------------------------------------------------------------------------------------------
+# Stage (B) for the TIME-PARALLEL forward solve of the device path: the same reference-driven histories on
+# hierarchies whose coarsest level has >= 64 steps, i.e. where the product's default forward_solve is the block form and no
+# longer the reference's step-by-step loop (mgrit.py:459-486). The reference runs its own sequential forward_solve on the
+# restated steps; the oracle's sequential form has to reproduce it to 1e-10 relative, the block form to
+# 1e-10 * conv + K * eps * ||u|| (tests/test_oracle_golden.py states K).
+# Same arithmetic as RestatedHeat1D, on Python floats (IEEE doubles, the same roundings as numpy's scalar operations) so that
+# config 2's 80 000 steps of 1022 values run in minutes.
+# --------------------------------------------------------------------------------------------------
+class RestatedHeat1DFast(Heat1D):
+    def step(self, u_start, t_start, t_stop):
+        dt = t_stop - t_start
+        beta, diag = dt * self.fac_, dt * (2.0 * self.fac_) + 1.0
+        d = (u_start.get_values() + self.rhs(self.x, t_stop) * dt).tolist()
+        n = len(d)
+        cp = [0.0] * n
+        piv = diag
+        cp[0] = -beta / piv
+        d[0] = d[0] / piv
+        for j in range(1, n):
+            piv = diag + beta * cp[j - 1]
+            cp[j] = -beta / piv
+            d[j] = (d[j] + beta * d[j - 1]) / piv
+        out = [0.0] * n
+        out[n - 1] = d[n - 1]
+        for j in range(n - 2, -1, -1):
+            out[j] = d[j] - cp[j] * out[j + 1]
+        ret = VectorHeat1D(n)
+        ret.set_values(np.array(out))
+        return ret
+
+
+class RestatedAdvection1D(Advection1D):
+    """reference Advection1D with step = the oracle's variant-0 periodic solve (oracle/mgrit_oracle.c advection1d_step_natural:
+    forward substitution of the bidiagonal part, closure through the last unknown), no SuperLU"""
+
+    def step(self, u_start, t_start, t_stop):
+        alpha = (t_stop - t_start) * self.fac_
+        D = alpha + 1.0
+        u = u_start.get_values().tolist()
+        n = len(u)
+        p, q = [0.0] * n, [0.0] * n
+        p[0] = u[0] / D
+        q[0] = alpha / D
+        for j in range(1, n):
+            p[j] = (u[j] + alpha * p[j - 1]) / D
+            q[j] = alpha * q[j - 1] / D
+        xl = p[n - 1] / (1.0 - q[n - 1])
+        out = [p[j] + q[j] * xl for j in range(n - 1)] + [xl]
+        ret = VectorAdvection1D(n)
+        ret.set_values(np.array(out))
+        return ret
+
+
+def restated_advection_levels(nx, ts):
+    out = []
+    for t in ts:
+        app = RestatedAdvection1D(c=1, x_start=-1, x_end=1, nx=nx, t_interval=t)
+        app.fac_ = 1.0 / (app.x[1] - app.x[0])       # c / dx exactly as cases.advection_level_spec computes it
+        out.append(app)
+    return out
+
+
+def make_restated_blk():
+    """inputs restated in tests/cases.restated_blk_cases; about ten minutes (config 2's shape dominates)"""
+    with open(os.path.join(HERE, "solve_restated.json")) as f:
+        out = json.load(f)
+
+    def lin(nts):
+        return [np.linspace(0, 2, nt) for nt in nts]
+
+    def heat(nx, ts):
+        return restated_levels([nx] * len(ts), ts, cls=RestatedHeat1DFast)
+    t0 = 2 * np.linspace(0, 1, 401) ** 1.3
+    out["restated_blk_config2"] = run(heat(1024, lin([4097, 1025, 257])), sample_pts=(2048, 4096), cf_iter=1, max_iter=5,
+                                      tol=1e-30)
+    out["restated_blk_nx2050_2lvl"] = run(heat(2050, lin([513, 129])), sample_pts=(512,), tol=1e-30, max_iter=5, cf_iter=2)
+    out["restated_blk_nonuniform_F"] = run(heat(129, [t0[::s] for s in (1, 2, 4)]), sample_pts=(400,), tol=1e-30, max_iter=6,
+                                           cycle_type='F')
+    out["restated_blk_nx257_3lvl"] = run(heat(257, lin([1025, 257, 65])), sample_pts=(1024,), tol=1e-30, max_iter=7)
+    out["restated_blk_advection_F"] = run(restated_advection_levels(257, lin([1025, 257, 65])), sample_pts=(1024,),
+                                          cycle_type='F', tol=1e-30, max_iter=6)
+    out["restated_blk_advection_nonuniform"] = run(restated_advection_levels(129, [t0[::s] for s in (1, 2, 4)]),
+                                                   sample_pts=(400,), tol=1e-30, max_iter=6, nested_iteration=False)
+    with open(os.path.join(HERE, "solve_restated.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("solve_restated.json:", {k: v["conv"] for k, v in out.items() if k.startswith("restated_blk_")})
+
+
 def ref_results():
     res = {}
     d = os.path.join(REF, "tests", "mpi", "results")
@@ -803,6 +892,10 @@ def main():
         return
     if "--only-restated" in sys.argv:
         make_restated()
+        make_restated_blk()
+        return
+    if "--only-restated-blk" in sys.argv:
+        make_restated_blk()
         return
     big = "--small" not in sys.argv
     lay = make_layout()
@@ -824,6 +917,7 @@ def main():
     make_local_conv_ranks()
     make_exchange_fuzz()
     make_restated()
+    make_restated_blk()
     res, kats = ref_results()
     with open(os.path.join(HERE, "ref_results.json"), "w") as f:
         json.dump({"tests_mpi_results": res}, f, indent=1)

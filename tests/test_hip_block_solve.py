@@ -98,12 +98,11 @@ def test_sequential_form_on_request(oracle):
     from test_hip_parity import _need_gpu, assert_state_equal, make_pair, randomize
     _need_gpu()
     grids = _grids(513, (4,))
-    was = options.coarse_solve
     try:
         options.coarse_solve = "sequential"
         mg, _ = make_pair(oracle, "heat", 1027, grids)
     finally:
-        options.coarse_solve = was
+        options.reset("coarse_solve")
     assert mg.backend.block_r[1] == 0
     specs = [cases.heat_level_spec(1027, t) for t in grids]
     op = oracle.OracleProblem(specs, variant=1, nested_iteration=False, block_solve=False)

@@ -91,12 +91,11 @@ def test_time_parallel_forward_solve_bit_exact(oracle, name, with_bc, nx, ny, po
         _equal(mg, op)
     mg.iteration(lvl=0, cycle_type='V', iteration=0, first_f=True); op.iteration(0, 'V', 0, True)
     _equal(mg, op)
-    was = options.coarse_solve
     try:
         options.coarse_solve = "sequential"
         mg2, _ = _pair(oracle, [cases.h2d_app(nx, ny, t, "BE", with_bc) for t in ts])
     finally:
-        options.coarse_solve = was
+        options.reset("coarse_solve")
     op2 = oracle.OracleProblem([cases.h2d_level_spec(a) for a in prob], nested_iteration=False, block_solve=False)
     assert mg2.backend.block_r[1] == 0
     _randomize(mg2, op2, nx)

@@ -221,6 +221,21 @@ def test_solve_matches_oracle_and_reference(oracle, name):
     n = min(len(ref), len(conv))
     assert np.all(np.abs(conv[:n] - ref[:n]) <= 1e-9 * ref[:n] + 2e-11), (name, conv, ref)
     assert np.array_equal(mg.backend.natural("u", 0), op.state("u", 0))
+    if cases.takes_block_solve(name):
+        # the coarsest level took the time-parallel forward solve, the reference steps through it
+        # (mgrit.py:459-486): residual history within 1e-10 relative + BLK_K eps ||u|| of the reference's, and of the SAME engine
+        # with the step-by-step solve within BLK_K_FORM eps ||u|| (tests/cases.py states the constants)
+        assert mg.backend.block_r[mg.lvl_max - 1] > 0
+        floor = cases.EPS * cases.spacetime_norm(op.state("u", 0))
+        assert np.all(np.abs(conv[:n] - ref[:n]) <= 1e-10 * ref[:n] + cases.BLK_K * floor), (name, conv, ref, floor)
+        from pymgrit_amd.core.options import options
+        try:
+            options.coarse_solve = "sequential"
+            prob2, tr2, _ = build_product(name)
+            seq = Mgrit(prob2, transfer=tr2, logging_lvl=30, **opts).solve()["conv"]
+        finally:
+            options.reset("coarse_solve")
+        assert len(seq) == len(conv) and np.all(np.abs(conv - seq) <= 1e-10 * seq + cases.BLK_K_FORM * floor), (name, conv, seq)
     for k, v in SOLVE[name].get("samples", {}).items():
         v = np.array(v)
         assert np.abs(mg.u[0][int(k)].get_values() - v).max() <= 1e-11 * max(1.0, np.abs(v).max())

@@ -408,3 +408,44 @@ def test_time_factor_of_a_forcing_term_is_the_point_by_point_one():
     assert _time_factor(grid_dependent, t).tobytes() == loop(grid_dependent).tobytes() and 1 in calls
     short = np.linspace(0.0, 1.0, 33)                                        # short grids are not worth the attempt
     assert _time_factor(smooth, short).tobytes() == np.asarray([smooth(tt) for tt in short]).tobytes()
+    #  callables that keep the shape but are NOT position-independent, on a grid too long to compare every point:
+    # the value depends on the entry's index parity (a SIMD-tail-like defect that 256 random samples could miss at a single
+    # point), on the array's length, or on earlier calls -- the shifted / half-length / repeated calls catch them
+    tl = np.linspace(0.0, 2.0, 65537)
+    loopl = lambda f: np.asarray([f(tt) for tt in tl], dtype=np.float64)     # noqa: E731
+
+    def last_entry_off(x):
+        y = np.sin(x)
+        if np.ndim(x):
+            y = y.copy()
+            y[-1] = np.nextafter(y[-1], 2.0)
+        return y
+    assert _time_factor(last_entry_off, tl).tobytes() == loopl(last_entry_off).tobytes()
+
+    def length_dependent(x):
+        return np.cos(x) * (1.0 + 1e-16 * np.size(x))
+    assert _time_factor(length_dependent, tl).tobytes() == loopl(length_dependent).tobytes()
+    seen = []
+
+    def stateful(x):
+        seen.append(1)
+        return np.cos(x) + (1e-13 if len(seen) == 1 else 0.0)
+    got = _time_factor(stateful, tl)
+    del seen[:]
+    seen.append(1)
+    assert got.tobytes() == loopl(stateful).tobytes()
+    # opting in (pymgrit_amd.elementwise) skips the shifted calls; options.time_factor = 'pointwise' never tries the array
+    from pymgrit_amd import elementwise
+    from pymgrit_amd.core.options import options
+    assert _time_factor(elementwise(smooth), tl).tobytes() == loopl(smooth).tobytes()
+    nd = []
+
+    def probe(x):
+        nd.append(np.ndim(x))
+        return np.sin(x)
+    try:
+        options.time_factor = "pointwise"
+        _time_factor(probe, t)
+    finally:
+        options.reset("time_factor")
+    assert nd and max(nd) == 0
