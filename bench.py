@@ -112,9 +112,12 @@ def cpu_baseline(nx, nt=16385):
                 break
         return upd_per_cycle * cycles / el, used, cycles, el
     v1, _, c1, e1 = run(1, 1, 0.0)
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # the cores this process may really use: the affinity mask cut down to the cgroup's CPU quota (a one-GPU box of the pool shows
+    # 256 logical CPUs and grants 16: threads beyond the quota are throttled, not run -- round 4's `by_threads` fell from 1.3e9 at 32
+    # threads to 2.8e8 at 256 for that reason, and its "256 cores" was never the box's share)
+    avail = cases.usable_cpus()
     tried = {}
-    for threads in sorted({min(avail, t) for t in (8, 16, 32, 64, 128, avail)}):
+    for threads in sorted({min(avail, t) for t in (4, 8, 16, 32, 64, 128, avail)}):
         if threads > 1:
             tried[threads] = run(threads, 2, 1.5)
     best = max(tried, key=lambda t: tried[t][0]) if tried else 1
@@ -143,9 +146,9 @@ def cpu_baseline(nx, nt=16385):
                  "port_sample": f"{c2} V-cycles incl. residual check in {e2:.2f} s on 1 core of this host"}
     return {"value": vn, "unit": "time-point-DOF updates/s", "cores": used, "kind": "port", "value_1core": v1,
             "reference_python": reference,
-            "host_cores": os.cpu_count(), "by_threads": {str(t): r[0] for t, r in tried.items()},
-            "sample": f"port = parity oracle variant 0 (Thomas solves, reference operation order), {used} of {os.cpu_count()} "
-                      f"cores: heat_1d nx={nx} nt={nts[0]} 3-level m=4 ({(nts[0] - 1) // 4} F-intervals per level-0 sweep), "
+            "host_cores": os.cpu_count(), "host_cores_usable": avail, "by_threads": {str(t): r[0] for t, r in tried.items()},
+            "sample": f"port = parity oracle variant 0 (Thomas solves, reference operation order), {used} of the {avail} CPUs this "
+                      f"process may use (cgroup quota / affinity; the host shows {os.cpu_count()}): heat_1d nx={nx} nt={nts[0]} 3-level m=4 ({(nts[0] - 1) // 4} F-intervals per level-0 sweep), "
                       f"V-cycles incl. residual check: {c1} cycle(s) in {e1:.1f} s on 1 core, {cn} cycles in {en:.1f} s on "
                       f"{used} OpenMP threads (tried {sorted(tried)}; {avail} usable cores)"}
 
@@ -186,9 +189,57 @@ def iters_to_tol(problem, nx, tol=1e-10):
     conv_cpu = orc.OracleProblem([cases.heat_level_spec(nx, g) for g in grids], variant=1, cf_iter=1, nested_iteration=True,
                                  max_iter=30, tol=tol).solve()
     k = min(len(conv_gpu), len(conv_cpu))
-    return {"tol": tol, "time_to_solution_ms": tts, "full_workload": {"gpu_iters": int(len(conv_full)), "conv_last": float(conv_full[-1])},
+    parity = coarse_solve_parity(problem, iters=5, cf_iter=1, cycle_type='V', nested_iteration=True)
+    return {"tol": tol, "time_to_solution_ms": tts, "parity": parity,
+            "full_workload": {"gpu_iters": int(len(conv_full)), "conv_last": float(conv_full[-1])},
             "sample_nt1025": {"gpu_iters": int(len(conv_gpu)), "cpu_iters": int(len(conv_cpu)),
                               "max_rel_conv_diff": float(np.max(np.abs(conv_gpu[:k] - conv_cpu[:k]) / np.abs(conv_cpu[:k])))}}
+
+
+def spacetime_norm_gpu(be):
+    """2-norm of the level-0 solution over space and time, on the device (padding positions of the rows left out)"""
+    U, perm = be.U[0], be.perm[0]
+    import torch
+    acc = torch.zeros((), dtype=torch.float64, device=U.device)
+    for a in range(0, U.shape[0], 4096):
+        blk = U[a:a + 4096][:, perm]
+        acc += (blk * blk).sum()
+    return float(acc.sqrt().item())
+
+
+def coarse_solve_parity(problem, iters=5, **kw):
+    """Which form of forward_solve the coarsest level takes by default, and what that costs in parity. The reference steps through
+    the coarsest level point by point (mgrit.py:459-486); the default here is the time-parallel block form wherever the level
+    qualifies -- the same solve in another association. Both forms are run on this GPU from the same start for
+    `iters` iterations (tol = 0); reported per iteration k: conv of both, the relative deviation, the absolute one, and the absolute
+    one in units of eps * ||u|| (2-norm of the solution over space and time: the rounding level of a residual). The bar
+    (tests/cases.py BLK_K_FORM; tests/test_oracle_golden.py pins both forms to the reference's histories): 1e-10 * conv + 2 eps ||u||."""
+    import gc
+    from pymgrit_amd import Mgrit
+    from pymgrit_amd.core.options import options
+    conv, norm_u, form = {}, None, None
+    for which in ("auto", "sequential"):
+        try:
+            options.coarse_solve = which
+            mg = Mgrit(problem, max_iter=iters, tol=0.0, logging_lvl=30, **kw)
+        finally:
+            options.reset("coarse_solve")
+        conv[which] = np.asarray(mg.solve()["conv"], dtype=np.float64)
+        if which == "auto":
+            norm_u = spacetime_norm_gpu(mg.backend)
+            r = getattr(mg.backend, "block_r", {}).get(mg.lvl_max - 1, 0)
+            form = f"time-parallel blocks of 16 steps ({r} modes)" if r else "sequential (the level does not qualify)"
+        del mg
+        gc.collect()
+    a, b = conv["auto"], conv["sequential"]
+    k = min(len(a), len(b))
+    eps = float(np.finfo(np.float64).eps)
+    dev = np.abs(a[:k] - b[:k])
+    bound = 1e-10 * b[:k] + 2.0 * eps * norm_u
+    return {"coarse_solve": form, "conv": a.tolist(), "conv_sequential": b.tolist(),
+            "rel_dev_vs_sequential": (dev / b[:k]).tolist(), "abs_dev": dev.tolist(),
+            "abs_dev_in_eps_norm_u": (dev / (eps * norm_u)).tolist(), "norm_u_spacetime": norm_u,
+            "bound": "1e-10 * conv + 2 * eps * ||u||_spacetime", "within_bound": bool(len(a) == len(b) and np.all(dev <= bound))}
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet, FP64 matrix (the on-box guide lists no f64 MFMA row)
@@ -395,6 +446,9 @@ KERNEL_OF = {"relax_f": "relax_kernel<1, 1, {g}, 0>", "relax_c": "relax_kernel<1
              "f_fas": "fas_fused1_kernel<4, true>"}
 LIMITED_BY = {"chain": "latency: the coarsest-level solve is sequential, one cross-workgroup exchange per step (measured floor "
                        "0.98 us/step = one store -> L2 -> load round trip); bytes are not what bounds it",
+              "chain_blocks": "the time-parallel forward solve (DESIGN.md 3.8): two batched passes over all blocks of 16 steps (HBM "
+                              "bandwidth where the level is large: config 3) around a modal recurrence over the blocks; on small "
+                              "levels (config 2) the launch latency of its six kernels",
               "default": "HBM bandwidth (one 1024-thread workgroup per CU streaming rows; 6.29 TB/s copy ceiling of the guide)"}
 
 
@@ -506,13 +560,15 @@ def sweep_table(mg, be, nts, m_list, dof, cycle, cycles=3):
     for key, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         kind = key.split()[0]
         sym = KERNEL_OF.get(kind, kind).format(g="true" if not key.endswith("L0") else "false")
+        why = kind
         if kind == "chain" and getattr(be, "block_r", {}).get(len(nts) - 1):
             sym = "blk_local_kernel + blk_scan_kernel + blk_finish_kernel"     # the time-parallel forward solve
+            why = "chain_blocks"
         elif kind == "chain" and dof <= 1024:
             sym = "chain_kernel<1, 1, true, true>"    # one group of values: the single-workgroup chain, no exchange
         table[key] = {"kernel_symbol": sym, "launches_per_cycle": n / cycles, "ms_per_launch": tot / n, "ms_per_cycle": tot / cycles,
                       "algorithmic_bytes_per_cycle": alg.get(key, 0.0),
-                      "limited_by": LIMITED_BY.get(kind, LIMITED_BY["default"])}
+                      "limited_by": LIMITED_BY.get(why, LIMITED_BY["default"])}
     return table
 
 
@@ -1036,6 +1092,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(nx)
             out["iters_to_tol"] = iters_to_tol(problem, nx)
             out["time_to_solution_ms"] = out["iters_to_tol"].pop("time_to_solution_ms", None)
+            out["parity"] = out["iters_to_tol"].pop("parity", None)
             if (nx, nt0) == (16384, 65537) and not args.all_configs and not args.at_k:
                 # the other GPU configurations of BASELINE.json, each measured in a child process of its own AFTER everything
                 # above, folded into this ONE line (the full lines: --all-configs); a failure there never touches the headline

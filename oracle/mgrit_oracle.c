@@ -500,10 +500,10 @@ static void heat_solve_spec(const orc_cset *c, int n, double *d, double *out) {
     }
 }
 
-static void heat1d_step_spec(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out) {
+/* (d: padded scratch; the threaded sweeps of orc_problem_set_threads give every thread its own) */
+static void heat1d_step_spec_ws(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out, double *d) {
     int n = st->n;
     orc_cset *c = get_cset(st, dt);
-    double *d = st->w1;
     /* d = u + dt*b(x, t_i) with the forcing folded as fma(s_k, tau_k*dt, .); a general forcing: d = u + (rhs*dt) row */
     for (int j = 0; j < n; ++j) {
         double v = u[j];
@@ -512,6 +512,10 @@ static void heat1d_step_spec(orc_stepper *st, int nt, int i_stop, double dt, con
         d[j] = v;
     }
     heat_solve_spec(c, n, d, out);
+}
+
+static void heat1d_step_spec(orc_stepper *st, int nt, int i_stop, double dt, const double *u, double *out) {
+    heat1d_step_spec_ws(st, nt, i_stop, dt, u, out, st->w1);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -586,10 +590,9 @@ static void twopts_step_spec(orc_stepper *st, int nt, int i_stop, double t_start
 }
 
 /* advection_1d.py:129-143: spsolve(dt*L + I, u), L = (c/dx)(I - S_periodic) */
-static void advection1d_step_natural(orc_stepper *st, double dt, const double *u, double *out) {
+static void advection1d_step_natural_ws(orc_stepper *st, double dt, const double *u, double *out, double *p, double *q) {
     int n = st->n;
     double alpha = dt * st->fac, D = alpha + 1.0;
-    double *p = st->w1, *q = st->w2;
     p[0] = u[0] / D; q[0] = alpha / D;
     for (int j = 1; j < n; ++j) { p[j] = (u[j] + alpha * p[j - 1]) / D; q[j] = alpha * q[j - 1] / D; }
     double xl = p[n - 1] / (1.0 - q[n - 1]);
@@ -597,10 +600,13 @@ static void advection1d_step_natural(orc_stepper *st, double dt, const double *u
     out[n - 1] = xl;
 }
 
-static void advection1d_step_spec(orc_stepper *st, double dt, const double *u, double *out) {
+static void advection1d_step_natural(orc_stepper *st, double dt, const double *u, double *out) {
+    advection1d_step_natural_ws(st, dt, u, out, st->w1, st->w2);
+}
+
+static void advection1d_step_spec_ws(orc_stepper *st, double dt, const double *u, double *out, double *d) {
     int n = st->n, NP = padded(n), G = NP / ORC_GROUP;
     orc_cset *c = get_cset(st, dt);
-    double *d = st->w1;
     double A[ORC_MAX_G] = {0}, C[ORC_MAX_G + 1] = {0};
     for (int j = 0; j < n; ++j) d[j] = u[j] * c->ik;
     for (int j = n; j < NP; ++j) d[j] = 0.0;
@@ -622,6 +628,10 @@ static void advection1d_step_spec(orc_stepper *st, double dt, const double *u, d
                 out[j] = fma(c->tab[j], xl, y);
             }
         }
+}
+
+static void advection1d_step_spec(orc_stepper *st, double dt, const double *u, double *out) {
+    advection1d_step_spec_ws(st, dt, u, out, st->w1);
 }
 
 /* dahlquist.py:88-111 */
@@ -677,39 +687,69 @@ static void h2d_tables(orc_stepper *st) {
     st->dinv_dt = -1.0;
 }
 
+/* The two half transforms below are loops over INDEPENDENT columns n, each output a dot product accumulated by fma in ascending k
+ * from 0 (the spec). Round 5: the column is gathered (and folded) once into a contiguous buffer, the forward
+ * transform walks k in the outer loop over an array of accumulators -- every accumulator still sees its own products in ascending k,
+ * so the bits are those of the plain triple loop --, and the columns are spread over orc_h2d_threads OpenMP threads
+ * (orc_set_h2d_threads; default 1): a 512 x 512 step falls from 0.5 s to ~10 ms, which is what lets the GPU tests compare BASELINE
+ * config 4 with the oracle AT its size (tests/test_hip_heat2d.py). */
+static int orc_h2d_threads = 1;
+int orc_set_h2d_threads(int threads) {
+#ifdef _OPENMP
+    orc_h2d_threads = threads > 1 ? threads : 1;
+#else
+    (void)threads;
+#endif
+    return orc_h2d_threads;
+}
+
 /* forward half transform along the rows of B (natural index k, m real rows, 2 HP stored): out[n][slot], slot = e or HP + o */
 static void h2d_fwd(const double *Fe, const double *Fo, int m, int HP, const double *B, int N, double *out) {
     int hE = (m + 1) / 2, hO = m / 2, P = 2 * HP;
-    for (int n = 0; n < N; ++n) {
-        for (int e = 0; e < HP; ++e) {
-            double c = 0.0;
+#pragma omp parallel num_threads(orc_h2d_threads) if (orc_h2d_threads > 1 && N >= 32)
+    {
+        double *xe = (double *)malloc(sizeof(double) * 2 * (size_t)(hE + 1)), *xo = xe + hE + 1;
+#pragma omp for schedule(static)
+        for (int n = 0; n < N; ++n) {
             for (int k = 0; k < hE; ++k) {
-                double x = k < hO ? B[(size_t)k * N + n] + B[(size_t)(m - 1 - k) * N + n] : B[(size_t)k * N + n];
-                c = fma(Fe[(size_t)k * HP + e], x, c);
+                xe[k] = k < hO ? B[(size_t)k * N + n] + B[(size_t)(m - 1 - k) * N + n] : B[(size_t)k * N + n];
+                if (k < hO) xo[k] = B[(size_t)k * N + n] - B[(size_t)(m - 1 - k) * N + n];
             }
-            out[(size_t)n * P + e] = c;
+            double *ce = out + (size_t)n * P, *co = ce + HP;
+            for (int e = 0; e < P; ++e) ce[e] = 0.0;
+            for (int k = 0; k < hE; ++k) {
+                const double *fe = Fe + (size_t)k * HP; double x = xe[k];
+                for (int e = 0; e < HP; ++e) ce[e] = fma(fe[e], x, ce[e]);
+            }
+            for (int k = 0; k < hO; ++k) {
+                const double *fo = Fo + (size_t)k * HP; double x = xo[k];
+                for (int o = 0; o < HP; ++o) co[o] = fma(fo[o], x, co[o]);
+            }
         }
-        for (int o = 0; o < HP; ++o) {
-            double c = 0.0;
-            for (int k = 0; k < hO; ++k)
-                c = fma(Fo[(size_t)k * HP + o], B[(size_t)k * N + n] - B[(size_t)(m - 1 - k) * N + n], c);
-            out[(size_t)n * P + HP + o] = c;
-        }
+        free(xe);
     }
 }
 
 /* inverse half transform along the rows of B (spectral slots): out[n][i] = Pe + Po, out[n][m-1-i] = Pe - Po */
 static void h2d_inv(const double *Fe, const double *Fo, int m, int HP, const double *B, int N, double *out) {
     int hE = (m + 1) / 2, hO = m / 2, P = 2 * HP;
-    for (int n = 0; n < N; ++n) {
-        for (int i = 0; i < P; ++i) out[(size_t)n * P + i] = 0.0;
-        for (int i = 0; i < hE; ++i) {
-            double pe = 0.0, po = 0.0;
-            for (int e = 0; e < hE; ++e) pe = fma(Fe[(size_t)i * HP + e], B[(size_t)e * N + n], pe);
-            for (int o = 0; o < hO; ++o) po = fma(Fo[(size_t)i * HP + o], B[(size_t)(HP + o) * N + n], po);
-            out[(size_t)n * P + i] = pe + po;
-            if (i < hO) out[(size_t)n * P + (m - 1 - i)] = pe - po;
+#pragma omp parallel num_threads(orc_h2d_threads) if (orc_h2d_threads > 1 && N >= 32)
+    {
+        double *col = (double *)malloc(sizeof(double) * (size_t)P);
+#pragma omp for schedule(static)
+        for (int n = 0; n < N; ++n) {
+            for (int e = 0; e < P; ++e) col[e] = B[(size_t)e * N + n];
+            for (int i = 0; i < P; ++i) out[(size_t)n * P + i] = 0.0;
+            for (int i = 0; i < hE; ++i) {
+                double pe = 0.0, po = 0.0;
+                const double *fe = Fe + (size_t)i * HP, *fo = Fo + (size_t)i * HP;
+                for (int e = 0; e < hE; ++e) pe = fma(fe[e], col[e], pe);
+                for (int o = 0; o < hO; ++o) po = fma(fo[o], col[HP + o], po);
+                out[(size_t)n * P + i] = pe + po;
+                if (i < hO) out[(size_t)n * P + (m - 1 - i)] = pe - po;
+            }
         }
+        free(col);
     }
 }
 
@@ -823,8 +863,8 @@ typedef struct {
     int64_t phi_count[ORC_MAX_LEVELS];
     int at_k;               /* > 0: AT-MGRIT (core/at_mgrit.py): truncated local solves of distance k on the coarsest level */
     int no_block_solve;     /* 1: forward_solve never takes the time-parallel form */
-    int threads;            /* > 1: the independent loops of the sweeps run on that many OpenMP threads (timing only; same
-                               arithmetic, same results). Heat1D natural variant with copy transfers only. */
+    int threads;            /* > 1: the independent loops of the sweeps run on that many OpenMP threads (same arithmetic, same
+                               results). Heat1D / Advection1D levels. */
 } orc_problem;
 
 orc_problem *orc_problem_create(int n_levels) {
@@ -969,15 +1009,26 @@ void orc_problem_set_transfer(orc_problem *p, int lvl, int kind) { p->L[lvl].tra
 
 /* Threaded sweeps for the CPU baseline of bench.py: the F-intervals / C-points of a sweep are independent -- the same
  * independence the reference's mpi4py path exploits across ranks (mgrit.py:313-331) -- so they are split over OpenMP
- * threads. Returns the thread count in effect (1 when the hierarchy is not all Heat1D / natural variant / copy transfer,
- * or the library was built without OpenMP). */
+ * threads. Returns the thread count in effect (1 when a level is neither Heat1D nor Advection1D, or the library was built
+ * without OpenMP). Both arithmetic variants (round 5: the full-size GPU parity tests run the spec
+ * variant at config 3's size, 72 s single-threaded). */
 int orc_problem_set_threads(orc_problem *p, int threads) {
     p->threads = 1;
 #ifdef _OPENMP
     int ok = threads > 1;
-    for (int l = 0; l < p->n_levels; ++l)
-        if (p->L[l].st.kind != ORC_HEAT1D || p->L[l].st.variant != 0 || (l < p->n_levels - 1 && p->L[l].transfer != 0)) ok = 0;
-    if (ok) p->threads = threads;
+    for (int l = 0; l < p->n_levels; ++l) {
+        orc_level *L = &p->L[l];
+        if (L->st.kind != ORC_HEAT1D && L->st.kind != ORC_ADVECTION1D) ok = 0;
+    }
+    if (ok) {
+        /* the spec steps look their coefficient set up by step size and build it on first use: every set exists before the
+           first parallel loop, so the threads only ever read the table */
+        for (int l = 0; l < p->n_levels; ++l) {
+            orc_level *L = &p->L[l];
+            if (L->st.variant) for (int i = 1; i < L->nt; ++i) (void)get_cset(&L->st, L->t[i] - L->t[i - 1]);
+        }
+        p->threads = threads;
+    }
 #else
     (void)threads;
 #endif
@@ -1087,7 +1138,12 @@ int64_t orc_phi_count(orc_problem *p, int lvl) { return p->phi_count[lvl]; }
 /* ---- threaded variants (timing path): identical arithmetic, one interval / C-point per loop trip ---- */
 static void phi_ws(orc_problem *p, int lvl, int i, const double *u_in, double *out, double *w1, double *w2) {
     orc_level *L = &p->L[lvl];
-    heat1d_step_natural_ws(&L->st, L->nt, i, L->t[i] - L->t[i - 1], u_in, out, w1, w2);
+    double dt = L->t[i] - L->t[i - 1];
+    if (L->st.kind == ORC_ADVECTION1D) {
+        if (L->st.variant) advection1d_step_spec_ws(&L->st, dt, u_in, out, w1);
+        else advection1d_step_natural_ws(&L->st, dt, u_in, out, w1, w2);
+    } else if (L->st.variant) heat1d_step_spec_ws(&L->st, L->nt, i, dt, u_in, out, w1);
+    else heat1d_step_natural_ws(&L->st, L->nt, i, dt, u_in, out, w1, w2);
 }
 
 static int has_adjacent_c(const orc_level *L) {
@@ -1138,17 +1194,17 @@ static void c_relax_mt(orc_problem *p, int lvl) {
 
 static void fas_residual_mt(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl], *C = &p->L[lvl + 1];
-    int n = L->n, np = padded(n);
+    int n = L->n, nc_ = C->n, np = padded(n);
     int *cidx = (int *)malloc(sizeof(int) * (size_t)C->nt), nc = 0;
     for (int i = 0; i < L->nt; ++i) if (L->is_c[i]) cidx[nc++] = i;
 #pragma omp parallel for schedule(static) num_threads(p->threads)
     for (int j = 0; j < nc; ++j) {
-        memcpy(ROW(C->u, C, j), ROW(L->u, L, cidx[j]), sizeof(double) * (size_t)n);
-        memcpy(ROW(C->v, C, j), ROW(L->u, L, cidx[j]), sizeof(double) * (size_t)n);
+        restrict_vec(L->transfer, ROW(L->u, L, cidx[j]), n, ROW(C->u, C, j), nc_);
+        memcpy(ROW(C->v, C, j), ROW(C->u, C, j), sizeof(double) * (size_t)nc_);
     }
 #pragma omp parallel num_threads(p->threads)
     {
-        double *w = (double *)malloc(sizeof(double) * 4 * (size_t)np), *w1 = w, *w2 = w + np, *a = w + 2 * np, *b = w + 3 * np;
+        double *w = (double *)malloc(sizeof(double) * 5 * (size_t)np), *w1 = w, *w2 = w + np, *a = w + 2 * np, *b = w + 3 * np, *r = w + 4 * np;
 #pragma omp for schedule(static)
         for (int j = 1; j < nc; ++j) {
             int i = cidx[j];
@@ -1156,9 +1212,10 @@ static void fas_residual_mt(orc_problem *p, int lvl) {
             const double *ui = ROW(L->u, L, i);
             if (lvl == 0) for (int k = 0; k < n; ++k) a[k] = a[k] - ui[k];
             else { const double *gi = ROW(L->g, L, i); for (int k = 0; k < n; ++k) a[k] = gi[k] - ui[k] + a[k]; }
+            restrict_vec(L->transfer, a, n, r, nc_);
             phi_ws(p, lvl + 1, j, ROW(C->v, C, j - 1), b, w1, w2);
             double *gj = ROW(C->g, C, j); const double *vj = ROW(C->v, C, j);
-            for (int k = 0; k < n; ++k) gj[k] = a[k] + vj[k] - b[k];
+            for (int k = 0; k < nc_; ++k) gj[k] = r[k] + vj[k] - b[k];
         }
         free(w);
     }
@@ -1167,14 +1224,21 @@ static void fas_residual_mt(orc_problem *p, int lvl) {
 
 static void error_correction_mt(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl], *C = &p->L[lvl + 1];
-    int n = L->n;
+    int n = L->n, nc_ = C->n, np = padded(n);
     int *cidx = (int *)malloc(sizeof(int) * (size_t)C->nt), nc = 0;
     for (int i = 0; i < L->nt; ++i) if (L->is_c[i]) cidx[nc++] = i;
-#pragma omp parallel for schedule(static) num_threads(p->threads)
-    for (int j = 1; j < nc; ++j) {
-        const double *uj = ROW(C->u, C, j), *vj = ROW(C->v, C, j);
-        double *ui = ROW(L->u, L, cidx[j]);
-        for (int k = 0; k < n; ++k) { double e = uj[k] - vj[k]; ui[k] = ui[k] + e; }
+#pragma omp parallel num_threads(p->threads)
+    {
+        double *w = (double *)malloc(sizeof(double) * 2 * (size_t)np), *e = w, *f = w + np;
+#pragma omp for schedule(static)
+        for (int j = 1; j < nc; ++j) {
+            const double *uj = ROW(C->u, C, j), *vj = ROW(C->v, C, j);
+            double *ui = ROW(L->u, L, cidx[j]);
+            for (int k = 0; k < nc_; ++k) e[k] = uj[k] - vj[k];
+            interp_vec(L->transfer, e, nc_, f, n);
+            for (int k = 0; k < n; ++k) ui[k] = ui[k] + f[k];
+        }
+        free(w);
     }
     free(cidx);
 }
@@ -1193,7 +1257,11 @@ static int compute_residual_mt(orc_problem *p, double *r_norm) {
             phi_ws(p, 0, i, ROW(L->u, L, i - 1), tmp, w1, w2);
             const double *ui = ROW(L->u, L, i);
             double ss = 0.0;
-            for (int j = 0; j < n; ++j) { double r = tmp[j] - ui[j]; ss += r * r; }
+            if (p->norm_spec) {
+                for (int j = 0; j < n; ++j) tmp[j] = tmp[j] - ui[j];
+                ss = orc_sumsq_spec(tmp, n);
+            } else
+                for (int j = 0; j < n; ++j) { double r = tmp[j] - ui[j]; ss += r * r; }
             r_norm[c] = sqrt(ss);
         }
         free(w);
@@ -1854,7 +1922,7 @@ int orc_compute_residual(orc_problem *p, double *r_norm) {
     orc_level *L = &p->L[0];
     int cnt = 0;
 #ifdef _OPENMP
-    if (p->threads > 1 && !p->norm_spec) return compute_residual_mt(p, r_norm);
+    if (p->threads > 1 && p->L[0].st.kind != ORC_HEAT1D_2PTS) return compute_residual_mt(p, r_norm);
 #endif
     for (int i = 1; i < L->nt; ++i) {
         if (!L->is_c[i]) continue;

@@ -59,6 +59,8 @@ def lib():
         L.orc_problem_set_transfer.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_problem_set_at.argtypes = [C.c_void_p, C.c_int]
         L.orc_problem_set_block_solve.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_h2d_threads.restype = C.c_int
+        L.orc_set_h2d_threads.argtypes = [C.c_int]
         L.orc_block_solve_rank.restype = C.c_int
         L.orc_block_solve_rank.argtypes = [C.c_int, C.c_double, C.c_int, dp, dp]
         L.orc_at_forward_solve.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -109,6 +111,12 @@ def block_solve_rank(n, fac, t):
     """modes kept by the time-parallel forward solve of a Heat1D level (0: the level is solved step by step), DESIGN.md 3.8"""
     t = _f64(t)
     return int(lib().orc_block_solve_rank(int(n), float(fac), t.size, _dp(t), None))
+
+
+def set_h2d_threads(threads):
+    """OpenMP threads over the independent columns of the Heat2D sine transforms (same bits for every count); returns the count
+    in effect. Process-wide."""
+    return int(lib().orc_set_h2d_threads(int(threads)))
 
 
 def split_into(n_points, n_procs):

@@ -797,29 +797,45 @@ class Mgrit(RankSchedules, PipelinedLoop):
             return self._solve_pipelined()
         self.log_info("Start solve")
         solve_start = time.time()
+        # where the host's time goes (milliseconds, summed over the iterations): enqueue = Mgrit.iteration() issuing the cycle's
+        # launches, wait = the device finishing them, criterion = the stopping value (its launch unless the way up has left the
+        # sums, the read-back, the norm), log = the reference's per-iteration line, final = the F-relaxation that puts every
+        # F-point in place + the last wait, tail = drain / barrier / run information
+        bd = self.solve_breakdown = dict(enqueue=0.0, wait=0.0, criterion=0.0, log=0.0, final=0.0, tail=0.0, iterations=0)
+        clock = time.perf_counter
         for iteration in range(self.iter_max):
             self.solve_iter = iteration + 1
             it_start = time.time()
+            c0 = clock()
             self.iteration(lvl=0, cycle_type=self.cycle_type, iteration=iteration, first_f=True)
+            c1 = clock()
             self.backend.sync()
+            c2 = clock()
             it_stop = time.time()
             self.convergence_criterion(iteration=iteration + 1)
+            c3 = clock()
             now, before = self.conv[iteration + 1], self.conv[iteration]
-            with np.errstate(divide='ignore', invalid='ignore'):     # a rank whose residuals are exactly zero
-                factor = '-' if iteration == 0 else str(now / before)
-            label = f" | conv: {now}" if self.global_conv_crit else f" | conv on process {self.comm_time_size - 1}: {now}"
-            self.log_info('{0: <7}'.format(f"iter {iteration + 1}") + '{0: <32}'.format(label) +
-                          '{0: <37}'.format(f" | conv factor: {factor}") +
-                          '{0: <35}'.format(f" | runtime: {it_stop - it_start} s"))
+            if logging.getLogger().isEnabledFor(logging.INFO):
+                with np.errstate(divide='ignore', invalid='ignore'):     # a rank whose residuals are exactly zero
+                    factor = '-' if iteration == 0 else str(now / before)
+                label = f" | conv: {now}" if self.global_conv_crit else f" | conv on process {self.comm_time_size - 1}: {now}"
+                self.log_info('{0: <7}'.format(f"iter {iteration + 1}") + '{0: <32}'.format(label) +
+                              '{0: <37}'.format(f" | conv factor: {factor}") +
+                              '{0: <35}'.format(f" | runtime: {it_stop - it_start} s"))
             if self.output_fcn is not None and self.output_lvl == 2:
                 self.output_fcn(self)
+            c4 = clock()
+            bd["enqueue"] += 1e3 * (c1 - c0); bd["wait"] += 1e3 * (c2 - c1); bd["criterion"] += 1e3 * (c3 - c2); bd["log"] += 1e3 * (c4 - c3)
+            bd["iterations"] += 1
             if now < self.tol or iteration == self.iter_max - 1:
                 if self.global_conv_crit or (self.finished[0] and self.pre_finished[0]) or iteration == self.iter_max - 1:
                     if not self.global_conv_crit and self.comm_time_size > 1:
                         self._leave_local(iteration)
                     break
+        c0 = clock()
         getattr(self.backend, 'materialise', lambda: None)()   # C-point storage on the way up: every F-point in place again
         self.backend.sync()
+        c1 = clock()
         getattr(self.comm_time, 'drain', lambda: None)()
         self.comm_time.barrier()
         self.runtime_solve = time.time() - solve_start
@@ -828,5 +844,6 @@ class Mgrit(RankSchedules, PipelinedLoop):
         if self.output_fcn is not None and self.output_lvl == 1:
             self.output_fcn(self)
         self.ouput_run_information()
+        bd["final"], bd["tail"] = 1e3 * (c1 - c0), 1e3 * (clock() - c1)
         return {'conv': self.conv[np.where(self.conv != 0)], 'time_setup': self.runtime_setup,
                 'time_solve': self.runtime_solve}

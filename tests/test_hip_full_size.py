@@ -81,7 +81,7 @@ def test_full_size_planned_cycles_match_the_oracle(oracle, monkeypatch):
     assert mg.backend.block_r[2] == 50 and mg._level_intervals(0) is not None
     op = oracle.OracleProblem([cases.heat_level_spec(nx, g) for g in grids], variant=1, cf_iter=1, nested_iteration=False, max_iter=8,
                               tol=0.0)
-    op.set_threads(min(32, os.cpu_count() or 1))
+    assert op.set_threads(cases.usable_cpus(32)) >= 1      # (same bits for every thread count: tests/test_oracle_golden.py)
     sample = [1, 2, 3, 4, 16381, 16384, 32768, 40001, 65533, 65535, 65536]
     for it in range(4):        # iteration 0, then three steady cycles: the last one is the capture and its first replay
         mg.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True)
@@ -93,6 +93,32 @@ def test_full_size_planned_cycles_match_the_oracle(oracle, monkeypatch):
     ref = op.state("u", 0)
     for i in sample:
         assert np.array_equal(np.asarray(mg.u[0][i].get_values()), ref[i]), i
+
+
+def test_full_size_both_forms_of_the_coarse_solve():
+    """config 3 at FULL size with the coarsest level's forward_solve in BOTH forms: the default time-parallel blocks (DESIGN.md
+    3.8) and the reference's step-by-step loop (mgrit.py:459-486; options.coarse_solve = 'sequential'), five iterations from the
+    nested-iteration start. Per iteration the residual norms agree within 1e-10 relative + 2 eps ||u|| (tests/cases.py BLK_K_FORM);
+    the deviations are recorded (gpurun_out/parity_config3_forms.json -> profiles/) and bench.py prints the same record as `parity`."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    import bench
+    import cases
+    from pymgrit_amd import Heat1D
+    nx, nt0 = 16384, 65537
+    t0 = np.linspace(0, 2.0 * (nt0 - 1) / 65536, nt0)
+    prob = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=bench.init_cond, rhs_separable=[(bench.rhs_space, bench.rhs_time)],
+                   t_interval=g) for g in (t0, t0[::4], t0[::16])]
+    rec = bench.coarse_solve_parity(prob, iters=5, cf_iter=1, cycle_type='V', nested_iteration=True)
+    print("parity of the two forms:", json.dumps(rec))
+    out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out_dir) and os.access(out_dir, os.W_OK):
+        with open(os.path.join(out_dir, "parity_config3_forms.json"), "w") as fh:
+            json.dump(rec, fh, indent=1)
+    assert rec["coarse_solve"].startswith("time-parallel") and len(rec["conv"]) == len(rec["conv_sequential"]) == 5
+    assert cases.BLK_K_FORM == 2 and rec["within_bound"], rec
 
 
 def test_full_size_config5_cycles_match_the_oracle(oracle, monkeypatch):
@@ -116,6 +142,7 @@ def test_full_size_config5_cycles_match_the_oracle(oracle, monkeypatch):
     assert mg.backend.block_r[3] == 2048 and all(mg._gen_intervals(lvl) is not None for lvl in range(3))
     op = oracle.OracleProblem([cases.advection_level_spec(n, g) for n, g in zip(nxs, grids)], transfer=[2, 2, 0], variant=1, cf_iter=1,
                               cycle_type='F', nested_iteration=False, max_iter=8, tol=0.0)
+    op.set_threads(cases.usable_cpus(32))      # (takes effect on hierarchies of copy transfers only: 1 here)
     for it in range(4):        # iteration 0, then three steady cycles: the last one is the capture and its first replay
         mg.iteration(lvl=0, cycle_type='F', iteration=it, first_f=True)
         got = np.asarray(mg.compute_residual())
@@ -139,6 +166,7 @@ def test_config4_timed_path_matches_the_oracle(oracle):
         pytest.fail("GPU test selected but no GPU visible")
     import cases
     from pymgrit_amd import Mgrit
+    oracle.set_h2d_threads(cases.usable_cpus(16))
     ts = cases.h2d_grids([513, 65])
     prob = [cases.h2d_app(256, 256, t, "BE", True) for t in ts]
     mg = Mgrit(prob, nested_iteration=False, max_iter=4, tol=0.0, logging_lvl=30)

@@ -156,11 +156,16 @@ def test_config4_size_properties():
     assert torch.equal(first * 4.0, U)
 
 
-def test_config4_full_size_properties():
+def _oracle_threads(oracle):
+    return oracle.set_h2d_threads(cases.usable_cpus(16))
+
+
+def test_config4_full_size_properties(oracle):
     """BASELINE config 4 at FULL size: 512x512 states, nt=16385, m=8 (34 GB level-0 slab). F-relax idempotence and zero
-    F-point residual over the whole grid, exact scaling linearity, agreement of a sampled interval with the host stepper."""
+    F-point residual over the whole grid, exact scaling linearity, and one sampled level-0 interval (its 7 F-points) bit for bit
+    the ORACLE's steps at 512 x 512 (reference heat_2d.py:322-366)."""
     from pymgrit_amd import Mgrit
-    from pymgrit_amd.heat.heat_2d import Heat2D, VectorHeat2D
+    from pymgrit_amd.heat.heat_2d import Heat2D
     free, _ = torch.cuda.mem_get_info()
     if free < 70 * 2 ** 30:
         pytest.skip("needs ~60 GB of free HBM")
@@ -180,16 +185,39 @@ def test_config4_full_size_properties():
     assert torch.equal(ref_rows, U[8 * 1000 + 1:8 * 1000 + 8]) and U.sum().item() == first_sum
     fpts = [int(i) for i in np.sort(mg.index_local_f[0])]
     assert max(mg.backend.residual_norms(fpts[:3000] + fpts[-3000:])) == 0.0
-    # host stepper on one interval (same algorithm in numpy: agreement to rounding)
-    v = VectorHeat2D(512, 512)
-    v.set_values((scale[1000] * base).numpy())
-    for k in range(1, 4):
-        v = prob[0].step(v, ts[0][8000 + k - 1], ts[0][8000 + k])
-        got = U[8000 + k, :512 * 512].cpu().numpy().reshape(512, 512)
-        assert np.abs(got - v.get_values()).max() <= 1e-12 * np.abs(got).max()
+    # the oracle on one interval, AT this size: a two-level oracle problem over the 9 time points of interval 1000 (Phi depends on
+    # the step's end points only: the same doubles), its 7 F-steps from the same C-point -- every value bit for bit
+    _oracle_threads(oracle)
+    t_int = np.ascontiguousarray(ts[0][8000:8009])
+    op = oracle.OracleProblem([cases.h2d_level_spec(Heat2D(x_start=0, x_end=1, y_start=0, y_end=1, nx=512, ny=512, a=1.0, method="BE",
+                                                             t_interval=t)) for t in (t_int, t_int[::8])], nested_iteration=False)
+    v = (scale[1000] * base).numpy().ravel()
+    for k in range(1, 8):
+        v = op.phi(0, k, v)
+        got = U[8000 + k, :512 * 512].cpu().numpy()
+        assert np.array_equal(got, v), (k, np.abs(got - v).max())
     U[::8, :512 * 512] = (2.0 * scale[:, None] * base.reshape(1, -1)).to(U.device)
     mg.f_relax(0)
     assert torch.equal(ref_rows * 2.0, U[8 * 1000 + 1:8 * 1000 + 8])
+
+
+def test_config4_size_block_solve_matches_the_oracle(oracle):
+    """512 x 512 states (BASELINE config 4's size, forcing and boundary values of the fixtures), 2 levels m = 8, nt = 513: the coarsest
+    level's 64 steps = 4 blocks of the time-parallel forward solve on the full 510 x 510 sine spectrum, from random
+    u / g rows, against the oracle's block solve at the same size -- every row of the level bit for bit; then a whole V-cycle with
+    its per-point residual norms. (The oracle's transforms run on up to 16 host threads: same bits, 30 ms per step.)"""
+    assert torch.cuda.is_available()
+    _oracle_threads(oracle)
+    prob = [cases.h2d_app(512, 512, t, "BE", True) for t in cases.h2d_grids([513, 65])]
+    mg, op = _pair(oracle, prob)
+    assert mg.backend.block_r[1] == 510 * 510
+    _randomize(mg, op, 512)
+    mg.forward_solve(1); op.forward_solve(1)
+    got, ref = mg.backend.natural("u", 1), op.state("u", 1)
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
+    mg.iteration(lvl=0, cycle_type='V', iteration=0, first_f=True); op.iteration(0, 'V', 0, True)
+    got, ref = np.array(mg.compute_residual()), op.residual_norms()
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
 
 
 @pytest.mark.parametrize("method", ["BE", "CN", "FE"])

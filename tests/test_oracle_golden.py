@@ -230,21 +230,35 @@ def test_phi_work_model(oracle):
 
 
 def test_threaded_sweeps_equal_serial_sweeps(oracle):
-    """the OpenMP path of the oracle (timing only, bench.py cpu_baseline) leaves every result bit-identical"""
-    nts = (129, 33, 9)
-    def build(threads):
-        p = oracle.OracleProblem([cases.heat_level_spec(259, cases.lin(0.01, nt)) for nt in nts], variant=0,
-                                 nested_iteration=True, max_iter=3, tol=0.0, norm_spec=False, weight_c=1.2)
-        assert p.set_threads(threads) == threads
-        return p
-    a, b = build(1), build(4)
-    ca, cb = a.solve(), b.solve()
-    assert np.array_equal(ca, cb)
-    for lvl in range(3):
-        for which in ("u", "v", "g") if lvl else ("u",):
-            assert np.array_equal(a.state(which, lvl), b.state(which, lvl))
-    spec = oracle.OracleProblem([cases.heat_level_spec(259, cases.lin(0.01, nt)) for nt in nts], variant=1)
-    assert spec.set_threads(4) == 1   # only the natural variant is threaded
+    """the OpenMP path of the oracle (bench.py cpu_baseline; the full-size GPU parity tests) leaves every result bit-identical:
+    both arithmetic variants, Heat1D and Advection1D, the spec norm and the plain one, the time-parallel forward solve"""
+    def heat(nts, nx=259, t_stop=0.01):
+        return [cases.heat_level_spec(nx, cases.lin(t_stop, nt)) for nt in nts]
+    configs = [
+        (heat((129, 33, 9)), dict(variant=0, nested_iteration=True, max_iter=3, tol=0.0, norm_spec=False, weight_c=1.2)),
+        (heat((129, 33, 9)), dict(variant=1, nested_iteration=True, max_iter=3, tol=0.0, weight_c=1.2)),
+        (heat((1025, 257, 65), nx=1100, t_stop=2.0), dict(variant=1, nested_iteration=False, max_iter=2, tol=0.0)),   # block solve, two groups
+        ([cases.advection_level_spec(257, cases.lin(2, nt)) for nt in (257, 65, 17)], dict(variant=1, cycle_type='F', max_iter=3, tol=0.0)),
+        ([cases.advection_level_spec(130, cases.lin(2, nt)) for nt in (65, 17)], dict(variant=0, max_iter=3, tol=0.0, norm_spec=False)),
+    ]
+    for levels, kw in configs:
+        a, b = oracle.OracleProblem(levels, **kw), oracle.OracleProblem(levels, **kw)
+        assert a.set_threads(1) == 1 and b.set_threads(4) == 4
+        ca, cb = a.solve(), b.solve()
+        assert np.array_equal(ca, cb), (kw, ca, cb)
+        for lvl in range(len(levels)):
+            for which in ("u", "v", "g") if lvl else ("u",):
+                assert np.array_equal(a.state(which, lvl), b.state(which, lvl)), (kw, which, lvl)
+    for name, kw in (("heat_spatial_coarsening", dict()), ("heat_spatial_coarsening_F", dict(cycle_type='F', max_iter=4, tol=0.0))):
+        sc = cases.solve_cases()[name]      # full weighting / linear interpolation between the levels
+        a, b = (oracle.OracleProblem(sc["levels"], transfer=sc["transfer"], variant=1, **kw) for _ in range(2))
+        assert b.set_threads(3) == 3
+        assert np.array_equal(a.solve(), b.solve()) and np.array_equal(a.state("u", 0), b.state("u", 0))
+    rec, nxs, ts, transfer, kw = cases.adv_sc_case("adv_sc_F")     # the periodic transfer (config 5's shape)
+    lv = [cases.advection_level_spec(n, t) for n, t in zip(nxs, ts)]
+    a, b = (oracle.OracleProblem(lv, transfer=transfer, variant=1, **kw) for _ in range(2))
+    assert b.set_threads(4) == 4
+    assert np.array_equal(a.solve(), b.solve()) and np.array_equal(a.state("u", 0), b.state("u", 0))
 
 
 # ------------------------------------------------------------------------------------------------------------------
