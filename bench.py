@@ -146,6 +146,9 @@ def cpu_baseline(nx, nt=16385):
                  "port_sample": f"{c2} V-cycles incl. residual check in {e2:.2f} s on 1 core of this host"}
     return {"value": vn, "unit": "time-point-DOF updates/s", "cores": used, "kind": "port", "value_1core": v1,
             "reference_python": reference,
+            # the same calibration as plain scalars (a consumer that keeps only the scalar fields of this object still sees it)
+            "reference_python_updates_per_s": reference["updates_per_s"], "reference_python_config": reference["config"],
+            "port_over_reference_python": reference["port_over_reference"],
             "host_cores": os.cpu_count(), "host_cores_usable": avail, "by_threads": {str(t): r[0] for t, r in tried.items()},
             "sample": f"port = parity oracle variant 0 (Thomas solves, reference operation order), {used} of the {avail} CPUs this "
                       f"process may use (cgroup quota / affinity; the host shows {os.cpu_count()}): heat_1d nx={nx} nt={nts[0]} 3-level m=4 ({(nts[0] - 1) // 4} F-intervals per level-0 sweep), "

@@ -349,6 +349,34 @@ __device__ __forceinline__ double *ld_uniform_ptr(double *const *p) {
     return reinterpret_cast<double *>(((unsigned long long)hi << 32) | lo);
 }
 
+// Row accesses with BOTH halves of a row addressed as (uniform base in SGPRs) + (the lane's one 32-bit offset) + immediate: the
+// second base, 4 KB on, is laundered through readfirstlane so that the compiler does not fold it back into a 64-bit per-lane
+// address (a VGPR pair per row that the 128-VGPR passes cannot afford to keep).
+__device__ __forceinline__ void row_load2(const double *__restrict__ row, unsigned s0, double (&x)[E], int streaming) {
+    typedef double dv2 __attribute__((ext_vector_type(2)));
+    const dv2 *lo = reinterpret_cast<const dv2 *>(row) + s0, *hi = reinterpret_cast<const dv2 *>(uniform_ptr(row + 512)) + s0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const dv2 *p = (q < 4 ? lo : hi) + (q & 3) * 64;
+        const dv2 v = streaming ? __builtin_nontemporal_load(p) : *p;
+        x[2 * q] = v.x;
+        x[2 * q + 1] = v.y;
+    }
+}
+__device__ __forceinline__ void row_store2(double *__restrict__ row, unsigned s0, const double (&x)[E], int streaming) {
+    typedef double dv2 __attribute__((ext_vector_type(2)));
+    dv2 *lo = reinterpret_cast<dv2 *>(row) + s0, *hi = reinterpret_cast<dv2 *>(const_cast<double *>(uniform_ptr(row + 512))) + s0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        dv2 v;
+        v.x = x[2 * q];
+        v.y = x[2 * q + 1];
+        dv2 *p = (q < 4 ? lo : hi) + (q & 3) * 64;
+        if (streaming) __builtin_nontemporal_store(v, p);
+        else *p = v;
+    }
+}
+
 __device__ __forceinline__ Smem carve_smem(char *base, int T, bool with_pt = true) {
     // with_pt = false (Advection1D: no backward scan, no Pt): 16 KB less, which at 8 groups is the difference between one and two
     // workgroups per CU (83 KB against 67 of the CU's 160)
@@ -593,7 +621,10 @@ __device__ __forceinline__ void heat_finish(double (&x)[E], const Coef &c, doubl
 // table traffic at all). With CLOSED the padding positions j >= n of the result are NOT zero (the table's entries there are,
 // the expression's are not): padding of a Heat1D row holds unspecified finite values, which the next step's zeroing between
 // its two scans, the masked norms (block_sumsq) and the host views ignore.
-template <bool CLOSED = false>
+// LDSBAR: the step's one barrier as lds_barrier() -- it orders the LDS exchange of the group totals and nothing else, so it does not
+// wait for the wave's global stores (__syncthreads() does: s_waitcnt vmcnt(0)). For passes that leave whole rows of stores in
+// flight behind them and go on with Phi that issue no vector load (cfas1_kernel): the rows drain under the arithmetic.
+template <bool CLOSED = false, bool LDSBAR = false>
 __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const LaneCoef &lc, const Smem &sm, double *ga,
                                            double *gb, int n, int t, int lane, int wave, int G) {
     const int j0 = t * E, li = lane & 15;
@@ -609,7 +640,8 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
         P = sm.wf[wv] * lc.f_in;
         Q = (lane <= l_last ? sm.wf[MAX_G + wv] : sm.wf[2 * MAX_G + wv]) * sm.lp[(l_last - lane) & (LANES - 1)];
     }
-    __syncthreads();
+    if (LDSBAR) lds_barrier();
+    else __syncthreads();
     double cm, zin, zf0;
     heat_chains(c, li < G ? ga[li] : 0.0, li < G ? gb[li] : 0.0, G, wave, lane, cm, zin, zf0);
     const double z0 = zf0 * c.ik;
@@ -617,6 +649,9 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
     const double2 *pt = sm.pt + (wave == G - 1 ? 512 : 0) + lane;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
+        // (LDSBAR kernels hold a second vector -- the forcing factor -- in registers: the eight Pt loads of the pass are requested two
+        // at a time there, not all at once as the scheduler would have it, 28 VGPRs less at the pass's peak)
+        if (LDSBAR && q > 0 && (q & 1) == 0) __builtin_amdgcn_sched_barrier(0);
         double2 w;
         if (CLOSED) {
             w.x = fma(-Q, c.pw[E - 1 - 2 * q], P * c.pw[2 * q]);
@@ -632,7 +667,7 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
 // advection_1d.py:129-143; arithmetic: DESIGN.md section 3). One workgroup barrier per application.
 // PART (Heat1D): 0 = the whole step; 1 = only the coefficient set and the forcing term d = u + dt*b; 2 = only the solve, for a
 // caller that puts work of its own between the two (cfas_kernel: its row stores)
-template <int KIND, int FORCE, bool CLOSED = false, int PART = 0>
+template <int KIND, int FORCE, bool CLOSED = false, int PART = 0, bool LDSBAR = false>
 __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const LevelDev &L, int i, const Smem &sm, int t,
                                           int lane, int wave, int G) {
     const int ci = (PART == 2 || L.one_cset) ? (PART == 2 ? ctx.cur : 0) : ld_uniform(L.cidx + i);
@@ -663,7 +698,7 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const Le
         static_assert(FORCE != 4 || CLOSED, "FORCE 4 keeps the forcing factor where the correction table would be");
         if (PART != 2) add_forcing<FORCE>(x, ctx, L, i, t, sm);
         if (PART == 1) { ctx.parity ^= 1; return; }   // (the solve of PART 2 flips the parity back to this step's)
-        heat_solve<CLOSED>(x, c, lc, sm, ga, gb, L.n, t, lane, wave, G);
+        heat_solve<CLOSED, LDSBAR>(x, c, lc, sm, ga, gb, L.n, t, lane, wave, G);
     } else {
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] * c.ik;
@@ -983,7 +1018,7 @@ __global__ void __launch_bounds__(1024) fas_fused_kernel(LevelDev L, LevelDev Lc
 // correction table, Pt and the forcing factors of Lc are read straight from global memory -- 144 KB per level that every
 // workgroup reads, so they stay in L2 and cost no HBM traffic -- and its scalar coefficients live only for this call (the
 // caller reloads its own set afterwards: both at once do not fit the SGPR file). Arithmetic identical to phi_apply on Lc.
-template <int FORCE>
+template <int FORCE, bool LDSBAR = false>
 __device__ __forceinline__ void phi_other_level(double (&w)[E], StepCtx &ctx, const LevelDev &Lc, int j, const Smem &sm, unsigned sl,
                                                 int t, int lane, int wave, int G) {
     const int cj = Lc.one_cset ? 0 : ld_uniform(Lc.cidx + j);
@@ -1012,7 +1047,7 @@ __device__ __forceinline__ void phi_other_level(double (&w)[E], StepCtx &ctx, co
     const LaneCoef lcc = lane_coef(smc.lp, lane);
     const int par = ctx.parity;
     ctx.parity ^= 1;
-    heat_solve<true>(w, ctx.c, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
+    heat_solve<true, LDSBAR>(w, ctx.c, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
 }
 
 __device__ __forceinline__ void stage_other_level(const Smem &sm, const LevelDev &Lc, int t) {
@@ -1129,6 +1164,162 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
     }
     wq.end(t);
     /*STAMP 7*/
+}
+
+// The same pass where both levels have ONE forcing term with the SAME space factor (same spatial grid, same rhs: bit for bit,
+// checked on the host, Level::same_factor_below), ONE coefficient set each (uniform time grids) and the C-points are pre-relaxed
+// (pre = 1): the factor lives in REGISTERS (FORCE 1, as in the stand-alone F-relaxation) for all five Phi of an interval, so no Phi
+// of the pass issues a vector load at all (cfas_kernel<2> streams the factor's 128 KB from L2 in every Phi: 1.7 us each by the
+// in-kernel stamps of round 4, and its coarse Phi reads Pt from global memory). What makes the registers fit -- round 4's attempt
+// at FORCE 1 spilled the lane constants -- :
+//   * never more than ONE state vector is live across a Phi: C'_j is PARKED in LDS (the table space the closed-form Phi leaves
+//     free; seven of a lane's eight pairs, the eighth stays in registers, which frees the 16 KB the coarse level's Pt needs) while
+//     the own-level steps run on it in place; the coarse Phi comes LAST: r~ = Phi_l(F'_last) is swapped into LDS for the parked
+//     C'_j and q = Phi_{l+1}(C'_j) is computed in place;
+//   * ONE instance of the Phi's code serves both levels -- lane powers, group factors and Pt of BOTH levels sit in LDS (staged once
+//     per workgroup), a step picks its set by wave-uniform selects --: two inlined copies cost 26-84 spilled VGPRs, and a scratch
+//     reload retires, in order, behind every row store in flight;
+//   * the step's barrier is LDS-only (heat_solve<.., LDSBAR>): C'_{j+1}'s row -- the one vector load of an interval -- and the
+//     3.25 rows of stores sit together at the interval's end and drain under the next interval's five Phi.
+// Same values as cfas_kernel: every Phi takes the same operands through the same expressions.
+struct Cfas1Smem {
+    double2 *park;            // [7 * T] pairs 0..6 of every lane: wave w, lane l, pair q at w * 448 + q * 64 + l
+    double2 *pt[2];           // [2][512] Pt of this level / of the coarse level
+    double *ga, *gb, *lp[2], *wf[2];
+};
+__host__ __device__ __forceinline__ size_t cfas1_smem_bytes(int T) {
+    return (size_t)7 * T * sizeof(double2) + 2 * 1024 * sizeof(double2) + (4 * MAX_G + 2 * LANES + 2 * 3 * MAX_G) * sizeof(double);
+}
+__global__ void __launch_bounds__(1024) cfas1_kernel(LevelDev L, LevelDev Lc, IntervalsDev I) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = blockDim.x >> 6;
+    const unsigned sl = slot0(t), slp = (unsigned)(wave * 448 + lane);
+    /*STAMP_INIT*/
+    Cfas1Smem cm;
+    {
+        cm.park = reinterpret_cast<double2 *>(smem_raw);
+        cm.pt[0] = cm.park + (size_t)7 * L.T;
+        cm.pt[1] = cm.pt[0] + 1024;
+        double *tail = reinterpret_cast<double *>(cm.pt[1] + 1024);
+        cm.ga = tail; cm.gb = tail + 2 * MAX_G;
+        cm.lp[0] = tail + 4 * MAX_G; cm.lp[1] = cm.lp[0] + LANES;
+        cm.wf[0] = cm.lp[1] + LANES; cm.wf[1] = cm.wf[0] + 3 * MAX_G;
+    }
+    __shared__ int wgq_slot[2];
+    WgQueue wq;
+    double s0[E];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const double2 v = L.sP[sl + q * 64];
+        s0[2 * q] = v.x;
+        s0[2 * q + 1] = v.y;
+    }
+    for (int r = t; r < 1024; r += (int)blockDim.x) { cm.pt[0][r] = L.ptP[r]; cm.pt[1][r] = Lc.ptP[r]; }
+    if (t < LANES) { cm.lp[0][t] = L.cs->lp[t]; cm.lp[1][t] = Lc.cs->lp[t]; }
+    if (t < 3 * MAX_G) { cm.wf[0][t] = (&L.cs->pg[0])[t]; cm.wf[1][t] = (&Lc.cs->pg[0])[t]; }   // pg | qg | qg2 are consecutive members
+    __syncthreads();
+    Coef c;
+    int par = 0;
+    // The stores of an interval are issued at the TOP of the next one (pend_*: which rows; the values wait in x, in the parked slots
+    // and in g14 / g15): whatever the register allocator spills around the end of an interval is reloaded at the loop's back edge,
+    // i.e. BEFORE the stores -- a scratch reload behind them would retire, in order, only after they have drained -- and behind the
+    // stores come the five Phi, which touch LDS and registers only.
+    int pend_ce = -1, pend_jc = 0, pend_keep = 0;
+    double g14 = 0.0, g15 = 0.0;
+    double x[E];
+#define CFAS1_FLUSH()                                                                                                       \
+    do {                                                                                                                    \
+        _Pragma("unroll") for (int e = 0; e < E; ++e) asm volatile("" : "+v"(s0[e]));   /* the factor is in registers here */ \
+        row_store2(L.u + (size_t)pend_ce * L.ld, sl, x, L.stream_rows);                                                      \
+        if (pend_keep & 1) row_store2(Lc.u + (size_t)pend_jc * Lc.ld, sl, x, Lc.stream_rows);                                \
+        if (pend_keep & 2) row_store2(Lc.v + (size_t)pend_jc * Lc.ld, sl, x, Lc.stream_rows);                                \
+        double g[E];                                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 7; ++q) {                                                                      \
+            const double2 r = cm.park[slp + q * 64];                                                                         \
+            g[2 * q] = r.x;                                                                                                  \
+            g[2 * q + 1] = r.y;                                                                                              \
+        }                                                                                                                    \
+        g[14] = g14;                                                                                                         \
+        g[15] = g15;                                                                                                         \
+        row_store2(Lc.g + (size_t)pend_jc * Lc.ld, sl, g, Lc.stream_rows);                                                   \
+        pend_ce = -1;                                                                                                        \
+    } while (0)
+    for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < I.n_chunks; wq.advance(t)) {
+        const int k = wq.cur;
+        wq.prefetch(t);
+        const int i0 = I.chunk_first[k], cnt = I.chunk_len[k];
+        if (pend_ce >= 0) CFAS1_FLUSH();   // the last interval of the chunk before
+        {
+            const int cs = I.cstart[i0];   // a relaxed first C-point: the row of the F-point before it holds C'_j (pre)
+            row_load2(L.u + (size_t)(I.chunk_start_coarse[k] >= 0 ? cs - 1 : cs) * L.ld, sl, x, L.stream_rows);
+        }
+        for (int it = i0; it < i0 + cnt; ++it) {
+            const int cs = I.cstart[it], ce = I.cend[it], jc = I.cend_coarse[it];
+            /*STAMP 10*/
+            if (pend_ce >= 0) CFAS1_FLUSH();   // x = C'_j, the interval before ended on it
+            /*STAMP 11*/
+#pragma unroll
+            for (int q = 0; q < 7; ++q) cm.park[slp + q * 64] = make_double2(x[2 * q], x[2 * q + 1]);   // C'_j parked (lane-private slots)
+            double k0 = x[14], k1 = x[15];                                                                // ... its eighth pair
+            const int m = ce - cs;
+            for (int step = 0; step <= m; ++step) {   // the F-steps, Phi_l(F'_last), then -- on C'_j again -- the coarse Phi
+                const bool coarse = step == m;
+                if (coarse) {   // r~ into LDS, C'_j back
+                    /*STAMP 12*/
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) {
+                        const double2 v = cm.park[slp + q * 64];
+                        cm.park[slp + q * 64] = make_double2(x[2 * q], x[2 * q + 1]);
+                        x[2 * q] = v.x;
+                        x[2 * q + 1] = v.y;
+                    }
+                    const double r0 = x[14], r1 = x[15];
+                    x[14] = k0; x[15] = k1;
+                    k0 = r0; k1 = r1;
+                }
+                const int lv = coarse ? 1 : 0;
+                const double c0 = ld_uniform(coarse ? Lc.tc + jc : L.tc + cs + 1 + step);
+                if (step == 0 || coarse) load_coef(c, coarse ? Lc.cs : L.cs);
+#pragma unroll
+                for (int e = 0; e < E; ++e) x[e] = fma(s0[e], c0, x[e]);
+                Smem sx;
+                sx.lp = cm.lp[lv]; sx.wf = cm.wf[lv]; sx.pt = cm.pt[lv];
+                const LaneCoef lc = lane_coef(sx.lp, lane);
+                heat_solve<true, true>(x, c, lc, sx, cm.ga + par * MAX_G, cm.gb + par * MAX_G, L.n, t, lane, wave, G);
+                par ^= 1;
+            }
+            // (the coarse Phi is FINISHED here, and nothing of the row load below moves up into it: left to itself the compiler sinks
+            // the Phi's finishing pass below the row traffic)
+#pragma unroll
+            for (int e = 0; e < E; ++e) asm volatile("" : "+v"(x[e]));
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            /*STAMP 13*/
+            // C'_{j+1}: the one vector load of the interval. g = ((r~ - C') + C') - q goes pair by pair INTO the parked slots (in the
+            // place of r~), C'_{j+1} takes q's registers
+            {
+                double b[E];
+                row_load2(L.u + (size_t)(ce - 1) * L.ld, sl, b, L.stream_rows);
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    const double2 r = cm.park[slp + q * 64];
+                    cm.park[slp + q * 64] = make_double2(((r.x - b[2 * q]) + b[2 * q]) - x[2 * q], ((r.y - b[2 * q + 1]) + b[2 * q + 1]) - x[2 * q + 1]);
+                    x[2 * q] = b[2 * q];
+                    x[2 * q + 1] = b[2 * q + 1];
+                }
+                g14 = ((k0 - b[14]) + b[14]) - x[14];
+                g15 = ((k1 - b[15]) + b[15]) - x[15];
+                x[14] = b[14];
+                x[15] = b[15];
+            }
+            pend_ce = ce;
+            pend_jc = jc;
+            pend_keep = __builtin_amdgcn_readfirstlane(I.keep[it]);
+            /*STAMP 14*/
+        }
+    }
+    if (pend_ce >= 0) CFAS1_FLUSH();
+#undef CFAS1_FLUSH
+    wq.end(t);
 }
 
 // (USE_G, !RES: the same pass on a coarser level -- error_correction + f_relax with the rows of g, every F-point stored, no
@@ -1771,6 +1962,7 @@ int setup_kernel_attrs() {
     FOR_EACH_STEPPER(ATTR_CHAIN_LOCAL)
     if ((rc = allow_big_lds(cfas_kernel<0>))) return rc;
     if ((rc = allow_big_lds(cfas_kernel<2>))) return rc;
+    if ((rc = allow_big_lds(cfas1_kernel))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<0, false, true>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<2, false, true>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<4, false, true>))) return rc;
@@ -3860,6 +4052,14 @@ static int fused_level_check(mgrit_hip_engine *e, int lvl, int ivals_id, const c
     return 0;
 }
 
+// MGRIT_HIP_CFAS_REGS=1: the level-0 way down as cfas1_kernel (forcing factor in registers, coarse Phi last, stores rotated to the top
+// of the next interval) where it applies. Bit-identical to cfas_kernel (tests/test_hip_level_fusion.py runs both) and, as measured in
+// round 5, not faster: 1.98 ms against 1.85 on config 3 (DESIGN.md section 8 has the stamps) -- so it is not the default.
+static bool cfas_regs() {
+    static const bool v = [] { const char *s = std::getenv("MGRIT_HIP_CFAS_REGS"); return s && s[0] == '1'; }();
+    return v;
+}
+
 int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id, int pre_relaxed) {
     int rc = fused_level_check(e, lvl, ivals_id, "fused C-F-relaxation + FAS residual", true);
     if (rc) return rc;
@@ -3868,7 +4068,10 @@ int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id, int pre_relaxed
     if (I.n_chunks == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_CF_FAS, lvl);
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
-    if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    if (lf.same_factor_below < 0) lf.same_factor_below = (force_mode(lf) == 1 && lf.s_host == lc.s_host) ? 1 : 0;   // (131 KB compared once)
+    if (pre_relaxed && force_mode(lf) == 1 && lf.same_factor_below == 1 && lf.dev.one_cset && lc.dev.one_cset && cfas_regs())
+        hipLaunchKernelGGL(cfas1_kernel, grid, block, cfas1_smem_bytes(lf.dev.T), e->stream, sched_dev(e, lf), lc.dev, I);   // the factor in registers
+    else if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
     else hipLaunchKernelGGL((cfas_kernel<2>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return 0;
