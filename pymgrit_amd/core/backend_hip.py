@@ -24,6 +24,10 @@ def _i32(a):
 
 def _cols(items, k):
     """the k columns of a list of equal-length int tuples as contiguous int32 arrays (one conversion, not k list walks)"""
+    if hasattr(items, "columns"):       # layout.IndexArray: the columns without a detour through Python objects
+        cols = items.columns()
+        if len(cols) == k:
+            return cols
     if not len(items):
         return [np.zeros(0, dtype=np.int32) for _ in range(k)]
     arr = np.asarray(items, dtype=np.int32).reshape(len(items), -1)
@@ -35,10 +39,11 @@ def _time_factor(f, t):
     rhs is called per step); evaluated point by point a level of BASELINE config 3 costs 65537 Python calls (70 ms of a 115 ms
     setup). options.time_factor: 'pointwise' = always the loop (the reference's calls, no question asked); 'auto' (default) =
     the callable is tried on the whole array and its result taken only if
-      * it has the right shape and a second call returns the same bits (no state),
-      * the calls on t[1:] and on the first half of t return the same bits for the same times (an elementwise function must not
-        depend on a value's position in the array -- SIMD lane or tail --, on the array's length or on its other entries),
-      * it agrees bit for bit with the point-by-point calls at EVERY point of a level of <= 4096 points, and at both ends + 256
+      * it has the right shape,
+      * later calls on t[1:] and on the first half of t return the same bits for the same times (no state between calls; an
+        elementwise function must not depend on a value's position in the array -- SIMD lane or tail --, on the array's length
+        or on its other entries),
+      * it agrees bit for bit with the point-by-point calls at EVERY point of a level of <= 1024 points, and at both ends + 64
         sampled points of a longer one;
     anything else -- an exception, a scalar, a different bit anywhere -- falls back to the loop. A callable carrying the
     attribute `elementwise = True` (pymgrit_amd.elementwise(f)) declares the property itself and skips the shifted calls.
@@ -51,14 +56,13 @@ def _time_factor(f, t):
             ok = v.shape == t.shape
             if ok and not getattr(f, "elementwise", False):
                 h = t.size // 2
-                ok = (np.asarray(f(t), dtype=np.float64).tobytes() == v.tobytes()
-                      and np.asarray(f(t[1:]), dtype=np.float64).tobytes() == v[1:].tobytes()
+                ok = (np.asarray(f(t[1:]), dtype=np.float64).tobytes() == v[1:].tobytes()
                       and np.asarray(f(t[:h]), dtype=np.float64).tobytes() == v[:h].tobytes())
             if ok:
-                if t.size <= 4096:
+                if t.size <= 1024:
                     idx = range(t.size)
                 else:
-                    idx = np.unique(np.concatenate(([0, 1, t.size - 2, t.size - 1], np.random.default_rng(t.size).integers(0, t.size, 256))))
+                    idx = np.unique(np.concatenate(([0, 1, t.size - 2, t.size - 1], np.random.default_rng(t.size).integers(0, t.size, 64))))
                 if all(np.float64(f(t[i])).tobytes() == v[i].tobytes() for i in idx):
                     return v
         except Exception:       # noqa: BLE001 -- whatever the callable does with an array is its business: ask it point by point
@@ -102,7 +106,11 @@ class SlabVectorList:
         if self.on_write is not None:
             self.on_write()
         vals = np.ascontiguousarray(np.asarray(vec.pack(), dtype=np.float64)).ravel()
-        self.slab[self._row(int(i))][self.perm] = torch.from_numpy(vals).to(self.slab.device)
+        # through pinned memory, enqueued behind whatever the stream still holds (the slab's zero fill, in the constructor): a
+        # pageable copy would make the host wait for all of it
+        host = torch.empty(vals.size, dtype=torch.float64, pin_memory=True)
+        host.numpy()[:] = vals
+        self.slab[self._row(int(i))][self.perm] = host.to(self.slab.device, non_blocking=True)
 
     def __iter__(self):
         return (self[k] for k in range(len(self)))
@@ -127,16 +135,19 @@ class HipBackend:
         # two-point states: the row is [first | second], each half lane-blocked like a 1-D row of n values
         self.ld = [((n + 15) // 16) * 16 if d["kind"] == "heat2d" else
                    (2 if d["kind"] == "heat1d_2pts" else 1) * hip_lib.row_stride(n) for n, d in zip(self.n, self.desc)]
-        self.perm = []
-        for n, d in zip(self.n, self.desc):
-            if d["kind"] == "heat2d":
-                perm = np.arange(n)
-            elif d["kind"] == "heat1d_2pts":
-                half = hip_lib.row_permutation(n)
-                perm = np.concatenate((half, half + hip_lib.row_stride(n)))
-            else:
-                perm = hip_lib.row_permutation(n)
-            self.perm.append(torch.from_numpy(np.asarray(perm, dtype=np.int64)).to(self.device))
+        self.perm, made = [], {}
+        for n, d in zip(self.n, self.desc):     # (levels of one spatial size share the tensor: one upload, in front of the slabs' zero fills)
+            key = (n, d["kind"])
+            if key not in made:
+                if d["kind"] == "heat2d":
+                    perm = np.arange(n)
+                elif d["kind"] == "heat1d_2pts":
+                    half = hip_lib.row_permutation(n)
+                    perm = np.concatenate((half, half + hip_lib.row_stride(n)))
+                else:
+                    perm = hip_lib.row_permutation(n)
+                made[key] = torch.from_numpy(np.asarray(perm, dtype=np.int64)).to(self.device)
+            self.perm.append(made[key])
         self._U, self.V, self.G, self.FB = [], [], [], {}
         self._f_stale = 0         # level-0 F-points: 0 all in place; 1 all but the last of every interval await materialise();
                                   # 2 as 1, and the last one's row holds Phi of it (the next C-relaxation's value, cf_fas pre)
@@ -558,7 +569,7 @@ class HipBackend:
     def _point_run_id(self, lvl, points):
         def create():
             rid = C.c_int(-1)
-            st, ln = _i32(list(points)), _i32([1] * len(points))
+            st, ln = _cols(points, 1)[0], np.ones(len(points), dtype=np.int32)
             check(self.lib.mgrit_hip_runs_create(self.h, lvl, len(points), _ptr(st), _ptr(ln), C.byref(rid)))
             return rid.value
         return self._handle(self._runs, lvl, points, "pts", create)
@@ -832,13 +843,13 @@ class HipBackend:
             handle = self.residual_begin(points)
             return self.residual_end(handle)
         cache = getattr(self, "_residual_cache", None)
-        if not (cache is not None and len(cache) == len(points) and (cache is points or cache == tuple(points))):
+        if not (cache is not None and len(cache) == len(points) and (cache is points or tuple(cache) == tuple(points))):
             self._settle(0)     # the residual kernel reads the last F-points
         if not len(points):
             return []
         host = np.empty(len(points), dtype=np.float64)
         cache = getattr(self, "_residual_cache", None)
-        if cache is not None and len(cache) == len(points) and (cache is points or cache == tuple(points)):
+        if cache is not None and len(cache) == len(points) and (cache is points or tuple(cache) == tuple(points)):
             check(self.lib.mgrit_hip_residual_fetch(self.h, len(points), _ptr(host)))
             return np.sqrt(host)
         check(self.lib.mgrit_hip_residual_host(self.h, 0, self._point_run_id(0, points), _ptr(host)))
@@ -872,7 +883,7 @@ class HipBackend:
         """launch the residual kernel and return at once; the per-point sums of squares land in pinned host memory that the
         kernel writes directly (no copy command), residual_end() waits for the event recorded behind the kernel"""
         cache = getattr(self, "_residual_cache", None)
-        if len(points) and cache is not None and len(cache) == len(points) and (cache is points or cache == tuple(points)):
+        if len(points) and cache is not None and len(cache) == len(points) and (cache is points or tuple(cache) == tuple(points)):
             # the way up (ec_relax_res) has left exactly these values in the engine's pinned buffer: a copy of their own for a
             # solver that looks at them some cycles late -- the next cycle overwrites the engine's buffer
             buf = self._ring_slot(len(points))
@@ -1116,7 +1127,7 @@ class HipBackend:
 
         def create():
             rid = C.c_int(-1)
-            st, ln, co = _i32([t[0] for t in triples]), _i32([t[1] for t in triples]), _i32([t[2] for t in triples])
+            st, ln, co = _cols(triples, 3)
             check(self.lib.mgrit_hip_ec_runs_create(self.h, lvl, len(triples), _ptr(st), _ptr(ln), _ptr(co), C.byref(rid)))
             return rid.value
         check(self.lib.mgrit_hip_ec_relax(self.h, lvl, self._handle(self._runs, lvl, triples, "ecruns", create)))
@@ -1240,7 +1251,7 @@ class HipBackend:
     def residual_ready(self, points):
         """the residual of exactly these level-0 points has been produced by the last ec_relax_res sweep(s) and level 0 has not
         been touched since (Mgrit._ec_f_relax sets it, every other sweep on level 0 clears it)"""
-        self._residual_cache = tuple(points) if not isinstance(points, tuple) else points
+        self._residual_cache = points      # (compared by identity first: Mgrit hands over the same cached list every time)
 
     def error_correction(self, lvl, pairs):
         self._before_c_write(lvl)

@@ -48,12 +48,22 @@ class LevelLayout:
     int_stop: float
 
 
+def member_mask(values, grid) -> np.ndarray:
+    """np.isin(values, grid) -- exact float membership -- for the usual case of a strictly ascending ``grid`` by binary search
+    (isin sorts the concatenation of both arrays: 1 ms per call at 65537 points, six calls per constructor)"""
+    values, grid = np.asarray(values), np.asarray(grid)
+    if grid.ndim != 1 or grid.size < 2 or not bool((grid[1:] > grid[:-1]).all()):
+        return np.isin(values, grid)
+    at = np.minimum(np.searchsorted(grid, values), grid.size - 1)
+    return grid[at] == values
+
+
 def global_c_mask(t_lvl: np.ndarray, t_next) -> np.ndarray:
     """C-points = exact float membership in the next coarser grid; every point on the coarsest level
     (mgrit.py:767-770)."""
     if t_next is None:
         return np.ones(len(t_lvl), dtype=bool)
-    return np.isin(t_lvl, t_next)
+    return member_mask(t_lvl, t_next)
 
 
 def compute_layout(global_t, lvl: int, rank: int, size: int) -> LevelLayout:
@@ -124,12 +134,84 @@ def compute_layout(global_t, lvl: int, rank: int, size: int) -> LevelLayout:
                        np.zeros(0, dtype=bool), int_start=int_start, int_stop=int_stop, **flags)
 
 
-def consecutive_runs(slots: np.ndarray):
-    """[(start, length)] of maximal runs of consecutive integers in the ascending array ``slots``."""
-    slots = np.asarray(slots, dtype=np.int64)
+class IndexArray:
+    """A sequence of equal-length tuples of ints (``arr`` of shape [N, k]) or of ints ([N]) held as ONE int64 array: the run /
+    pair / triple / interval lists of a level (16384 six-tuples per list at BASELINE config 3) are built by array arithmetic and
+    handed to the device library column by column without ever becoming Python objects -- as lists of tuples they cost ~20 ms of
+    the first iteration of ``Mgrit.solve()``. Read like a list of tuples where somebody does (tests, the plugin backend, the
+    sharded schedules): len, truth, iteration, integer and slice indexing, comparison with a list, ``+``; like a list built by
+    ``Mgrit._cached`` it can carry the backend's device handles as attributes."""
+
+    def __init__(self, arr, width=None):
+        arr = np.asarray(arr, dtype=np.int64)
+        if width is not None:
+            arr = arr.reshape(-1, width)
+        self.arr = np.ascontiguousarray(arr)
+        self._items = None
+
+    def columns(self, dtype=np.int32):
+        """the k columns as contiguous arrays (one for a sequence of ints)"""
+        a = self.arr if self.arr.ndim == 2 else self.arr.reshape(-1, 1)
+        return [np.ascontiguousarray(a[:, c], dtype=dtype) for c in range(a.shape[1])]
+
+    def tolist(self):
+        if self._items is None:
+            self._items = [tuple(r) for r in self.arr.tolist()] if self.arr.ndim == 2 else self.arr.tolist()
+        return self._items
+
+    def __len__(self):
+        return int(self.arr.shape[0])
+
+    def __bool__(self):
+        return self.arr.shape[0] > 0
+
+    def __iter__(self):
+        return iter(self.tolist())
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return IndexArray(self.arr[i])
+        row = self.arr[i]
+        return tuple(row.tolist()) if self.arr.ndim == 2 else int(row)
+
+    def __eq__(self, other):
+        if isinstance(other, IndexArray):
+            return self.arr.shape == other.arr.shape and bool(np.array_equal(self.arr, other.arr))
+        if isinstance(other, (list, tuple)):
+            return self.tolist() == [tuple(x) if isinstance(x, (list, tuple)) else x for x in other]
+        return NotImplemented
+
+    def __ne__(self, other):
+        eq = self.__eq__(other)
+        return eq if eq is NotImplemented else not eq
+
+    __hash__ = None
+
+    def __add__(self, other):
+        return self.tolist() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self.tolist()
+
+    def __repr__(self):
+        return f"IndexArray({self.tolist()!r})"
+
+
+def as_index_array(items, width):
+    """``items`` (IndexArray, list of tuples, empty list) as an [N, width] int64 array"""
+    if isinstance(items, IndexArray):
+        return items.arr if items.arr.ndim == 2 else items.arr.reshape(-1, 1)
+    if not len(items):
+        return np.zeros((0, width), dtype=np.int64)
+    return np.asarray(items, dtype=np.int64).reshape(len(items), width)
+
+
+def consecutive_runs(slots):
+    """(start, length) of the maximal runs of consecutive integers in the ascending array ``slots``, as an IndexArray."""
+    slots = slots.arr if isinstance(slots, IndexArray) else np.asarray(slots, dtype=np.int64)
     if slots.size == 0:
-        return []
+        return IndexArray(np.zeros((0, 2), dtype=np.int64))
     cuts = np.nonzero(np.diff(slots) != 1)[0] + 1
     first = np.concatenate(([0], cuts))
     length = np.diff(np.concatenate((first, [slots.size])))
-    return list(zip(slots[first].tolist(), length.tolist()))
+    return IndexArray(np.stack((slots[first], length), axis=1))

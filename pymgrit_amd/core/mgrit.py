@@ -29,8 +29,8 @@ from pymgrit_amd.core.grid_transfer import GridTransfer
 from pymgrit_amd.core.grid_transfer_copy import GridTransferCopy
 from pymgrit_amd.core.pipelined import PipelinedLoop
 from pymgrit_amd.core.rank_schedules import RankSchedules
-from pymgrit_amd.core.layout import compute_layout, consecutive_runs, split_into as _split_into, \
-    split_points as _split_points
+from pymgrit_amd.core.layout import IndexArray, as_index_array, compute_layout, consecutive_runs, member_mask, \
+    split_into as _split_into, split_points as _split_points
 
 
 def time_norm(values: np.ndarray, ord) -> float:
@@ -132,7 +132,7 @@ class Mgrit(RankSchedules, PipelinedLoop):
             if lvl != self.lvl_max - 1:
                 self.restriction.append(transfer[lvl].restriction)
                 self.interpolation.append(transfer[lvl].interpolation)
-                cp = np.where(np.isin(problem[lvl].t, problem[lvl + 1].t))[0]
+                cp = np.where(member_mask(problem[lvl].t, problem[lvl + 1].t))[0]
                 gaps = np.diff(cp)
                 self.m.append(int(gaps[0]))
                 if not np.all(np.isclose(gaps, gaps[0])) and self.comm_time_rank == 0:
@@ -179,7 +179,10 @@ class Mgrit(RankSchedules, PipelinedLoop):
         if output_lvl not in [0, 1, 2]:
             raise Exception("Unknown output level. Choose 0, 1 or 2.")
         for lvl in range(1, len(problem)):
-            if np.count_nonzero(np.isin(np.unique(problem[lvl].t), problem[lvl - 1].t)) != len(problem[lvl].t):
+            t_l = np.asarray(problem[lvl].t)
+            if t_l.size > 1 and not bool((t_l[1:] > t_l[:-1]).all()):
+                t_l = np.unique(t_l)        # (an ascending grid is its own set of unique values)
+            if np.count_nonzero(member_mask(t_l, problem[lvl - 1].t)) != len(problem[lvl].t):
                 raise Exception('Some points from level ' + str(lvl - 1) + ' are not points of level ' + str(lvl))
         if t_norm not in [1, 2, 3]:
             raise Exception('Unknown norm. Please choose 1 (one norm), 2 (two-norm) or 3 (inf-norm)')
@@ -291,7 +294,8 @@ class Mgrit(RankSchedules, PipelinedLoop):
         backend's device-side handle, see IndexList)"""
         store = self.__dict__.setdefault('_index_lists', {})
         if key not in store:
-            store[key] = IndexList(build())
+            got = build()
+            store[key] = got if isinstance(got, IndexArray) else IndexList(got)
         return store[key]
 
     def _f_runs(self, lvl):
@@ -301,10 +305,10 @@ class Mgrit(RankSchedules, PipelinedLoop):
     def _c_points(self, lvl):
         """local C-point slots that are relaxed: all except global index 0 (mgrit.py:357,408,525)."""
         def build():
-            pts = [int(i) for i in self.index_local_c[lvl]]
-            if self.comm_time_rank == 0 and pts and pts[0] == 0:
+            pts = np.asarray(self.index_local_c[lvl], dtype=np.int64)
+            if self.comm_time_rank == 0 and pts.size and pts[0] == 0:
                 pts = pts[1:]
-            return pts
+            return IndexArray(pts)
         return self._cached(('c', lvl), build)
 
     def _c_runs(self, lvl):
@@ -313,11 +317,12 @@ class Mgrit(RankSchedules, PipelinedLoop):
     def _pairs(self, lvl, skip_first):
         """(fine slot of the i-th local C-point, coarse slot index_local[lvl+1][i]) (mgrit.py:498-500,528,722-726)."""
         def build():
-            fine, coarse = self.index_local_c[lvl], self.index_local[lvl + 1]
-            out = list(zip(np.asarray(fine, dtype=np.int64).tolist(), np.asarray(coarse, dtype=np.int64)[:len(fine)].tolist()))
+            fine = np.asarray(self.index_local_c[lvl], dtype=np.int64)
+            coarse = np.asarray(self.index_local[lvl + 1], dtype=np.int64)[:fine.size]
+            out = np.stack((fine[:coarse.size], coarse), axis=1)
             if skip_first and self.comm_time_rank == 0:
                 out = out[1:]
-            return out
+            return IndexArray(out, width=2)
         return self._cached(('pair', lvl, bool(skip_first)), build)
 
     def _exchange(self, lvl, send_idx=None, recv_idx=None, dest=None, src=None, op=None):
@@ -599,8 +604,13 @@ class Mgrit(RankSchedules, PipelinedLoop):
             self.backend.relax(lvl, runs, 'F')
             return
         def build():   # (start, length, coarse slot of the corrected C-point in front of the run, or -1)
-            coarse_of = dict(self._pairs(lvl, skip_first=True))
-            return [(st, ln, coarse_of.get(st - 1, -1)) for st, ln in runs]
+            P, R = as_index_array(self._pairs(lvl, skip_first=True), 2), as_index_array(runs, 2)
+            co = np.full(R.shape[0], -1, dtype=np.int64)
+            if P.shape[0]:      # (the fine slots of the pairs ascend)
+                at = np.minimum(np.searchsorted(P[:, 0], R[:, 0] - 1), P.shape[0] - 1)
+                hit = P[at, 0] == R[:, 0] - 1
+                co[hit] = P[at[hit], 1]
+            return IndexArray(np.column_stack((R, co)), width=3)
         self.backend.ec_relax(lvl, self._cached(('ec_' + tag, lvl), build))
 
     def _ec_f_relax(self, lvl: int) -> None:
@@ -608,8 +618,8 @@ class Mgrit(RankSchedules, PipelinedLoop):
         by a local F-interval folded into that interval's launch; the remaining C-points (the last local point, C-points
         followed by another C-point) are corrected up front -- in particular before op 0 sends the last local C-point."""
         def leftover():
-            fused = {st - 1 for st, _ in self._f_runs(lvl)}
-            return [p for p in self._pairs(lvl, skip_first=True) if p[0] not in fused]
+            P, R = as_index_array(self._pairs(lvl, skip_first=True), 2), as_index_array(self._f_runs(lvl), 2)
+            return IndexArray(P[~np.isin(P[:, 0], R[:, 0] - 1)], width=2)
         self.backend.error_correction(lvl, self._cached(('ec_left', lvl), leftover))
         self.f_relax(lvl, ec=True)
 
@@ -730,8 +740,11 @@ class Mgrit(RankSchedules, PipelinedLoop):
         be = self.backend
         all_pairs = self._pairs(lvl, skip_first=False)
         head = self._cached(('pair_head', lvl), lambda: all_pairs[:1])
-        triples = self._cached(('triples', lvl), lambda: [(all_pairs[k][0], all_pairs[k - 1][0], all_pairs[k][1])
-                                                          for k in range(1, len(all_pairs))])
+
+        def build_triples():   # (fine slot, fine slot of the C-point before it, coarse slot)
+            P = as_index_array(all_pairs, 2)
+            return IndexArray(np.column_stack((P[1:, 0], P[:-1, 0], P[1:, 1])), width=3)
+        triples = self._cached(('triples', lvl), build_triples)
         self._exchange(lvl, send_idx=self._last_slot(lvl) if self.last_is_f_point[lvl] else None,
                        recv_idx=0 if self.first_is_c_point[lvl] else None, dest=self.send_to[lvl], src=self.get_from[lvl], op=3)
         be.restrict_u(lvl, head)

@@ -4,6 +4,7 @@ exchange points of the reference (mgrit.py:693-713). Host logic only -- a mixin 
 in round 4; every list is built once per (kind, level) and cached (``Mgrit._cached``)."""
 import numpy as np
 
+from pymgrit_amd.core.layout import IndexArray, as_index_array
 from pymgrit_amd.core.options import options
 
 
@@ -50,7 +51,9 @@ class RankSchedules:
         grid on rank 0 (it is an owned C-point there), the ghost point (slot 0 on both levels) on an aligned rank > 0"""
         def build():
             own = self._pairs(lvl, skip_first=False)
-            return ([(0, 0)] + list(own)) if (self.comm_time_rank > 0 and getattr(self, "_aligned", False)) else own
+            if self.comm_time_rank > 0 and getattr(self, "_aligned", False):
+                return IndexArray(np.concatenate((np.zeros((1, 2), dtype=np.int64), as_index_array(own, 2))), width=2)
+            return own
         return self._cached(('xpair', lvl), build)
 
     def _x0(self, lvl, send_row=None, staged=None):
@@ -149,8 +152,8 @@ class RankSchedules:
             if (down is None or self.conv_crit != 0 or
                     not self._can_fuse_ec(lvl) or getattr(self.backend, "residual_reserve", None) is None):
                 return [None]
-            ivals, c0_run, edge = down
-            cpts = self._c_points(lvl)
+            ivals, c0_run, edge = (list(x) for x in down)
+            cpts = list(self._c_points(lvl))
             pos = {c: i for i, c in enumerate(cpts)}
             if any(iv[1] not in pos for iv in ivals):
                 return [None]
@@ -181,7 +184,7 @@ class RankSchedules:
                     self.weight_c == 1.0 and self.cf_iter[lvl] == 1 and self.global_conv_crit and
                     not getattr(self, "_sweep_timing", False) and can is not None and can(lvl)):
                 return [None]
-            pairs = self._pairs(lvl, skip_first=False)
+            pairs = list(self._pairs(lvl, skip_first=False))
             if len(pairs) < 3:
                 return [None]
             c0, ck = pairs[0][0], pairs[-1][0]
@@ -215,7 +218,7 @@ class RankSchedules:
                     self.weight_c == 1.0 and self.global_conv_crit and not getattr(self, "_sweep_timing", False) and
                     can is not None and can(lvl) and getattr(be, "can_fuse_fas", lambda l: False)(lvl)):
                 return [None]
-            pairs = self._pairs(lvl, skip_first=False)               # (fine slot, coarse slot) of every local C-point
+            pairs = list(self._pairs(lvl, skip_first=False))         # (fine slot, coarse slot) of every local C-point
             if len(pairs) < 3:
                 return [None]
             c0, ck = pairs[0][0], pairs[-1][0]
@@ -253,13 +256,14 @@ class RankSchedules:
                     self.cf_iter[lvl] in (0, 1) and not getattr(self, "_sweep_timing", False) and can is not None and can(lvl)):
                 return [None]
             pairs = self._xpairs(lvl)
-            if len(pairs) < 2 or pairs[0][0] != 0:
+            P, R = as_index_array(pairs, 2), as_index_array(self._f_runs(lvl), 2)
+            if P.shape[0] < 2 or P[0, 0] != 0:
                 return [None]
-            want = [(pairs[k][0] + 1, pairs[k + 1][0] - pairs[k][0] - 1) for k in range(len(pairs) - 1)]
-            if [tuple(r) for r in self._f_runs(lvl)] != want or any(ln < 1 for _, ln in want):
+            want = np.stack((P[:-1, 0] + 1, P[1:, 0] - P[:-1, 0] - 1), axis=1)   # one run of F-points between two C-points
+            if R.shape != want.shape or not np.array_equal(R, want) or (want[:, 1] < 1).any():
                 return [None]
-            fc_runs = [(st, ln + 1) for st, ln in want]                       # the F-points and the C-point closing them
-            triples = [(pairs[k][0], pairs[k - 1][0], pairs[k][1]) for k in range(1, len(pairs))]
+            fc_runs = IndexArray(want + np.array([0, 1]), width=2)             # the F-points and the C-point closing them
+            triples = IndexArray(np.column_stack((P[1:, 0], P[:-1, 0], P[1:, 1])), width=3)
             skip_u = lvl + 1 == self.lvl_max - 1 and self._coarsest_u_unread()
             return [(fc_runs, triples, pairs[:1] if self.comm_time_rank == 0 else [], skip_u)]
         return self._cached(('coarse_down', lvl), build)[0]
@@ -280,11 +284,11 @@ class RankSchedules:
                     can is not None and can(lvl) and (not up or self._can_fuse_ec(lvl))):
                 return [None]
             pairs = self._xpairs(lvl)
-            P = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
-            if len(pairs) < 2 or pairs[0][0] != 0 or not np.array_equal(np.asarray(self._c_points(lvl), dtype=np.int64), P[1:, 0]):
+            P = as_index_array(pairs, 2)
+            if len(pairs) < 2 or P[0, 0] != 0 or not np.array_equal(as_index_array(self._c_points(lvl), 1)[:, 0], P[1:, 0]):
                 return [None]
             # every interval between two C-points is one run of F-points, at least one (compared as arrays: 16384 of them at config 3)
-            R = np.asarray(self._f_runs(lvl), dtype=np.int64).reshape(-1, 2)
+            R = as_index_array(self._f_runs(lvl), 2)
             want_len = P[1:, 0] - P[:-1, 0] - 1
             if R.shape[0] != P.shape[0] - 1 or not np.array_equal(R[:, 0], P[:-1, 0] + 1) or not np.array_equal(R[:, 1], want_len) or \
                     (want_len < 1).any():
@@ -310,7 +314,7 @@ class RankSchedules:
                 keep[-1] |= 3
             jcs = P[:-1, 1].copy()
             jcs[0] = -1
-            return [list(zip(P[:-1, 0].tolist(), P[1:, 0].tolist(), jcs.tolist(), jce.tolist(), range(len(pairs) - 1), keep.tolist()))]
+            return [IndexArray(np.column_stack((P[:-1, 0], P[1:, 0], jcs, jce, np.arange(len(pairs) - 1), keep)), width=6)]
         got = self._cached(('intervals', lvl, up), build)[0]
         if got is None:
             return None
@@ -330,14 +334,16 @@ class RankSchedules:
                     not getattr(self, "_sweep_timing", False) and can is not None and can(lvl) and
                     True):
                 return [None]
-            pairs = self._xpairs(lvl)
-            if len(pairs) < 2 or pairs[0][0] != 0 or self._c_points(lvl) != [p[0] for p in pairs[1:]]:
+            P, R = as_index_array(self._xpairs(lvl), 2), as_index_array(self._f_runs(lvl), 2)
+            if P.shape[0] < 2 or P[0, 0] != 0 or not np.array_equal(as_index_array(self._c_points(lvl), 1)[:, 0], P[1:, 0]):
                 return [None]
-            want = [(pairs[k][0] + 1, pairs[k + 1][0] - pairs[k][0] - 1) for k in range(len(pairs) - 1)]
-            if [tuple(r) for r in self._f_runs(lvl)] != want or any(ln < 1 for _, ln in want):
+            want = np.stack((P[:-1, 0] + 1, P[1:, 0] - P[:-1, 0] - 1), axis=1)
+            if R.shape != want.shape or not np.array_equal(R, want) or (want[:, 1] < 1).any():
                 return [None]
-            return [[(pairs[k][0], pairs[k + 1][0], pairs[k][1] if k >= 1 else -1, pairs[k + 1][1], k, 3)
-                     for k in range(len(pairs) - 1)]]
+            jcs = P[:-1, 1].copy()
+            jcs[0] = -1
+            n_iv = P.shape[0] - 1
+            return [IndexArray(np.column_stack((P[:-1, 0], P[1:, 0], jcs, P[1:, 1], np.arange(n_iv), np.full(n_iv, 3))), width=6)]
         got = self._cached(('gen_intervals', lvl), build)[0]
         if got is None:
             return None

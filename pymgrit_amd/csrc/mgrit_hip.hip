@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1629,7 +1630,56 @@ struct WideHost {
     size_t cap = 0;
 };
 
+// Small uploads (index lists, coefficient sets, time factors) without a stream synchronisation: device memory carved from 8 MB
+// chunks, the source copied into a pinned mirror of the chunk that lives as long as the engine, the copy enqueued on the engine's
+// stream -- ordered in front of every launch that reads it, and the host runs on. (As hipMalloc + hipMemcpyAsync from a
+// temporary + hipStreamSynchronize per array, every list created during the first cycle of a solve waited for the sweep that
+// was still running on the stream: ~1.3 ms per list, 11 ms per solve of BASELINE config 3, and the constructor's tables waited
+// for the zero-fill of the level before.) Pinned chunks are expensive to make (page locking): they go back to a process-wide
+// pool when an engine is destroyed -- its stream has been drained by then.
+struct UploadArena {
+    static constexpr size_t CHUNK = (size_t)8 << 20, SMALL = (size_t)1 << 20;
+    struct Chunk { char *dev, *host; };
+    std::vector<Chunk> chunks;
+    size_t off = CHUNK;
+    static std::vector<char *> &pool() { static std::vector<char *> p; return p; }
+    static std::mutex &pool_lock() { static std::mutex m; return m; }
+    int take(size_t bytes, char **dev, char **host) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (off + bytes > CHUNK) {
+            Chunk c{nullptr, nullptr};
+            {
+                std::lock_guard<std::mutex> g(pool_lock());
+                if (!pool().empty()) { c.host = pool().back(); pool().pop_back(); }
+            }
+            if (!c.host && hipHostMalloc(reinterpret_cast<void **>(&c.host), CHUNK, hipHostMallocDefault) != hipSuccess) return 1;
+            if (hipMalloc(reinterpret_cast<void **>(&c.dev), CHUNK) != hipSuccess) {
+                std::lock_guard<std::mutex> g(pool_lock());
+                pool().push_back(c.host);
+                return 1;
+            }
+            chunks.push_back(c);
+            off = 0;
+        }
+        *dev = chunks.back().dev + off;
+        *host = chunks.back().host + off;
+        off += bytes;
+        return 0;
+    }
+    void release() {   // the engine's streams are idle
+        std::lock_guard<std::mutex> g(pool_lock());
+        for (auto &c : chunks) {
+            (void)hipFree(c.dev);
+            if (pool().size() < 8) pool().push_back(c.host);
+            else (void)hipHostFree(c.host);
+        }
+        chunks.clear();
+        off = CHUNK;
+    }
+};
+
 struct Level {
+    UploadArena *arena = nullptr;   // the engine's (set by mgrit_hip_create)
     WideHost *wide = nullptr;
     int order = 0;   // two-point steppers: BDF order (1 or 2)
     bool set = false;
@@ -1657,6 +1707,7 @@ struct Level {
     double fac = 0.0;                // Heat1D: a / dx^2
     std::vector<double> t_host;      // the local time grid as described
     BlkDev blk{};                    // time-parallel forward solve (mgrit_hip_blk.inc); blk.r = 0: step by step
+    std::shared_ptr<double> blk_q;   // the level's share of the sine-mode table (process-wide cache, blk_mode_table_cached)
     double *blk_part = nullptr;      // [G chunks][B][BLK_RMAX] the chunks' sums of the inner products (blk_project_kernel)
     int blk_state = -1;              // -1: not configured yet (mgrit_hip_block_solve_config), else configured
 };
@@ -1702,6 +1753,7 @@ struct mgrit_hip_engine {
     std::vector<Link> links;      // mgrit_hip_link_*: the rank's ends of its exchange links
     double *xscratch = nullptr;   // exchange scratch (zeros of a fresh chain state / a dropped hand-over)
     size_t xscratch_len = 0;
+    UploadArena arena;            // small uploads of every level (dev_upload)
 };
 
 namespace {
@@ -1879,6 +1931,16 @@ template <typename T>
 int dev_upload(Level &lv, hipStream_t st, const std::vector<T> &h, T **out) {
     void *d = nullptr;
     const size_t bytes = sizeof(T) * (h.empty() ? 1 : h.size());
+    if (lv.arena && bytes <= UploadArena::SMALL) {
+        char *dv = nullptr, *hs = nullptr;
+        if (lv.arena->take(bytes, &dv, &hs)) return fail(MGRIT_HIP_EHIP, "no memory for an upload of %zu bytes", bytes);
+        if (!h.empty()) {
+            std::memcpy(hs, h.data(), sizeof(T) * h.size());
+            HIP_TRY(hipMemcpyAsync(dv, hs, sizeof(T) * h.size(), hipMemcpyHostToDevice, st));
+        }
+        *out = reinterpret_cast<T *>(dv);
+        return 0;
+    }
     HIP_TRY(hipMalloc(&d, bytes));
     lv.allocs.push_back(d);
     if (!h.empty()) {
@@ -1981,6 +2043,8 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(blk_finish_kernel<MGRIT_HIP_STEPPER_HEAT1D, F>, blk_smem_bytes(MAX_G)))) return rc;
     ATTR_BLK(0) ATTR_BLK(2) ATTR_BLK(3) ATTR_BLK(4)
     if ((rc = allow_big_lds(blk_local_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>, blk_smem_bytes(MAX_G)))) return rc;
+    if ((rc = allow_big_lds(blk_local_lo_kernel<0>, blk_smem_bytes(MAX_G)))) return rc;
+    if ((rc = allow_big_lds(blk_local_lo_kernel<2>, blk_smem_bytes(MAX_G)))) return rc;
     if ((rc = allow_big_lds(blk_finish_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>, blk_smem_bytes(MAX_G)))) return rc;
     if ((rc = allow_big_lds(adv_fft_rows_kernel, (size_t)BLK_FOURIER_MAX_N * sizeof(double2)))) return rc;
 #define ATTR_2PTS(O, F)                                                                                              \
@@ -2910,6 +2974,12 @@ int blk_handover_len(const Level &lv) { return lv.blk.r == 0 ? 0 : lv.blk.fourie
 // Advection1D: the Fourier form needs n = 2^p, 64 <= n <= BLK_FOURIER_MAX_N (one workgroup's LDS holds a row's n complex values)
 bool blk_fourier_ok(int n, int nt) { return n >= 64 && n <= BLK_FOURIER_MAX_N && (n & (n - 1)) == 0 && blk_count(nt) > 0; }
 
+// MGRIT_HIP_BLK_LO_MAX: most blocks for which the first pass takes its latency form (blk_local_lo_kernel); 0 = never (measurement switch)
+int blk_lo_max_blocks() {
+    static const int v = [] { const char *s = std::getenv("MGRIT_HIP_BLK_LO_MAX"); return s ? std::atoi(s) : 128; }();
+    return v;
+}
+
 int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     BlkDev &bk = lv.blk;
     const int fm = force_mode(lv), F = fm == 1 ? 4 : fm;
@@ -2921,7 +2991,11 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     const size_t fft_lds = (size_t)n * sizeof(double2);
     if (phases & 1) {
         const dim3 grid(std::min(bk.B, cap));
+        // fewer blocks than half the chip's CUs (a rank's share of a sharded level): the latency form of the first pass
+        const bool lo = !adv && (F == 0 || F == 4) && bk.B <= blk_lo_max_blocks();
         if (adv) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>), grid, block, lds, e->stream, lv.dev, bk);
+        else if (lo && F == 0) hipLaunchKernelGGL((blk_local_lo_kernel<0>), grid, block, lds, e->stream, lv.dev, bk);
+        else if (lo) hipLaunchKernelGGL((blk_local_lo_kernel<2>), grid, block, lds, e->stream, lv.dev, bk);
         else if (F == 0) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 0>), grid, block, lds, e->stream, lv.dev, bk);
         else if (F == 2) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 2>), grid, block, lds, e->stream, lv.dev, bk);
         else if (F == 3) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 3>), grid, block, lds, e->stream, lv.dev, bk);
@@ -2963,6 +3037,24 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     return 0;
 }
 
+// process-wide cache of sine-mode tables (blk_config): the four most recent (n, ld, rows); a table in use by a level stays alive
+// through the level's shared_ptr after it has left the cache
+struct BlkModeKey { int n, ld, rows; std::shared_ptr<double> tab; };
+std::vector<BlkModeKey> &blk_mode_cache() { static std::vector<BlkModeKey> c; return c; }
+std::mutex &blk_mode_lock() { static std::mutex m; return m; }
+std::shared_ptr<double> blk_mode_table_cached(int n, int ld, int rows) {
+    std::lock_guard<std::mutex> g(blk_mode_lock());
+    for (auto &k : blk_mode_cache())
+        if (k.n == n && k.ld == ld && k.rows >= rows) return k.tab;
+    return nullptr;
+}
+void blk_mode_table_store(int n, int ld, int rows, const std::shared_ptr<double> &tab) {
+    std::lock_guard<std::mutex> g(blk_mode_lock());
+    auto &c = blk_mode_cache();
+    if (c.size() >= 4) c.erase(c.begin());
+    c.push_back({n, ld, rows, tab});
+}
+
 int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_successor, double *uh_in, double *uh_out) {
     Level &lv = e->L[lvl];
     lv.blk = BlkDev{};
@@ -2993,7 +3085,7 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
     if (heat) {
         if (r > BLK_RMAX || r > n) return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve: r = %d modes outside [1, %d]", r, std::min(BLK_RMAX, n));
         // D_b(k) = prod over the block's steps of 1 / (1 + dt_i fac 4 sin^2(theta_k / 2)), products in step order
-        std::vector<double> Dt((size_t)B * BLK_RMAX, 0.0), Q((size_t)((r + 15) / 16 * 16) * ld, 0.0);   // (zero rows up to a multiple of 16 modes)
+        std::vector<double> Dt((size_t)B * BLK_RMAX, 0.0);
         for (int b = 0; b < B; ++b) {
             const int first = BLK_K * b + 1, last = b == B - 1 ? nt - 1 : BLK_K * (b + 1);
             for (int k = 0; k < BLK_RMAX && k < n; ++k) {
@@ -3003,25 +3095,40 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
                 Dt[(size_t)b * BLK_RMAX + k] = d;
             }
         }
-        const double sc = std::sqrt(2.0 / (double)(n + 1));
-        {   // the r mode rows are independent: on a few host threads (r n calls of sin -- 0.8 M at config 3 -- were 15 ms of a solve's setup)
-            auto rows = [&](int k0, int k1) {
-                for (int k = k0; k < k1; ++k)
-                    for (int j = 0; j < n; ++j) {
-                        const long m = ((long)(k + 1) * (long)(j + 1)) % (2L * (n + 1));
-                        Q[(size_t)k * ld + row_pos(j)] = sc * std::sin(M_PI * (double)m / (double)(n + 1));
-                    }
-            };
-            const unsigned hw = std::thread::hardware_concurrency();
-            const int nth = (size_t)r * n < 65536 ? 1 : std::max(1, std::min({8, (int)(hw ? hw : 1), r}));
-            std::vector<std::thread> pool;
-            for (int w = 1; w < nth; ++w) pool.emplace_back(rows, (int)((long)r * w / nth), (int)((long)r * (w + 1) / nth));
-            rows(0, r / nth);
-            for (std::thread &th : pool) th.join();
+        // the sine modes in row storage order: a table of (r rounded up to 16) x ld doubles that depends on (n, ld, rows) only -- 8 MB and
+        // 0.8 M calls of sin at config 3. A process that builds solver after solver on the same spatial grid (a service; the second
+        // constructor of bench.py's time-to-solution) finds it in a small process-wide cache, device resident and immutable
+        const int q_rows = (r + 15) / 16 * 16;
+        std::shared_ptr<double> qtab = blk_mode_table_cached(n, ld, q_rows);
+        if (!qtab) {
+            std::vector<double> Q((size_t)q_rows * ld, 0.0);   // (zero rows up to a multiple of 16 modes)
+            const double sc = std::sqrt(2.0 / (double)(n + 1));
+            {   // the mode rows are independent: on a few host threads (r n calls of sin -- 0.8 M at config 3 -- were 15 ms of a solve's setup)
+                auto rows = [&](int k0, int k1) {
+                    for (int k = k0; k < k1; ++k)
+                        for (int j = 0; j < n; ++j) {
+                            const long m = ((long)(k + 1) * (long)(j + 1)) % (2L * (n + 1));
+                            Q[(size_t)k * ld + row_pos(j)] = sc * std::sin(M_PI * (double)m / (double)(n + 1));
+                        }
+                };
+                const int rq = std::min(q_rows, n);    // (every row of the table is a mode: a later level with more modes may reuse it)
+                const unsigned hw = std::thread::hardware_concurrency();
+                const int nth = (size_t)rq * n < 65536 ? 1 : std::max(1, std::min({8, (int)(hw ? hw : 1), rq}));
+                std::vector<std::thread> pool;
+                for (int w = 1; w < nth; ++w) pool.emplace_back(rows, (int)((long)rq * w / nth), (int)((long)rq * (w + 1) / nth));
+                rows(0, rq / nth);
+                for (std::thread &th : pool) th.join();
+            }
+            double *raw = nullptr;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&raw), sizeof(double) * Q.size()));
+            qtab = std::shared_ptr<double>(raw, [](double *p) { (void)hipFree(p); });
+            HIP_TRY(hipMemcpyAsync(raw, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            blk_mode_table_store(n, ld, q_rows, qtab);
         }
+        lv.blk_q = qtab;
         std::vector<double> zeros((size_t)B * BLK_RMAX, 0.0);
-        double *dQ, *dD, *dW, *dC;
-        if ((rc = dev_upload(lv, e->stream, Q, &dQ))) return rc;
+        double *dQ = qtab.get(), *dD, *dW, *dC;
         if ((rc = dev_upload(lv, e->stream, Dt, &dD))) return rc;
         if ((rc = dev_upload(lv, e->stream, zeros, &dW))) return rc;
         if ((rc = dev_upload(lv, e->stream, zeros, &dC))) return rc;
@@ -3109,6 +3216,7 @@ int mgrit_hip_create(mgrit_hip_engine **out, int n_levels, void *stream) {
     e->n_levels = n_levels;
     e->stream = static_cast<hipStream_t>(stream);
     e->L.resize(n_levels);
+    for (auto &lv : e->L) lv.arena = &e->arena;
     *out = e;
     return 0;
 }
@@ -3133,6 +3241,7 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
         for (void *p : lv.allocs) (void)hipFree(p);
         if (lv.scratch) (void)hipFree(lv.scratch);
     }
+    e->arena.release();
     if (e->chain_gran) (void)hipFree(e->chain_gran);
     if (e->sched) (void)hipFree(e->sched);
     if (e->chain_err) (void)hipHostFree(e->chain_err);
