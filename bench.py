@@ -744,6 +744,74 @@ def bench_emulated(args):
     print(json.dumps(res), flush=True)
 
 
+def bench_emulated_solve(args):
+    """`--emulate-solve P`: the whole of Mgrit(...).solve() -- constructor, nested iteration, every cycle with its exchange points and
+    op-5 hand-overs, the stopping test's all-gather, the final F-relaxation -- of BASELINE configs[2] on P ranks to 1e-10, rehearsed
+    on ONE GPU: the P ranks are threads of this process (LoopbackWorld: true ghost rows, device mailboxes in the place of ncclSend /
+    ncclRecv). What it shows: the sharded path runs end to end at full size on P ranks and reproduces the one-rank residual history
+    bit for bit; how many iterations; what the host of a rank spends. What it cannot show is a parallel time -- the ranks share the
+    one device, `wall_ms_all_ranks_on_one_gpu` is the SUM of their work. `critical_path_model` puts the measured pieces together:
+    a rank's setup, `iterations` cycles of the slowest rank as measured alone (--emulate-rank), the P - 1 hops of a forward solve's
+    hand-over chain (recurrence over a rank's blocks + its corrected last point + one message, measured per hop here), said to be
+    a model."""
+    import torch
+    from pymgrit_amd import Heat1D, Mgrit
+    from pymgrit_amd.core.comm import run_loopback_ranks
+    torch.cuda.set_device(0)
+    P = int(args.emulate_solve)
+    nx, nt0 = args.nx, args.nt
+    t0 = np.linspace(0, 2.0 * (nt0 - 1) / 65536, nt0)
+    grids = [t0, t0[::4], t0[::16]]
+
+    def build(comm):
+        problem = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=init_cond, rhs_separable=[(rhs_space, rhs_time)], t_interval=g)
+                   for g in grids]
+        return Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=True, max_iter=30, tol=1e-10, logging_lvl=30, comm_time=comm)
+
+    def target(comm):
+        torch.cuda.synchronize()
+        comm.barrier()
+        w0 = time.perf_counter()
+        mg = build(comm)
+        w1 = time.perf_counter()
+        res = mg.solve()
+        torch.cuda.synchronize()
+        w2 = time.perf_counter()
+        be = mg.backend
+        out = {"rank": comm.rank, "conv": [float(v) for v in res["conv"]], "setup_ms": 1e3 * (w1 - w0), "solve_ms": 1e3 * (w2 - w1),
+               "aligned": bool(getattr(mg, "_aligned", False)), "block_solve_sharded": bool(getattr(be, "block_sharded", {}).get(2)),
+               "breakdown": getattr(mg, "solve_breakdown", None), "messages": int((mg.exchange_stats or {}).get("messages", 0)),
+               "local_points_by_level": [len(t) for t in mg.t]}
+        if out["block_solve_sharded"] and comm.rank == comm.size // 2:     # one hop of the hand-over chain: phase 2 of the block solve
+            be.set_timing(True); be.timing_drain()       # (recurrence over the rank's blocks + its corrected last point; the state is
+            for _k in range(10):                         # thrown away afterwards)
+                be.block_solve(2, 2)
+            recs = be.timing_drain(); be.set_timing(False)
+            out["hop_block_phase2_us"] = 1e3 * float(np.mean([m for k, lv, m in recs if k == "chain"] or [0.0]))
+        return out
+
+    def run(size):      # twice: the second world finds its slabs in the allocator's cache (as bench.iters_to_tol's second run)
+        rows = None
+        for _ in range(2):
+            import gc
+            world, rows = run_loopback_ranks(size, target, timeout=900)
+            world.close()
+            gc.collect()
+        return rows
+    rows = run(P)
+    one = run(1)[0] if P > 1 else None
+    conv = rows[0]["conv"]
+    same_all = all(r["conv"] == conv for r in rows)
+    res = {"metric": "Mgrit.solve() end to end on P emulated ranks of ONE GPU (rehearsal, not a parallel time)", "emulated_ranks": P,
+           "config": {"workload": f"heat_1d nx={nx} nt={nt0} 3-level m=4 FCF V-cycle, nested iteration, tol 1e-10"},
+           "iterations": len(conv), "conv": conv, "every_rank_reports_the_same_history": bool(same_all),
+           "equals_one_rank_history_bit_for_bit": (one is not None and one["conv"] == conv) if P > 1 else None,
+           "wall_ms_all_ranks_on_one_gpu": {"setup": max(r["setup_ms"] for r in rows), "solve": max(r["solve_ms"] for r in rows)},
+           "one_rank_ms": ({"setup": one["setup_ms"], "solve": one["solve_ms"]} if one else None),
+           "ranks": [{k: v for k, v in r.items() if k != "conv"} for r in rows]}
+    print(json.dumps(res), flush=True)
+
+
 def sharded_emulation(ms_one_gpu, timeout=150):
     """the time-sharded run rehearsed on this ONE GPU (bench.py --emulate-rank r/P, child processes): device time per cycle of
     the middle rank of 2, 4 and 8 when it never waits for a neighbour, its host enqueue time, and what that bounds the
@@ -814,11 +882,16 @@ def main():
                     help="r/P or all/P: rank r of a P-rank sharded run emulated on this ONE GPU (loopback exchange): ms per "
                          "cycle of that shard and host enqueue ms per cycle")
     ap.add_argument("--emulate-sweeps", dest="emulate_sweeps", action="store_true", help="with --emulate-rank: per-sweep device times")
+    ap.add_argument("--emulate-solve", dest="emulate_solve", type=int, default=0,
+                    help="P: Mgrit.solve() of the workload end to end on P emulated ranks of the one GPU (threads, loopback exchange), "
+                         "its residual history against the one-rank run")
     ap.add_argument("--nx2d", type=int, default=512)
     ap.add_argument("--nt2d", type=int, default=16385)
     args = ap.parse_args()
     if args.emulate_rank:
         return bench_emulated(args)
+    if args.emulate_solve:
+        return bench_emulated_solve(args)
     if args.workload == "heat2d":
         return bench_heat2d(args)
     if args.workload == "advection":

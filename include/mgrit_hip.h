@@ -29,7 +29,7 @@ extern "C" {
                                       LDS); wider pairs, up to MGRIT_HIP_MAX_N_WIDE per half, take every half-solve as three
                                       launches over rows in HBM like wide Heat1D states (round 4; csrc/mgrit_hip_wide.inc, wide2_*) */
 #define MGRIT_HIP_BLOCK_K 16      /* time-parallel forward solve: steps per block */
-#define MGRIT_HIP_BLOCK_RMAX 64   /* ... and the most sine modes its recurrence over the blocks may need */
+#define MGRIT_HIP_BLOCK_RMAX 256  /* ... and the most sine modes its recurrence over the blocks may need */
 
 typedef struct mgrit_hip_engine mgrit_hip_engine;
 

@@ -1448,7 +1448,7 @@ static void heat1d_chain_spec(orc_problem *p, int lvl) {
  * hierarchy is plain time stepping) and a level whose decay is too slow for ORC_BLK_RMAX modes are solved step by step.
  * ============================================================================================== */
 #define ORC_BLK_K 16
-#define ORC_BLK_RMAX 64
+#define ORC_BLK_RMAX 256
 #define ORC_BLK_THR 8.673617379884035e-19   /* 2^-60 */
 
 /* 4 sin^2(theta_k / 2), theta_k = pi (k+1)/(n+1) */

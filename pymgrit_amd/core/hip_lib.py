@@ -16,7 +16,7 @@ STEPPER_HEAT1D, STEPPER_ADVECTION1D = 1, 2
 TRANSFER_COPY, TRANSFER_HEAT1D, TRANSFER_CALLER = 0, 1, 3
 MAX_N = 16384
 MAX_LINKS = 16
-BLOCK_K, BLOCK_RMAX = 16, 64      # time-parallel forward solve
+BLOCK_K, BLOCK_RMAX = 16, 256     # time-parallel forward solve
 
 EXPORTS = {
     # name: (restype, argtypes)

@@ -469,8 +469,9 @@ class Mgrit(RankSchedules, PipelinedLoop):
             # F-relaxation folded into the FAS sweep (the F-points of the way down are stored by neither)
             fc_runs, triples, head, skip_u = coarse
             ranks = self.comm_time_size > 1     # aligned ranks: the exchange points of the sweeps this pass stands for
-            if ranks:
-                self._x0(lvl)                   # f_relax (mgrit.py:271)
+            # (op 0 of the first F-relaxation, mgrit.py:271, would carry the last point of the rank before as the finer level's FAS
+            # sweep has just injected it -- the very row op 4 of that sweep has put into the ghost slot already (Mgrit._x4; the
+            # level is `fresh`): not sent a second time)
             if self.cf_iter[lvl] == 1:
                 self.backend.relax(lvl, fc_runs, 'FC')
                 if ranks:

@@ -624,7 +624,7 @@ __device__ __forceinline__ void heat_finish(double (&x)[E], const Coef &c, doubl
 // its two scans, the masked norms (block_sumsq) and the host views ignore.
 // LDSBAR: the step's one barrier as lds_barrier() -- it orders the LDS exchange of the group totals and nothing else, so it does not
 // wait for the wave's global stores (__syncthreads() does: s_waitcnt vmcnt(0)). For passes that leave whole rows of stores in
-// flight behind them and go on with Phi that issue no vector load (cfas1_kernel): the rows drain under the arithmetic.
+// flight behind them and go on with Phi that issue no vector load (the block solve's passes): the rows drain under the arithmetic.
 template <bool CLOSED = false, bool LDSBAR = false>
 __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const LaneCoef &lc, const Smem &sm, double *ga,
                                            double *gb, int n, int t, int lane, int wave, int G) {
@@ -1165,162 +1165,6 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
     }
     wq.end(t);
     /*STAMP 7*/
-}
-
-// The same pass where both levels have ONE forcing term with the SAME space factor (same spatial grid, same rhs: bit for bit,
-// checked on the host, Level::same_factor_below), ONE coefficient set each (uniform time grids) and the C-points are pre-relaxed
-// (pre = 1): the factor lives in REGISTERS (FORCE 1, as in the stand-alone F-relaxation) for all five Phi of an interval, so no Phi
-// of the pass issues a vector load at all (cfas_kernel<2> streams the factor's 128 KB from L2 in every Phi: 1.7 us each by the
-// in-kernel stamps of round 4, and its coarse Phi reads Pt from global memory). What makes the registers fit -- round 4's attempt
-// at FORCE 1 spilled the lane constants -- :
-//   * never more than ONE state vector is live across a Phi: C'_j is PARKED in LDS (the table space the closed-form Phi leaves
-//     free; seven of a lane's eight pairs, the eighth stays in registers, which frees the 16 KB the coarse level's Pt needs) while
-//     the own-level steps run on it in place; the coarse Phi comes LAST: r~ = Phi_l(F'_last) is swapped into LDS for the parked
-//     C'_j and q = Phi_{l+1}(C'_j) is computed in place;
-//   * ONE instance of the Phi's code serves both levels -- lane powers, group factors and Pt of BOTH levels sit in LDS (staged once
-//     per workgroup), a step picks its set by wave-uniform selects --: two inlined copies cost 26-84 spilled VGPRs, and a scratch
-//     reload retires, in order, behind every row store in flight;
-//   * the step's barrier is LDS-only (heat_solve<.., LDSBAR>): C'_{j+1}'s row -- the one vector load of an interval -- and the
-//     3.25 rows of stores sit together at the interval's end and drain under the next interval's five Phi.
-// Same values as cfas_kernel: every Phi takes the same operands through the same expressions.
-struct Cfas1Smem {
-    double2 *park;            // [7 * T] pairs 0..6 of every lane: wave w, lane l, pair q at w * 448 + q * 64 + l
-    double2 *pt[2];           // [2][512] Pt of this level / of the coarse level
-    double *ga, *gb, *lp[2], *wf[2];
-};
-__host__ __device__ __forceinline__ size_t cfas1_smem_bytes(int T) {
-    return (size_t)7 * T * sizeof(double2) + 2 * 1024 * sizeof(double2) + (4 * MAX_G + 2 * LANES + 2 * 3 * MAX_G) * sizeof(double);
-}
-__global__ void __launch_bounds__(1024) cfas1_kernel(LevelDev L, LevelDev Lc, IntervalsDev I) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = blockDim.x >> 6;
-    const unsigned sl = slot0(t), slp = (unsigned)(wave * 448 + lane);
-    /*STAMP_INIT*/
-    Cfas1Smem cm;
-    {
-        cm.park = reinterpret_cast<double2 *>(smem_raw);
-        cm.pt[0] = cm.park + (size_t)7 * L.T;
-        cm.pt[1] = cm.pt[0] + 1024;
-        double *tail = reinterpret_cast<double *>(cm.pt[1] + 1024);
-        cm.ga = tail; cm.gb = tail + 2 * MAX_G;
-        cm.lp[0] = tail + 4 * MAX_G; cm.lp[1] = cm.lp[0] + LANES;
-        cm.wf[0] = cm.lp[1] + LANES; cm.wf[1] = cm.wf[0] + 3 * MAX_G;
-    }
-    __shared__ int wgq_slot[2];
-    WgQueue wq;
-    double s0[E];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const double2 v = L.sP[sl + q * 64];
-        s0[2 * q] = v.x;
-        s0[2 * q + 1] = v.y;
-    }
-    for (int r = t; r < 1024; r += (int)blockDim.x) { cm.pt[0][r] = L.ptP[r]; cm.pt[1][r] = Lc.ptP[r]; }
-    if (t < LANES) { cm.lp[0][t] = L.cs->lp[t]; cm.lp[1][t] = Lc.cs->lp[t]; }
-    if (t < 3 * MAX_G) { cm.wf[0][t] = (&L.cs->pg[0])[t]; cm.wf[1][t] = (&Lc.cs->pg[0])[t]; }   // pg | qg | qg2 are consecutive members
-    __syncthreads();
-    Coef c;
-    int par = 0;
-    // The stores of an interval are issued at the TOP of the next one (pend_*: which rows; the values wait in x, in the parked slots
-    // and in g14 / g15): whatever the register allocator spills around the end of an interval is reloaded at the loop's back edge,
-    // i.e. BEFORE the stores -- a scratch reload behind them would retire, in order, only after they have drained -- and behind the
-    // stores come the five Phi, which touch LDS and registers only.
-    int pend_ce = -1, pend_jc = 0, pend_keep = 0;
-    double g14 = 0.0, g15 = 0.0;
-    double x[E];
-#define CFAS1_FLUSH()                                                                                                       \
-    do {                                                                                                                    \
-        _Pragma("unroll") for (int e = 0; e < E; ++e) asm volatile("" : "+v"(s0[e]));   /* the factor is in registers here */ \
-        row_store2(L.u + (size_t)pend_ce * L.ld, sl, x, L.stream_rows);                                                      \
-        if (pend_keep & 1) row_store2(Lc.u + (size_t)pend_jc * Lc.ld, sl, x, Lc.stream_rows);                                \
-        if (pend_keep & 2) row_store2(Lc.v + (size_t)pend_jc * Lc.ld, sl, x, Lc.stream_rows);                                \
-        double g[E];                                                                                                         \
-        _Pragma("unroll") for (int q = 0; q < 7; ++q) {                                                                      \
-            const double2 r = cm.park[slp + q * 64];                                                                         \
-            g[2 * q] = r.x;                                                                                                  \
-            g[2 * q + 1] = r.y;                                                                                              \
-        }                                                                                                                    \
-        g[14] = g14;                                                                                                         \
-        g[15] = g15;                                                                                                         \
-        row_store2(Lc.g + (size_t)pend_jc * Lc.ld, sl, g, Lc.stream_rows);                                                   \
-        pend_ce = -1;                                                                                                        \
-    } while (0)
-    for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < I.n_chunks; wq.advance(t)) {
-        const int k = wq.cur;
-        wq.prefetch(t);
-        const int i0 = I.chunk_first[k], cnt = I.chunk_len[k];
-        if (pend_ce >= 0) CFAS1_FLUSH();   // the last interval of the chunk before
-        {
-            const int cs = I.cstart[i0];   // a relaxed first C-point: the row of the F-point before it holds C'_j (pre)
-            row_load2(L.u + (size_t)(I.chunk_start_coarse[k] >= 0 ? cs - 1 : cs) * L.ld, sl, x, L.stream_rows);
-        }
-        for (int it = i0; it < i0 + cnt; ++it) {
-            const int cs = I.cstart[it], ce = I.cend[it], jc = I.cend_coarse[it];
-            /*STAMP 10*/
-            if (pend_ce >= 0) CFAS1_FLUSH();   // x = C'_j, the interval before ended on it
-            /*STAMP 11*/
-#pragma unroll
-            for (int q = 0; q < 7; ++q) cm.park[slp + q * 64] = make_double2(x[2 * q], x[2 * q + 1]);   // C'_j parked (lane-private slots)
-            double k0 = x[14], k1 = x[15];                                                                // ... its eighth pair
-            const int m = ce - cs;
-            for (int step = 0; step <= m; ++step) {   // the F-steps, Phi_l(F'_last), then -- on C'_j again -- the coarse Phi
-                const bool coarse = step == m;
-                if (coarse) {   // r~ into LDS, C'_j back
-                    /*STAMP 12*/
-#pragma unroll
-                    for (int q = 0; q < 7; ++q) {
-                        const double2 v = cm.park[slp + q * 64];
-                        cm.park[slp + q * 64] = make_double2(x[2 * q], x[2 * q + 1]);
-                        x[2 * q] = v.x;
-                        x[2 * q + 1] = v.y;
-                    }
-                    const double r0 = x[14], r1 = x[15];
-                    x[14] = k0; x[15] = k1;
-                    k0 = r0; k1 = r1;
-                }
-                const int lv = coarse ? 1 : 0;
-                const double c0 = ld_uniform(coarse ? Lc.tc + jc : L.tc + cs + 1 + step);
-                if (step == 0 || coarse) load_coef(c, coarse ? Lc.cs : L.cs);
-#pragma unroll
-                for (int e = 0; e < E; ++e) x[e] = fma(s0[e], c0, x[e]);
-                Smem sx;
-                sx.lp = cm.lp[lv]; sx.wf = cm.wf[lv]; sx.pt = cm.pt[lv];
-                const LaneCoef lc = lane_coef(sx.lp, lane);
-                heat_solve<true, true>(x, c, lc, sx, cm.ga + par * MAX_G, cm.gb + par * MAX_G, L.n, t, lane, wave, G);
-                par ^= 1;
-            }
-            // (the coarse Phi is FINISHED here, and nothing of the row load below moves up into it: left to itself the compiler sinks
-            // the Phi's finishing pass below the row traffic)
-#pragma unroll
-            for (int e = 0; e < E; ++e) asm volatile("" : "+v"(x[e]));
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            /*STAMP 13*/
-            // C'_{j+1}: the one vector load of the interval. g = ((r~ - C') + C') - q goes pair by pair INTO the parked slots (in the
-            // place of r~), C'_{j+1} takes q's registers
-            {
-                double b[E];
-                row_load2(L.u + (size_t)(ce - 1) * L.ld, sl, b, L.stream_rows);
-#pragma unroll
-                for (int q = 0; q < 7; ++q) {
-                    const double2 r = cm.park[slp + q * 64];
-                    cm.park[slp + q * 64] = make_double2(((r.x - b[2 * q]) + b[2 * q]) - x[2 * q], ((r.y - b[2 * q + 1]) + b[2 * q + 1]) - x[2 * q + 1]);
-                    x[2 * q] = b[2 * q];
-                    x[2 * q + 1] = b[2 * q + 1];
-                }
-                g14 = ((k0 - b[14]) + b[14]) - x[14];
-                g15 = ((k1 - b[15]) + b[15]) - x[15];
-                x[14] = b[14];
-                x[15] = b[15];
-            }
-            pend_ce = ce;
-            pend_jc = jc;
-            pend_keep = __builtin_amdgcn_readfirstlane(I.keep[it]);
-            /*STAMP 14*/
-        }
-    }
-    if (pend_ce >= 0) CFAS1_FLUSH();
-#undef CFAS1_FLUSH
-    wq.end(t);
 }
 
 // (USE_G, !RES: the same pass on a coarser level -- error_correction + f_relax with the rows of g, every F-point stored, no
@@ -2024,7 +1868,6 @@ int setup_kernel_attrs() {
     FOR_EACH_STEPPER(ATTR_CHAIN_LOCAL)
     if ((rc = allow_big_lds(cfas_kernel<0>))) return rc;
     if ((rc = allow_big_lds(cfas_kernel<2>))) return rc;
-    if ((rc = allow_big_lds(cfas1_kernel))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<0, false, true>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<2, false, true>))) return rc;
     if ((rc = allow_big_lds(ecfr_kernel<4, false, true>))) return rc;
@@ -2043,8 +1886,6 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(blk_finish_kernel<MGRIT_HIP_STEPPER_HEAT1D, F>, blk_smem_bytes(MAX_G)))) return rc;
     ATTR_BLK(0) ATTR_BLK(2) ATTR_BLK(3) ATTR_BLK(4)
     if ((rc = allow_big_lds(blk_local_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>, blk_smem_bytes(MAX_G)))) return rc;
-    if ((rc = allow_big_lds(blk_local_lo_kernel<0>, blk_smem_bytes(MAX_G)))) return rc;
-    if ((rc = allow_big_lds(blk_local_lo_kernel<2>, blk_smem_bytes(MAX_G)))) return rc;
     if ((rc = allow_big_lds(blk_finish_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>, blk_smem_bytes(MAX_G)))) return rc;
     if ((rc = allow_big_lds(adv_fft_rows_kernel, (size_t)BLK_FOURIER_MAX_N * sizeof(double2)))) return rc;
 #define ATTR_2PTS(O, F)                                                                                              \
@@ -2974,12 +2815,6 @@ int blk_handover_len(const Level &lv) { return lv.blk.r == 0 ? 0 : lv.blk.fourie
 // Advection1D: the Fourier form needs n = 2^p, 64 <= n <= BLK_FOURIER_MAX_N (one workgroup's LDS holds a row's n complex values)
 bool blk_fourier_ok(int n, int nt) { return n >= 64 && n <= BLK_FOURIER_MAX_N && (n & (n - 1)) == 0 && blk_count(nt) > 0; }
 
-// MGRIT_HIP_BLK_LO_MAX: most blocks for which the first pass takes its latency form (blk_local_lo_kernel); 0 = never (measurement switch)
-int blk_lo_max_blocks() {
-    static const int v = [] { const char *s = std::getenv("MGRIT_HIP_BLK_LO_MAX"); return s ? std::atoi(s) : 128; }();
-    return v;
-}
-
 int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     BlkDev &bk = lv.blk;
     const int fm = force_mode(lv), F = fm == 1 ? 4 : fm;
@@ -2991,11 +2826,7 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     const size_t fft_lds = (size_t)n * sizeof(double2);
     if (phases & 1) {
         const dim3 grid(std::min(bk.B, cap));
-        // fewer blocks than half the chip's CUs (a rank's share of a sharded level): the latency form of the first pass
-        const bool lo = !adv && (F == 0 || F == 4) && bk.B <= blk_lo_max_blocks();
         if (adv) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>), grid, block, lds, e->stream, lv.dev, bk);
-        else if (lo && F == 0) hipLaunchKernelGGL((blk_local_lo_kernel<0>), grid, block, lds, e->stream, lv.dev, bk);
-        else if (lo) hipLaunchKernelGGL((blk_local_lo_kernel<2>), grid, block, lds, e->stream, lv.dev, bk);
         else if (F == 0) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 0>), grid, block, lds, e->stream, lv.dev, bk);
         else if (F == 2) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 2>), grid, block, lds, e->stream, lv.dev, bk);
         else if (F == 3) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 3>), grid, block, lds, e->stream, lv.dev, bk);
@@ -3127,14 +2958,16 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
             blk_mode_table_store(n, ld, q_rows, qtab);
         }
         lv.blk_q = qtab;
-        std::vector<double> zeros((size_t)B * BLK_RMAX, 0.0);
-        double *dQ = qtab.get(), *dD, *dW, *dC;
+        double *dQ = qtab.get(), *dD, *dW;
         if ((rc = dev_upload(lv, e->stream, Dt, &dD))) return rc;
-        if ((rc = dev_upload(lv, e->stream, zeros, &dW))) return rc;
-        if ((rc = dev_upload(lv, e->stream, zeros, &dC))) return rc;
-        bk.Q = dQ; bk.D = dD; bk.what = dW; bk.C = dC;
-        std::vector<double> pz((size_t)lv.G * B * BLK_RMAX, 0.0);
-        if ((rc = dev_upload(lv, e->stream, pz, &lv.blk_part))) return rc;
+        // amplitudes, propagated amplitudes and the chunks' partial sums: one slab, zeroed on the device ([2 + G][B][BLK_RMAX]: 9 MB at
+        // config 3 -- modes past r are never written and must read as zero)
+        const size_t per = (size_t)B * BLK_RMAX, slab = (size_t)(2 + lv.G) * per;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dW), sizeof(double) * slab));
+        lv.allocs.push_back(dW);
+        HIP_TRY(hipMemsetAsync(dW, 0, sizeof(double) * slab, e->stream));
+        bk.Q = dQ; bk.D = dD; bk.what = dW; bk.C = dW + per;
+        lv.blk_part = dW + 2 * per;
     } else {
         if (r != n || !(n >= 64 && n <= BLK_FOURIER_MAX_N && (n & (n - 1)) == 0))
             return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve of an Advection1D level: all n modes, n a power of two in [64, %d] (n = %d, r = %d)", BLK_FOURIER_MAX_N, n, r);
@@ -4161,14 +3994,6 @@ static int fused_level_check(mgrit_hip_engine *e, int lvl, int ivals_id, const c
     return 0;
 }
 
-// MGRIT_HIP_CFAS_REGS=1: the level-0 way down as cfas1_kernel (forcing factor in registers, coarse Phi last, stores rotated to the top
-// of the next interval) where it applies. Bit-identical to cfas_kernel (tests/test_hip_level_fusion.py runs both) and, as measured in
-// round 5, not faster: 1.98 ms against 1.85 on config 3 (DESIGN.md section 8 has the stamps) -- so it is not the default.
-static bool cfas_regs() {
-    static const bool v = [] { const char *s = std::getenv("MGRIT_HIP_CFAS_REGS"); return s && s[0] == '1'; }();
-    return v;
-}
-
 int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id, int pre_relaxed) {
     int rc = fused_level_check(e, lvl, ivals_id, "fused C-F-relaxation + FAS residual", true);
     if (rc) return rc;
@@ -4177,10 +4002,7 @@ int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id, int pre_relaxed
     if (I.n_chunks == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_CF_FAS, lvl);
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
-    if (lf.same_factor_below < 0) lf.same_factor_below = (force_mode(lf) == 1 && lf.s_host == lc.s_host) ? 1 : 0;   // (131 KB compared once)
-    if (pre_relaxed && force_mode(lf) == 1 && lf.same_factor_below == 1 && lf.dev.one_cset && lc.dev.one_cset && cfas_regs())
-        hipLaunchKernelGGL(cfas1_kernel, grid, block, cfas1_smem_bytes(lf.dev.T), e->stream, sched_dev(e, lf), lc.dev, I);   // the factor in registers
-    else if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
     else hipLaunchKernelGGL((cfas_kernel<2>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -52,6 +52,37 @@ def test_bench_two_ranks_line():
     assert b["exchange"]["messages_per_cycle"] > 0 and b["exchange"]["backend"] == "gloo" and b["nccl_ranks"] == 0
 
 
+def test_bench_four_ranks_line():
+    """four real processes (gloo) on the one GPU, config 3's layout shrunk: every share ends on a block border of the coarsest level
+    (257 points: 4 blocks of 16 steps per rank), so the time-parallel forward solve hands its amplitudes over across three rank
+    boundaries; rank 0's line. (Six processes may use the card at once: the test runner, the launcher's four ranks.)"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--nx", "1024",
+                        "--nt", "4097", "--steps", "3", "--warmup", "1", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    b = _last_json(r.stdout)
+    assert b["n_gpus"] == 4 and b["value"] > 0 and b["scaling"] == "strong" and b["exchange"]["messages_per_cycle"] > 0
+    assert b["exchange"]["backend"] == "gloo" and b["nccl_ranks"] == 0
+
+
+def test_bench_emulated_solve_line():
+    """`--emulate-solve 8`: Mgrit.solve() end to end on eight loopback ranks (config 3's layout at nx = 1024, nt = 8193: aligned
+    ranks, block-solve hand-over across seven boundaries), the residual history of the one-rank run bit for bit"""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emulate-solve", "8", "--nx", "1024", "--nt", "8193"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    b = _last_json(r.stdout)
+    assert b["emulated_ranks"] == 8 and b["every_rank_reports_the_same_history"] and b["equals_one_rank_history_bit_for_bit"]
+    assert all(row["aligned"] and row["block_solve_sharded"] for row in b["ranks"]) and b["iterations"] >= 2
+
+
 @pytest.mark.parametrize("extra,levels", [(["--nx", "1024", "--nt", "2049"], 3), (["--workload", "advection", "--nt-adv", "1025"], 4)])
 def test_bench_emulated_ranks_line(extra, levels):
     """`--emulate-rank all/2`: both ranks of a two-rank run rehearsed on the one GPU (loopback exchange), configs[2] and configs[4]

@@ -29,6 +29,9 @@ SHAPES = [
     ("nx2050_nonuniform", "heat", 2050, NONUNIFORM, True),                # every step its own size, 100 steps = 5 x 16 + 20
     ("nx4099", "heat", 4099, _grids(641, (2, 2)), True),                  # 160 steps, five groups
     ("nx16384", "heat", 16384, _grids(129, (2,)), True),                  # the widest register-resident state, 64 steps
+    # short time intervals: the blocks damp slowly, more than 64 sine modes take part (up to MGRIT_HIP_BLOCK_RMAX = 256 since round 5)
+    ("nx1025_r127", "heat", 1025, [cases.lin(0.02, 1025), cases.lin(0.02, 1025)[::4]], True),
+    ("nx4099_r200", "heat", 4099, [cases.lin(0.004, 257), cases.lin(0.004, 257)[::2]], True),
     # Advection1D: all n Fourier modes (n = nx - 1 a power of two)
     ("adv_n64", "advection", 65, _grids(1025, (4, 4)), None),             # the smallest transform, 64 steps
     ("adv_n1024_rem", "advection", 1025, _grids(309, (4,)), None),        # one group, last block of 29 steps

@@ -88,7 +88,7 @@ def test_device_exchange_pipelined(case, world, depth):
 ALIGNED = [("heat_nx33_V_nested", [2, 4]), ("heat_nx33_V_nonested", [2, 4]), ("heat_nx33_F_nested", [2, 4]), ("heat_nx33_F_nonested", [4]),
            ("heat_nx33_V_cf2", [2]), ("heat_nx33_V_cflist", [4]), ("heat_nx33_V_cf0", [2, 4]), ("heat_nx33_V_tnorm3", [2]),
            ("heat_nx33_V_jump", [4]), ("heat_nx33_V_weight13", [2]), ("heat_nx33_2lvl_m8", [2, 4]),
-           ("heat_nx33_noforcing", [4]), ("heat_nx257_nt257", [4, 16]), ("heat_example_F5", [2, 4]), ("heat_config2", [2, 8]),
+           ("heat_nx33_noforcing", [4]), ("heat_nx257_nt257", [4, 16]), ("heat_example_F5", [2, 4]), ("heat_config2", [2, 8]), ("heat_blk_r127_2lvl", [4]),
            ("heat_nx2050_wide", [2, 4]), ("heat_nx1500_wide_F", [2]), ("heat_nx3100_wide_2lvl", [2, 4]),
            ("heat_spatial_coarsening_F", [2]), ("advection_3lvl_F", [4]), ("advection_nx2049_wide", [2, 4]),
            ("heat_spatial_coarsening", [2, 4]), ("advsc:adv_sc_F", [2, 4]), ("advsc:adv_sc_V", [2]), ("advection_example", [2, 4])]

@@ -176,10 +176,13 @@ def build_product(name):
         # coarsest levels whose forward solve takes the time-parallel form
         "heat_blk_nx257_3lvl": ("heat", 257, 1.0, True), "heat_blk_nx2050_2lvl": ("heat", 2050, 1.0, True),
         "heat_blk_nonuniform_F": ("heat", 129, 1.0, True), "heat_blk_noforcing_cf0": ("heat", 65, 1.0, False),
+        "heat_blk_r127_2lvl": ("heat", 1025, 1.0, True),
         "advection_blk_nx257_3lvl_F": ("advection", 257, None, None), "advection_blk_nx1025_2lvl": ("advection", 1025, None, None),
         "advection_blk_nonuniform": ("advection", 129, None, None),
     }
     c = cases.solve_cases()[name]
+    if name not in P and not name.startswith("heat_nx33_"):
+        raise KeyError(f"solve case {name!r} has no entry in test_hip_parity.build_product")
     kind, nx, x_end, forcing = P.get(name, ("heat", 33, 1.0, True))
     grids = [spec["t"] for spec in c["levels"]]
     nxs = nx if isinstance(nx, list) else [nx] * len(grids)

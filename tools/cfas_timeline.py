@@ -21,11 +21,6 @@ PHASES = ["coarse Phi + park", "F-steps of the interval", "request of the old la
           "own coefficient set back (load_coef)"]
 
 
-PHASES1 = ["back edge: spilled registers reloaded, loop control", "stores of the interval before issued (3.25 rows)",
-           "C'_j parked, four own-level Phi (factor from registers)", "swap with LDS, coarse Phi",
-           "row of C'_{j+1} requested, arrived, g into LDS"]
-
-
 def build():
     src = os.path.join(WORK, "src")
     shutil.rmtree(src, ignore_errors=True)
@@ -40,8 +35,6 @@ def build():
     body = s.index(head)
     anchor = s.index("constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;", body)
     s = s[:anchor] + "unsigned long long last_ = __builtin_amdgcn_s_memrealtime();\n    " + s[anchor:]
-    assert s.count("/*STAMP_INIT*/") == 1       # cfas1_kernel (round 5): stamps 10..14
-    s = s.replace("/*STAMP_INIT*/", "unsigned long long last_ = __builtin_amdgcn_s_memrealtime();")
     s = re.sub(r"/\*STAMP (\d+)\*/", lambda m: f"STAMP({m.group(1)});", s)
     s = s.replace("/*DRAIN*/", "__builtin_amdgcn_s_waitcnt(0x0070);")
     s = s.rstrip() + '''
@@ -97,11 +90,6 @@ def run():
     for k, name in enumerate(PHASES):
         print(f"  {name:48s} {per[k].mean():6.2f} us  [{per[k].min():6.2f} .. {per[k].max():6.2f}]")
     print(f"  sum {per[:10].sum(axis=0).mean():.2f} us per interval")
-    if per[10:15].sum() > 0:      # the pass ran as cfas1_kernel (forcing factor in registers, round 5)
-        print("cfas1_kernel, per interval:")
-        for k, name in zip(range(10, 15), PHASES1):
-            print(f"  {name:64s} {per[k].mean():6.2f} us  [{per[k].min():6.2f} .. {per[k].max():6.2f}]")
-        print(f"  sum {per[10:15].sum(axis=0).mean():.2f} us per interval")
 
 
 if __name__ == "__main__":
