@@ -332,7 +332,8 @@ def bench_advection(args):
     torch.cuda.set_device(0)
     nt0 = args.nt_adv
     t0 = np.linspace(0, 2, nt0)
-    nxs = [8193, 4097, 2049, 2049]
+    nx0 = args.nx_adv          # (default 8193; e.g. 8001: periodic grids that are not powers of two, coarsest-level transforms as ordered sums)
+    nxs = [nx0, (nx0 - 1) // 2 + 1, (nx0 - 1) // 4 + 1, (nx0 - 1) // 4 + 1]
     prob = [Advection1D(c=1, x_start=-1, x_end=1, nx=nx, t_interval=t0[::2 ** lvl]) for lvl, nx in enumerate(nxs)]
     transfer = [GridTransferAdvection(), GridTransferAdvection(), GridTransferCopy()]
     mg = Mgrit(prob, transfer=transfer, cf_iter=1, cycle_type='F', nested_iteration=False, max_iter=1, tol=0.0, logging_lvl=30,
@@ -365,7 +366,7 @@ def bench_advection(args):
     out = {"metric": "time-point-DOF updates/sec per MGRIT F-cycle", "value": None, "unit": "time-point-DOF updates/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"advection_1d nx=8193 nt={nt0} 4-level m=2 F-cycle, spatial coarsening on the first two "
+           "config": {"workload": f"advection_1d nx={nxs[0]} nt={nt0} 4-level m=2 F-cycle, spatial coarsening on the first two "
                                   f"level pairs + residual check (BASELINE configs[4])", "dof_by_level": [n - 1 for n in nxs]},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": None, "kernel": "relax_kernel<ADVECTION1D,false,ROLE_F> (level-0 F-relax)", "launch_ms": f_ms,
@@ -864,6 +865,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "smoke-test the N>1 path with several ranks on ONE GPU)")
     ap.add_argument("--nt-adv", dest="nt_adv", type=int, default=32769)
+    ap.add_argument("--nx-adv", dest="nx_adv", type=int, default=8193, help="--workload advection: level-0 grid points (nx - 1 periodic "
+                    "values, a multiple of 4; default BASELINE configs[4])")
     ap.add_argument("--at-k", dest="at_k", type=int, default=0,
                     help="AT-MGRIT with local coarse grids of k points instead of MGRIT (not the headline algorithm)")
     ap.add_argument("--pipeline-depth", dest="pipeline_depth", type=int, default=None,

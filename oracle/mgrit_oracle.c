@@ -1589,7 +1589,7 @@ static int adv_block_solve_on(const orc_problem *p, const orc_level *L, int lvl)
     const orc_stepper *st = &L->st;
     int n = st->n;
     if (p->no_block_solve || lvl == 0 || st->kind != ORC_ADVECTION1D || !st->variant) return 0;
-    if (n < 64 || n > 8192 || (n & (n - 1)) != 0) return 0;
+    if (n < 64 || n > 8192) return 0;      /* (n a power of two: radix-2 transforms; any other n: the plain sums, orc_dft_*) */
     return blk_count(L->nt) > 0;
 }
 
@@ -1627,6 +1627,45 @@ void orc_fft_twiddles(int n, double *W /* [n/2][2] */) {
     }
 }
 
+/* n NOT a power of two (round 5): the transforms as the plain sums over a table of all n roots of unity, T[m] = (cos, -sin)(2 pi m/n),
+ * every sum one fma chain in ascending index order from 0.0 (what a K loop of v_mfma_f64_16x16x4 computes):
+ *   forward  what(k) = ( sum_j x_j T[(j k) mod n].re , sum_j x_j T[(j k) mod n].im )
+ *   inverse  y_j = sum_k ( c(k).re T[(j k) mod n].re , then c(k).im T[(j k) mod n].im )   = Re(sum_k c(k) e^{+i th}), unscaled */
+void orc_dft_table(int n, double *T /* [n][2] */) {
+    for (int m = 0; m < n; ++m) {
+        double ang = 2.0 * M_PI * (double)m / (double)n;
+        T[2 * m] = sep_cos(ang); T[2 * m + 1] = -sep_sin(ang);
+    }
+}
+
+void orc_dft_fwd_spec(const double *x, int n, const double *T, double *out /* [n][2] */) {
+#pragma omp parallel for schedule(static) num_threads(orc_h2d_threads) if (orc_h2d_threads > 1 && n >= 256)     /* (independent sums) */
+    for (int k = 0; k < n; ++k) {
+        double re = 0.0, im = 0.0;
+        long m = 0;
+        for (int j = 0; j < n; ++j) {
+            re = fma(x[j], T[2 * m], re);
+            im = fma(x[j], T[2 * m + 1], im);
+            m += k; if (m >= n) m -= n;
+        }
+        out[2 * k] = re; out[2 * k + 1] = im;
+    }
+}
+
+void orc_dft_inv_real_spec(const double *c /* [n][2] */, int n, const double *T, double *y /* [n] */) {
+#pragma omp parallel for schedule(static) num_threads(orc_h2d_threads) if (orc_h2d_threads > 1 && n >= 256)
+    for (int j = 0; j < n; ++j) {
+        double acc = 0.0;
+        long m = 0;
+        for (int k = 0; k < n; ++k) {
+            acc = fma(c[2 * k], T[2 * m], acc);
+            acc = fma(c[2 * k + 1], T[2 * m + 1], acc);
+            m += j; if (m >= n) m -= n;
+        }
+        y[j] = acc;
+    }
+}
+
 /* D[b][k] complex, k < n, of block b (steps K b + 1 .. its end) */
 void orc_adv_block_propagators(int n, double fac, int nt, const double *t, double *D /* [B][n][2] */) {
     int B = blk_count(nt);
@@ -1650,8 +1689,11 @@ void orc_adv_block_propagators(int n, double fac, int nt, const double *t, doubl
 static void advection_block_solve_spec(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl];
     int n = L->n, nt = L->nt, B = blk_count(nt);
-    double *W = (double *)malloc(sizeof(double) * (size_t)n), *D = (double *)malloc(sizeof(double) * (size_t)B * n * 2);
-    orc_fft_twiddles(n, W);
+    const int pow2 = (n & (n - 1)) == 0;
+    double *W = (double *)malloc(sizeof(double) * (size_t)2 * n), *D = (double *)malloc(sizeof(double) * (size_t)B * n * 2);
+    double *yd = (double *)malloc(sizeof(double) * (size_t)n);
+    if (pow2) orc_fft_twiddles(n, W);
+    else orc_dft_table(n, W);
     orc_adv_block_propagators(n, L->st.fac, nt, L->t, D);
     double *x = (double *)calloc((size_t)n, sizeof(double)), *y = (double *)calloc((size_t)n, sizeof(double));
     double *what = (double *)calloc((size_t)B * n * 2, sizeof(double)), *Ws = (double *)calloc((size_t)B * n, sizeof(double));
@@ -1669,8 +1711,10 @@ static void advection_block_solve_spec(orc_problem *p, int lvl) {
         memcpy(Ws + (size_t)b * n, x, sizeof(double) * (size_t)n);
         if (b < B - 1) {
             double *wb = what + (size_t)b * n * 2;
-            for (int j = 0; j < n; ++j) { wb[2 * j] = x[j]; wb[2 * j + 1] = 0.0; }
-            orc_fft_spec(wb, n, W, 0);
+            if (pow2) {
+                for (int j = 0; j < n; ++j) { wb[2 * j] = x[j]; wb[2 * j + 1] = 0.0; }
+                orc_fft_spec(wb, n, W, 0);
+            } else orc_dft_fwd_spec(x, n, W, wb);
         }
     }
     memcpy(Uh, what, sizeof(double) * (size_t)2 * n);
@@ -1685,8 +1729,13 @@ static void advection_block_solve_spec(orc_problem *p, int lvl) {
             c[2 * k + 1] = fma(di, ur, dr * ui);
         }
         if (b < B - 1) for (int k = 0; k < 2 * n; ++k) Uh[k] = wb[k] + c[k];
-        orc_fft_spec(c, n, W, 1);
-        for (int j = 0; j < n; ++j) ue[j] = ue[j] + (ws[j] + c[2 * j] * inv_n);
+        if (pow2) {
+            orc_fft_spec(c, n, W, 1);
+            for (int j = 0; j < n; ++j) ue[j] = ue[j] + (ws[j] + c[2 * j] * inv_n);
+        } else {
+            orc_dft_inv_real_spec(c, n, W, yd);
+            for (int j = 0; j < n; ++j) ue[j] = ue[j] + (ws[j] + yd[j] * inv_n);
+        }
     }
     for (int b = 0; b < B; ++b) {   /* phase 3 */
         int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
@@ -1698,7 +1747,7 @@ static void advection_block_solve_spec(orc_problem *p, int lvl) {
             memcpy(ROW(L->u, L, i), x, sizeof(double) * (size_t)n);
         }
     }
-    free(W); free(D); free(x); free(y); free(what); free(Ws); free(Uh); free(c);
+    free(W); free(D); free(x); free(y); free(what); free(Ws); free(Uh); free(c); free(yd);
 }
 
 /* ------------------------------------------------------------------------------------------------

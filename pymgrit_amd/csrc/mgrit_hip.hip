@@ -2812,8 +2812,9 @@ int blk_wgs_per_cu(const Level &lv) { return std::max(1, std::min((int)(160 * 10
 // doubles behind the point in the hand-over of a sharded solve: the amplitudes at the rank's last point
 int blk_handover_len(const Level &lv) { return lv.blk.r == 0 ? 0 : lv.blk.fourier ? 2 * lv.dev.n : BLK_RMAX; }
 
-// Advection1D: the Fourier form needs n = 2^p, 64 <= n <= BLK_FOURIER_MAX_N (one workgroup's LDS holds a row's n complex values)
-bool blk_fourier_ok(int n, int nt) { return n >= 64 && n <= BLK_FOURIER_MAX_N && (n & (n - 1)) == 0 && blk_count(nt) > 0; }
+// Advection1D: the Fourier form for 64 <= n <= BLK_FOURIER_MAX_N -- n = 2^p: radix-2 transforms inside one workgroup's LDS (a row's n
+// complex values); any other n: the transforms as ordered sums on the matrix cores (adv_dft_*_kernel)
+bool blk_fourier_ok(int n, int nt) { return n >= 64 && n <= BLK_FOURIER_MAX_N && blk_count(nt) > 0; }
 
 int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     BlkDev &bk = lv.blk;
@@ -2821,7 +2822,7 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     const size_t lds = blk_smem_bytes(lv.G);
     const int cap = 256 * blk_wgs_per_cu(lv);
     const dim3 block(lv.dev.T);
-    const bool adv = bk.fourier != 0;
+    const bool adv = bk.fourier != 0, dft = bk.fourier == 2;
     const int n = lv.dev.n, fft_threads = std::min(n / 2, 1024);
     const size_t fft_lds = (size_t)n * sizeof(double2);
     if (phases & 1) {
@@ -2833,7 +2834,8 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
         else hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 4>), grid, block, lds, e->stream, lv.dev, bk);
         const int cnt = bk.B - 1 + (bk.project_last ? 1 : 0);     // blocks whose amplitudes the recurrence reads
         if (adv) {   // what_b = FFT(W_b)
-            if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, 0, 0);
+            if (cnt > 0 && dft) hipLaunchKernelGGL(adv_dft_fwd_kernel, dim3((cnt + 15) / 16, (n + 15) / 16, 2), dim3(64), 0, e->stream, lv.dev, bk, 0, cnt);
+            else if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, 0, 0);
         } else if (cnt > 0) {   // what_b(k) = <q_k, W_b> on the matrix cores, chunk by chunk, then the chunks in order
             hipLaunchKernelGGL(blk_project_kernel, dim3((cnt + 15) / 16, (bk.r + 15) / 16, lv.G), dim3(64), 0, e->stream, bk, lv.dev.ld, lv.blk_part);
             hipLaunchKernelGGL(blk_sum_chunks_kernel, dim3(cnt), dim3(BLK_RMAX), 0, e->stream, bk, lv.G, lv.blk_part);
@@ -2843,7 +2845,8 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
         if (adv) hipLaunchKernelGGL(adv_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, bk, n);
         else hipLaunchKernelGGL(blk_scan_kernel, dim3(1), dim3(BLK_RMAX), 0, e->stream, bk);
         if (bk.project_last) {   // the last point, which the next rank waits for
-            if (adv) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(1), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, bk.B - 1, 1);
+            if (adv && dft) hipLaunchKernelGGL(adv_dft_inv_kernel, dim3(1, (n + 15) / 16), dim3(64), 0, e->stream, lv.dev, bk, bk.B - 1, 1);
+            else if (adv) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(1), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, bk.B - 1, 1);
             else hipLaunchKernelGGL(blk_last_kernel, dim3(8, lv.G), dim3(LANES), 0, e->stream, lv.dev, bk);
         }
     }
@@ -2852,7 +2855,8 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
         b2.skip_last_row = bk.project_last;
         if (adv) {   // u[e_b] += W_b + Re(IFFT(c_b)) / n for the block ends not yet corrected, then the second pass
             const int cnt = bk.B - (bk.project_last ? 1 : 0);
-            if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, 0, 1);
+            if (cnt > 0 && dft) hipLaunchKernelGGL(adv_dft_inv_kernel, dim3((cnt + 15) / 16, (n + 15) / 16), dim3(64), 0, e->stream, lv.dev, bk, 0, cnt);
+            else if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, 0, 1);
         }
         else hipLaunchKernelGGL(blk_correct_kernel, dim3((bk.B + 15) / 16, lv.dev.ld / 64), dim3(64), 0, e->stream, lv.dev, bk,
                                 bk.B - (bk.project_last ? 1 : 0));
@@ -2969,11 +2973,14 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
         bk.Q = dQ; bk.D = dD; bk.what = dW; bk.C = dW + per;
         lv.blk_part = dW + 2 * per;
     } else {
-        if (r != n || !(n >= 64 && n <= BLK_FOURIER_MAX_N && (n & (n - 1)) == 0))
-            return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve of an Advection1D level: all n modes, n a power of two in [64, %d] (n = %d, r = %d)", BLK_FOURIER_MAX_N, n, r);
-        // twiddles and the blocks' complex propagators (the oracle's orc_fft_twiddles / orc_adv_block_propagators: same expressions)
-        std::vector<double> W((size_t)n, 0.0), Dt((size_t)B * n * 2, 0.0);
-        for (int t = 0; t < n / 2; ++t) {
+        if (r != n || !(n >= 64 && n <= BLK_FOURIER_MAX_N))
+            return fail(MGRIT_HIP_EINVAL, "time-parallel forward solve of an Advection1D level: all n modes, n in [64, %d] (n = %d, r = %d)", BLK_FOURIER_MAX_N, n, r);
+        // twiddles (n a power of two: the first n/2 roots of unity; else all n: orc_dft_table) and the blocks' complex propagators
+        // (the oracle's orc_fft_twiddles / orc_adv_block_propagators: same expressions)
+        const bool pow2 = (n & (n - 1)) == 0;
+        const int n_tw = pow2 ? n / 2 : n;
+        std::vector<double> W((size_t)2 * n_tw, 0.0), Dt((size_t)B * n * 2, 0.0);
+        for (int t = 0; t < n_tw; ++t) {
             const double ang = 2.0 * M_PI * (double)t / (double)n;
             W[2 * (size_t)t] = sep_cos(ang); W[2 * (size_t)t + 1] = -sep_sin(ang);
         }
@@ -2992,14 +2999,15 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
                 Dt[((size_t)b * n + k) * 2] = pr; Dt[((size_t)b * n + k) * 2 + 1] = pi;
             }
         }
-        std::vector<double> zeros((size_t)B * n * 2, 0.0);
-        double *dT, *dD, *dW, *dC;
+        double *dT, *dD, *dW;
         if ((rc = dev_upload(lv, e->stream, W, &dT))) return rc;
         if ((rc = dev_upload(lv, e->stream, Dt, &dD))) return rc;
-        if ((rc = dev_upload(lv, e->stream, zeros, &dW))) return rc;
-        if ((rc = dev_upload(lv, e->stream, zeros, &dC))) return rc;
-        bk.tw = reinterpret_cast<const double2 *>(dT); bk.D = dD; bk.what = dW; bk.C = dC;
-        bk.fourier = 1;
+        const size_t per = (size_t)B * n * 2;       // amplitudes and propagated amplitudes: zeroed on the device
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dW), sizeof(double) * 2 * per));
+        lv.allocs.push_back(dW);
+        HIP_TRY(hipMemsetAsync(dW, 0, sizeof(double) * 2 * per, e->stream));
+        bk.tw = reinterpret_cast<const double2 *>(dT); bk.D = dD; bk.what = dW; bk.C = dW + per;
+        bk.fourier = pow2 ? 1 : 2;                  // 1: radix-2 in LDS, 2: ordered sums on the matrix cores
         bk.lg_n = 0;
         while ((1 << bk.lg_n) < n) ++bk.lg_n;
     }

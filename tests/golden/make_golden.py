@@ -871,6 +871,25 @@ def main():
         with open(os.path.join(HERE, "solve.json"), "w") as f:
             json.dump(sol, f, separators=(",", ":"))
         return
+    if "--only-adv-dft" in sys.argv:
+        # round 5: Advection1D levels whose periodic grid is NOT a power of two (n = 200): the time-parallel forward solve takes its
+        # transforms as ordered sums -- reference Mgrit with SuperLU into solve.json, on the restated steps into
+        # solve_restated.json (inputs restated in tests/cases.block_cases / restated_blk_cases)
+        ts = [np.linspace(0, 2, nt) for nt in (1025, 257, 65)]
+        with open(os.path.join(HERE, "solve.json")) as f:
+            sol = json.load(f)
+        sol["advection_blk_nx201_3lvl_F"] = run([Advection1D(c=1, x_start=-1, x_end=1, nx=201, t_interval=t) for t in ts], cycle_type='F',
+                                                max_iter=6, sample_pts=(512, 1024))
+        with open(os.path.join(HERE, "solve.json"), "w") as f:
+            json.dump(sol, f, separators=(",", ":"))
+        with open(os.path.join(HERE, "solve_restated.json")) as f:
+            out = json.load(f)
+        out["restated_blk_advection_n200_F"] = run(restated_advection_levels(201, ts), sample_pts=(1024,), cycle_type='F', tol=1e-30,
+                                                   max_iter=6)
+        with open(os.path.join(HERE, "solve_restated.json"), "w") as f:
+            json.dump(out, f, separators=(",", ":"))
+        print(sol["advection_blk_nx201_3lvl_F"]["conv"], out["restated_blk_advection_n200_F"]["conv"])
+        return
     if "--only-blk-wide-rank" in sys.argv:
         # round 5: a coarsest level whose blocks leave 127 sine modes above 2^-60 (the cap on the modes was 64 until then: DESIGN.md
         # 3.8) -- reference Mgrit with SuperLU into solve.json, reference Mgrit on the restated Thomas steps into solve_restated.json

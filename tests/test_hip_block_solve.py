@@ -37,15 +37,21 @@ SHAPES = [
     ("adv_n1024_rem", "advection", 1025, _grids(309, (4,)), None),        # one group, last block of 29 steps
     ("adv_n2048_nonuniform", "advection", 2049, NONUNIFORM, None),        # two groups (config 5's coarsest level), every step its own size
     ("adv_n8192", "advection", 8193, _grids(129, (2,)), None),            # the largest transform: 128 KB of LDS
+    # n not a power of two: the transforms as ordered sums on the matrix cores (round 5)
+    ("adv_n200", "advection", 201, _grids(1025, (4, 4)), None),           # 64 steps
+    ("adv_n1001_rem", "advection", 1002, _grids(309, (4,)), None),        # an odd n, last block of 29 steps
+    ("adv_n2000_nonuniform", "advection", 2001, NONUNIFORM, None),        # config-5-like coarsest level at nx = 8001, every step its own size
+    ("adv_n6000", "advection", 6001, _grids(129, (2,)), None),            # six groups
 ]
 
 
 def test_fourier_rule():
-    """Advection1D: all n modes when n is a power of two in [64, 8192] and the level has at least 64 steps, else step by step"""
+    """Advection1D: all n modes when 64 <= n <= 8192 (radix-2 transforms for a power of two, ordered sums for any other n since
+    round 5) and the level has at least 64 steps, else step by step"""
     from pymgrit_amd.core import hip_lib
     lib = hip_lib.load()
     t = np.linspace(0, 1, 200)
-    for n, nt, want in [(64, 200, 64), (2048, 65, 2048), (8192, 200, 8192), (16384, 200, 0), (32, 200, 0), (96, 200, 0), (1024, 64, 0)]:
+    for n, nt, want in [(64, 200, 64), (2048, 65, 2048), (8192, 200, 8192), (16384, 200, 0), (32, 200, 0), (96, 200, 96), (8000, 200, 8000), (8193, 200, 0), (1024, 64, 0)]:
         r = C.c_int(-7)
         hip_lib.check(lib.mgrit_hip_block_solve_rank(hip_lib.STEPPER_ADVECTION1D, n, 3.0, nt, np.ascontiguousarray(t[:nt]).ctypes.data_as(C.c_void_p), C.byref(r)))
         assert r.value == want, (n, nt)

@@ -91,7 +91,8 @@ ALIGNED = [("heat_nx33_V_nested", [2, 4]), ("heat_nx33_V_nonested", [2, 4]), ("h
            ("heat_nx33_noforcing", [4]), ("heat_nx257_nt257", [4, 16]), ("heat_example_F5", [2, 4]), ("heat_config2", [2, 8]), ("heat_blk_r127_2lvl", [4]),
            ("heat_nx2050_wide", [2, 4]), ("heat_nx1500_wide_F", [2]), ("heat_nx3100_wide_2lvl", [2, 4]),
            ("heat_spatial_coarsening_F", [2]), ("advection_3lvl_F", [4]), ("advection_nx2049_wide", [2, 4]),
-           ("heat_spatial_coarsening", [2, 4]), ("advsc:adv_sc_F", [2, 4]), ("advsc:adv_sc_V", [2]), ("advection_example", [2, 4])]
+           ("heat_spatial_coarsening", [2, 4]), ("advsc:adv_sc_F", [2, 4]), ("advsc:adv_sc_V", [2]), ("advection_example", [2, 4]),
+           ("advection_blk_nx201_3lvl_F", [2, 4])]
 
 
 @pytest.mark.parametrize("case,sizes", ALIGNED, ids=[c for c, _ in ALIGNED])

@@ -178,7 +178,7 @@ def build_product(name):
         "heat_blk_nonuniform_F": ("heat", 129, 1.0, True), "heat_blk_noforcing_cf0": ("heat", 65, 1.0, False),
         "heat_blk_r127_2lvl": ("heat", 1025, 1.0, True),
         "advection_blk_nx257_3lvl_F": ("advection", 257, None, None), "advection_blk_nx1025_2lvl": ("advection", 1025, None, None),
-        "advection_blk_nonuniform": ("advection", 129, None, None),
+        "advection_blk_nonuniform": ("advection", 129, None, None), "advection_blk_nx201_3lvl_F": ("advection", 201, None, None),
     }
     c = cases.solve_cases()[name]
     if name not in P and not name.startswith("heat_nx33_"):
