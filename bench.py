@@ -830,6 +830,18 @@ def sharded_emulation(ms_one_gpu, timeout=150):
                          "aligned": k["aligned"], "one_gpu_ms_over_rank_ms": ms_one_gpu / k["ms_per_cycle"]})
         except Exception as exc:   # noqa: BLE001 - secondary numbers: report, never fail the headline
             rows.append({"ranks": P, "error": repr(exc)[:300]})
+    # ... and Mgrit.solve() end to end on eight emulated ranks (bench.py --emulate-solve 8): iterations, the one-rank history bit for bit
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--emulate-solve", "8"], capture_output=True, text=True, timeout=timeout)
+        b = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        rows.append({"solve_rehearsal_ranks": 8, "iterations": b["iterations"], "equals_one_rank_history_bit_for_bit": b["equals_one_rank_history_bit_for_bit"],
+                     "every_rank_reports_the_same_history": b["every_rank_reports_the_same_history"],
+                     "all_ranks_aligned_with_sharded_block_solve": all(x["aligned"] and x["block_solve_sharded"] for x in b["ranks"]),
+                     "hop_block_phase2_us": next((x["hop_block_phase2_us"] for x in b["ranks"] if "hop_block_phase2_us" in x), None),
+                     "wall_ms_all_ranks_on_one_gpu": b["wall_ms_all_ranks_on_one_gpu"],
+                     "note": "threads of one process sharing the GPU: a rehearsal of the sharded path at full size, not a parallel time"})
+    except Exception as exc:   # noqa: BLE001
+        rows.append({"solve_rehearsal_ranks": 8, "error": repr(exc)[:300]})
     return rows
 
 
@@ -1182,6 +1194,21 @@ def main():
                     if "ms_per_cycle" in row:   # the solve's iterations on that rank when it never waits for a neighbour: a lower
                         row["cycles_to_tol"] = iters       # bound of the sharded time to solution (one GPU: iterations x ms_per_step)
                         row["iterations_ms_if_never_waiting"] = iters * row["ms_per_cycle"]
+                r8 = next((r for r in out["sharded_rank_emulation"] if r.get("ranks") == 8 and "ms_per_cycle" in r), None)
+                reh = next((r for r in out["sharded_rank_emulation"] if r.get("solve_rehearsal_ranks") == 8 and "iterations" in r), None)
+                if r8 and reh and out.get("time_to_solution_ms"):
+                    hop = (reh.get("hop_block_phase2_us") or 0.0) + 10.0      # + one message of 131 KB + 2 KB, ASSUMED 10 us (no link was measured)
+                    tts = out["time_to_solution_ms"]
+                    reh["critical_path_model_ms"] = {
+                        "setup_host_of_a_rank": tts["setup_ms"],      # host-bound (tables, lists): does not shrink with the rank count
+                        "iterations": reh["iterations"] * r8["ms_per_cycle"],
+                        "handover_chain_fill": 7 * hop * 1e-3,        # the last rank's first forward solve waits for seven hops; later ones overlap (lagged stopping test)
+                        "final_f_relaxation": out["sweeps"].get("ec_relax_res L0", {}).get("ms_per_cycle", 0.0) / 8.0,
+                        "one_gpu_wall_ms": tts["wall_ms"],
+                        "note": "a MODEL from pieces measured on one GPU (rank cycle replayed alone, hop = block-solve phase 2 + an assumed "
+                                "10 us message): sum = setup + iterations + fill + final; no multi-GPU hardware has run it"}
+                    m = reh["critical_path_model_ms"]
+                    m["sum"] = m["setup_host_of_a_rank"] + m["iterations"] + m["handover_chain_fill"] + m["final_f_relaxation"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

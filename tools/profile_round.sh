@@ -8,7 +8,7 @@
 # (Round 4: the coarsest-level solves are time-parallel -- DESIGN.md 3.8 --, so no workload's default cycle uses CU-masked streams
 # any more and the Heat2D profile is the path the bench times.)
 set -o pipefail
-tag=${1:-r04}
+tag=${1:-r05}
 from=${2:-1}     # first step to run (a rerun after a failed step: bash tools/profile_round.sh r03 7)
 out=$PWD/gpurun_out
 mkdir -p "$out"
@@ -29,6 +29,7 @@ if [ "$from" -le 11 ]; then timeout -k 10 300 rocprofv3 --kernel-trace --stats -
 if [ "$from" -le 12 ]; then timeout -k 10 300 python3 "$B" --emulate-rank all/8 --steps 20 --warmup 3 > "$out/${tag}_bench_all8.log" 2> "$out/${tag}_bench_all8.err" || exit 10; fi
 if [ "$from" -le 13 ]; then timeout -k 10 300 python3 "$B" --emulate-rank all/4 --steps 20 --warmup 3 > "$out/${tag}_bench_all4.log" 2> "$out/${tag}_bench_all4.err" || exit 11; fi
 if [ "$from" -le 14 ]; then timeout -k 10 300 python3 "$B" --emulate-rank all/2 --steps 20 --warmup 3 > "$out/${tag}_bench_all2.log" 2> "$out/${tag}_bench_all2.err" || exit 12; fi
+if [ "$from" -le 15 ]; then for P in 2 4 8; do timeout -k 10 300 python3 "$B" --emulate-solve $P > "$out/${tag}_bench_solve$P.log" 2> "$out/${tag}_bench_solve$P.err" || exit 15; done; fi
 if [ "$from" -le 15 ]; then for P in 2 4 8; do timeout -k 10 200 python3 "$B" --workload advection --emulate-rank all/$P --steps 10 --warmup 3 > "$out/${tag}_bench_advection_all$P.log" 2> "$out/${tag}_bench_advection_all$P.err" || exit 15; done; fi
 W="$(dirname "$B")/tools/wide_bench.py"
 if [ "$from" -le 16 ]; then timeout -k 10 200 python3 "$W" > "$out/${tag}_bench_wide.log" 2> "$out/${tag}_bench_wide.err" || exit 16; fi
@@ -43,6 +44,7 @@ cd "$(dirname "$B")" && python3 tools/summarize_profiles.py "$tag" > "$out/${tag
 cd /tmp
 if [ "$from" -le 20 ]; then timeout -k 10 500 python3 "$B" --all-configs > "$out/${tag}_bench_all.log" 2> "$out/${tag}_bench_all.err" || exit 1; fi
 if [ "$from" -le 21 ]; then timeout -k 10 200 python3 "$B" --workload advection --steps 10 --warmup 3 > "$out/${tag}_bench_advection.log" 2> "$out/${tag}_bench_advection.err" || exit 21; fi
+if [ "$from" -le 22 ]; then timeout -k 10 200 python3 "$B" --workload advection --nx-adv 8001 --steps 10 --warmup 3 > "$out/${tag}_bench_advection_nx8001.log" 2> "$out/${tag}_bench_advection_nx8001.err" || exit 22; fi
 cd "$(dirname "$B")" && python3 tools/summarize_profiles.py "$tag" > "$out/${tag}_summarize2.log" 2>&1
 mkdir -p "$out/${tag}_profiles" && cp profiles/${tag}_* "$out/${tag}_profiles/"
 find "$out" -name '*_results.db' -delete
