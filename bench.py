@@ -526,16 +526,24 @@ def pmc_traffic(nx, nt0, world, name="traffic"):
     must carry the stamp of THIS build (build_stamp): counters collected on other kernels price nothing -- ({}, reason, True)."""
     if not (world == 1 and nx == 16384 and nt0 == 65537):
         return {}, None, False
-    for tag in ("r04",):
-        tfile = os.path.join(ROOT, "profiles", f"{tag}_{name}.json")
-        if os.path.exists(tfile):
-            rec = json.load(open(tfile))
-            have, want = (rec.get("build") or {}).get("source_sha256"), build_stamp()["source_sha256"]
-            if have != want:
-                return {}, f"profiles/{tag}_{name}.json was collected on another build (sources {str(have)[:12]} there, {want[:12]} here): not used", True
-            return rec["kernels"], (f"profiles/{tag}_{name}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KiB units, read "
-                                    f"side doubled per the guide's gfx950 note; collected on this build, sources {want[:12]}; not "
-                                    f"collected in this run)"), False
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{name}.json")), reverse=True)     # newest round first
+    want = build_stamp()["source_sha256"]
+    stale = None
+    for tfile in files:
+        tag = re.match(r"(r\d\d)_", os.path.basename(tfile)).group(1)
+        rec = json.load(open(tfile))
+        have = (rec.get("build") or {}).get("source_sha256")
+        if have != want:
+            stale = stale or (f"profiles/{tag}_{name}.json was collected on another build (sources {str(have)[:12]} there, {want[:12]} here): "
+                              f"not used")
+            continue
+        return rec["kernels"], (f"profiles/{tag}_{name}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KiB units, read "
+                                f"side doubled per the guide's gfx950 note; collected on this build, sources {want[:12]}; not "
+                                f"collected in this run)"), False
+    if stale:
+        return {}, stale, True
     return {}, None, False
 
 

@@ -1760,7 +1760,7 @@ static void advection_block_solve_spec(orc_problem *p, int lvl) {
  * ---------------------------------------------------------------------------------------------- */
 static int h2d_block_solve_on(const orc_problem *p, const orc_level *L, int lvl) {
     const orc_stepper *st = &L->st;
-    if (p->no_block_solve || lvl == 0 || st->kind != ORC_HEAT2D || st->theta != 1.0) return 0;
+    if (p->no_block_solve || lvl == 0 || st->kind != ORC_HEAT2D || !(st->theta == 1.0 || st->theta == 0.5)) return 0;
     return blk_count(L->nt) > 0;
 }
 
@@ -1777,7 +1777,25 @@ static void h2d_dinv_table(const orc_stepper *st, double dt, double *tab) {
     }
 }
 
-static void heat2d_block_solve_spec(orc_problem *p, int lvl) {
+/* the propagator of one step in mode (a, b): backward Euler 1 / (1 + dt lam); Crank-Nicolson (round 5) (1 - theta dt lam) * (1 / (1 +
+ * theta dt lam)) -- the explicit half of heat_2d.py:309 carries theta as well. For an error whose RIM is zero the explicit stencil
+ * reads interior values only and is diagonal in the sine basis; heat2d_block_solve_spec checks exactly that. */
+static void h2d_prop_table(const orc_stepper *st, double dt, double *tab) {
+    h2d_dinv_table(st, dt, tab);
+    if (st->theta == 1.0) return;
+    int mi = st->mi, mj = st->mj, Mi = st->Mi, Mj = st->Mj;
+    int hxe = (mi + 1) / 2, hxo = mi / 2, hye = (mj + 1) / 2, hyo = mj / 2;
+    double thdt = st->theta * dt;
+    for (int a = 0; a < Mi; ++a) {
+        if (!((a < hxe) || (a >= st->HPx && a < st->HPx + hxo))) continue;
+        for (int b = 0; b < Mj; ++b)
+            if ((b < hye) || (b >= st->HPy && b < st->HPy + hyo))
+                tab[(size_t)a * Mj + b] = (1.0 - thdt * (st->lx[a] + st->ly[b])) * tab[(size_t)a * Mj + b];
+    }
+}
+
+/* returns 0 when the level has to be solved step by step after all (theta < 1 and an error with a non-zero rim): nothing was changed */
+static int heat2d_block_solve_spec(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl];
     orc_stepper *st = &L->st;
     int n = L->n, nt = L->nt, B = blk_count(nt), ny = st->ny, mi = st->mi, mj = st->mj, Mi = st->Mi, Mj = st->Mj;
@@ -1805,6 +1823,23 @@ static void heat2d_block_solve_spec(orc_problem *p, int lvl) {
             h2d_fwd(st->Fye, st->Fyo, mj, st->HPy, X, Mi, what + (size_t)b * per);
         }
     }
+    if (st->theta != 1.0) {
+        /* theta < 1: the explicit half of a step reads the rim of its input. An error with a zero rim -- every state of the level
+         * carries the boundary values there, the usual case -- propagates through interior values alone, which is what the modes
+         * describe; otherwise (a C-point never relaxed that still holds an initial guess with another rim) the level is stepped */
+        int rim = 0;
+        for (int b = 0; b < B - 1 && !rim; ++b) {
+            const double *ws = Ws + (size_t)b * n;
+            for (int a = 0; a < st->nx && !rim; ++a)
+                for (int q = 0; q < ny; ++q)
+                    if ((a == 0 || a == st->nx - 1 || q == 0 || q == ny - 1) && ws[(size_t)a * ny + q] != 0.0) { rim = 1; break; }
+        }
+        if (rim) {
+            st->dinv_dt = -1.0;
+            free(x); free(y); free(what); free(Ws); free(D); free(dv); free(Uh); free(c); free(P); free(X);
+            return 0;
+        }
+    }
     memcpy(Uh, what, sizeof(double) * per);
     for (int b = 0; b < B; ++b) {   /* recurrence over the blocks + block ends: u[e_b] = (u[e_b] + W_b) + the propagated part (interior) */
         int first = ORC_BLK_K * b + 1, last = blk_end(nt, B, b);
@@ -1813,7 +1848,7 @@ static void heat2d_block_solve_spec(orc_problem *p, int lvl) {
         for (int j = 0; j < n; ++j) ue[j] = ue[j] + ws[j];
         if (b == 0) continue;
         for (int i = first; i <= last; ++i) {
-            h2d_dinv_table(st, L->t[i] - L->t[i - 1], dv);
+            h2d_prop_table(st, L->t[i] - L->t[i - 1], dv);
             if (i == first) memcpy(D, dv, sizeof(double) * per);
             else for (size_t q = 0; q < per; ++q) D[q] = D[q] * dv[q];
         }
@@ -1839,6 +1874,7 @@ static void heat2d_block_solve_spec(orc_problem *p, int lvl) {
     }
     st->dinv_dt = -1.0;
     free(x); free(y); free(what); free(Ws); free(D); free(dv); free(Uh); free(c); free(P); free(X);
+    return 1;
 }
 
 void orc_problem_set_block_solve(orc_problem *p, int on) { p->no_block_solve = !on; }
@@ -1847,7 +1883,7 @@ void orc_forward_solve(orc_problem *p, int lvl) {
     orc_level *L = &p->L[lvl];
     { int r = block_solve_on(p, L, lvl); if (r > 0) { heat1d_block_solve_spec(p, lvl, r); return; } }
     if (adv_block_solve_on(p, L, lvl)) { advection_block_solve_spec(p, lvl); return; }
-    if (h2d_block_solve_on(p, L, lvl)) { heat2d_block_solve_spec(p, lvl); return; }
+    if (h2d_block_solve_on(p, L, lvl) && heat2d_block_solve_spec(p, lvl)) return;
     if (chain_overlapped(L, lvl)) { heat1d_chain_spec(p, lvl); return; }
     for (int i = 1; i < L->nt; ++i) {
         if (lvl == 0) phi(p, lvl, i, ROW(L->u, L, i - 1), ROW(L->u, L, i));

@@ -294,7 +294,7 @@ class HipBackend:
         self.block_uh = getattr(self, "block_uh", {})
         r = C.c_int(0)
         if d["kind"] == "heat2d":
-            # Heat2D (backward Euler, one rank): the engine's own rule (level > 0, theta = 1, >= 64 steps), full sine spectrum
+            # Heat2D (backward Euler or Crank-Nicolson, one rank): the engine's own rule (level > 0, theta = 1 or 1/2, >= 64 steps), full sine spectrum
             want = (lvl > 0 and lvl == mg.lvl_max - 1 and options.coarse_solve != "sequential" and mg.comm_time_size == 1 and
                     getattr(type(mg).forward_solve, "__qualname__", "") == "Mgrit.forward_solve")
             check(self.lib.mgrit_hip_block_solve_config(self.h, lvl, -1 if want else 0, 1, 0, None, None))

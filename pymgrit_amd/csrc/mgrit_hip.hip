@@ -1461,6 +1461,8 @@ struct H2DHost {
         std::vector<std::vector<H2DPlan>> p1, p3;
         int32_t *d_iota = nullptr, *d_end_all = nullptr, *d_end_tail = nullptr, *d_dsel = nullptr;   // 0 .. B-1; rows e_0 .. e_{B-1}; e_1 .. e_{B-1}; table of block b
         double *spec = nullptr, *Dtab = nullptr, *X = nullptr, *Y = nullptr;   // spectra; propagator tables; the blocks' errors x and inputs u + x
+        unsigned *rim_flag = nullptr;   // pinned, device-mapped (theta < 1): set when an error at a block end has a non-zero rim
+        hipEvent_t rim_ev = nullptr;
     } blk;
     double *Wc0 = nullptr, *Wc1 = nullptr;   // one item each: the work buffers of the coarsest-level chain, which in a planned
                                              // cycle steps on a second stream BESIDE sweeps that apply this level's Phi too (the
@@ -2294,7 +2296,9 @@ int h2d_relax(mgrit_hip_engine *e, int lvl, RunList *rl, int mode, double weight
 // (h2d_inv_kernel<true>, H2D_OP_ADD); second pass: the block interiors from the corrected block starts, again one batch per step
 // index. ~2 K batches of B states instead of K B single-state steps.
 bool h2d_block_ok(const Level &lv, int lvl) {
-    if (!lv.h2d || lvl == 0 || lv.h2d->dev.theta != 1.0) return false;
+    // backward Euler, and (round 5) Crank-Nicolson: the explicit half of a step is diagonal in the same sine basis for an error
+    // whose rim is zero -- every state of the level carries the boundary values there --, which h2d_block_solve checks per solve
+    if (!lv.h2d || lvl == 0 || !(lv.h2d->dev.theta == 1.0 || lv.h2d->dev.theta == 0.5)) return false;
     const int N = lv.dev.n_pts - 1;
     return N >= 4 * MGRIT_HIP_BLOCK_K && N / MGRIT_HIP_BLOCK_K <= H2D_MAX_BATCH;
 }
@@ -2343,7 +2347,11 @@ int h2d_block_build(mgrit_hip_engine *e, Level &lv) {
                 for (int a = 0; a < H.Mi; ++a) {
                     if (!((a < hxe) || (a >= h.HPx && a < h.HPx + hxo))) continue;
                     for (int c = 0; c < H.Mj; ++c)
-                        if ((c < hye) || (c >= h.HPy && c < h.HPy + hyo)) dv[(size_t)a * H.Mj + c] = 1.0 / (1.0 + thdt * (h.lx[a] + h.ly[c]));
+                        if ((c < hye) || (c >= h.HPy && c < h.HPy + hyo)) {
+                            const double lam = h.lx[a] + h.ly[c], inv = 1.0 / (1.0 + thdt * lam);
+                            // (theta < 1: the step's explicit half carries theta as well, heat_2d.py:309; oracle h2d_prop_table)
+                            dv[(size_t)a * H.Mj + c] = H.theta == 1.0 ? inv : (1.0 - thdt * lam) * inv;
+                        }
                 }
                 if (i == first(b)) std::copy(dv.begin(), dv.end(), tabs.begin() + (long)off);
                 else for (size_t q = 0; q < per; ++q) tabs[off + q] = tabs[off + q] * dv[q];
@@ -2364,13 +2372,20 @@ int h2d_block_build(mgrit_hip_engine *e, Level &lv) {
         HIP_TRY(hipMemsetAsync(*buf, 0, sizeof(double) * doubles, e->stream));
     }
     if ((rc = h2d_reserve(lv, std::min(H2D_MAX_BATCH, B)))) return rc;
+    if (H.theta != 1.0) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&k.rim_flag), 256, hipHostMallocMapped));
+        *k.rim_flag = 0u;
+        HIP_TRY(hipEventCreateWithFlags(&k.rim_ev, hipEventDisableTiming));
+    }
     HIP_TRY(hipStreamSynchronize(e->stream));
     k.B = B;
     k.built = true;
     return 0;
 }
 
-int h2d_block_solve(mgrit_hip_engine *e, int lvl) {
+// *stepped = true: the level has to be solved step by step after all (theta < 1 and an error with a non-zero rim); nothing was changed
+int h2d_block_solve(mgrit_hip_engine *e, int lvl, bool *stepped) {
+    *stepped = false;
     Level &lv = e->L[lvl];
     H2DHost &h = *lv.h2d;
     H2DHost::Blk &k = h.blk;
@@ -2387,6 +2402,21 @@ int h2d_block_solve(mgrit_hip_engine *e, int lvl) {
                                    lv.dev.u, pl.d_a, -1, k.X, pl.d_in);
             if ((rc = h2d_phi_op(e, lv, pl, s == 0 ? lv.dev.u : k.Y, k.X, ld, lv.dev.g, lv.dev.u, H2D_OP_DEFECT, 1, 1.0))) return rc;
         }
+    if (H.theta != 1.0) {
+        // the explicit half of a step reads the rim of its input: the modes describe the propagation of an error whose rim is
+        // zero. That holds whenever every state of the level carries the boundary values on its rim (any state a Phi has produced
+        // does); a level that still holds an initial guess with another rim -- C-points never relaxed, cf_iter = 0 -- is stepped.
+        // One word read back per solve (a Heat2D forward solve is tens of milliseconds of launches).
+        *k.rim_flag = 0u;
+        hipLaunchKernelGGL(h2d_rim_check_kernel, dim3(B - 1), dim3(256), 0, e->stream, H, k.X, ld, k.rim_flag);
+        HIP_TRY(hipEventRecord(k.rim_ev, e->stream));
+        for (;;) {
+            const hipError_t q = hipEventQuery(k.rim_ev);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return fail(MGRIT_HIP_EHIP, "hipEventQuery: %s", hipGetErrorString(q));
+        }
+        if (*k.rim_flag != 0u) { *stepped = true; return 0; }
+    }
     // spectra of the errors at the block ends e_0 .. e_{B-2}
     const dim3 fx(H.Mj / 64, H.Mi / 64, B - 1), fy(H.Mi / 64, H.Mj / 64, B - 1);
     hipLaunchKernelGGL(h2d_pack_kernel, dim3((H.Mj + 255) / 256, H.Mi, B - 1), dim3(256), 0, e->stream, H, k.X, k.d_iota, h.W0);
@@ -3072,6 +3102,8 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
             if (lv.h2d->rowsq) (void)hipFree(lv.h2d->rowsq);
             if (lv.h2d->Wc0) (void)hipFree(lv.h2d->Wc0);
             if (lv.h2d->Wc1) (void)hipFree(lv.h2d->Wc1);
+            if (lv.h2d->blk.rim_flag) (void)hipHostFree(lv.h2d->blk.rim_flag);
+            if (lv.h2d->blk.rim_ev) (void)hipEventDestroy(lv.h2d->blk.rim_ev);
             delete lv.h2d;
         }
         if (lv.wide) {
@@ -3379,7 +3411,11 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     const bool whole_chain = mode == MGRIT_HIP_RELAX_CHAIN && lvl > 0 && rl->n == 1 && rl->h_start[0] == 1 && rl->h_len[0] == lv.dev.n_pts - 1;
     // the whole level: the time-parallel form where the level qualifies (not configured yet: the engine's own rule)
     if (whole_chain && lv.blk_state < 0 && (rc = mgrit_hip_block_solve_config(e, lvl, -1, 1, 0, nullptr, nullptr))) return rc;
-    if (lv.h2d && whole_chain && lv.blk_state > 0) return h2d_block_solve(e, lvl);
+    if (lv.h2d && whole_chain && lv.blk_state > 0) {
+        bool stepped = false;
+        rc = h2d_block_solve(e, lvl, &stepped);
+        if (rc || !stepped) return rc;
+    }
     if (lv.h2d) return h2d_relax(e, lvl, rl, mode, weight_c);
     if (lv.wide) return wide_relax(e, lvl, rl, mode, weight_c);
     if (is_2pts(lv)) {

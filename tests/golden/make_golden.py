@@ -392,6 +392,12 @@ def make_heat2d():
     # coarsest levels of >= 64 steps: the device path's time-parallel forward solve (backward Euler)
     solve("be_blk_2lvl_bc", levels(12, 10, [513, 65], with_bc=True), tol=1e-9, max_iter=6, nested_iteration=False)
     solve("be_blk_3lvl_F", levels(9, 14, [641, 161, 81]), cycle_type='F', tol=1e-9, max_iter=5, nested_iteration=False)
+    # ... with Crank-Nicolson (round 5): boundary values, an F-cycle, and cf_iter = 0 with boundary values -- C-points that still hold
+    # the zero initial guess (another rim than the boundary values) in the first cycle: the device path steps that solve
+    solve("cn_blk_2lvl_bc", levels(12, 10, [513, 65], method="CN", with_bc=True, a=0.1), tol=1e-9, max_iter=6, nested_iteration=False)
+    solve("cn_blk_3lvl_F", levels(9, 14, [641, 161, 81], method="CN", a=0.1), cycle_type='F', tol=1e-9, max_iter=5, nested_iteration=False)
+    solve("cn_blk_cf0_bc", levels(10, 11, [513, 129], method="CN", with_bc=True, a=0.1), cf_iter=0, tol=1e-9, max_iter=6,
+          nested_iteration=False)
     with open(os.path.join(HERE, "heat2d.json"), "w") as f:
         json.dump(meta, f, indent=1)
     np.savez_compressed(os.path.join(HERE, "heat2d.npz"), **arrays)
