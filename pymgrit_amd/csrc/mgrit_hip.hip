@@ -650,9 +650,6 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
     const double2 *pt = sm.pt + (wave == G - 1 ? 512 : 0) + lane;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        // (LDSBAR kernels hold a second vector -- the forcing factor -- in registers: the eight Pt loads of the pass are requested two
-        // at a time there, not all at once as the scheduler would have it, 28 VGPRs less at the pass's peak)
-        if (LDSBAR && q > 0 && (q & 1) == 0) __builtin_amdgcn_sched_barrier(0);
         double2 w;
         if (CLOSED) {
             w.x = fma(-Q, c.pw[E - 1 - 2 * q], P * c.pw[2 * q]);
