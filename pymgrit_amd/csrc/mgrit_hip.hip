@@ -1887,6 +1887,8 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(blk_local_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>, blk_smem_bytes(MAX_G)))) return rc;
     if ((rc = allow_big_lds(blk_finish_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>, blk_smem_bytes(MAX_G)))) return rc;
     if ((rc = allow_big_lds(adv_fft_rows_kernel, (size_t)BLK_FOURIER_MAX_N * sizeof(double2)))) return rc;
+    if ((rc = allow_big_lds(adv_dft_fwd_kernel, (size_t)BLK_FOURIER_MAX_N * sizeof(double2)))) return rc;
+    if ((rc = allow_big_lds(adv_dft_inv_kernel, (size_t)BLK_FOURIER_MAX_N * sizeof(double2)))) return rc;
 #define ATTR_2PTS(O, F)                                                                                              \
     if ((rc = allow_big_lds(relax2_kernel<O, F, false, false>, smem2_bytes(MAX_G2)))) return rc;                     \
     if ((rc = allow_big_lds(relax2_kernel<O, F, true, false>, smem2_bytes(MAX_G2)))) return rc;                      \
@@ -2852,6 +2854,8 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     const bool adv = bk.fourier != 0, dft = bk.fourier == 2;
     const int n = lv.dev.n, fft_threads = std::min(n / 2, 1024);
     const size_t fft_lds = (size_t)n * sizeof(double2);
+    const size_t dft_lds = (size_t)n * sizeof(double2);                          // the table of all n roots of unity
+    const unsigned dft_gy = (unsigned)(((n + 15) / 16 + DFT_WAVES - 1) / DFT_WAVES);   // DFT_WAVES tiles of 16 per workgroup
     if (phases & 1) {
         const dim3 grid(std::min(bk.B, cap));
         if (adv) hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_ADVECTION1D, 0>), grid, block, lds, e->stream, lv.dev, bk);
@@ -2861,7 +2865,7 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
         else hipLaunchKernelGGL((blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, 4>), grid, block, lds, e->stream, lv.dev, bk);
         const int cnt = bk.B - 1 + (bk.project_last ? 1 : 0);     // blocks whose amplitudes the recurrence reads
         if (adv) {   // what_b = FFT(W_b)
-            if (cnt > 0 && dft) hipLaunchKernelGGL(adv_dft_fwd_kernel, dim3((cnt + 15) / 16, (n + 15) / 16, 2), dim3(64), 0, e->stream, lv.dev, bk, 0, cnt);
+            if (cnt > 0 && dft) hipLaunchKernelGGL(adv_dft_fwd_kernel, dim3((cnt + 15) / 16, dft_gy), dim3(64 * DFT_WAVES), dft_lds, e->stream, lv.dev, bk, 0, cnt);
             else if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, 0, 0);
         } else if (cnt > 0) {   // what_b(k) = <q_k, W_b> on the matrix cores, chunk by chunk, then the chunks in order
             hipLaunchKernelGGL(blk_project_kernel, dim3((cnt + 15) / 16, (bk.r + 15) / 16, lv.G), dim3(64), 0, e->stream, bk, lv.dev.ld, lv.blk_part);
@@ -2872,7 +2876,7 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
         if (adv) hipLaunchKernelGGL(adv_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, bk, n);
         else hipLaunchKernelGGL(blk_scan_kernel, dim3(1), dim3(BLK_RMAX), 0, e->stream, bk);
         if (bk.project_last) {   // the last point, which the next rank waits for
-            if (adv && dft) hipLaunchKernelGGL(adv_dft_inv_kernel, dim3(1, (n + 15) / 16), dim3(64), 0, e->stream, lv.dev, bk, bk.B - 1, 1);
+            if (adv && dft) hipLaunchKernelGGL(adv_dft_inv_kernel, dim3(1, dft_gy), dim3(64 * DFT_WAVES), dft_lds, e->stream, lv.dev, bk, bk.B - 1, 1);
             else if (adv) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(1), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, bk.B - 1, 1);
             else hipLaunchKernelGGL(blk_last_kernel, dim3(8, lv.G), dim3(LANES), 0, e->stream, lv.dev, bk);
         }
@@ -2882,7 +2886,7 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
         b2.skip_last_row = bk.project_last;
         if (adv) {   // u[e_b] += W_b + Re(IFFT(c_b)) / n for the block ends not yet corrected, then the second pass
             const int cnt = bk.B - (bk.project_last ? 1 : 0);
-            if (cnt > 0 && dft) hipLaunchKernelGGL(adv_dft_inv_kernel, dim3((cnt + 15) / 16, (n + 15) / 16), dim3(64), 0, e->stream, lv.dev, bk, 0, cnt);
+            if (cnt > 0 && dft) hipLaunchKernelGGL(adv_dft_inv_kernel, dim3((cnt + 15) / 16, dft_gy), dim3(64 * DFT_WAVES), dft_lds, e->stream, lv.dev, bk, 0, cnt);
             else if (cnt > 0) hipLaunchKernelGGL(adv_fft_rows_kernel, dim3(cnt), dim3(fft_threads), fft_lds, e->stream, lv.dev, bk, 0, 1);
         }
         else hipLaunchKernelGGL(blk_correct_kernel, dim3((bk.B + 15) / 16, lv.dev.ld / 64), dim3(64), 0, e->stream, lv.dev, bk,

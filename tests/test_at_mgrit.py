@@ -33,7 +33,7 @@ def heat(nx, nts, host_only, x_end=1.0):
 def check(mg, g):
     conv = mg.solve()["conv"]
     assert len(conv) == len(g["conv"])
-    assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-8 * np.array(g["conv"]) + 2e-11)
+    assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-9 * np.array(g["conv"]) + 2e-11)
     for i, vals in g["samples"].items():
         assert np.allclose(np.asarray(mg.u[0][int(i)].get_values()).ravel(), vals, rtol=1e-9, atol=1e-11)
 
@@ -97,7 +97,7 @@ def test_oracle_matches_reference(oracle, name):
         conv = op.solve()
         g = GOLD[name]
         assert len(conv) == len(g["conv"])
-        assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-8 * np.array(g["conv"]) + 2e-11)
+        assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-9 * np.array(g["conv"]) + 2e-11)
 
 
 @pytest.mark.parametrize("size", [2, 3, 5])
@@ -136,7 +136,7 @@ def test_hip_path_matches_oracle_and_reference(oracle, name):
     assert len(conv) == len(ref) and np.all(np.abs(conv - ref) <= 1e-10 * np.abs(ref))
     assert np.array_equal(mg.backend.natural("u", 0), op.state("u", 0))
     g = GOLD[name]
-    assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-8 * np.array(g["conv"]) + 2e-11)
+    assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-9 * np.array(g["conv"]) + 2e-11)
 
 
 @pytest.mark.gpu

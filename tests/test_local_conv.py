@@ -23,7 +23,7 @@ def heat_levels(host_only):
 def check(mg, g):
     conv = mg.solve()["conv"]
     assert len(conv) == len(g["conv"])
-    assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-8 * np.array(g["conv"]) + 2e-11)
+    assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-9 * np.array(g["conv"]) + 2e-11)
     for i, vals in g["samples"].items():
         assert np.allclose(np.asarray(mg.u[0][int(i)].get_values()).ravel(), vals, rtol=1e-9, atol=1e-11)
 
@@ -101,7 +101,7 @@ def test_local_criterion_on_several_ranks_matches_the_reference(key):
     res = run_ranks(int(size), target, timeout=30)
     for (conv, own, u), g in zip(res, RANKS[key]):
         assert len(conv) == len(g["conv"]), (key, [len(r[0]) for r in res], [len(x["conv"]) for x in RANKS[key]])
-        assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-7 * np.abs(np.array(g["conv"])) + 2e-11)
+        assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-9 * np.abs(np.array(g["conv"])) + 2e-11)
         assert len(own) == g["n_owned"]
         for j, vals in g["u"].items():
             assert np.allclose(u[int(j)], vals, rtol=1e-9, atol=1e-11)
@@ -110,7 +110,7 @@ def test_local_criterion_on_several_ranks_matches_the_reference(key):
 def _check_against_reference(res, key):
     for (conv, u), g in zip(res, RANKS[key]):
         assert len(conv) == len(g["conv"])
-        assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-7 * np.abs(np.array(g["conv"])) + 2e-11)
+        assert np.all(np.abs(conv - np.array(g["conv"])) <= 1e-9 * np.abs(np.array(g["conv"])) + 2e-11)
         assert u.shape[0] == g["n_owned"]
         for j, vals in g["u"].items():
             assert np.allclose(u[int(j)], vals, rtol=1e-9, atol=1e-11)
