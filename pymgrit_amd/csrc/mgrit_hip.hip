@@ -630,9 +630,13 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
                                            double *gb, int n, int t, int lane, int wave, int G) {
     const int j0 = t * E, li = lane & 15;
     const double a = scan_fwd(x, c, lc, lane);
+    // padding positions (j >= n) exist in the LAST group only: a wave-uniform branch, so that the other waves do not spend 16
+    // compares and 32 selects per Phi on a condition that is never true for them (the Phi is bound by the CU's issue slots)
+    if (__builtin_amdgcn_readfirstlane(wave) == __builtin_amdgcn_readfirstlane(G) - 1) {
 #pragma unroll
-    for (int k = 0; k < E; ++k)
-        if (j0 + k >= n) x[k] = 0.0;
+        for (int k = 0; k < E; ++k)
+            if (j0 + k >= n) x[k] = 0.0;
+    }
     const double b = scan_bwd(x, c, lc, lane);
     if (lane == 0) { ga[wave] = a; gb[wave] = b; }
     double P = 0.0, Q = 0.0;
@@ -719,12 +723,23 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const Le
         const double ylast = fma(c.pi_last, sm.lp[ll] * c_last, gb[0]);
         const double xl = ylast * c.scal;
         const double cf = lc.f_in * cm;
+        // (padding positions exist in the last group only: a wave-uniform branch, see heat_solve)
+        if (__builtin_amdgcn_readfirstlane(wave) == __builtin_amdgcn_readfirstlane(G) - 1) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const double2 w = sm.tab[slot0(t) + q * 64];
-            const double y0 = fma(c.pw[2 * q + 1], cf, x[2 * q]), y1 = fma(c.pw[2 * q + 2], cf, x[2 * q + 1]);
-            x[2 * q] = (j0 + 2 * q < L.n) ? fma(w.x, xl, y0) : 0.0;
-            x[2 * q + 1] = (j0 + 2 * q + 1 < L.n) ? fma(w.y, xl, y1) : 0.0;
+            for (int q = 0; q < 8; ++q) {
+                const double2 w = sm.tab[slot0(t) + q * 64];
+                const double y0 = fma(c.pw[2 * q + 1], cf, x[2 * q]), y1 = fma(c.pw[2 * q + 2], cf, x[2 * q + 1]);
+                x[2 * q] = (j0 + 2 * q < L.n) ? fma(w.x, xl, y0) : 0.0;
+                x[2 * q + 1] = (j0 + 2 * q + 1 < L.n) ? fma(w.y, xl, y1) : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double2 w = sm.tab[slot0(t) + q * 64];
+                const double y0 = fma(c.pw[2 * q + 1], cf, x[2 * q]), y1 = fma(c.pw[2 * q + 2], cf, x[2 * q + 1]);
+                x[2 * q] = fma(w.x, xl, y0);
+                x[2 * q + 1] = fma(w.y, xl, y1);
+            }
         }
     }
 }
@@ -733,8 +748,13 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const Le
 __device__ __forceinline__ double block_sumsq(const double (&r)[E], const Smem &sm, int n, int t, int lane, int wave, int G) {
     double acc = 0.0;
     const int kv = n - t * E;   // padding positions (unspecified values, heat_solve) do not count
+    if (__builtin_amdgcn_readfirstlane(wave) == __builtin_amdgcn_readfirstlane(G) - 1) {   // (they exist in the last group only)
 #pragma unroll
-    for (int k = 0; k < E; ++k) acc = fma(zero_unless_gt(r[k], kv, k), r[k], acc);
+        for (int k = 0; k < E; ++k) acc = fma(zero_unless_gt(r[k], kv, k), r[k], acc);
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc = fma(r[k], r[k], acc);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
     __syncthreads();
