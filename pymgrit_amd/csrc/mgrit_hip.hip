@@ -267,7 +267,7 @@ __device__ __forceinline__ double dpp_mov(double v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138;
+constexpr int DPP_ROW_SHL = 0x100, DPP_ROW_SHR = 0x110, DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
 __device__ __forceinline__ double read_lane(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -408,10 +408,10 @@ __device__ __forceinline__ double scan_fwd(double (&x)[E], const Coef &c, const 
     a = fma(c.sc[2], dpp_mov<DPP_ROW_SHR + 4>(a), a);
     a = fma(c.sc[3], dpp_mov<DPP_ROW_SHR + 8>(a), a);
     {
-        const double s15 = read_lane(a, 15), s47 = read_lane(a, 47);
-        a = fma(lc.f_row, lane < 32 ? s15 : s47, a);
-        const double s31 = read_lane(a, 31);
-        a = fma(lc.f_hi, s31, a);
+        // lane 15 -> row 1, lane 47 -> row 3 (row_bcast15 also hands lane 31 to row 2, whose coefficient is 0), then lane 31 -> rows
+        // 2 and 3: the wave-scan broadcasts of DPP, two moves each instead of four readlanes, four moves and two selects
+        a = fma(lc.f_row, dpp_mov<DPP_ROW_BCAST15>(a), a);
+        a = fma(lc.f_hi, dpp_mov<DPP_ROW_BCAST31>(a), a);
     }
     const double prev = dpp_mov<DPP_WAVE_SHR1>(a);  // lane 0 has no source lane: 0
 #pragma unroll
@@ -630,8 +630,11 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
                                            double *gb, int n, int t, int lane, int wave, int G) {
     const int j0 = t * E, li = lane & 15;
     const double a = scan_fwd(x, c, lc, lane);
-    // padding positions (j >= n) exist in the LAST group only: a wave-uniform branch, so that the other waves do not spend 16
-    // compares and 32 selects per Phi on a condition that is never true for them (the Phi is bound by the CU's issue slots)
+    // padding positions (j >= n) exist in the LAST group only: a wave-uniform branch, so that the other waves do not spend 32
+    // mask reloads and 32 selects per Phi on a condition that is never true for them (the compiler computes the sixteen lane masks
+    // once per kernel, keeps them in 32 SGPRs, spills them and reads them back lane by lane in every Phi; a Phi is bound by the CU's
+    // issue slots). Measured and not kept: compare + selects back to back on vcc here (zero_unless_gt: 64 fewer spilled SGPRs,
+    // but 19 more spilled VGPRs in cfas_kernel -- 1.93 ms against 1.75)
     if (__builtin_amdgcn_readfirstlane(wave) == __builtin_amdgcn_readfirstlane(G) - 1) {
 #pragma unroll
         for (int k = 0; k < E; ++k)
