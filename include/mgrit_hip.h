@@ -117,14 +117,16 @@ int mgrit_hip_chain_resume(mgrit_hip_engine *e, int lvl, int on);
  * over the blocks in the r lowest sine modes (the steps share their eigenvectors; over one block all other modes decay below
  * 2^-60), the block interiors stepped again from the corrected block starts. The same solve up to rounding; 2 Phi per step, all
  * blocks at once, instead of 1 Phi per step one after the other.
- * Advection1D levels (periodic upwind: circulant steps, Fourier modes, nothing decays) take the same scheme on ALL n modes through
- * a radix-2 FFT of the block ends: n a power of two in [64, 8192]; r = n, and the hand-over buffers hold n complex amplitudes
- * (2 n doubles).
+ * Advection1D levels (periodic upwind: circulant steps, Fourier modes, nothing decays) take the same scheme on ALL n modes, 64 <= n
+ * <= 8192: through a radix-2 FFT of the block ends where n is a power of two, through the transforms as ordered sums on the matrix
+ * cores for any other n; r = n, and the hand-over buffers hold n complex amplitudes (2 n doubles).
+ * Heat2D levels (one rank): the full sine spectrum of the interior, backward Euler and Crank-Nicolson (the latter checks per solve
+ * that the errors at the block ends have zero rims and steps through the level otherwise).
  *   mgrit_hip_block_solve_rank    the rule (pure host arithmetic) for a stepper kind MGRIT_HIP_STEPPER_HEAT1D / _ADVECTION1D:
  *                                 *r_out = modes needed for the time grid t[0..nt-1] (the level's
  *                                 GLOBAL grid when it is sharded: every owner must take the same form), 0 = the level is solved
  *                                 step by step (fewer than 4 blocks; Heat1D: more than MGRIT_HIP_BLOCK_RMAX modes; Advection1D: n
- *                                 not a power of two in [64, 8192]).
+ *                                 outside [64, 8192]).
  *   mgrit_hip_block_solve_config  r > 0: the level's CHAIN relax over all its steps takes this form with r modes; r = 0: never;
  *                                 r = -1: the engine applies the rule to its local grid (one rank). first_real = 0: the rank has
  *                                 a predecessor -- its first block starts from zero too, and the recurrence starts from the

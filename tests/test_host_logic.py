@@ -449,3 +449,31 @@ def test_time_factor_of_a_forcing_term_is_the_point_by_point_one():
     finally:
         options.reset("time_factor")
     assert nd and max(nd) == 0
+
+
+def test_index_array_reads_like_a_list_of_tuples():
+    """core/layout.IndexArray (round 5): the run / pair / triple / interval lists of a level as ONE int64 array that reads like the
+    list of tuples it replaced -- the plugin backend, the sharded schedules and the tests index, slice, iterate and compare it"""
+    from pymgrit_amd.core.layout import IndexArray, as_index_array, consecutive_runs, member_mask
+    runs = consecutive_runs(np.array([1, 2, 3, 5, 6, 9]))
+    assert isinstance(runs, IndexArray) and runs == [(1, 3), (5, 2), (9, 1)] and runs != [(1, 3)] and len(runs) == 3 and bool(runs)
+    assert runs[0] == (1, 3) and runs[-1] == (9, 1) and isinstance(runs[1][0], int)
+    assert runs[1:] == [(5, 2), (9, 1)] and isinstance(runs[1:], IndexArray) and runs[:0] == [] and not runs[:0]
+    assert [st + ln for st, ln in runs] == [4, 7, 10] and list(runs) == [(1, 3), (5, 2), (9, 1)]
+    assert [(0, 0)] + runs == [(0, 0), (1, 3), (5, 2), (9, 1)] and runs + [(7, 7)] == [(1, 3), (5, 2), (9, 1), (7, 7)]
+    assert dict(runs) == {1: 3, 5: 2, 9: 1}
+    cols = runs.columns()
+    assert [c.dtype for c in cols] == [np.int32, np.int32] and cols[0].tolist() == [1, 5, 9] and cols[1].flags["C_CONTIGUOUS"]
+    pts = IndexArray(np.array([4, 8, 12]))
+    assert pts == [4, 8, 12] and pts[1] == 8 and pts[1:] == [8, 12] and set(pts) == {4, 8, 12} and pts.columns()[0].tolist() == [4, 8, 12]
+    assert consecutive_runs(pts) == [(4, 1), (8, 1), (12, 1)] and consecutive_runs(np.zeros(0, dtype=int)) == []
+    runs.handle = 7                       # (device handles travel as attributes, as on Mgrit's IndexList)
+    assert runs.handle == 7
+    assert as_index_array([(1, 2), (3, 4)], 2).shape == (2, 2) and as_index_array([], 3).shape == (0, 3) and as_index_array(runs, 2) is runs.arr
+    with pytest.raises(TypeError):
+        hash(runs)
+    # exact float membership in an ascending grid = np.isin; anything else falls back to it
+    grid = np.linspace(0, 2, 17)
+    vals = np.concatenate((grid[::4], grid[3:5] + 1e-16, [np.nan, -1.0, 5.0]))
+    assert np.array_equal(member_mask(vals, grid), np.isin(vals, grid))
+    assert np.array_equal(member_mask(vals, grid[::-1]), np.isin(vals, grid[::-1]))
