@@ -248,7 +248,10 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id);
  * bit 1 = v^{l+1} (not needed when mgrit_hip_ec_relax_res performs the error correction: it takes the same bits from the fine
  * C-point; the library adds the bit where a chunk ends). Chunks are cut where res_pos is a multiple of `chunk`, so all lists
  * of a level are cut alike (chunk = 0: 1, 2 or 4 by res_len and the level's state width -- 1 while the level has fewer intervals
- * than the chip holds workgroups); the lists given to mgrit_hip_cf_fas and mgrit_hip_ec_relax_res within one cycle must be the same. */
+ * than the chip holds workgroups; chunk = MGRIT_HIP_CHUNK_LONG: the same rule up to 16 where a workgroup still gets four chunks,
+ * for the lists of mgrit_hip_cf_fas / mgrit_hip_ec_relax_res -- a chunk's start costs the way down a row, the way up two);
+ * the lists given to mgrit_hip_cf_fas and mgrit_hip_ec_relax_res within one cycle must be the same. */
+#define MGRIT_HIP_CHUNK_LONG (-1)
 int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_t *cstart, const int32_t *cend,
                                const int32_t *cstart_coarse, const int32_t *cend_coarse, const int32_t *res_pos, int res_len,
                                int chunk, const int32_t *keep, int *id_out);

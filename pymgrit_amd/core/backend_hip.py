@@ -1180,8 +1180,8 @@ class HipBackend:
             # (0 = chosen by the library from the level's size: 4 on config 3, 1 where the level has fewer intervals than the chip
             # holds workgroups)
             ch = chunk
-            if ch is None:
-                ch = 0 if lvl == 0 else 1
+            if ch is None:      # the Heat1D whole-level passes: level 0 by the library's rule for them (up to 16 intervals in a row)
+                ch = hip_lib.CHUNK_LONG if lvl == 0 else 1
             res_len = len(self.mg._c_points(lvl))
             check(self.lib.mgrit_hip_intervals_create(self.h, lvl, len(intervals), _ptr(cols[0]), _ptr(cols[1]), _ptr(cols[2]),
                                                       _ptr(cols[3]), _ptr(cols[4]), res_len, ch, _ptr(cols[5]), C.byref(iid)))

@@ -17,6 +17,7 @@ TRANSFER_COPY, TRANSFER_HEAT1D, TRANSFER_CALLER = 0, 1, 3
 MAX_N = 16384
 MAX_LINKS = 16
 BLOCK_K, BLOCK_RMAX = 16, 256     # time-parallel forward solve
+CHUNK_LONG = -1                   # mgrit_hip_intervals_create: the library's rule for the Heat1D whole-level passes (up to 16)
 
 EXPORTS = {
     # name: (restype, argtypes)

@@ -3999,14 +3999,21 @@ int mgrit_hip_intervals_create(mgrit_hip_engine *e, int lvl, int n, const int32_
     int rc = check_level(e, lvl);
     if (rc) return rc;
     if (lvl + 1 >= e->n_levels || !e->L[lvl + 1].set) return fail(MGRIT_HIP_EINVAL, "level %d has no described coarser level", lvl);
-    if (n < 0 || chunk < 0 || res_len < n || !id_out || (n > 0 && (!cstart || !cend || !cstart_coarse || !cend_coarse || !res_pos)))
+    if (n < 0 || chunk < MGRIT_HIP_CHUNK_LONG || res_len < n || !id_out || (n > 0 && (!cstart || !cend || !cstart_coarse || !cend_coarse || !res_pos)))
         return fail(MGRIT_HIP_EINVAL, "bad interval list");
     Level &lv = e->L[lvl];
     const Level &lc = e->L[lvl + 1];
-    if (chunk == 0) {   // by the level's size: walking several intervals in a row saves a row and a Phi per interval joined, but a
+    if (chunk <= 0) {   // by the level's size: walking several intervals in a row saves a row and a Phi per interval joined, but a
                         // level with fewer intervals than the chip holds workgroups wants every one of them running at once
+        const bool longer = chunk == MGRIT_HIP_CHUNK_LONG;
         const int per_slot = res_len / (2 * 256 * wgs_per_cu(lv));
         chunk = per_slot >= 4 ? 4 : per_slot >= 2 ? 2 : 1;
+        // (round 5, config 3's 16384 intervals through cfas_kernel / ecfr_kernel: chunks of 4 / 8 / 16 / 32 -> 6.67 / 6.61 / 6.46 / 6.62 ms
+        // per cycle -- a chunk's start costs the way down a row and ~5 us, the way up two rows; at 32 a workgroup has two chunks and
+        // the launch a tail. The general passes of config 5 were slower with 8 than with 4: 5.19 against 4.99 ms)
+        if (longer) chunk = per_slot >= 32 ? 16 : per_slot >= 16 ? 8 : chunk;
+        static const int forced = [] { const char *s = std::getenv("MGRIT_HIP_CHUNK"); return s ? std::atoi(s) : 0; }();   // (measurement switch)
+        if (forced > 0) chunk = forced;
     }
     for (int i = 0; i < n; ++i) {
         if (cstart[i] < 0 || cend[i] >= lv.dev.n_pts || cend[i] - cstart[i] < 2)
