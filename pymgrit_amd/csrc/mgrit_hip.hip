@@ -2928,20 +2928,22 @@ int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
 
 // process-wide cache of sine-mode tables (blk_config): the four most recent (n, ld, rows); a table in use by a level stays alive
 // through the level's shared_ptr after it has left the cache
-struct BlkModeKey { int n, ld, rows; std::shared_ptr<double> tab; };
+struct BlkModeKey { int dev, n, ld, rows; std::shared_ptr<double> tab; };
 std::vector<BlkModeKey> &blk_mode_cache() { static std::vector<BlkModeKey> c; return c; }
 std::mutex &blk_mode_lock() { static std::mutex m; return m; }
+int blk_mode_device() { int d = -1; (void)hipGetDevice(&d); return d; }    // (a table lives in ONE device's memory)
 std::shared_ptr<double> blk_mode_table_cached(int n, int ld, int rows) {
+    const int dev = blk_mode_device();
     std::lock_guard<std::mutex> g(blk_mode_lock());
     for (auto &k : blk_mode_cache())
-        if (k.n == n && k.ld == ld && k.rows >= rows) return k.tab;
+        if (k.dev == dev && k.n == n && k.ld == ld && k.rows >= rows) return k.tab;
     return nullptr;
 }
 void blk_mode_table_store(int n, int ld, int rows, const std::shared_ptr<double> &tab) {
     std::lock_guard<std::mutex> g(blk_mode_lock());
     auto &c = blk_mode_cache();
     if (c.size() >= 4) c.erase(c.begin());
-    c.push_back({n, ld, rows, tab});
+    c.push_back({blk_mode_device(), n, ld, rows, tab});
 }
 
 int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_successor, double *uh_in, double *uh_out) {
