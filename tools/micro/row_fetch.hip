@@ -1,5 +1,6 @@
 // Micro-measurement: what one workgroup of 1024 threads (one CU) pays for a 128 KB row, by where the row is (HBM, memory-side
-// cache, L2), by how many rows it keeps in flight, by how many CUs do the same at once.   hipcc --offload-arch=gfx950 -O3 row_fetch.hip
+// cache, L2), by how many rows it keeps in flight, by how many CUs do the same at once.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/micro/row_fetch tools/micro/row_fetch.hip; gpurun -- tools/micro/row_fetch   (profiles/r05_row_fetch.txt)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
