@@ -138,12 +138,21 @@ int mgrit_hip_chain_resume(mgrit_hip_engine *e, int lvl, int on);
  *                                 1 = first pass (needs nothing from the predecessor), 2 = recurrence over the blocks (needs
  *                                 uh_in) and, with a successor, the corrected last point, 4 = corrections + second pass (needs
  *                                 the ghost point). mgrit_hip_relax(CHAIN) over all steps = the three phases in a row.
- *   mgrit_hip_block_solve_state   *r_out = modes in effect on the level (0: step by step). */
+ *   mgrit_hip_block_solve_state   *r_out = modes in effect on the level (0: step by step).
+ *   mgrit_hip_block_solve_form    *form_out = MGRIT_HIP_BLOCK_FORM_STEPS (step by step), _PHASES (a launch or more per phase) or
+ *                                 _ONE_LAUNCH: a small Heat1D level on one rank -- one group of values (n <= 1024), at most 128
+ *                                 blocks and 64 modes -- whose three phases run as ONE launch with device-wide barriers between them
+ *                                 (the launch gaps are most of the solve at that size; same bits; MGRIT_HIP_BLK_ONE=0 in the
+ *                                 environment keeps the per-phase launches). */
+#define MGRIT_HIP_BLOCK_FORM_STEPS 0
+#define MGRIT_HIP_BLOCK_FORM_PHASES 1
+#define MGRIT_HIP_BLOCK_FORM_ONE_LAUNCH 2
 int mgrit_hip_block_solve_rank(int stepper, int n, double fac, int nt, const double *t, int *r_out);
 int mgrit_hip_block_solve_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_successor, double *uh_in,
                                  double *uh_out);
 int mgrit_hip_block_solve(mgrit_hip_engine *e, int lvl, int phases);
 int mgrit_hip_block_solve_state(mgrit_hip_engine *e, int lvl, int *r_out);
+int mgrit_hip_block_solve_form(mgrit_hip_engine *e, int lvl, int *form_out);
 /* Spatial transfer between lvl and lvl+1: GridTransferCopy (core/grid_transfer_copy.py:23-47) or the full-weighting
  * / linear-interpolation pair of examples/example_spatial_coarsening.py:33-82 (fine n = 2*coarse n + 1), or its periodic
  * analogue for Advection1D grids (fine n = 2*coarse n; no reference class exists, BASELINE config 5). */

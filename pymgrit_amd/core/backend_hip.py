@@ -347,6 +347,13 @@ class HipBackend:
         self._settle(lvl)
         check(self.lib.mgrit_hip_block_solve(self.h, lvl, int(phases)))
 
+    def block_solve_form(self, lvl):
+        """how the level's forward solve runs (mgrit_hip_block_solve_form): 0 step by step, 1 a launch or more per phase of the
+        time-parallel form, 2 the whole time-parallel solve in one launch (small Heat1D levels)"""
+        form = C.c_int(0)
+        check(self.lib.mgrit_hip_block_solve_form(self.h, lvl, C.byref(form)))
+        return form.value
+
     def finalize(self):
         """after every level is described: register the spatial transfers"""
         mg = self.mg

@@ -51,6 +51,7 @@ EXPORTS = {
     "mgrit_hip_block_solve_config": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mgrit_hip_block_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_block_solve_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "mgrit_hip_block_solve_form": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "mgrit_hip_level_transfer": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mgrit_hip_runs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mgrit_hip_pairs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),

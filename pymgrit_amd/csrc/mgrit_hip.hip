@@ -1295,14 +1295,14 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         if (PROP) {
             // ONE call site of the fine Phi for the F-steps and for the step onto the C-point (two inlined copies made the
             // register allocator spill 250 VGPRs): every step is x = w + Phi(x) with w = g_k, and w = g_i - u_i for the last
-            load_row_nt(L.u + (size_t)ip * L.ld, sl, x, L.stream_rows);
+            row_load2(L.u + (size_t)ip * L.ld, sl, x, L.stream_rows);
             for (int k = ip + 1; k <= i; ++k) {
-                load_row_nt(L.g + (size_t)k * L.ld, sl, w, L.stream_rows);   // in flight while Phi runs (PROP implies use_g)
+                row_load2(L.g + (size_t)k * L.ld, sl, w, L.stream_rows);   // in flight while Phi runs (PROP implies use_g)
                 if (k == i) {
                     double ui[E];
-                    load_row(L.u + (size_t)i * L.ld, sl, ui);
-                    if (!(opts & 2)) store_row_nt(Lc.u + (size_t)j * Lc.ld, sl, ui, Lc.stream_rows);
-                    store_row_nt(Lc.v + (size_t)j * Lc.ld, sl, ui, Lc.stream_rows);
+                    row_load2(L.u + (size_t)i * L.ld, sl, ui, 0);
+                    if (!(opts & 2)) row_store2(Lc.u + (size_t)j * Lc.ld, sl, ui, Lc.stream_rows);
+                    row_store2(Lc.v + (size_t)j * Lc.ld, sl, ui, Lc.stream_rows);
 #pragma unroll
                     for (int e = 0; e < E; ++e) w[e] = w[e] - ui[e];
                 }
@@ -1310,15 +1310,15 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
 #pragma unroll
                 for (int e = 0; e < E; ++e) x[e] = w[e] + x[e];
             }
-            load_row(L.u + (size_t)i * L.ld, sl, w);   // u^l_i once more (one live vector less while Phi runs)
+            row_load2(L.u + (size_t)i * L.ld, sl, w, 0);   // u^l_i once more (one live vector less while Phi runs)
         } else {
-            load_row(L.u + (size_t)(i - 1) * L.ld, sl, x);
-            load_row(L.u + (size_t)i * L.ld, sl, w);
-            if (!(opts & 2)) store_row_nt(Lc.u + (size_t)j * Lc.ld, sl, w, Lc.stream_rows);
-            store_row_nt(Lc.v + (size_t)j * Lc.ld, sl, w, Lc.stream_rows);
+            row_load2(L.u + (size_t)(i - 1) * L.ld, sl, x, 0);
+            row_load2(L.u + (size_t)i * L.ld, sl, w, 0);
+            if (!(opts & 2)) row_store2(Lc.u + (size_t)j * Lc.ld, sl, w, Lc.stream_rows);
+            row_store2(Lc.v + (size_t)j * Lc.ld, sl, w, Lc.stream_rows);
             if (use_g) {
                 double gi[E];
-                load_row(L.g + (size_t)i * L.ld, sl, gi);
+                row_load2(L.g + (size_t)i * L.ld, sl, gi, 0);
 #pragma unroll
                 for (int k = 0; k < E; ++k) w[k] = gi[k] - w[k];
             }
@@ -1326,9 +1326,9 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
             if (use_g) {
 #pragma unroll
                 for (int k = 0; k < E; ++k) x[k] = w[k] + x[k];
-                load_row(L.u + (size_t)i * L.ld, sl, w);   // u^l_i once more (one live vector less while Phi runs)
+                row_load2(L.u + (size_t)i * L.ld, sl, w, 0);   // u^l_i once more (one live vector less while Phi runs)
             } else {
-                load_row(L.u + (size_t)i * L.ld, sl, w);   // likewise: re-read (an L2 hit) instead of held across Phi
+                row_load2(L.u + (size_t)i * L.ld, sl, w, 0);   // likewise: re-read (an L2 hit) instead of held across Phi
 #pragma unroll
                 for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
             }
@@ -1336,7 +1336,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] + w[k];   // + v_j : the partial g of the coarse level
         // ---- coarse Phi on v_{j-1} = u^l_{ip}
-        load_row_nt(L.u + (size_t)ip * L.ld, sl, w, L.stream_rows);
+        row_load2(L.u + (size_t)ip * L.ld, sl, w, L.stream_rows);
         const int cj = Lc.one_cset ? 0 : ld_uniform(Lc.cidx + j);
         const CSet *gc = Lc.cs + cj;
         smc.wf = Lc.one_cset ? sm.wf2 : const_cast<double *>(gc->pg);   // (staged in LDS: stage_other_level)
@@ -1371,7 +1371,7 @@ __global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev L
         }
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
-        store_row_nt(Lc.g + (size_t)j * Lc.ld, sl, x, Lc.stream_rows);
+        row_store2(Lc.g + (size_t)j * Lc.ld, sl, x, Lc.stream_rows);
     }
     wq.end(t);
 }
@@ -1576,6 +1576,9 @@ struct Level {
     std::shared_ptr<double> blk_q;   // the level's share of the sine-mode table (process-wide cache, blk_mode_table_cached)
     double *blk_part = nullptr;      // [G chunks][B][BLK_RMAX] the chunks' sums of the inner products (blk_project_kernel)
     int blk_state = -1;              // -1: not configured yet (mgrit_hip_block_solve_config), else configured
+    double *blk_qt = nullptr;        // blk_one_kernel (small levels, one launch): the modes transposed; null: the six-launch form
+    unsigned *blk_sync = nullptr;    //   its barrier counters (device) ...
+    unsigned *blk_err = nullptr;     //   ... and the word a barrier that gave up sets (pinned, host-visible)
 };
 
 // ghost exchange (mgrit_hip_comm.inc): one direction of one pair of ranks
@@ -2236,12 +2239,19 @@ int h2d_phi_batch(mgrit_hip_engine *e, Level &lv, const H2DPlan &pl, const doubl
     double *const W0 = chain ? h.Wc0 : h.W0, *const W1 = chain ? h.Wc1 : h.W1;
     double *dinv = nullptr;
     if ((rc = h2d_dinv(e, lv, pl.dtbits, &dinv))) return rc;
-    hipLaunchKernelGGL(h2d_rhs_kernel, dim3((H.Mj + 255) / 256, H.Mi, pl.count), dim3(256), 0, e->stream, H, in_slab, pl.d_in,
-                       pl.d_step, W0);
     // W1[j][i'] = x to spectral slots ; W0[i'][j'] = y to spectral slots, o D ; W1[j'][i] = x back ; W0[i][j] = y back = U
     const dim3 fx(H.Mj / 64, H.Mi / 64, pl.count), fy(H.Mi / 64, H.Mj / 64, pl.count);        // (n tiles, slot tiles, items)
     const dim3 ix(H.Mj / 64, h.HPx / 64, pl.count), iy(H.Mi / 64, h.HPy / 64, pl.count);      // (n tiles, i tiles, items)
-    hipLaunchKernelGGL((h2d_fwd_kernel<false>), fx, dim3(256), 0, e->stream, h.Fxe, h.Fxo, H.mi, h.HPx, W0, H.Mj, W1, nullptr, per);
+    if (H.theta == 1.0 && H.K == 0 && !H.fb && !H.has_w && H.mj >= 2) {
+        // the homogeneous backward-Euler step: the right-hand side IS the interior of u -- the first transform stages it from the
+        // state rows (h2d_kloop<.., GRID>), no rhs launch
+        hipLaunchKernelGGL((h2d_fwd_kernel<false, true>), fx, dim3(256), 0, e->stream, h.Fxe, h.Fxo, H.mi, h.HPx, in_slab, H.ny, W1,
+                           nullptr, per, pl.d_in, H.ld, H.mj);
+    } else {
+        hipLaunchKernelGGL(h2d_rhs_kernel, dim3((H.Mj + 255) / 256, H.Mi, pl.count), dim3(256), 0, e->stream, H, in_slab, pl.d_in,
+                           pl.d_step, W0);
+        hipLaunchKernelGGL((h2d_fwd_kernel<false>), fx, dim3(256), 0, e->stream, h.Fxe, h.Fxo, H.mi, h.HPx, W0, H.Mj, W1, nullptr, per);
+    }
     hipLaunchKernelGGL((h2d_fwd_kernel<true>), fy, dim3(256), 0, e->stream, h.Fye, h.Fyo, H.mj, h.HPy, W1, H.Mi, W0, dinv, per);
     const H2DFin none{};
     hipLaunchKernelGGL((h2d_inv_kernel<false>), ix, dim3(256), 0, e->stream, h.FxeT, h.FxoT, H.mi, h.HPx, W0, H.Mj, W1, per, H, none);
@@ -2868,10 +2878,27 @@ int blk_handover_len(const Level &lv) { return lv.blk.r == 0 ? 0 : lv.blk.fourie
 // complex values); any other n: the transforms as ordered sums on the matrix cores (adv_dft_*_kernel)
 bool blk_fourier_ok(int n, int nt) { return n >= 64 && n <= BLK_FOURIER_MAX_N && blk_count(nt) > 0; }
 
+// MGRIT_HIP_BLK_ONE=0: small levels take the six launches too (measurement and comparison switch; same bits)
+bool blk_one_launch_enabled() {
+    const char *s = std::getenv("MGRIT_HIP_BLK_ONE");
+    return !(s && std::atoi(s) == 0);
+}
+
 int blk_launch(mgrit_hip_engine *e, Level &lv, int phases) {
     BlkDev &bk = lv.blk;
     const int fm = force_mode(lv), F = fm == 1 ? 4 : fm;
     const size_t lds = blk_smem_bytes(lv.G);
+    if (lv.blk_err && *lv.blk_err)
+        return fail(MGRIT_HIP_EHIP, "time-parallel forward solve in one launch: a device-wide barrier gave up (workgroups not resident together)");
+    if (phases == 7 && lv.blk_qt && bk.first_real && !bk.project_last) {
+        const dim3 grid(bk.B), block(LANES);
+        if (F == 0) hipLaunchKernelGGL((blk_one_kernel<0>), grid, block, lds, e->stream, lv.dev, bk, reinterpret_cast<const double2 *>(lv.blk_qt), lv.blk_sync, lv.blk_err);
+        else if (F == 2) hipLaunchKernelGGL((blk_one_kernel<2>), grid, block, lds, e->stream, lv.dev, bk, reinterpret_cast<const double2 *>(lv.blk_qt), lv.blk_sync, lv.blk_err);
+        else if (F == 3) hipLaunchKernelGGL((blk_one_kernel<3>), grid, block, lds, e->stream, lv.dev, bk, reinterpret_cast<const double2 *>(lv.blk_qt), lv.blk_sync, lv.blk_err);
+        else hipLaunchKernelGGL((blk_one_kernel<4>), grid, block, lds, e->stream, lv.dev, bk, reinterpret_cast<const double2 *>(lv.blk_qt), lv.blk_sync, lv.blk_err);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const int cap = 256 * blk_wgs_per_cu(lv);
     const dim3 block(lv.dev.T);
     const bool adv = bk.fourier != 0, dft = bk.fourier == 2;
@@ -3074,6 +3101,25 @@ int blk_config(mgrit_hip_engine *e, int lvl, int r, int first_real, int has_succ
         HIP_TRY(hipMemsetAsync(dWs, 0, sizeof(double) * (size_t)B * ld, e->stream));
         bk.Ws = dWs;
     }
+    lv.blk_qt = nullptr;
+    if (heat && lv.G == 1 && lv.dev.T == LANES && ld == GROUP && r <= BLK_ONE_MAX_R && B <= BLK_ONE_MAX_B && first_real && !has_successor &&
+        blk_one_launch_enabled()) {
+        // a small level: the whole solve as one launch (blk_one_kernel)
+        double *qt = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&qt), sizeof(double) * (size_t)GROUP * BLK_ONE_MAX_R));
+        lv.allocs.push_back(qt);
+        hipLaunchKernelGGL(blk_transpose_modes_kernel, dim3(GROUP / 2), dim3(BLK_ONE_MAX_R), 0, e->stream, bk.Q, ld, (r + 15) / 16 * 16,
+                           reinterpret_cast<double2 *>(qt));
+        HIP_TRY(hipGetLastError());
+        if (!lv.blk_sync) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lv.blk_sync), 256));
+            lv.allocs.push_back(lv.blk_sync);
+            HIP_TRY(hipMemsetAsync(lv.blk_sync, 0, 256, e->stream));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&lv.blk_err), 256, hipHostMallocMapped));
+            *lv.blk_err = 0u;
+        }
+        lv.blk_qt = qt;
+    }
     bk.uh_in = uh_in; bk.uh_out = has_successor ? uh_out : nullptr;
     bk.r = r; bk.B = B; bk.n_steps = nt - 1;
     bk.first_real = first_real ? 1 : 0;
@@ -3122,6 +3168,7 @@ int mgrit_hip_destroy(mgrit_hip_engine *e) {
     if (!e) return 0;
     (void)hipStreamSynchronize(e->stream);
     for (auto &lv : e->L) {
+        if (lv.blk_err) (void)hipHostFree(lv.blk_err);
         if (lv.h2d) {
             if (lv.h2d->W0) (void)hipFree(lv.h2d->W0);
             if (lv.h2d->W1) (void)hipFree(lv.h2d->W1);
@@ -3338,6 +3385,18 @@ int mgrit_hip_block_solve_state(mgrit_hip_engine *e, int lvl, int *r_out) {
     if (!r_out) return fail(MGRIT_HIP_EINVAL, "null output");
     const Level &lv = e->L[lvl];
     *r_out = lv.blk_state < 0 ? 0 : (lv.h2d ? (lv.blk_state > 0 ? lv.h2d->dev.mi * lv.h2d->dev.mj : 0) : lv.blk.r);
+    return 0;
+}
+
+int mgrit_hip_block_solve_form(mgrit_hip_engine *e, int lvl, int *form_out) {
+    int rc = check_level(e, lvl), r = 0;
+    if (rc) return rc;
+    if (!form_out) return fail(MGRIT_HIP_EINVAL, "null output");
+    if ((rc = mgrit_hip_block_solve_state(e, lvl, &r))) return rc;
+    const Level &lv = e->L[lvl];
+    *form_out = r == 0 ? MGRIT_HIP_BLOCK_FORM_STEPS
+                       : (!lv.h2d && lv.blk_qt && lv.blk.first_real && !lv.blk.project_last) ? MGRIT_HIP_BLOCK_FORM_ONE_LAUNCH
+                                                                                            : MGRIT_HIP_BLOCK_FORM_PHASES;
     return 0;
 }
 

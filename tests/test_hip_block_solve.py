@@ -29,6 +29,8 @@ SHAPES = [
     ("nx2050_nonuniform", "heat", 2050, NONUNIFORM, True),                # every step its own size, 100 steps = 5 x 16 + 20
     ("nx4099", "heat", 4099, _grids(641, (2, 2)), True),                  # 160 steps, five groups
     ("nx16384", "heat", 16384, _grids(129, (2,)), True),                  # the widest register-resident state, 64 steps
+    ("nx1024_nonuniform", "heat", 1024, NONUNIFORM, True),                # one group (the one-launch form, round 5): every step its own size, a last block of 20
+    ("nx513_128blocks", "heat", 513, _grids(8193, (4,)), True),           # ... its largest grid: 2048 steps = 128 workgroups around two device-wide barriers
     # short time intervals: the blocks damp slowly, more than 64 sine modes take part (up to MGRIT_HIP_BLOCK_RMAX = 256 since round 5)
     ("nx1025_r127", "heat", 1025, [cases.lin(0.02, 1025), cases.lin(0.02, 1025)[::4]], True),
     ("nx4099_r200", "heat", 4099, [cases.lin(0.004, 257), cases.lin(0.004, 257)[::2]], True),
@@ -97,6 +99,35 @@ def test_forward_solve_bit_exact(oracle, name, kind, nx, grids, forcing):
     assert_state_equal(mg, op, what=("u",))
     got, ref = np.array(mg.compute_residual()), op.residual_norms()
     assert np.array_equal(got, ref), np.abs(got - ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,grids,forcing", [(1024, _grids(4097, (4, 4)), True), (33, _grids(1025, (4, 4)), False), (700, NONUNIFORM, True)],
+                         ids=["config2", "nx33", "nx700_nonuniform"])
+def test_one_launch_form_equals_the_phase_launches(oracle, monkeypatch, nx, grids, forcing):
+    """small Heat1D levels (one group of values, <= 128 blocks, <= 64 modes, one rank) run the three phases of the solve as ONE
+    launch with device-wide barriers (blk_one_kernel): the same bits as the per-phase launches (MGRIT_HIP_BLK_ONE=0), solve after
+    solve on the same engine (the barrier counters are reused) and through whole cycles; wider levels keep the phases"""
+    from test_hip_parity import _need_gpu, make_pair, randomize
+    _need_gpu()
+    mg1, op = make_pair(oracle, "heat", nx, grids, forcing=forcing)
+    monkeypatch.setenv("MGRIT_HIP_BLK_ONE", "0")
+    mg6, _ = make_pair(oracle, "heat", nx, grids, forcing=forcing)
+    monkeypatch.delenv("MGRIT_HIP_BLK_ONE")
+    lvl = mg1.lvl_max - 1
+    assert mg1.backend.block_solve_form(lvl) == 2 and mg6.backend.block_solve_form(lvl) == 1
+    assert mg1.backend.block_r[lvl] == mg6.backend.block_r[lvl] > 0
+    randomize(mg1, op, seed=nx)
+    randomize(mg6, op, seed=nx)
+    for rep in range(3):
+        mg1.forward_solve(lvl); mg6.forward_solve(lvl)
+        assert np.array_equal(mg1.backend.natural("u", lvl), mg6.backend.natural("u", lvl))
+    for it in range(3):
+        mg1.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True); mg6.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True)
+    for l in range(mg1.lvl_max):
+        assert np.array_equal(mg1.backend.natural("u", l), mg6.backend.natural("u", l))
+    wide, _ = make_pair(oracle, "heat", 1027, _grids(513, (4,)))
+    assert wide.backend.block_solve_form(1) == 1
 
 
 @pytest.mark.gpu

@@ -53,20 +53,41 @@ def test_sweeps_bit_exact(oracle, method, with_bc, nx, ny):
     for w in (1.0, 1.3):
         mg, op = _pair(oracle, prob, weight_c=w)
         _randomize(mg, op, nx + ny)
-        for lvl in range(mg.lvl_max - 1):
-            mg.f_relax(lvl); op.f_relax(lvl)
-            _equal(mg, op)
-            mg.c_relax(lvl); op.c_relax(lvl)
-            _equal(mg, op)
-            mg.fas_residual(lvl); op.fas_residual(lvl)
-            _equal(mg, op)
-        mg.forward_solve(mg.lvl_max - 1); op.forward_solve(mg.lvl_max - 1)
+        _every_sweep_once(mg, op)
+
+
+def _every_sweep_once(mg, op):
+    for lvl in range(mg.lvl_max - 1):
+        mg.f_relax(lvl); op.f_relax(lvl)
         _equal(mg, op)
-        for lvl in range(mg.lvl_max - 2, -1, -1):
-            mg.error_correction(lvl); op.error_correction(lvl)
-            _equal(mg, op)
-        got, ref = np.array(mg.compute_residual()), op.residual_norms()
-        assert np.array_equal(got, ref), np.abs(got - ref).max()
+        mg.c_relax(lvl); op.c_relax(lvl)
+        _equal(mg, op)
+        mg.fas_residual(lvl); op.fas_residual(lvl)
+        _equal(mg, op)
+    mg.forward_solve(mg.lvl_max - 1); op.forward_solve(mg.lvl_max - 1)
+    _equal(mg, op)
+    for lvl in range(mg.lvl_max - 2, -1, -1):
+        mg.error_correction(lvl); op.error_correction(lvl)
+        _equal(mg, op)
+    got, ref = np.array(mg.compute_residual()), op.residual_norms()
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
+
+
+@pytest.mark.parametrize("nx,ny", [(9, 12), (20, 17), (4, 3), (66, 67), (67, 130), (131, 129), (200, 66)])
+def test_homogeneous_backward_euler_sweeps_bit_exact(oracle, nx, ny):
+    """the reference's default right-hand side (zero, heat_2d.py:148) with zero boundary values: the step's right-hand side is the
+    interior of u itself, and the first transform reads it from the state rows (no rhs launch; h2d_kloop GRID) -- sizes with odd
+    and even interiors, below / at / above the 64-wide tiles, random states with random rims (which must not leak in)"""
+    assert torch.cuda.is_available()
+    prob = [cases.h2d_app(nx, ny, t, "BE", False, forcing=False) for t in cases.h2d_grids([33, 9, 3])]
+    d = prob[0].device_stepper()
+    assert len(d["forcing_time"]) == 0 and not np.any(d["bc"])
+    mg, op = _pair(oracle, prob)
+    _randomize(mg, op, nx + ny)
+    _every_sweep_once(mg, op)
+    for it in range(2):
+        mg.iteration(lvl=0, cycle_type='V', iteration=it, first_f=True); op.iteration(0, 'V', it, True)
+        _equal(mg, op)
 
 
 BLK_SHAPES = [("be_bc_66x67_uniform", True, 66, 67, None), ("be_130x131_nonuniform", False, 130, 131, 1.3), ("be_bc_20x17_rem", True, 20, 17, None),

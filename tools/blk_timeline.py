@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORK = os.path.join(ROOT, "scratch", "blk_timeline")
 LIB = os.path.join(WORK, "libmgrit_hip_stamps.so")
 NAMES = {0: "finish: block start row + first g requested", 1: "finish: Phi", 2: "finish: add, next g requested, store issued", 3: "finish: tail",
+         8: "one launch: prologue + pass 1 (16 Phi)", 9: "one launch: amplitudes (1024-long chains)", 10: "one launch: first device-wide barrier",
+         11: "one launch: recurrence + block end", 12: "one launch: second device-wide barrier", 13: "one launch: pass 2 (15 Phi)",
          4: "local: prologue + first row", 5: "local: g requested + Phi", 6: "local: u_i requested, arrived, arithmetic", 7: "local: W_b stored, tail",
          }
 
@@ -50,7 +52,7 @@ extern "C" int mgrit_hip_debug_bstamps(unsigned long long *out, int reset) {
     print("built", LIB)
 
 
-def run():
+def run(small=False):
     os.environ["PYMGRIT_AMD_LIB"] = LIB
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -62,6 +64,9 @@ def run():
     # a rank's share of config 3's coarsest level as a coarsest level of its own: 513 points, 32 blocks, same step size
     nx, nt0 = 16384, 8193
     t0 = np.linspace(0, 2.0 * (nt0 - 1) / 65536, nt0)
+    if small:   # BASELINE config 2: the coarsest level (257 points of 1022 values) takes the one-launch form
+        nx, nt0 = 1024, 4097
+        t0 = np.linspace(0, 2.0 * (nt0 - 1) / 65536, nt0)
     problem = [Heat1D(x_start=0, x_end=1, nx=nx, a=1, init_cond=bench.init_cond, rhs_separable=[(bench.rhs_space, bench.rhs_time)],
                       t_interval=g) for g in (t0, t0[::4], t0[::16])]
     mg = Mgrit(problem, cf_iter=1, cycle_type='V', nested_iteration=False, max_iter=3, tol=0.0, logging_lvl=30, plan_blocks=1)
@@ -91,4 +96,4 @@ def run():
 
 
 if __name__ == "__main__":
-    {"build": build, "run": run}[sys.argv[1]]()
+    {"build": build, "run": run, "run_small": lambda: run(True)}[sys.argv[1]]()
