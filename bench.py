@@ -297,7 +297,8 @@ def bench_heat2d(args):
                       "phi_per_cycle_by_level": counts, "dof": dof},
            "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                        "kernel": "level-0 F-relax = per Phi 2 x h2d_fwd_kernel + 2 x h2d_inv_kernel (f64 MFMA, half-size transforms) + rhs + epilogue",
+                        "kernel": "level-0 F-relax = per Phi 2 x h2d_fwd_kernel (the first reads the state rows: no rhs launch for the "
+                                  "homogeneous step) + 2 x h2d_inv_kernel (f64 MFMA, half-size transforms; the sweep's arithmetic in the last one) + rim",
                         "flops_per_phi": flops_per_phi,
                         "launch_ms": f_ms, "us_per_phi": 1e3 * f_ms / n_f}}
     out["sweeps"] = timed_sweeps(mg, be, cycle, cycles=1)
@@ -315,7 +316,8 @@ def bench_heat2d(args):
     out["roofline_level0_f_relax"] = out["roofline"]
     out["roofline"] = {"bound": "mfma", "achieved": drow.get("tflops"), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": drow.get("mfma_frac"), "traffic": None, "kernel": f"{dominant}: per Phi 2 x h2d_fwd_kernel + 2 x "
-                       "h2d_inv_kernel (f64 MFMA, half-size transforms) + rhs + epilogue", "flops_per_phi": flops_per_phi,
+                       "h2d_inv_kernel (f64 MFMA, half-size transforms; no rhs launch for the homogeneous step) + rim", "flops_per_phi": flops_per_phi,
+                       "mfma_sustained_frac_of_peak": 0.89,   # tools/micro/mfma_f64_peak.hip, LDS operands (profiles/r05_mfma_f64_peak.txt)
                        "launch_ms": drow["ms_per_launch"], "launches_per_cycle": drow["launches_per_cycle"], "ms_per_cycle": drow["ms_per_cycle"],
                        "limited_by": "MFMA issue + operand traffic of the batched half-size transforms" if not dominant.startswith("chain") else
                        "latency: the sequential coarsest-level solve, one state per step (64 output tiles for 256 CUs)"}
@@ -452,7 +454,7 @@ LIMITED_BY = {"chain": "latency: the coarsest-level solve is sequential, one cro
                        "0.98 us/step = one store -> L2 -> load round trip); bytes are not what bounds it",
               "chain_blocks": "the time-parallel forward solve (DESIGN.md 3.8): two batched passes over all blocks of 16 steps (HBM "
                               "bandwidth where the level is large: config 3) around a modal recurrence over the blocks; on small "
-                              "levels (config 2) the launch latency of its six kernels",
+                              "levels (config 2: one launch, blk_one_kernel) the latency of 2 x 16 Phi of a single wave",
               "default": "HBM bandwidth (one 1024-thread workgroup per CU streaming rows; 6.29 TB/s copy ceiling of the guide)"}
 
 
@@ -576,6 +578,8 @@ def sweep_table(mg, be, nts, m_list, dof, cycle, cycles=3):
         if kind == "chain" and getattr(be, "block_r", {}).get(len(nts) - 1):
             sym = "blk_local_kernel + blk_scan_kernel + blk_finish_kernel"     # the time-parallel forward solve
             why = "chain_blocks"
+            if getattr(be, "block_solve_form", lambda lvl: 1)(len(nts) - 1) == 2:
+                sym = "blk_one_kernel"       # small levels: the whole solve in one launch
         elif kind == "chain" and dof <= 1024:
             sym = "chain_kernel<1, 1, true, true>"    # one group of values: the single-workgroup chain, no exchange
         table[key] = {"kernel_symbol": sym, "launches_per_cycle": n / cycles, "ms_per_launch": tot / n, "ms_per_cycle": tot / cycles,

@@ -2137,7 +2137,7 @@ int level_heat1d_2pts(mgrit_hip_engine *e, int lvl, int n_pts, const double *t_l
 // ---------------------------------------------------------------------------------------------------------------
 // Heat2D host side: tables, batch plans, the batched Phi pipeline
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int H2D_MAX_BATCH = 1024;  // items per GEMM batch (work buffers: 2 x 1024 x Mi x Mj doubles)
+constexpr int H2D_MAX_BATCH = 1024;  // items per GEMM batch (work buffers: 2 x 1024 x Mi x Mj doubles; 2048 measured no faster)
 
 uint64_t dbl_bits(double v) { uint64_t b; std::memcpy(&b, &v, 8); return b; }
 

@@ -46,6 +46,12 @@ if [ "$from" -le 20 ]; then timeout -k 10 500 python3 "$B" --all-configs > "$out
 if [ "$from" -le 21 ]; then timeout -k 10 200 python3 "$B" --workload advection --steps 10 --warmup 3 > "$out/${tag}_bench_advection.log" 2> "$out/${tag}_bench_advection.err" || exit 21; fi
 if [ "$from" -le 22 ]; then timeout -k 10 200 python3 "$B" --workload advection --nx-adv 8001 --steps 10 --warmup 3 > "$out/${tag}_bench_advection_nx8001.log" 2> "$out/${tag}_bench_advection_nx8001.err" || exit 22; fi
 cd "$(dirname "$B")" && python3 tools/summarize_profiles.py "$tag" > "$out/${tag}_summarize2.log" 2>&1
+# round 5: the FP64 matrix rate this card sustains (register operands / LDS operands), the matrix-pipe counters of the Heat2D
+# transforms (one --pmc pass), the phase timeline of the one-launch block solve at config 2 (stamped experiment build, if built:
+# python tools/blk_timeline.py build)
+if [ "$from" -le 23 ] && [ -x tools/micro/mfma_f64_peak ]; then timeout -k 10 120 tools/micro/mfma_f64_peak > "profiles/${tag}_mfma_f64_peak.txt" 2>&1 || true; fi
+if [ "$from" -le 24 ]; then bash tools/pmc_pass.sh "${tag}_heat2d" "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE" bench.py --workload heat2d --steps 1 --warmup 0 --nt2d 4097 > /dev/null 2>&1; cp "$out/${tag}_heat2d_pmc.txt" "profiles/${tag}_pmc_heat2d.txt" 2>/dev/null || true; fi
+if [ "$from" -le 25 ] && [ -f scratch/blk_timeline/libmgrit_hip_stamps.so ]; then timeout -k 10 200 python3 tools/blk_timeline.py run_small > "profiles/${tag}_blk_one_timeline.txt" 2> "$out/${tag}_blk_one_timeline.err" || true; fi
 mkdir -p "$out/${tag}_profiles" && cp profiles/${tag}_* "$out/${tag}_profiles/"
 find "$out" -name '*_results.db' -delete
 find "$out" -name '*kernel_trace.csv' -size +20M -delete
