@@ -803,8 +803,19 @@ extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 // follows is folded into the FAS pass, fas_fused1_kernel PROP, and the way up rewrites them).
 enum { ROLE_F = 0, ROLE_C = 1, ROLE_C_WEIGHTED = 2, ROLE_FC = 3 };
 
-template <int KIND, int FORCE, bool USE_G, int ROLE>
-__global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *__restrict__ run_start,
+// TB (the sweeps of a Heat1D cycle: relax_kernel ROLE_FC, ecf_kernel, cfas_kernel, ecfr_kernel, fas_fused1_kernel): the workgroup
+// size the instance is compiled for. States of one group (n <= 1024) run one WAVE per state, and a lone wave issues about one
+// instruction per 8 cycles -- every instruction counts; compiled for 1024 threads the kernels keep to 128 VGPRs and spill 100-350
+// SGPRs and up to 90 VGPRs, whose reloads are instructions in every Phi. The TB = 64 instances (512 VGPRs, no spill code) take the
+// launches of such levels: config 2's five sweeps 17-32 us -> 14-27 us each. Same source, same operations, same bits
+// (MGRIT_HIP_SMALL_WG=0: the 1024-thread instances everywhere).
+bool small_wg_instances() {
+    const char *s = std::getenv("MGRIT_HIP_SMALL_WG");      // (read per launch: a test compares the two families in one process)
+    return !(s && s[0] == '0' && s[1] == 0);
+}
+
+template <int KIND, int FORCE, bool USE_G, int ROLE, int TB = 1024>
+__global__ void __launch_bounds__(TB) relax_kernel(LevelDev L, const int32_t *__restrict__ run_start,
                                                      const int32_t *__restrict__ run_len, int n_runs, double w, double w1) {
     WG_PROLOGUE;
     // persistent workgroups: the grid is sized to the chip (not to the run list), each workgroup walks the runs with
@@ -838,8 +849,8 @@ __global__ void __launch_bounds__(1024) relax_kernel(LevelDev L, const int32_t *
 // predecessor is a corrected C-point applies the correction itself -- u_c = u_c + (u^{l+1}_j - v^{l+1}_j), same operation
 // order as interp_rows_kernel, with v^{l+1}_j taken from u_c itself (see below) -- writes the C-point back and goes on with the F-points, so the C-point travels through HBM
 // once instead of twice. ec_coarse[r] = coarse slot j of run r's predecessor, or -1 (ghost / uncorrected predecessor).
-template <int KIND, int FORCE, bool USE_G>
-__global__ void __launch_bounds__(1024) ecf_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ run_start,
+template <int KIND, int FORCE, bool USE_G, int TB = 1024>
+__global__ void __launch_bounds__(TB) ecf_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ run_start,
                                                    const int32_t *__restrict__ run_len, const int32_t *__restrict__ ec_coarse,
                                                    int n_runs) {
     WG_PROLOGUE;
@@ -1113,8 +1124,8 @@ struct IntervalsDev {
 // experiment build of its own: profiles/r04_cfas_timeline.txt. Per interval of config 3: five Phi at ~2.1 us of solve each plus
 // ~1.7 us each for streaming the forcing factor from L2 -- LDS, where ecfr_kernel keeps it, holds q here --, 4.4 us of row
 // traffic that the wave waits for, 2 us until the stores of the interval before have drained.)
-template <int FORCE>
-__global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, int pre) {
+template <int FORCE, int TB = 1024>
+__global__ void __launch_bounds__(TB) cfas_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, int pre) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
     WG_PROLOGUE;
     stage_other_level(sm, Lc, t);
@@ -1202,8 +1213,8 @@ __global__ void __launch_bounds__(1024) cfas_kernel(LevelDev L, LevelDev Lc, Int
 //                                                                 way up -- for the C-point a chunk starts from), stored
 //   out[res_pos] = || Phi_l(F''_last) - C''_{j+1} ||^2
 // 2 rows read + m written per interval instead of 2 + m (correction + F-relaxation) and 2 more for the residual.
-template <int FORCE, bool USE_G, bool RES>
-__global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, double *__restrict__ out, int store_f,
+template <int FORCE, bool USE_G, bool RES, int TB = 1024>
+__global__ void __launch_bounds__(TB) ecfr_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, double *__restrict__ out, int store_f,
                                                     double *const *__restrict__ mirror, int mirror_row0) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
     constexpr bool CF = FORCE == 4;   // forcing factor in LDS, so every Phi in closed form
@@ -1272,8 +1283,8 @@ __global__ void __launch_bounds__(1024) ecfr_kernel(LevelDev L, LevelDev Lc, Int
 // scalar coefficients of the level in use reloaded in front of each Phi (scalar loads; both sets at once would not fit the
 // SGPR file). The partial g of the two-phase form never leaves the registers: 3 vectors read (+g_i), 3 written per C-point
 // instead of 4-5 and 4. Arithmetic identical to fas_fused_kernel.
-template <int FORCE, bool PROP>
-__global__ void __launch_bounds__(1024) fas_fused1_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ fine_idx,
+template <int FORCE, bool PROP, int TB = 1024>
+__global__ void __launch_bounds__(TB) fas_fused1_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ fine_idx,
                                                           const int32_t *__restrict__ prev_idx,
                                                           const int32_t *__restrict__ coarse_idx, int n_items, int use_g,
                                                           int opts) {
@@ -3599,7 +3610,15 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     RELAX_CASE(K, F, false, ROLE_F) RELAX_CASE(K, F, true, ROLE_F) RELAX_CASE(K, F, false, ROLE_C)                  \
     RELAX_CASE(K, F, true, ROLE_C) RELAX_CASE(K, F, false, ROLE_C_WEIGHTED) RELAX_CASE(K, F, true, ROLE_C_WEIGHTED) \
     RELAX_CASE(K, F, true, ROLE_FC)
-        FOR_EACH_STEPPER(RELAX_CASES)
+        // (one-group Heat1D levels: the F+C pass of a cycle compiled for ONE wave per workgroup, see small_wg_instances)
+        if (lv.dev.T == LANES && small_wg_instances() && lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && use_g && role == ROLE_FC && fm <= 2) {
+#define RELAX_SMALL(F)                                                                                                                \
+    if (fm == F) hipLaunchKernelGGL((relax_kernel<MGRIT_HIP_STEPPER_HEAT1D, F, true, ROLE_FC, LANES>), grid, block, lds, e->stream, \
+                                    sched_dev(e, lv), rl->d_start, rl->d_len, rl->n, w, w1);
+            RELAX_SMALL(0) RELAX_SMALL(1) RELAX_SMALL(2)
+        } else {
+            FOR_EACH_STEPPER(RELAX_CASES)
+        }
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -3817,10 +3836,16 @@ int mgrit_hip_fas_fused_opts(mgrit_hip_engine *e, int lvl, int triples_id, int o
         // level's factor is the same vector (same spatial grid, same rhs), so the coarse Phi takes it from there too
         if (lf.same_factor_below < 0) lf.same_factor_below = (fm == 1 && lf.s_host == lc.s_host) ? 1 : 0;   // (131 KB compared once)
         const int kopts = opts | (lf.same_factor_below ? 4 : 0);
+        const bool small = lf.dev.T == LANES && small_wg_instances();
 #define FAS1_CASE(F_, P_)                                                                                                  \
-    if ((fm == 0 ? 0 : fm == 1 ? 4 : 2) == F_ && ((opts & MGRIT_HIP_FAS_WITH_F_RELAX) != 0) == P_)                          \
-        hipLaunchKernelGGL((fas_fused1_kernel<F_, P_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, \
-                           pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g, kopts);
+    if ((fm == 0 ? 0 : fm == 1 ? 4 : 2) == F_ && ((opts & MGRIT_HIP_FAS_WITH_F_RELAX) != 0) == P_) {                        \
+        if (small)                                                                                                         \
+            hipLaunchKernelGGL((fas_fused1_kernel<F_, P_, LANES>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), \
+                               lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g, kopts);                          \
+        else                                                                                                               \
+            hipLaunchKernelGGL((fas_fused1_kernel<F_, P_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), \
+                               lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g, kopts);                          \
+    }
         FAS1_CASE(0, false) FAS1_CASE(2, false) FAS1_CASE(4, false) FAS1_CASE(0, true) FAS1_CASE(2, true) FAS1_CASE(4, true)
         HIP_TRY(hipGetLastError());
         return 0;
@@ -3970,7 +3995,14 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id) {
         hipLaunchKernelGGL((ecf_kernel<K, F, G_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, rl->d_start,  \
                            rl->d_len, rl->d_ec, rl->n);
 #define ECF_CASES(K, F) ECF_CASE(K, F, false) ECF_CASE(K, F, true)
-    FOR_EACH_STEPPER(ECF_CASES)
+    if (lf.dev.T == LANES && small_wg_instances() && lf.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && use_g && fm <= 2) {
+#define ECF_SMALL(F)                                                                                                                  \
+    if (fm == F) hipLaunchKernelGGL((ecf_kernel<MGRIT_HIP_STEPPER_HEAT1D, F, true, LANES>), grid, block, smem_bytes(lf.G, lf.dev.kind), \
+                                    e->stream, sched_dev(e, lf), lc.dev, rl->d_start, rl->d_len, rl->d_ec, rl->n);
+        ECF_SMALL(0) ECF_SMALL(1) ECF_SMALL(2)
+    } else {
+        FOR_EACH_STEPPER(ECF_CASES)
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -4138,7 +4170,10 @@ int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id, int pre_relaxed
     if (I.n_chunks == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_CF_FAS, lvl);
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
-    if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    const bool small = lf.dev.T == LANES && small_wg_instances();   // (one wave per state: the instances compiled for it)
+    if (force_mode(lf) == 0 && small) hipLaunchKernelGGL((cfas_kernel<0, LANES>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    else if (small) hipLaunchKernelGGL((cfas_kernel<2, LANES>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    else if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
     else hipLaunchKernelGGL((cfas_kernel<2>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -4164,9 +4199,13 @@ static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int sto
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
     if (lvl > 0) {   // coarser level: rows of g, every F-point stored (the finer level's correction reads them), no residual
         Timed timed(e, MGRIT_HIP_T_EC_RELAX, lvl);
-        if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, true, false>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);
-        else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, true, false>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);   // one term: its space factor in LDS
-        else hipLaunchKernelGGL((ecfr_kernel<2, true, false>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);
+        const int fme = force_mode(lf) == 0 ? 0 : force_mode(lf) == 1 ? 4 : 2;   // (one term: its space factor in LDS)
+        const bool small = lf.dev.T == LANES && small_wg_instances();
+#define ECFR_UP(F, ...)                                                                                                               \
+    if (fme == F) hipLaunchKernelGGL((ecfr_kernel<F, true, false, ##__VA_ARGS__>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, \
+                                     sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);
+        if (small) { ECFR_UP(0, LANES) ECFR_UP(4, LANES) ECFR_UP(2, LANES) }
+        else { ECFR_UP(0) ECFR_UP(4) ECFR_UP(2) }
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -4176,9 +4215,13 @@ static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int sto
     Timed timed(e, MGRIT_HIP_T_EC_RELAX_RES, lvl);
     double *const *mirror = e->mirror_cur;   // null until mgrit_hip_cpoint_mirror has been called
     const int row0 = e->mirror_row0;
-    if (force_mode(lf) == 0) hipLaunchKernelGGL((ecfr_kernel<0, false, true>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
-    else if (force_mode(lf) == 1) hipLaunchKernelGGL((ecfr_kernel<4, false, true>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
-    else hipLaunchKernelGGL((ecfr_kernel<2, false, true>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
+    const int fme = force_mode(lf) == 0 ? 0 : force_mode(lf) == 1 ? 4 : 2;
+    const bool small = lf.dev.T == LANES && small_wg_instances();
+#define ECFR_RES(F, ...)                                                                                                              \
+    if (fme == F) hipLaunchKernelGGL((ecfr_kernel<F, false, true, ##__VA_ARGS__>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, \
+                                     sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
+    if (small) { ECFR_RES(0, LANES) ECFR_RES(4, LANES) ECFR_RES(2, LANES) }
+    else { ECFR_RES(0) ECFR_RES(4) ECFR_RES(2) }
     HIP_TRY(hipGetLastError());
     return 0;
 }
