@@ -582,6 +582,8 @@ def sweep_table(mg, be, nts, m_list, dof, cycle, cycles=3):
                 sym = "blk_one_kernel"       # small levels: the whole solve in one launch
         elif kind == "chain" and dof <= 1024:
             sym = "chain_kernel<1, 1, true, true>"    # one group of values: the single-workgroup chain, no exchange
+        if dof <= 1024 and kind in ("cf_fas", "ec_relax_res", "relax_fc", "f_fas", "fas_fused") or (dof <= 1024 and kind == "ec_relax" and not key.endswith("L0")):
+            sym = sym[:-1] + ", 64>"                  # levels of one group of values: the instances compiled for one wave per workgroup
         table[key] = {"kernel_symbol": sym, "launches_per_cycle": n / cycles, "ms_per_launch": tot / n, "ms_per_cycle": tot / cycles,
                       "algorithmic_bytes_per_cycle": alg.get(key, 0.0),
                       "limited_by": LIMITED_BY.get(why, LIMITED_BY["default"])}

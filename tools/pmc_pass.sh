@@ -22,7 +22,7 @@ for k, c, v in rows:
     acc[k][c].append(v)
 lines = []
 for k, cs in sorted(acc.items(), key=lambda kv: -sum(sum(v) for v in kv[1].values())):
-    nm = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
+    nm = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].replace(", 1024>", ">")[:60]
     lines.append(f"{nm:60s} n={len(next(iter(cs.values()))):5d} " + "  ".join(f"{c}={sum(v) / len(v):.4g}" for c, v in sorted(cs.items())))
 open(sys.argv[2], "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:14]))

@@ -23,7 +23,9 @@ def stamp():
 
 
 def short(name):
-    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+    """kernel name without namespace, return type and argument list; the sweeps' default workgroup-size argument (", 1024>", round 5)
+    is dropped, so that a kernel keeps the name earlier rounds' files know it by (the single-wave instances keep their ", 64>")"""
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace(", 1024>", ">")
 
 
 def newest(paths):
