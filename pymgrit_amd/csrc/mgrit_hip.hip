@@ -625,7 +625,7 @@ __device__ __forceinline__ void heat_finish(double (&x)[E], const Coef &c, doubl
 // LDSBAR: the step's one barrier as lds_barrier() -- it orders the LDS exchange of the group totals and nothing else, so it does not
 // wait for the wave's global stores (__syncthreads() does: s_waitcnt vmcnt(0)). For passes that leave whole rows of stores in
 // flight behind them and go on with Phi that issue no vector load (the block solve's passes): the rows drain under the arithmetic.
-template <bool CLOSED = false, bool LDSBAR = false>
+template <bool CLOSED = false, bool LDSBAR = false, bool ONE = false>
 __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const LaneCoef &lc, const Smem &sm, double *ga,
                                            double *gb, int n, int t, int lane, int wave, int G) {
     const int j0 = t * E, li = lane & 15;
@@ -641,17 +641,27 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
             if (j0 + k >= n) x[k] = 0.0;
     }
     const double b = scan_bwd(x, c, lc, lane);
-    if (lane == 0) { ga[wave] = a; gb[wave] = b; }
+    // ONE group, known at compile time (the TB = 64 instances of the sweeps and blk_one_kernel pass ONE = true): the carries into
+    // the only group are zero and Zf_0 is its own backward total -- what heat_chains computes from the totals through LDS, a
+    // barrier, two cross-group scans and three lane reads (C_0 = 0, Zf_1 = 0, Zf_0 = fma(0, pi, B_0) + 0 = B_0; a zero may come
+    // out with the other sign, nothing else). A lone wave's Phi is a chain of dependent instructions, ~1.45 us: 1.2 without these.
+    // ONE is a template argument: every other instance compiles exactly the code it had.
+    constexpr bool one_group = ONE;
+    if (!one_group && lane == 0) { ga[wave] = a; gb[wave] = b; }
     double P = 0.0, Q = 0.0;
     if (CLOSED) {
         const int wv = __builtin_amdgcn_readfirstlane(wave), l_last = ((n - 1) / E) & (LANES - 1);
         P = sm.wf[wv] * lc.f_in;
         Q = (lane <= l_last ? sm.wf[MAX_G + wv] : sm.wf[2 * MAX_G + wv]) * sm.lp[(l_last - lane) & (LANES - 1)];
     }
-    if (LDSBAR) lds_barrier();
-    else __syncthreads();
     double cm, zin, zf0;
-    heat_chains(c, li < G ? ga[li] : 0.0, li < G ? gb[li] : 0.0, G, wave, lane, cm, zin, zf0);
+    if (one_group) {
+        cm = 0.0; zin = 0.0; zf0 = b;
+    } else {
+        if (LDSBAR) lds_barrier();
+        else __syncthreads();
+        heat_chains(c, li < G ? ga[li] : 0.0, li < G ? gb[li] : 0.0, G, wave, lane, cm, zin, zf0);
+    }
     const double z0 = zf0 * c.ik;
     const double cb = lc.b_in * zin;
     const double2 *pt = sm.pt + (wave == G - 1 ? 512 : 0) + lane;
@@ -664,7 +674,12 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
         } else {
             w = sm.tab[slot0(t) + q * 64];
         }
-        heat_finish(x, c, cm, cb, z0, q, w, pt[q * 64]);
+        if (one_group) {   // heat_finish with both carries zero: fma(0, p, x) = x and fma(pw, 0, x) = x (up to the sign of a zero) -- no Pt read
+            x[2 * q] = fma(-z0, w.x, x[2 * q] * c.ik);
+            x[2 * q + 1] = fma(-z0, w.y, x[2 * q + 1] * c.ik);
+        } else {
+            heat_finish(x, c, cm, cb, z0, q, w, pt[q * 64]);
+        }
     }
 }
 
@@ -672,7 +687,7 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
 // advection_1d.py:129-143; arithmetic: DESIGN.md section 3). One workgroup barrier per application.
 // PART (Heat1D): 0 = the whole step; 1 = only the coefficient set and the forcing term d = u + dt*b; 2 = only the solve, for a
 // caller that puts work of its own between the two (cfas_kernel: its row stores)
-template <int KIND, int FORCE, bool CLOSED = false, int PART = 0, bool LDSBAR = false>
+template <int KIND, int FORCE, bool CLOSED = false, int PART = 0, bool LDSBAR = false, bool ONE = false>
 __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const LevelDev &L, int i, const Smem &sm, int t,
                                           int lane, int wave, int G) {
     const int ci = (PART == 2 || L.one_cset) ? (PART == 2 ? ctx.cur : 0) : ld_uniform(L.cidx + i);
@@ -687,8 +702,9 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const Le
             for (int q = 0; q < 8; ++q) sm.tab[slot0(t) + q * 64] = src[q * 64];
         }
         if (t < LANES) sm.lp[t] = g->lp[t];
-        if (KIND == MGRIT_HIP_STEPPER_HEAT1D && t < 2 * 512) sm.pt[t] = L.ptP[(size_t)ci * 1024 + t];
-        if (KIND == MGRIT_HIP_STEPPER_HEAT1D && L.T < 1024)
+        // (ONE: a single group's finishing pass has no carries to apply and never reads Pt -- 16 KB less to stage per workgroup)
+        if (KIND == MGRIT_HIP_STEPPER_HEAT1D && !ONE && t < 2 * 512) sm.pt[t] = L.ptP[(size_t)ci * 1024 + t];
+        if (KIND == MGRIT_HIP_STEPPER_HEAT1D && !ONE && L.T < 1024)
             for (int r = t + L.T; r < 1024; r += L.T) sm.pt[r] = L.ptP[(size_t)ci * 1024 + r];
         load_coef(ctx.c, g);
         ctx.cur = ci;
@@ -703,7 +719,7 @@ __device__ __forceinline__ void phi_apply(double (&x)[E], StepCtx &ctx, const Le
         static_assert(FORCE != 4 || CLOSED, "FORCE 4 keeps the forcing factor where the correction table would be");
         if (PART != 2) add_forcing<FORCE>(x, ctx, L, i, t, sm);
         if (PART == 1) { ctx.parity ^= 1; return; }   // (the solve of PART 2 flips the parity back to this step's)
-        heat_solve<CLOSED, LDSBAR>(x, c, lc, sm, ga, gb, L.n, t, lane, wave, G);
+        heat_solve<CLOSED, LDSBAR, ONE>(x, c, lc, sm, ga, gb, L.n, t, lane, wave, G);
     } else {
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] * c.ik;
@@ -784,8 +800,8 @@ __device__ __forceinline__ void stage_forcing(const Smem &sm, const LevelDev &L,
 
 extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
-#define WG_PROLOGUE                                                                        \
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = blockDim.x >> 6;          \
+#define WG_PROLOGUE_G(WAVE_, G_)                                                           \
+    const int t = threadIdx.x, lane = t & 63, wave = (WAVE_), G = (G_);                    \
     const Smem sm = carve_smem(smem_raw, L.T, KIND != MGRIT_HIP_STEPPER_ADVECTION1D);      \
     const unsigned sl = slot0(t);                                                          \
     StepCtx ctx;                                                                           \
@@ -793,6 +809,10 @@ extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     WgQueue wq;                                                                            \
     (void)wgq_slot; (void)wq;                                                              \
     ctx_init<KIND, FORCE>(ctx, L, t)
+#define WG_PROLOGUE WG_PROLOGUE_G(t >> 6, (int)(blockDim.x >> 6))
+// an instance compiled for TB threads: TB = 64 is ONE wave (G = 1, wave = 0 as constants); such a kernel also passes ONE = true to
+// its Phi, and heat_solve then drops the exchange of the group totals, its barrier and the cross-group scans -- see there
+#define WG_PROLOGUE_TB(TB_) WG_PROLOGUE_G((TB_) == LANES ? 0 : (int)(threadIdx.x >> 6), (TB_) == LANES ? 1 : (int)(blockDim.x >> 6))
 
 // f_relax / c_relax / forward_solve (mgrit.py:292-370,459-486). ROLE only separates the launches by purpose (distinct
 // kernel symbols in rocprof traces; the weighted C-relaxation is the only one that re-reads the old u_i).
@@ -817,7 +837,8 @@ bool small_wg_instances() {
 template <int KIND, int FORCE, bool USE_G, int ROLE, int TB = 1024>
 __global__ void __launch_bounds__(TB) relax_kernel(LevelDev L, const int32_t *__restrict__ run_start,
                                                      const int32_t *__restrict__ run_len, int n_runs, double w, double w1) {
-    WG_PROLOGUE;
+    WG_PROLOGUE_TB(TB);
+    constexpr bool ONE = TB == LANES;   // one wave per state: Phi without the cross-group exchange (heat_solve)
     // persistent workgroups: the grid is sized to the chip (not to the run list), each workgroup walks the runs with
     // stride gridDim.x and keeps the coefficient tables of its current time-step size in LDS / SGPRs across runs
     for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < n_runs; wq.advance(t)) {
@@ -828,7 +849,7 @@ __global__ void __launch_bounds__(TB) relax_kernel(LevelDev L, const int32_t *__
         load_row_nt((ROLE == ROLE_FC ? L.v : L.u) + (size_t)(start - 1) * L.ld, sl, x, ROLE == ROLE_FC ? L.stream_rows : 0);
         for (int i = start; i < start + len; ++i) {
             if (USE_G) load_row_nt(L.g + (size_t)i * L.ld, sl, gi, ROLE == ROLE_FC ? L.stream_rows : 0);  // in flight while Phi runs
-            phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+            phi_apply<KIND, FORCE, false, 0, false, ONE>(x, ctx, L, i, sm, t, lane, wave, G);
             if (USE_G) {
 #pragma unroll
                 for (int k = 0; k < E; ++k) x[k] = gi[k] + x[k];
@@ -853,7 +874,8 @@ template <int KIND, int FORCE, bool USE_G, int TB = 1024>
 __global__ void __launch_bounds__(TB) ecf_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ run_start,
                                                    const int32_t *__restrict__ run_len, const int32_t *__restrict__ ec_coarse,
                                                    int n_runs) {
-    WG_PROLOGUE;
+    WG_PROLOGUE_TB(TB);
+    constexpr bool ONE = TB == LANES;   // one wave per state: Phi without the cross-group exchange (heat_solve)
     for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < n_runs; wq.advance(t)) {
         const int r = wq.cur;
         wq.prefetch(t);
@@ -871,7 +893,7 @@ __global__ void __launch_bounds__(TB) ecf_kernel(LevelDev L, LevelDev Lc, const 
         }
         for (int i = start; i < start + len; ++i) {
             if (USE_G) load_row_nt(L.g + (size_t)i * L.ld, sl, gi, L.stream_rows);
-            phi_apply<KIND, FORCE>(x, ctx, L, i, sm, t, lane, wave, G);
+            phi_apply<KIND, FORCE, false, 0, false, ONE>(x, ctx, L, i, sm, t, lane, wave, G);
             if (USE_G) {
 #pragma unroll
                 for (int k = 0; k < E; ++k) x[k] = gi[k] + x[k];
@@ -1050,7 +1072,7 @@ __global__ void __launch_bounds__(1024) fas_fused_kernel(LevelDev L, LevelDev Lc
 // correction table, Pt and the forcing factors of Lc are read straight from global memory -- 144 KB per level that every
 // workgroup reads, so they stay in L2 and cost no HBM traffic -- and its scalar coefficients live only for this call (the
 // caller reloads its own set afterwards: both at once do not fit the SGPR file). Arithmetic identical to phi_apply on Lc.
-template <int FORCE, bool LDSBAR = false>
+template <int FORCE, bool LDSBAR = false, bool ONE = false>
 __device__ __forceinline__ void phi_other_level(double (&w)[E], StepCtx &ctx, const LevelDev &Lc, int j, const Smem &sm, unsigned sl,
                                                 int t, int lane, int wave, int G) {
     const int cj = Lc.one_cset ? 0 : ld_uniform(Lc.cidx + j);
@@ -1079,7 +1101,7 @@ __device__ __forceinline__ void phi_other_level(double (&w)[E], StepCtx &ctx, co
     const LaneCoef lcc = lane_coef(smc.lp, lane);
     const int par = ctx.parity;
     ctx.parity ^= 1;
-    heat_solve<true, LDSBAR>(w, ctx.c, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
+    heat_solve<true, LDSBAR, ONE>(w, ctx.c, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
 }
 
 __device__ __forceinline__ void stage_other_level(const Smem &sm, const LevelDev &Lc, int t) {
@@ -1127,7 +1149,8 @@ struct IntervalsDev {
 template <int FORCE, int TB = 1024>
 __global__ void __launch_bounds__(TB) cfas_kernel(LevelDev L, LevelDev Lc, IntervalsDev I, int pre) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
-    WG_PROLOGUE;
+    WG_PROLOGUE_TB(TB);
+    constexpr bool ONE = TB == LANES;   // one wave per state: Phi without the cross-group exchange (heat_solve)
     stage_other_level(sm, Lc, t);
     for (wq.begin(L.sched, L.xcc0_limit, wgq_slot, t); wq.cur < I.n_chunks; wq.advance(t)) {
         const int k = wq.cur;
@@ -1140,7 +1163,7 @@ __global__ void __launch_bounds__(TB) cfas_kernel(LevelDev L, LevelDev Lc, Inter
                 load_row_nt(L.u + (size_t)(cs - 1) * L.ld, sl, x, L.stream_rows);
                 if (!pre) {
                     if (ctx.cur >= 0) load_coef(ctx.c, L.cs + ctx.cur);
-                    phi_apply<KIND, FORCE, true>(x, ctx, L, cs, sm, t, lane, wave, G);
+                    phi_apply<KIND, FORCE, true, 0, false, ONE>(x, ctx, L, cs, sm, t, lane, wave, G);
                 }
             } else {
                 load_row_nt(L.u + (size_t)cs * L.ld, sl, x, L.stream_rows);
@@ -1154,29 +1177,29 @@ __global__ void __launch_bounds__(TB) cfas_kernel(LevelDev L, LevelDev Lc, Inter
                 double w[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e) w[e] = x[e];
-                phi_other_level<FORCE>(w, ctx, Lc, jc, sm, sl, t, lane, wave, G);
+                phi_other_level<FORCE, false, ONE>(w, ctx, Lc, jc, sm, sl, t, lane, wave, G);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) sm.tab[sl + q * 64] = make_double2(w[2 * q], w[2 * q + 1]);   // parked in LDS
             }
             /*STAMP 0*/
             load_coef(ctx.c, L.cs + (ctx.cur >= 0 ? ctx.cur : 0));   // back to this level's set (ctx.cur < 0: any set, phi_apply loads the right one)
             /*STAMP 9*/
-            for (int i = cs + 1; i < ce; ++i) phi_apply<KIND, FORCE, true>(x, ctx, L, i, sm, t, lane, wave, G);
+            for (int i = cs + 1; i < ce; ++i) phi_apply<KIND, FORCE, true, 0, false, ONE>(x, ctx, L, i, sm, t, lane, wave, G);
             /*STAMP 1*/
             double b[E];
             load_row_nt(L.u + (size_t)(ce - 1) * L.ld, sl, b, L.stream_rows);   // (requested one Phi earlier it costs more in spills than it hides)
             /*STAMP 2*/
-            if (!pre) phi_apply<KIND, FORCE, true>(b, ctx, L, ce, sm, t, lane, wave, G);
+            if (!pre) phi_apply<KIND, FORCE, true, 0, false, ONE>(b, ctx, L, ce, sm, t, lane, wave, G);
             // the residual Phi in two parts around the row stores: its forcing term (vector loads of the space factor) AHEAD of
             // them -- a load issued behind stores retires behind them (vmcnt counts in order), and the Phi would wait for their
             // round trip to HBM --, its solve (LDS and registers only) behind them
-            phi_apply<KIND, FORCE, true, 1>(x, ctx, L, ce, sm, t, lane, wave, G);
+            phi_apply<KIND, FORCE, true, 1, false, ONE>(x, ctx, L, ce, sm, t, lane, wave, G);
             store_row_nt(L.u + (size_t)ce * L.ld, sl, b, L.stream_rows);
             const int keep = __builtin_amdgcn_readfirstlane(I.keep[it]);
             if (keep & 1) store_row_nt(Lc.u + (size_t)jc * Lc.ld, sl, b, Lc.stream_rows);
             if (keep & 2) store_row_nt(Lc.v + (size_t)jc * Lc.ld, sl, b, Lc.stream_rows);
             /*STAMP 3*/
-            phi_apply<KIND, FORCE, true, 2>(x, ctx, L, ce, sm, t, lane, wave, G);
+            phi_apply<KIND, FORCE, true, 2, false, ONE>(x, ctx, L, ce, sm, t, lane, wave, G);
             /*STAMP 4*/
 #pragma unroll
             for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
@@ -1218,7 +1241,8 @@ __global__ void __launch_bounds__(TB) ecfr_kernel(LevelDev L, LevelDev Lc, Inter
                                                     double *const *__restrict__ mirror, int mirror_row0) {
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
     constexpr bool CF = FORCE == 4;   // forcing factor in LDS, so every Phi in closed form
-    WG_PROLOGUE;
+    WG_PROLOGUE_TB(TB);
+    constexpr bool ONE = TB == LANES;   // one wave per state: Phi without the cross-group exchange (heat_solve)
     stage_forcing<FORCE>(sm, L, sl);
     // C-point mirror (mgrit_hip_cpoint_mirror): every corrected C-point also goes to row mirror_row0 + res_pos of the slab the
     // caller has named for THIS cycle (read once per workgroup: the caller changes it between cycles, on the stream)
@@ -1245,7 +1269,7 @@ __global__ void __launch_bounds__(TB) ecfr_kernel(LevelDev L, LevelDev Lc, Inter
             for (int i = cs + 1; i < ce; ++i) {
                 double gi[E];
                 if (USE_G) load_row_nt(L.g + (size_t)i * L.ld, sl, gi, L.stream_rows);   // in flight while Phi runs
-                phi_apply<KIND, FORCE, CF>(x, ctx, L, i, sm, t, lane, wave, G);
+                phi_apply<KIND, FORCE, CF, 0, false, ONE>(x, ctx, L, i, sm, t, lane, wave, G);
                 if (USE_G) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) x[e] = gi[e] + x[e];
@@ -1263,7 +1287,7 @@ __global__ void __launch_bounds__(TB) ecfr_kernel(LevelDev L, LevelDev Lc, Inter
             store_row_nt(L.u + (size_t)ce * L.ld, sl, b, L.stream_rows);
             if (RES && mir) store_row_nt(mir + (size_t)(mirror_row0 + I.res_pos[it]) * L.ld, sl, b, 1);
             if (RES) {
-                phi_apply<KIND, FORCE, CF>(x, ctx, L, ce, sm, t, lane, wave, G);
+                phi_apply<KIND, FORCE, CF, 0, false, ONE>(x, ctx, L, ce, sm, t, lane, wave, G);
                 if (store_f == 2) store_row_nt(L.u + (size_t)(ce - 1) * L.ld, sl, x, L.stream_rows);   // Phi(last F-point): the next C-relaxation's value
 #pragma unroll
                 for (int e = 0; e < E; ++e) x[e] = x[e] - b[e];
@@ -1293,7 +1317,8 @@ __global__ void __launch_bounds__(TB) fas_fused1_kernel(LevelDev L, LevelDev Lc,
     //   the way up rewrites them); bit 1: u^{l+1}_j is not stored (a coarsest level that forward_solve overwrites unread)
     constexpr int KIND = MGRIT_HIP_STEPPER_HEAT1D;
     constexpr bool CF = FORCE == 4;   // forcing factor in LDS, so every Phi in closed form
-    WG_PROLOGUE;
+    WG_PROLOGUE_TB(TB);
+    constexpr bool ONE = TB == LANES;   // one wave per state: Phi without the cross-group exchange (heat_solve)
     stage_forcing<FORCE>(sm, L, sl);
     stage_other_level(sm, Lc, t);
     Smem smc = sm;
@@ -1317,7 +1342,7 @@ __global__ void __launch_bounds__(TB) fas_fused1_kernel(LevelDev L, LevelDev Lc,
 #pragma unroll
                     for (int e = 0; e < E; ++e) w[e] = w[e] - ui[e];
                 }
-                phi_apply<KIND, FORCE, CF>(x, ctx, L, k, sm, t, lane, wave, G);
+                phi_apply<KIND, FORCE, CF, 0, false, ONE>(x, ctx, L, k, sm, t, lane, wave, G);
 #pragma unroll
                 for (int e = 0; e < E; ++e) x[e] = w[e] + x[e];
             }
@@ -1333,7 +1358,7 @@ __global__ void __launch_bounds__(TB) fas_fused1_kernel(LevelDev L, LevelDev Lc,
 #pragma unroll
                 for (int k = 0; k < E; ++k) w[k] = gi[k] - w[k];
             }
-            phi_apply<KIND, FORCE, CF>(x, ctx, L, i, sm, t, lane, wave, G);
+            phi_apply<KIND, FORCE, CF, 0, false, ONE>(x, ctx, L, i, sm, t, lane, wave, G);
             if (use_g) {
 #pragma unroll
                 for (int k = 0; k < E; ++k) x[k] = w[k] + x[k];
@@ -1378,7 +1403,7 @@ __global__ void __launch_bounds__(TB) fas_fused1_kernel(LevelDev L, LevelDev Lc,
             const LaneCoef lcc = lane_coef(smc.lp, lane);
             const int par = ctx.parity;
             ctx.parity ^= 1;
-            heat_solve<true>(w, cc, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
+            heat_solve<true, false, ONE>(w, cc, lcc, smc, sm.ga + par * MAX_G, sm.gb + par * MAX_G, Lc.n, t, lane, wave, G);
         }
 #pragma unroll
         for (int k = 0; k < E; ++k) x[k] = x[k] - w[k];
