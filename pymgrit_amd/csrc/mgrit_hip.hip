@@ -644,8 +644,8 @@ __device__ __forceinline__ void heat_solve(double (&x)[E], const Coef &c, const 
     // ONE group, known at compile time (the TB = 64 instances of the sweeps and blk_one_kernel pass ONE = true): the carries into
     // the only group are zero and Zf_0 is its own backward total -- what heat_chains computes from the totals through LDS, a
     // barrier, two cross-group scans and three lane reads (C_0 = 0, Zf_1 = 0, Zf_0 = fma(0, pi, B_0) + 0 = B_0; a zero may come
-    // out with the other sign, nothing else). A lone wave's Phi is a chain of dependent instructions, ~1.45 us: 1.2 without these.
-    // ONE is a template argument: every other instance compiles exactly the code it had.
+    // out with the other sign, nothing else). A lone wave's Phi is a chain of dependent instructions: 1.45 us in the general form,
+    // 1.05 us with this and the finishing pass below. ONE is a template argument: every other instance compiles exactly the code it had.
     constexpr bool one_group = ONE;
     if (!one_group && lane == 0) { ga[wave] = a; gb[wave] = b; }
     double P = 0.0, Q = 0.0;
@@ -824,11 +824,12 @@ extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 enum { ROLE_F = 0, ROLE_C = 1, ROLE_C_WEIGHTED = 2, ROLE_FC = 3 };
 
 // TB (the sweeps of a Heat1D cycle: relax_kernel ROLE_FC, ecf_kernel, cfas_kernel, ecfr_kernel, fas_fused1_kernel): the workgroup
-// size the instance is compiled for. States of one group (n <= 1024) run one WAVE per state, and a lone wave issues about one
-// instruction per 8 cycles -- every instruction counts; compiled for 1024 threads the kernels keep to 128 VGPRs and spill 100-350
-// SGPRs and up to 90 VGPRs, whose reloads are instructions in every Phi. The TB = 64 instances (512 VGPRs, no spill code) take the
-// launches of such levels: config 2's five sweeps 17-32 us -> 14-27 us each. Same source, same operations, same bits
-// (MGRIT_HIP_SMALL_WG=0: the 1024-thread instances everywhere).
+// size the instance is compiled for. States of one group (n <= 1024) run one WAVE per state: nothing hides behind other waves, the
+// kernel's time is that wave's chain of dependent instructions. Compiled for 1024 threads the kernels keep to 128 VGPRs and spill
+// 100-350 SGPRs and up to 90 VGPRs, whose reloads sit in that chain in every Phi; the TB = 64 instances (512 VGPRs, no VGPR spill)
+// take the launches of such levels and know at compile time that the state is ONE group (heat_solve<.., ONE>): config 2's five
+// sweeps 17-32 us -> 11-20 us each. Same source; the values of the 1024-thread instances (MGRIT_HIP_SMALL_WG=0 launches those
+// everywhere), up to the sign of a zero.
 bool small_wg_instances() {
     const char *s = std::getenv("MGRIT_HIP_SMALL_WG");      // (read per launch: a test compares the two families in one process)
     return !(s && s[0] == '0' && s[1] == 0);
