@@ -834,6 +834,15 @@ bool small_wg_instances() {
     const char *s = std::getenv("MGRIT_HIP_SMALL_WG");      // (read per launch: a test compares the two families in one process)
     return !(s && s[0] == '0' && s[1] == 0);
 }
+// ... and TB = 512 for states of up to 8192 values (workgroups of 128 .. 512 threads): 256 VGPRs, no VGPR spills -- these sweeps are
+// bound by memory bandwidth and by Phi's issue slots, and spill traffic costs both (heat_1d 8192 x 16385: 1.14 -> 1.01 ms per cycle).
+// MGRIT_HIP_MID_WG=0: the 1024-thread instances for them.
+bool mid_wg_instances() {
+    const char *s = std::getenv("MGRIT_HIP_MID_WG");
+    return !(s && s[0] == '0' && s[1] == 0);
+}
+// the instance (its TB) that takes a launch of T threads
+int sweep_tb(int T) { return T == LANES ? (small_wg_instances() ? LANES : 1024) : T <= 512 ? (mid_wg_instances() ? 512 : 1024) : 1024; }
 
 template <int KIND, int FORCE, bool USE_G, int ROLE, int TB = 1024>
 __global__ void __launch_bounds__(TB) relax_kernel(LevelDev L, const int32_t *__restrict__ run_start,
@@ -1918,7 +1927,12 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(gen_down_kernel<K, F, true>))) return rc;                                                \
     if ((rc = allow_big_lds(gen_up_kernel<K, F, false, false>))) return rc;                                          \
     if ((rc = allow_big_lds(gen_up_kernel<K, F, false, true>))) return rc;                                           \
-    if ((rc = allow_big_lds(gen_up_kernel<K, F, true, false>))) return rc;
+    if ((rc = allow_big_lds(gen_up_kernel<K, F, true, false>))) return rc;                                           \
+    if ((rc = allow_big_lds(gen_down_kernel<K, F, false, 512>))) return rc;                                          \
+    if ((rc = allow_big_lds(gen_down_kernel<K, F, true, 512>))) return rc;                                           \
+    if ((rc = allow_big_lds(gen_up_kernel<K, F, false, false, 512>))) return rc;                                     \
+    if ((rc = allow_big_lds(gen_up_kernel<K, F, false, true, 512>))) return rc;                                      \
+    if ((rc = allow_big_lds(gen_up_kernel<K, F, true, false, 512>))) return rc;
     FOR_EACH_STEPPER(ATTR_ALL)
 #define ATTR_CHAIN_LOCAL(K, F)                                                                                       \
     if ((rc = allow_big_lds(chain_local_kernel<K, F, false>, chain_local_lds(CHAIN_LOCAL_MAX_G)))) return rc;          \
@@ -1943,6 +1957,19 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(fas_fused1_kernel<4, false>))) return rc;
     if ((rc = allow_big_lds(fas_fused1_kernel<4, true>))) return rc;
     if ((rc = allow_big_lds(jump_kernel))) return rc;
+    // the sweeps' instances compiled for 512 threads (sweep_tb): up to 83 KB of LDS
+#define ATTR_MID(F)                                                                                                                    \
+    if ((rc = allow_big_lds(relax_kernel<MGRIT_HIP_STEPPER_HEAT1D, F, true, ROLE_FC, 512>))) return rc;                                \
+    if ((rc = allow_big_lds(ecf_kernel<MGRIT_HIP_STEPPER_HEAT1D, F, true, 512>))) return rc;
+    ATTR_MID(0) ATTR_MID(1) ATTR_MID(2)
+#define ATTR_MID2(F)                                                                                                                   \
+    if ((rc = allow_big_lds(ecfr_kernel<F, false, true, 512>))) return rc;                                                             \
+    if ((rc = allow_big_lds(ecfr_kernel<F, true, false, 512>))) return rc;                                                             \
+    if ((rc = allow_big_lds(fas_fused1_kernel<F, false, 512>))) return rc;                                                             \
+    if ((rc = allow_big_lds(fas_fused1_kernel<F, true, 512>))) return rc;
+    ATTR_MID2(0) ATTR_MID2(2) ATTR_MID2(4)
+    if ((rc = allow_big_lds(cfas_kernel<0, 512>))) return rc;
+    if ((rc = allow_big_lds(cfas_kernel<2, 512>))) return rc;
 #define ATTR_BLK(F)                                                                                                   \
     if ((rc = allow_big_lds(blk_local_kernel<MGRIT_HIP_STEPPER_HEAT1D, F>, blk_smem_bytes(MAX_G)))) return rc;        \
     if ((rc = allow_big_lds(blk_finish_kernel<MGRIT_HIP_STEPPER_HEAT1D, F>, blk_smem_bytes(MAX_G)))) return rc;
@@ -2613,6 +2640,12 @@ int check_bound(const Level &lv, bool need_vg) {
 
 // grid of persistent workgroups: as many as stay resident on the chip (LDS- and thread-limited), at most one per item
 bool is_2pts(const Level &lv) { return lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D_2PTS; }
+
+// MGRIT_HIP_GEN_512=0: the general whole-level passes in their 1024-thread instances everywhere (measurement and comparison; same bits)
+bool gen_half_instances() {
+    const char *s = std::getenv("MGRIT_HIP_GEN_512");
+    return !(s && s[0] == '0' && s[1] == 0);
+}
 
 int wgs_per_cu(const Level &lv) {
     const size_t lds = is_2pts(lv) ? smem2_bytes(lv.G) : smem_bytes(lv.G, lv.dev.kind);
@@ -3637,11 +3670,12 @@ int mgrit_hip_relax(mgrit_hip_engine *e, int lvl, int runs_id, int mode, double 
     RELAX_CASE(K, F, true, ROLE_C) RELAX_CASE(K, F, false, ROLE_C_WEIGHTED) RELAX_CASE(K, F, true, ROLE_C_WEIGHTED) \
     RELAX_CASE(K, F, true, ROLE_FC)
         // (one-group Heat1D levels: the F+C pass of a cycle compiled for ONE wave per workgroup, see small_wg_instances)
-        if (lv.dev.T == LANES && small_wg_instances() && lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && use_g && role == ROLE_FC && fm <= 2) {
-#define RELAX_SMALL(F)                                                                                                                \
-    if (fm == F) hipLaunchKernelGGL((relax_kernel<MGRIT_HIP_STEPPER_HEAT1D, F, true, ROLE_FC, LANES>), grid, block, lds, e->stream, \
-                                    sched_dev(e, lv), rl->d_start, rl->d_len, rl->n, w, w1);
-            RELAX_SMALL(0) RELAX_SMALL(1) RELAX_SMALL(2)
+        const int tb = sweep_tb(lv.dev.T);
+        if (tb != 1024 && lv.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && use_g && role == ROLE_FC && fm <= 2) {
+#define RELAX_SMALL(F, TB_)                                                                                                           \
+    if (fm == F && tb == TB_) hipLaunchKernelGGL((relax_kernel<MGRIT_HIP_STEPPER_HEAT1D, F, true, ROLE_FC, TB_>), grid, block, lds, e->stream, \
+                                                 sched_dev(e, lv), rl->d_start, rl->d_len, rl->n, w, w1);
+            RELAX_SMALL(0, LANES) RELAX_SMALL(1, LANES) RELAX_SMALL(2, LANES) RELAX_SMALL(0, 512) RELAX_SMALL(1, 512) RELAX_SMALL(2, 512)
         } else {
             FOR_EACH_STEPPER(RELAX_CASES)
         }
@@ -3862,11 +3896,14 @@ int mgrit_hip_fas_fused_opts(mgrit_hip_engine *e, int lvl, int triples_id, int o
         // level's factor is the same vector (same spatial grid, same rhs), so the coarse Phi takes it from there too
         if (lf.same_factor_below < 0) lf.same_factor_below = (fm == 1 && lf.s_host == lc.s_host) ? 1 : 0;   // (131 KB compared once)
         const int kopts = opts | (lf.same_factor_below ? 4 : 0);
-        const bool small = lf.dev.T == LANES && small_wg_instances();
+        const int tb = sweep_tb(lf.dev.T);
 #define FAS1_CASE(F_, P_)                                                                                                  \
     if ((fm == 0 ? 0 : fm == 1 ? 4 : 2) == F_ && ((opts & MGRIT_HIP_FAS_WITH_F_RELAX) != 0) == P_) {                        \
-        if (small)                                                                                                         \
+        if (tb == LANES)                                                                                                   \
             hipLaunchKernelGGL((fas_fused1_kernel<F_, P_, LANES>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), \
+                               lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g, kopts);                          \
+        else if (tb == 512)                                                                                                \
+            hipLaunchKernelGGL((fas_fused1_kernel<F_, P_, 512>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), \
                                lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g, kopts);                          \
         else                                                                                                               \
             hipLaunchKernelGGL((fas_fused1_kernel<F_, P_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), \
@@ -4021,11 +4058,12 @@ int mgrit_hip_ec_relax(mgrit_hip_engine *e, int lvl, int ec_runs_id) {
         hipLaunchKernelGGL((ecf_kernel<K, F, G_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, rl->d_start,  \
                            rl->d_len, rl->d_ec, rl->n);
 #define ECF_CASES(K, F) ECF_CASE(K, F, false) ECF_CASE(K, F, true)
-    if (lf.dev.T == LANES && small_wg_instances() && lf.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && use_g && fm <= 2) {
-#define ECF_SMALL(F)                                                                                                                  \
-    if (fm == F) hipLaunchKernelGGL((ecf_kernel<MGRIT_HIP_STEPPER_HEAT1D, F, true, LANES>), grid, block, smem_bytes(lf.G, lf.dev.kind), \
-                                    e->stream, sched_dev(e, lf), lc.dev, rl->d_start, rl->d_len, rl->d_ec, rl->n);
-        ECF_SMALL(0) ECF_SMALL(1) ECF_SMALL(2)
+    const int tb = sweep_tb(lf.dev.T);
+    if (tb != 1024 && lf.dev.kind == MGRIT_HIP_STEPPER_HEAT1D && use_g && fm <= 2) {
+#define ECF_SMALL(F, TB_)                                                                                                             \
+    if (fm == F && tb == TB_) hipLaunchKernelGGL((ecf_kernel<MGRIT_HIP_STEPPER_HEAT1D, F, true, TB_>), grid, block, smem_bytes(lf.G, lf.dev.kind), \
+                                                 e->stream, sched_dev(e, lf), lc.dev, rl->d_start, rl->d_len, rl->d_ec, rl->n);
+        ECF_SMALL(0, LANES) ECF_SMALL(1, LANES) ECF_SMALL(2, LANES) ECF_SMALL(0, 512) ECF_SMALL(1, 512) ECF_SMALL(2, 512)
     } else {
         FOR_EACH_STEPPER(ECF_CASES)
     }
@@ -4196,9 +4234,11 @@ int mgrit_hip_cf_fas(mgrit_hip_engine *e, int lvl, int ivals_id, int pre_relaxed
     if (I.n_chunks == 0) return 0;
     Timed timed(e, MGRIT_HIP_T_CF_FAS, lvl);
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
-    const bool small = lf.dev.T == LANES && small_wg_instances();   // (one wave per state: the instances compiled for it)
-    if (force_mode(lf) == 0 && small) hipLaunchKernelGGL((cfas_kernel<0, LANES>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
-    else if (small) hipLaunchKernelGGL((cfas_kernel<2, LANES>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    const int tb = sweep_tb(lf.dev.T);   // (one wave per state / up to 512 threads: the instances compiled for it)
+    if (force_mode(lf) == 0 && tb == LANES) hipLaunchKernelGGL((cfas_kernel<0, LANES>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    else if (tb == LANES) hipLaunchKernelGGL((cfas_kernel<2, LANES>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    else if (force_mode(lf) == 0 && tb == 512) hipLaunchKernelGGL((cfas_kernel<0, 512>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
+    else if (tb == 512) hipLaunchKernelGGL((cfas_kernel<2, 512>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
     else if (force_mode(lf) == 0) hipLaunchKernelGGL((cfas_kernel<0>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
     else hipLaunchKernelGGL((cfas_kernel<2>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, pre_relaxed ? 1 : 0);
     HIP_TRY(hipGetLastError());
@@ -4226,11 +4266,12 @@ static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int sto
     if (lvl > 0) {   // coarser level: rows of g, every F-point stored (the finer level's correction reads them), no residual
         Timed timed(e, MGRIT_HIP_T_EC_RELAX, lvl);
         const int fme = force_mode(lf) == 0 ? 0 : force_mode(lf) == 1 ? 4 : 2;   // (one term: its space factor in LDS)
-        const bool small = lf.dev.T == LANES && small_wg_instances();
+        const int tb = sweep_tb(lf.dev.T);
 #define ECFR_UP(F, ...)                                                                                                               \
     if (fme == F) hipLaunchKernelGGL((ecfr_kernel<F, true, false, ##__VA_ARGS__>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, \
                                      sched_dev(e, lf), lc.dev, I, (double *)nullptr, 1, (double *const *)nullptr, 0);
-        if (small) { ECFR_UP(0, LANES) ECFR_UP(4, LANES) ECFR_UP(2, LANES) }
+        if (tb == LANES) { ECFR_UP(0, LANES) ECFR_UP(4, LANES) ECFR_UP(2, LANES) }
+        else if (tb == 512) { ECFR_UP(0, 512) ECFR_UP(4, 512) ECFR_UP(2, 512) }
         else { ECFR_UP(0) ECFR_UP(4) ECFR_UP(2) }
         HIP_TRY(hipGetLastError());
         return 0;
@@ -4242,11 +4283,12 @@ static int ec_relax_res_impl(mgrit_hip_engine *e, int lvl, int ivals_id, int sto
     double *const *mirror = e->mirror_cur;   // null until mgrit_hip_cpoint_mirror has been called
     const int row0 = e->mirror_row0;
     const int fme = force_mode(lf) == 0 ? 0 : force_mode(lf) == 1 ? 4 : 2;
-    const bool small = lf.dev.T == LANES && small_wg_instances();
+    const int tb = sweep_tb(lf.dev.T);
 #define ECFR_RES(F, ...)                                                                                                              \
     if (fme == F) hipLaunchKernelGGL((ecfr_kernel<F, false, true, ##__VA_ARGS__>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, \
                                      sched_dev(e, lf), lc.dev, I, out, store_all_f, mirror, row0);
-    if (small) { ECFR_RES(0, LANES) ECFR_RES(4, LANES) ECFR_RES(2, LANES) }
+    if (tb == LANES) { ECFR_RES(0, LANES) ECFR_RES(4, LANES) ECFR_RES(2, LANES) }
+    else if (tb == 512) { ECFR_RES(0, 512) ECFR_RES(4, 512) ECFR_RES(2, 512) }
     else { ECFR_RES(0) ECFR_RES(4) ECFR_RES(2) }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -4301,9 +4343,12 @@ int mgrit_hip_gen_down_part(mgrit_hip_engine *e, int lvl, int ivals_id, int part
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
     const bool use_g = lvl > 0;
     const int fm = force_mode(lf);
+    const bool half = lf.dev.T <= 512 && gen_half_instances();   // (states of <= 8192 values: the instances compiled for 512 threads)
 #define GEN_DOWN_CASE(K, F, G_)                                                                                     \
-    if (lf.dev.kind == K && fm == F && use_g == G_)                                                                 \
-        hipLaunchKernelGGL((gen_down_kernel<K, F, G_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, Cb, tk);
+    if (lf.dev.kind == K && fm == F && use_g == G_) {                                                               \
+        if (half) hipLaunchKernelGGL((gen_down_kernel<K, F, G_, 512>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, Cb, tk); \
+        else hipLaunchKernelGGL((gen_down_kernel<K, F, G_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, Cb, tk); \
+    }
 #define GEN_DOWN_CASES(K, F) GEN_DOWN_CASE(K, F, false) GEN_DOWN_CASE(K, F, true)
     FOR_EACH_STEPPER(GEN_DOWN_CASES)
     HIP_TRY(hipGetLastError());
@@ -4331,9 +4376,12 @@ int mgrit_hip_gen_up(mgrit_hip_engine *e, int lvl, int ivals_id, int with_residu
     const dim3 grid(persistent_grid(lf, I.n_chunks)), block(lf.dev.T);
     const bool use_g = lvl > 0, res = with_residual != 0;
     const int fm = force_mode(lf), tk = lf.transfer;
+    const bool half = lf.dev.T <= 512 && gen_half_instances();
 #define GEN_UP_CASE(K, F, G_, R_)                                                                                    \
-    if (lf.dev.kind == K && fm == F && use_g == G_ && res == R_)                                                      \
-        hipLaunchKernelGGL((gen_up_kernel<K, F, G_, R_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, Cb, out, tk);
+    if (lf.dev.kind == K && fm == F && use_g == G_ && res == R_) {                                                    \
+        if (half) hipLaunchKernelGGL((gen_up_kernel<K, F, G_, R_, 512>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, Cb, out, tk); \
+        else hipLaunchKernelGGL((gen_up_kernel<K, F, G_, R_>), grid, block, smem_bytes(lf.G, lf.dev.kind), e->stream, sched_dev(e, lf), lc.dev, I, Cb, out, tk); \
+    }
 #define GEN_UP_CASES(K, F) GEN_UP_CASE(K, F, false, false) GEN_UP_CASE(K, F, false, true) GEN_UP_CASE(K, F, true, false)
     FOR_EACH_STEPPER(GEN_UP_CASES)
     HIP_TRY(hipGetLastError());

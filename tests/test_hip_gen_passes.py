@@ -49,6 +49,21 @@ def test_general_passes_bit_identical_to_the_sweeps(case):
             assert np.array_equal(a, b), (case, blocks)
 
 
+@pytest.mark.parametrize("case", ["heat_spatial_coarsening_F", "advsc:adv_sc_F", "advection_nx2049_wide"])
+def test_512_thread_instances_equal_the_1024_thread_instances(case, monkeypatch):
+    """states of up to 8192 values launch the passes in instances compiled for 512 threads (no VGPR spills; config 5 5.4 -> 4.9 ms):
+    the same source, so the same bits as the 1024-thread instances (MGRIT_HIP_GEN_512=0)"""
+    if not torch.cuda.is_available():
+        pytest.fail("needs the GPU")
+    conv_a, states_a, used_a = solve(case, gen=True)
+    monkeypatch.setenv("MGRIT_HIP_GEN_512", "0")
+    conv_b, states_b, used_b = solve(case, gen=True)
+    assert used_a == used_b and used_a
+    assert np.array_equal(conv_a, conv_b)
+    for a, b in zip(states_a, states_b):
+        assert np.array_equal(a, b)
+
+
 def _by_hand(mg, op, lvl_pairs, top):
     """a cycle by hand: the general passes on the device, the reference's sweeps on the oracle"""
     from test_hip_parity import assert_state_equal

@@ -157,26 +157,29 @@ def test_first_time_point_is_injected_again_after_a_write(blocks):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nx,switch", [(1024, "MGRIT_HIP_SMALL_WG"), (4099, "MGRIT_HIP_MID_WG"), (8100, "MGRIT_HIP_MID_WG")], ids=["one_wave", "five_waves", "eight_waves"])
 @pytest.mark.parametrize("forcing", [True, False], ids=["forcing", "noforcing"])
-def test_single_wave_instances_equal_the_1024_thread_instances(oracle, monkeypatch, forcing):
+def test_single_wave_instances_equal_the_1024_thread_instances(oracle, monkeypatch, forcing, nx, switch):
     """levels of one group of values (n <= 1024) launch the cycle's sweeps compiled for ONE wave per workgroup (TB = 64 instances of
-    relax<FC>, ecf, cfas, ecfr, fas_fused1: no spill code in a wave that issues one instruction per ~8 cycles); the same source, so
-    the same bits as the 1024-thread instances (MGRIT_HIP_SMALL_WG=0) over whole V- and F-cycles, and both equal to the oracle"""
+    relax<FC>, ecf, cfas, ecfr, fas_fused1: no spill code, the single-group form of Phi), levels of up to 8192 values the instances
+    compiled for 512 threads (no VGPR spills); the same source, so the values of the 1024-thread instances (MGRIT_HIP_SMALL_WG=0 /
+    MGRIT_HIP_MID_WG=0) over whole V- and F-cycles, and both equal to the oracle"""
     from test_hip_parity import _need_gpu, assert_state_equal, make_pair, randomize
     _need_gpu()
-    grids = [cases.lin(2, 257), cases.lin(2, 257)[::4], cases.lin(2, 257)[::16]]
+    nt = 257 if nx <= 1024 else 65
+    grids = [cases.lin(2, nt), cases.lin(2, nt)[::4], cases.lin(2, nt)[::16]]
     for cyc in ("V", "F"):
-        mg_s, op = make_pair(oracle, "heat", 1024, grids, forcing=forcing)
-        mg_b, _ = make_pair(oracle, "heat", 1024, grids, forcing=forcing)
+        mg_s, op = make_pair(oracle, "heat", nx, grids, forcing=forcing)
+        mg_b, _ = make_pair(oracle, "heat", nx, grids, forcing=forcing)
         randomize(mg_s, op, seed=5)
         randomize(mg_b, op, seed=5)
         for it in range(3):
             mg_s.iteration(lvl=0, cycle_type=cyc, iteration=it, first_f=True)
             op.iteration(0, cyc, it, True)
-            monkeypatch.setenv("MGRIT_HIP_SMALL_WG", "0")
+            monkeypatch.setenv(switch, "0")
             mg_b.iteration(lvl=0, cycle_type=cyc, iteration=it, first_f=True)
             mg_b.backend.sync()
-            monkeypatch.delenv("MGRIT_HIP_SMALL_WG")
+            monkeypatch.delenv(switch)
         mg_s.backend.materialise(); mg_b.backend.materialise()
         for l in range(mg_s.lvl_max):
             assert np.array_equal(mg_s.backend.natural("u", l), mg_b.backend.natural("u", l)), (cyc, l)
