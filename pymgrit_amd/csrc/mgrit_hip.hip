@@ -1030,8 +1030,8 @@ __global__ void __launch_bounds__(1024) fas_coarse_kernel(LevelDev L, const int3
 // are loaded into LDS once per workgroup instead of twice per C-point: phase 1 applies the fine Phi to all of the
 // workgroup's points (writes u, v and the partial g of the coarse level), phase 2 the coarse Phi (reads u^l_{ip} and the
 // partial g it wrote itself). 4-5 vectors read, 4 written per C-point instead of 11-12.
-template <int KIND, int FORCE>
-__global__ void __launch_bounds__(1024) fas_fused_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ fine_idx,
+template <int KIND, int FORCE, int TB = 1024>   // (TB = 512: the instance for states of up to 8192 values, sweep_tb; 46-100 spilled VGPRs otherwise)
+__global__ void __launch_bounds__(TB) fas_fused_kernel(LevelDev L, LevelDev Lc, const int32_t *__restrict__ fine_idx,
                                                          const int32_t *__restrict__ prev_idx,
                                                          const int32_t *__restrict__ coarse_idx, int n_items, int use_g) {
     WG_PROLOGUE;
@@ -1920,6 +1920,7 @@ int setup_kernel_attrs() {
     if ((rc = allow_big_lds(fas_fine_kernel<K, F>))) return rc;                                                      \
     if ((rc = allow_big_lds(fas_coarse_kernel<K, F>))) return rc;                                                    \
     if ((rc = allow_big_lds(fas_fused_kernel<K, F>))) return rc;                                                     \
+    if ((rc = allow_big_lds(fas_fused_kernel<K, F, 512>))) return rc;                                                \
     if ((rc = allow_big_lds(ecf_kernel<K, F, false>))) return rc;                                                    \
     if ((rc = allow_big_lds(ecf_kernel<K, F, true>))) return rc;                                                     \
     if ((rc = allow_big_lds(at_kernel<K, F>))) return rc;                                                           \
@@ -3914,10 +3915,16 @@ int mgrit_hip_fas_fused_opts(mgrit_hip_engine *e, int lvl, int triples_id, int o
         return 0;
     }
     if (opts) return fail(MGRIT_HIP_EUNSUPPORTED, "fused FAS residual with options: Heat1D levels (one-pass form) only");
+    const bool mid = lf.dev.T <= 512 && mid_wg_instances();
 #define FUSED_CASE(K_, F_)                                                                                         \
-    if (lf.dev.kind == K_ && force_mode(lf) == F_)                                                                  \
-        hipLaunchKernelGGL((fas_fused_kernel<K_, F_>), dim3(persistent_grid(lf, pl->n)), dim3(lf.dev.T), smem_bytes(lf.G, lf.dev.kind),  \
-                           e->stream, lf.dev, lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);
+    if (lf.dev.kind == K_ && force_mode(lf) == F_) {                                                                \
+        if (mid)                                                                                                   \
+            hipLaunchKernelGGL((fas_fused_kernel<K_, F_, 512>), dim3(persistent_grid(lf, pl->n)), dim3(lf.dev.T), smem_bytes(lf.G, lf.dev.kind), \
+                               e->stream, lf.dev, lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);       \
+        else                                                                                                       \
+            hipLaunchKernelGGL((fas_fused_kernel<K_, F_>), dim3(persistent_grid(lf, pl->n)), dim3(lf.dev.T), smem_bytes(lf.G, lf.dev.kind), \
+                               e->stream, lf.dev, lc.dev, pl->d_fine, pl->d_prev, pl->d_coarse, pl->n, use_g);       \
+    }
     FOR_EACH_STEPPER(FUSED_CASE)
     HIP_TRY(hipGetLastError());
     return 0;
